@@ -1,0 +1,121 @@
+/*
+ * mit_hip.h — C-ABI of the MI355X (gfx950) dense-stage engine for manga-image-translator.
+ *
+ * This is the drop-in boundary beneath the reference's Python plugin classes
+ * (SURVEY.md §8b).  Nothing native exists in the reference for this path: every FLOP goes
+ * through stock ATen ops called from `async _infer()` bodies.  Each entry point below names
+ * the reference call site whose device work it replaces; the Python shim that binds it
+ * (ctypes) is `manga_image_translator_amd/lib.py`, and INTEGRATION.md shows the stub a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / HIP types in signatures.  `stream` is a
+ *     hipStream_t passed as void* (0 = default stream).
+ *   - every pointer named *_dev is a DEVICE pointer (e.g. torch.Tensor.data_ptr()).
+ *   - all functions return 0 on success, non-zero on error; `mit_last_error()` returns a
+ *     thread-local, NUL-terminated description (the Python shim raises RuntimeError with it;
+ *     reference errors are Python exceptions: manga_translator.py:469-477,496-502,583-590).
+ *   - all kernels are asynchronous on `stream`; nothing synchronises unless documented.
+ *   - activations are fp32 NHWC ("pixel-major, channel-contiguous").
+ */
+#ifndef MIT_HIP_H
+#define MIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIT_ABI_VERSION 1
+#define MIT_MAX_TAPS 64
+
+/* activation codes for fused epilogues */
+enum MitAct {
+    MIT_ACT_NONE = 0,
+    MIT_ACT_RELU = 1,    /* nn.ReLU            (inpainting_lama_mpe.py:372-399, basemodel.py:20-22) */
+    MIT_ACT_LEAKY = 2,   /* nn.LeakyReLU(alpha) (yolov5/common.py:39-40: 0.1; esrgan: 0.2)          */
+    MIT_ACT_SILU = 3,    /* nn.SiLU             (yolov5/common.py:37)                                */
+    MIT_ACT_SIGMOID = 4, /* nn.Sigmoid          (basemodel.py:52,107,136; lama generator :599-600)   */
+    MIT_ACT_GELU = 5     /* nn.GELU (erf)       (model_48px.py:199,534)                              */
+};
+
+enum MitPad {
+    MIT_PAD_ZERO = 0,    /* nn.Conv2d default                                   */
+    MIT_PAD_REFLECT = 1  /* padding_mode='reflect' / nn.ReflectionPad2d (inpainting_lama_mpe.py:334-340,554,597) */
+};
+
+/* Addressing of a logical [z][nb][oy][ox][n] fp32 tensor, element strides.
+ * z = z1 * zdiv + z0.  Column n maps to (n / nsplit) * nhi + (n % nsplit); nsplit == 0
+ * means plain contiguous columns.  base == NULL disables the operand. */
+typedef struct MitTensorMap {
+    float *base;
+    int64_t zs1, zs0, bs, ys, xs;
+    int64_t nhi;
+    int32_t nsplit;
+    int32_t _pad;
+} MitTensorMap;
+
+/* mit_conv_gemm — the one dense contraction kernel of the engine (implicit-GEMM on
+ * v_mfma_f32_32x32x2_f32, exact fp32, k-ordered fmaf chain).
+ *
+ *   C[z][m][n] = epilogue( sum_{t<ntaps} sum_{ci<Cin} A[z][m, t, ci] * W[z][t*Cin+ci][n] )
+ *
+ *   m = (nb, oy, ox), nb < NB, oy < Ho, ox < Wo
+ *   A[z][m,t,ci] = a[z1*a_zs1 + z0*a_zs0 + nb*a_bs + iy*a_ys + ix*a_xs + tap_off[t] + ci]
+ *        iy = oy*sy + tap_dy[t], ix = ox*sx + tap_dx[t]; outside [0,Hi)x[0,Wi): zero or reflect
+ *   W[z][k][n]   = w[z1*w_zs1 + z0*w_zs0 + k*ldw + n]          (rows k >= Kw, cols n >= Nw read as 0)
+ *   epilogue(v)  = act( (v + pre[..]) * scale[n] + bias[n] ) + post[..]
+ *
+ * Replaces (with BatchNorm folded into scale/bias by the packer):
+ *   nn.Conv2d / nn.ConvTranspose2d (as stride-parity sub-convolutions) / nn.Linear calls in
+ *   inpainting_lama_mpe.py:349-369,286-307,603-613; ctd_utils/basemodel.py:56-72,100-119;
+ *   ctd_utils/yolov5/common.py:30-49,94-135; ocr/model_48px.py:203-276,327-394,548-572;
+ *   and torch.fft.rfftn / irfftn of FourierUnit (inpainting_lama_mpe.py:228,252) expressed as
+ *   dense DFT matrices (W operand = activations, A operand = the DFT matrix).
+ *
+ * Requirements: Cin % 4 == 0, ldw % 4 == 0, Nw % 4 == 0, all bases 16-byte aligned,
+ *   a_xs/a_ys/a_bs/tap_off multiples of 4 (float4 loads).
+ */
+typedef struct MitConvGemm {
+    /* A operand */
+    const float *a;
+    int64_t a_zs1, a_zs0, a_bs, a_ys, a_xs;
+    int32_t NB, Hi, Wi, Cin;
+    int32_t Ho, Wo, sy, sx;
+    int32_t ntaps, pad_mode;
+    int8_t tap_dy[MIT_MAX_TAPS];
+    int8_t tap_dx[MIT_MAX_TAPS];
+    int32_t tap_off[MIT_MAX_TAPS];
+    /* W operand */
+    const float *w;
+    int64_t w_zs1, w_zs0, ldw;
+    int32_t Kw, Nw;
+    /* problem */
+    int32_t N;      /* output columns actually stored */
+    int32_t Z, zdiv;
+    /* epilogue */
+    MitTensorMap c, pre, post;
+    const float *scale, *bias;
+    int32_t act;
+    float act_alpha;
+} MitConvGemm;
+
+const char *mit_last_error(void);
+int mit_abi_version(void);
+
+/* device / runtime ------------------------------------------------------------------- */
+int mit_device_count(int *count);
+int mit_device_name(int device, char *buf, int buflen);
+
+/* dense contraction -------------------------------------------------------------------- */
+int mit_conv_gemm(const MitConvGemm *desc, void *stream);
+/* tile configuration override for tuning/tests: cfg = -1 auto, else index into the table
+ * reported by mit_conv_gemm_config_name(). */
+int mit_conv_gemm_cfg(const MitConvGemm *desc, int cfg, void *stream);
+const char *mit_conv_gemm_config_name(int cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIT_HIP_H */

@@ -1,0 +1,375 @@
+// conv_gemm.hip — implicit-GEMM convolution / batched GEMM on gfx950 fp32 MFMA.
+//
+// One kernel family serves every dense contraction of the hot path:
+// Conv2d (any k, stride, zero/reflect padding), the stride-parity sub-convolutions of
+// ConvTranspose2d, nn.Linear, and the DFT-as-GEMM stages of LaMa's FourierUnit.
+//
+// Tiling (wave64, v_mfma_f32_32x32x2_f32 — exact fp32, 64 cycles/instruction/SIMD):
+//   workgroup = 256 threads = 4 waves arranged WAVES_M x WAVES_N, block tile BM x BN,
+//   K-tile BK.  A (gathered NHWC activations, k contiguous in HBM) is staged
+//   global -> VGPR (float4) -> LDS transposed to [k][m]; W ([K][N], n contiguous) is staged
+//   global -> VGPR -> LDS [k][n].  Both LDS images are read with conflict-free ds_read_b32
+//   (lanes 0-31 read 32 consecutive dwords of row k, lanes 32-63 row k+1), which is exactly
+//   the 32x32x2 fragment layout (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]).  fp32 MFMA is slow
+//   enough (64 cyc) that LDS bandwidth is <5 % utilised; the loop is MFMA-issue bound when
+//   the next tile's global loads (issued before the MFMA block, written to the other LDS
+//   buffer after it) land in time.  One barrier per K-tile.
+//
+// Summation order is k-sequential (tap-major, channel-minor) inside one accumulator, so
+// results do not depend on the tile configuration or grid.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mit_hip.h"
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct RowOff {
+    int64_t c, pre, post;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+    switch (act) {
+        case MIT_ACT_RELU: return v > 0.f ? v : 0.f;
+        case MIT_ACT_LEAKY: return v > 0.f ? v : v * alpha;
+        case MIT_ACT_SILU: return v / (1.f + __expf(-v));
+        case MIT_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case MIT_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, const int M, const int MT,
+                                                          const int NT, const int KT) {
+    constexpr int WM = BM / WAVES_M;  // wave tile rows
+    constexpr int WN = BN / WAVES_N;
+    constexpr int TM = WM / 32;  // 32x32 blocks per wave
+    constexpr int TN = WN / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    constexpr int KQ = BK / 4;                    // float4 chunks along k
+    constexpr int A_ITERS = BM * KQ / 256;        // float4 loads of A per thread per K-tile
+    constexpr int A_MSTEP = 256 / KQ;             // rows covered per iteration
+    constexpr int NQ = BN / 4;                    // float4 chunks along n
+    constexpr int B_ITERS = (BK * NQ + 255) / 256;
+    constexpr int B_KSTEP = 256 / NQ;
+    constexpr bool B_PARTIAL = (BK * NQ) < 256;  // fewer float4 chunks than threads
+    static_assert(A_ITERS >= 1 && (BM * KQ) % 256 == 0, "A tile must fill the workgroup");
+    constexpr int LDA = BM + (BK == 16 ? 2 : 1);  // ds_write_b32 conflict-free transposed store
+    constexpr int LDB = BN + 4;
+    constexpr int A_TILE = BK * LDA;
+    constexpr int B_TILE = BK * LDB;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;               // [2][BK][LDA]
+    float *Bs = smem + 2 * A_TILE;  // [2][BK][LDB]
+    int *tapinfo = reinterpret_cast<int *>(smem + 2 * A_TILE + 2 * B_TILE);  // [ntaps][2]: packed dy/dx, off
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    // ---- block -> tile mapping (XCD-aware: block b runs on XCD b % 8; give each XCD a
+    // contiguous run of tiles, n fastest, so tiles sharing an A panel share an L2) ----
+    const int nwg = MT * NT;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / NT, nt = bid - mt * NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.y;
+    const int z1 = z / p.zdiv, z0 = z - z1 * p.zdiv;
+
+    const float *__restrict__ a_base = p.a + z1 * p.a_zs1 + z0 * p.a_zs0;
+    const float *__restrict__ w_base = p.w + z1 * p.w_zs1 + z0 * p.w_zs0;
+
+    for (int t = tid; t < p.ntaps; t += 256) {
+        tapinfo[2 * t] = (int(p.tap_dy[t]) & 0xffff) | (int(p.tap_dx[t]) << 16);
+        tapinfo[2 * t + 1] = p.tap_off[t];
+    }
+
+    // ---- per-thread A rows (fixed across the K loop) ----
+    const int aq = tid % KQ;  // float4 chunk along k
+    const int am = tid / KQ;  // first row
+    int64_t a_rowbase[A_ITERS];
+    int a_iy0[A_ITERS], a_ix0[A_ITERS];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int m = m0 + am + i * A_MSTEP;
+        if (m < M) {
+            const int nb = m / HoWo;
+            const int rem = m - nb * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a_rowbase[i] = (int64_t)nb * p.a_bs;
+            a_iy0[i] = oy * p.sy;
+            a_ix0[i] = ox * p.sx;
+        } else {
+            a_rowbase[i] = 0;
+            a_iy0[i] = -(1 << 28);  // forces out-of-range -> zero (also under reflect, see below)
+            a_ix0[i] = 0;
+        }
+    }
+    const int bn4 = tid % NQ;
+    const int bk = tid / NQ;
+    const bool b_ncol_ok = (n0 + bn4 * 4) < p.Nw;
+
+    const int Ktot = p.ntaps * p.Cin;
+
+    f32x4 a_reg[A_ITERS];
+    f32x4 b_reg[B_ITERS];
+
+    __syncthreads();  // tapinfo visible
+
+    auto load_tile = [&](int kt) {
+        // A: gather
+        const int kk = kt * BK + aq * 4;
+        const bool kvalid = kk < Ktot;
+        int tap = 0, ci = 0, dy = 0, dx = 0, toff = 0;
+        if (kvalid) {
+            tap = kk / p.Cin;
+            ci = kk - tap * p.Cin;
+            const int packed = tapinfo[2 * tap];
+            dy = (int)(short)(packed & 0xffff);
+            dx = packed >> 16;
+            toff = tapinfo[2 * tap + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            int iy = a_iy0[i] + dy;
+            int ix = a_ix0[i] + dx;
+            bool ok = kvalid && (a_iy0[i] >= 0);
+            if (p.pad_mode == MIT_PAD_REFLECT) {
+                iy = iy < 0 ? -iy : (iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy);
+                ix = ix < 0 ? -ix : (ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix);
+            } else {
+                ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float *ptr = a_base + a_rowbase[i] + (int64_t)iy * p.a_ys + (int64_t)ix * p.a_xs + toff + ci;
+                v = *reinterpret_cast<const f32x4 *>(ptr);
+            }
+            a_reg[i] = v;
+        }
+        // W
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int k = kt * BK + bk + i * B_KSTEP;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ncol_ok && k < p.Kw && (!B_PARTIAL || bk < BK)) {
+                const float *ptr = w_base + (int64_t)k * p.ldw + n0 + bn4 * 4;
+                v = *reinterpret_cast<const f32x4 *>(ptr);
+            }
+            b_reg[i] = v;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float *as = As + buf * A_TILE;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int ml = am + i * A_MSTEP;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) as[(aq * 4 + j) * LDA + ml] = a_reg[i][j];
+        }
+        float *bs = Bs + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int kl = bk + i * B_KSTEP;
+            if (!B_PARTIAL || bk < BK) *reinterpret_cast<f32x4 *>(bs + kl * LDB + bn4 * 4) = b_reg[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int wm0 = (wave / WAVES_N) * WM;
+    const int wn0 = (wave % WAVES_N) * WN;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float *as = As + cur * A_TILE + lh * LDA + wm0 + li;
+        const float *bs = Bs + cur * B_TILE + lh * LDB + wn0 + li;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) af[mi] = as[(2 * ks) * LDA + mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) bf[ni] = bs[(2 * ks) * LDB + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: row offsets computed once per row, shared through LDS ----
+    RowOff *rowoff = reinterpret_cast<RowOff *>(smem);  // BM entries (<= A/B staging area)
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        RowOff ro = {-1, 0, 0};
+        if (m < M) {
+            const int nb = m / HoWo;
+            const int rem = m - nb * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            ro.c = z1 * p.c.zs1 + z0 * p.c.zs0 + (int64_t)nb * p.c.bs + (int64_t)oy * p.c.ys + (int64_t)ox * p.c.xs;
+            ro.pre = z1 * p.pre.zs1 + z0 * p.pre.zs0 + (int64_t)nb * p.pre.bs + (int64_t)oy * p.pre.ys +
+                     (int64_t)ox * p.pre.xs;
+            ro.post = z1 * p.post.zs1 + z0 * p.post.zs0 + (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys +
+                      (int64_t)ox * p.post.xs;
+        }
+        rowoff[r] = ro;
+    }
+    __syncthreads();
+
+    const bool has_pre = p.pre.base != nullptr;
+    const bool has_post = p.post.base != nullptr;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + li;
+        if (n >= p.N) continue;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float bi = p.bias ? p.bias[n] : 0.f;
+        int64_t ncol_c = n, ncol_pre = n, ncol_post = n;
+        if (p.c.nsplit) ncol_c = (int64_t)(n / p.c.nsplit) * p.c.nhi + (n % p.c.nsplit);
+        if (has_pre && p.pre.nsplit) ncol_pre = (int64_t)(n / p.pre.nsplit) * p.pre.nhi + (n % p.pre.nsplit);
+        if (has_post && p.post.nsplit) ncol_post = (int64_t)(n / p.post.nsplit) * p.post.nhi + (n % p.post.nsplit);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const RowOff ro = rowoff[row];
+                if (ro.c < 0) continue;
+                float v = acc[mi][ni][r];
+                if (has_pre) v += p.pre.base[ro.pre + ncol_pre];
+                v = v * sc + bi;
+                v = apply_act(v, p.act, p.act_alpha);
+                if (has_post) v += p.post.base[ro.post + ncol_post];
+                p.c.base[ro.c + ncol_c] = v;
+            }
+        }
+    }
+}
+
+struct CfgEntry {
+    const char *name;
+    int BM, BN, BK;
+    void (*launch)(const MitConvGemm &, int M, int MT, int NT, int KT, hipStream_t);
+    size_t smem;
+};
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+size_t smem_bytes() {
+    constexpr int LDA = BM + (BK == 16 ? 2 : 1);
+    constexpr int LDB = BN + 4;
+    size_t staging = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + MIT_MAX_TAPS * 2 * sizeof(int);
+    size_t rows = (size_t)BM * sizeof(RowOff);
+    return staging > rows ? staging : rows;
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+void launch_cfg(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
+    dim3 grid(MT * NT, p.Z, 1);
+    size_t smem = smem_bytes<BM, BN, BK, WAVES_M, WAVES_N>();
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N>), grid, dim3(256), smem, s, p, M, MT, NT, KT);
+}
+
+#define CFG(BM, BN, BK, WM_, WN_) \
+    { #BM "x" #BN "x" #BK, BM, BN, BK, launch_cfg<BM, BN, BK, WM_, WN_>, 0 }
+
+const CfgEntry kCfgs[] = {
+    CFG(128, 128, 16, 2, 2),  // 0: general
+    CFG(128, 64, 16, 2, 2),   // 1: Cout <= 64
+    CFG(128, 32, 16, 4, 1),   // 2: Cout <= 32
+    CFG(256, 128, 16, 2, 2),  // 3: large M & N, best arithmetic intensity
+    CFG(128, 128, 32, 2, 2),  // 4: Cin % 32 == 0, full 128-B lines per pixel
+    CFG(256, 64, 16, 4, 1),   // 5
+    CFG(64, 64, 16, 2, 2),    // 6: small problems
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+int pick_cfg(const MitConvGemm &p, int64_t M) {
+    // measured on MI355X (scripts/bench_conv.py): 128x128x16 is the best general tile
+    // (3 waves/SIMD); the 256-row tiles run 1 wave/SIMD and lose ~20 %.
+    if (p.N <= 32) return 2;
+    if (p.N <= 64) return 1;
+    const int rem = p.N % 128;
+    if (rem != 0 && rem <= 64) return 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
+    return 0;
+}
+
+}  // namespace
+
+extern "C" const char *mit_conv_gemm_config_name(int cfg) {
+    if (cfg < 0 || cfg >= kNumCfgs) return nullptr;
+    return kCfgs[cfg].name;
+}
+
+extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
+    if (!d) return mit_set_error("mit_conv_gemm: null descriptor");
+    const MitConvGemm &p = *d;
+    if (!p.a || !p.w || !p.c.base) return mit_set_error("mit_conv_gemm: null operand");
+    if (p.Cin <= 0 || (p.Cin & 3)) return mit_set_error("mit_conv_gemm: Cin must be a positive multiple of 4 (got %d)", p.Cin);
+    if ((p.ldw & 3) || (p.Nw & 3)) return mit_set_error("mit_conv_gemm: ldw/Nw must be multiples of 4 (ldw=%lld Nw=%d)", (long long)p.ldw, p.Nw);
+    if (p.ntaps <= 0 || p.ntaps > MIT_MAX_TAPS) return mit_set_error("mit_conv_gemm: ntaps %d out of range", p.ntaps);
+    if (p.NB <= 0 || p.Ho <= 0 || p.Wo <= 0 || p.N <= 0 || p.Z <= 0 || p.zdiv <= 0)
+        return mit_set_error("mit_conv_gemm: empty problem");
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15))
+        return mit_set_error("mit_conv_gemm: operands must be 16-byte aligned");
+    if ((p.a_xs & 3) || (p.a_ys & 3) || (p.a_bs & 3) || (p.a_zs0 & 3) || (p.a_zs1 & 3) || (p.w_zs0 & 3) || (p.w_zs1 & 3))
+        return mit_set_error("mit_conv_gemm: strides must be multiples of 4 elements");
+    for (int t = 0; t < p.ntaps; ++t)
+        if (p.tap_off[t] & 3) return mit_set_error("mit_conv_gemm: tap_off must be multiples of 4");
+    if (p.pad_mode == MIT_PAD_REFLECT) {
+        for (int t = 0; t < p.ntaps; ++t) {
+            int ady = p.tap_dy[t] < 0 ? -p.tap_dy[t] : p.tap_dy[t];
+            int adx = p.tap_dx[t] < 0 ? -p.tap_dx[t] : p.tap_dx[t];
+            if (ady >= p.Hi || adx >= p.Wi) return mit_set_error("mit_conv_gemm: reflect pad larger than input");
+        }
+    }
+    const int64_t M64 = (int64_t)p.NB * p.Ho * p.Wo;
+    if (M64 > 0x7fffffffLL) return mit_set_error("mit_conv_gemm: M too large");
+    if (p.Z > 65535) return mit_set_error("mit_conv_gemm: Z too large");
+    if (cfg < 0) cfg = pick_cfg(p, M64);
+    if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
+    const CfgEntry &c = kCfgs[cfg];
+    const int M = (int)M64;
+    const int MT = (M + c.BM - 1) / c.BM;
+    const int NT = (p.N + c.BN - 1) / c.BN;
+    const int Ktot = p.ntaps * p.Cin;
+    const int KT = (Ktot + c.BK - 1) / c.BK;
+    if ((int64_t)MT * NT > 0x7fffffffLL) return mit_set_error("mit_conv_gemm: grid too large");
+    c.launch(p, M, MT, NT, KT, reinterpret_cast<hipStream_t>(stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mit_set_error("mit_conv_gemm: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int mit_conv_gemm(const MitConvGemm *d, void *stream) { return mit_conv_gemm_cfg(d, -1, stream); }

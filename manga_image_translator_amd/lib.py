@@ -1,0 +1,117 @@
+"""ctypes binding of the C-ABI in ``include/mit_hip.h``.
+
+The library is the product: if it cannot be loaded the import of any op raises — there is
+no CPU or PyTorch fallback behind these entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+MIT_MAX_TAPS = 64
+MIT_ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+
+class MitTensorMap(C.Structure):
+    _fields_ = [
+        ("base", C.c_void_p),
+        ("zs1", C.c_int64),
+        ("zs0", C.c_int64),
+        ("bs", C.c_int64),
+        ("ys", C.c_int64),
+        ("xs", C.c_int64),
+        ("nhi", C.c_int64),
+        ("nsplit", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class MitConvGemm(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p),
+        ("a_zs1", C.c_int64),
+        ("a_zs0", C.c_int64),
+        ("a_bs", C.c_int64),
+        ("a_ys", C.c_int64),
+        ("a_xs", C.c_int64),
+        ("NB", C.c_int32),
+        ("Hi", C.c_int32),
+        ("Wi", C.c_int32),
+        ("Cin", C.c_int32),
+        ("Ho", C.c_int32),
+        ("Wo", C.c_int32),
+        ("sy", C.c_int32),
+        ("sx", C.c_int32),
+        ("ntaps", C.c_int32),
+        ("pad_mode", C.c_int32),
+        ("tap_dy", C.c_int8 * MIT_MAX_TAPS),
+        ("tap_dx", C.c_int8 * MIT_MAX_TAPS),
+        ("tap_off", C.c_int32 * MIT_MAX_TAPS),
+        ("w", C.c_void_p),
+        ("w_zs1", C.c_int64),
+        ("w_zs0", C.c_int64),
+        ("ldw", C.c_int64),
+        ("Kw", C.c_int32),
+        ("Nw", C.c_int32),
+        ("N", C.c_int32),
+        ("Z", C.c_int32),
+        ("zdiv", C.c_int32),
+        ("c", MitTensorMap),
+        ("pre", MitTensorMap),
+        ("post", MitTensorMap),
+        ("scale", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("act", C.c_int32),
+        ("act_alpha", C.c_float),
+    ]
+
+
+# every symbol include/mit_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mit_last_error": (C.c_char_p, []),
+    "mit_abi_version": (C.c_int, []),
+    "mit_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mit_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "mit_conv_gemm": (C.c_int, [C.POINTER(MitConvGemm), C.c_void_p]),
+    "mit_conv_gemm_cfg": (C.c_int, [C.POINTER(MitConvGemm), C.c_int, C.c_void_p]),
+    "mit_conv_gemm_config_name": (C.c_char_p, [C.c_int]),
+}
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return Path(__file__).resolve().parent / "libmit_hip.so"
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load ``libmit_hip.so`` (building it with hipcc if absent). Raises on any failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing: run `python -m manga_image_translator_amd.build`")
+        from . import build as _build
+
+        _build.build()
+    lib = C.CDLL(str(path))
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.mit_abi_version() != MIT_ABI_VERSION:
+        raise RuntimeError(f"libmit_hip.so ABI {lib.mit_abi_version()} != binding {MIT_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    """Turn a non-zero status into RuntimeError carrying ``mit_last_error()``."""
+    if rc != 0:
+        msg = load().mit_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg}" if what else msg)

@@ -1,0 +1,273 @@
+"""Host-side operators over the C-ABI: weight packing, descriptors, launches.
+
+PyTorch is used only for device memory and streams (``torch.Tensor.data_ptr()``,
+``torch.cuda.current_stream()``); every FLOP runs in ``libmit_hip.so``.
+
+Activations are fp32 NHWC tensors ``[B, H, W, C]`` (any strides as long as the channel
+stride is 1 — channel slices and spatially strided views are passed straight to the kernel,
+which is how concat and the sub-pixel form of ConvTranspose2d are expressed without copies).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as _lib
+from .lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, MIT_MAX_TAPS, PAD_REFLECT,
+                  PAD_ZERO, MitConvGemm, MitTensorMap)
+
+__all__ = [
+    "ACT_NONE", "ACT_RELU", "ACT_LEAKY", "ACT_SILU", "ACT_SIGMOID", "ACT_GELU", "PAD_ZERO", "PAD_REFLECT",
+    "Conv2d", "ConvTranspose2d", "fold_bn", "conv_gemm_desc", "launch_conv_gemm", "current_stream",
+]
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _check_nhwc(t: torch.Tensor, what: str) -> None:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: expected float32, got {t.dtype}")
+    if t.dim() != 4:
+        raise ValueError(f"{what}: expected [B,H,W,C], got shape {tuple(t.shape)}")
+    if t.shape[-1] > 1 and t.stride(-1) != 1:
+        raise ValueError(f"{what}: channel stride must be 1, got strides {t.stride()}")
+
+
+def tensor_map(t: Optional[torch.Tensor], zs1: int = 0, zs0: int = 0, nsplit: int = 0, nhi: int = 0) -> MitTensorMap:
+    """MitTensorMap of a ``[NB, Ho, Wo, N]`` view (or a disabled map for ``None``)."""
+    m = MitTensorMap()
+    if t is None:
+        m.base = None
+        return m
+    _check_nhwc(t, "tensor_map")
+    m.base = t.data_ptr()
+    m.zs1, m.zs0 = zs1, zs0
+    m.bs, m.ys, m.xs = t.stride(0), t.stride(1), t.stride(2)
+    m.nsplit, m.nhi = nsplit, nhi
+    return m
+
+
+def conv_gemm_desc(*, a: torch.Tensor, NB: int, Hi: int, Wi: int, Cin: int, a_strides: Tuple[int, int, int],
+                   Ho: int, Wo: int, sy: int, sx: int, taps: Sequence[Tuple[int, int, int]], pad_mode: int,
+                   w: torch.Tensor, ldw: int, Kw: int, Nw: int, N: int, c: MitTensorMap,
+                   pre: Optional[MitTensorMap] = None, post: Optional[MitTensorMap] = None,
+                   scale: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                   alpha: float = 0.0, Z: int = 1, zdiv: int = 1, a_zs: Tuple[int, int] = (0, 0),
+                   w_zs: Tuple[int, int] = (0, 0)) -> MitConvGemm:
+    """Fill a ``MitConvGemm`` descriptor. Pure host logic (usable without a GPU)."""
+    if len(taps) == 0 or len(taps) > MIT_MAX_TAPS:
+        raise ValueError(f"ntaps {len(taps)} out of range")
+    d = MitConvGemm()
+    d.a = a.data_ptr()
+    d.a_zs1, d.a_zs0 = a_zs
+    d.a_bs, d.a_ys, d.a_xs = a_strides
+    d.NB, d.Hi, d.Wi, d.Cin = NB, Hi, Wi, Cin
+    d.Ho, d.Wo, d.sy, d.sx = Ho, Wo, sy, sx
+    d.ntaps, d.pad_mode = len(taps), pad_mode
+    for i, (dy, dx, off) in enumerate(taps):
+        d.tap_dy[i], d.tap_dx[i], d.tap_off[i] = dy, dx, off
+    d.w = w.data_ptr()
+    d.w_zs1, d.w_zs0 = w_zs
+    d.ldw, d.Kw, d.Nw = ldw, Kw, Nw
+    d.N, d.Z, d.zdiv = N, Z, zdiv
+    d.c = c
+    d.pre = pre if pre is not None else tensor_map(None)
+    d.post = post if post is not None else tensor_map(None)
+    d.scale = _ptr(scale)
+    d.bias = _ptr(bias)
+    d.act, d.act_alpha = act, alpha
+    return d
+
+
+def launch_conv_gemm(desc: MitConvGemm, cfg: int = -1, stream: Optional[int] = None) -> None:
+    lib = _lib.load()
+    s = current_stream() if stream is None else stream
+    _lib.check(lib.mit_conv_gemm_cfg(C.byref(desc), cfg, C.c_void_p(s)), "mit_conv_gemm")
+
+
+def fold_bn(gamma: torch.Tensor, beta: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, eps: float,
+            conv_bias: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval-mode BatchNorm2d after a conv as per-channel (scale, bias): y = conv*scale + bias.
+
+    Same algebra as the reference's own fuse step (ctd_utils/utils/yolov5_utils.py:22-42), but
+    the scale stays in the epilogue instead of being multiplied into the weights.
+    """
+    g, b, m, v = (t.detach().to(torch.float64) for t in (gamma, beta, mean, var))
+    scale = g / torch.sqrt(v + eps)
+    bias = b - m * scale
+    if conv_bias is not None:
+        bias = bias + conv_bias.detach().to(torch.float64) * scale
+    return scale.to(torch.float32), bias.to(torch.float32)
+
+
+def pack_weight_kn(w_kn: torch.Tensor, device) -> Tuple[torch.Tensor, int, int]:
+    """Zero-pad a [K, N] matrix to [Kp(16), Np(4)] fp32 on ``device``; returns (w, Kp, Np)."""
+    K, N = w_kn.shape
+    Kp, Np = _round_up(K, 16), _round_up(N, 4)
+    out = torch.zeros(Kp, Np, dtype=torch.float32)
+    out[:K, :N] = w_kn.detach().to(torch.float32)
+    return out.to(device).contiguous(), Kp, Np
+
+
+@dataclass
+class _Packed:
+    w: torch.Tensor
+    Kp: int
+    Np: int
+    taps: List[Tuple[int, int, int]]
+
+
+class Conv2d:
+    """nn.Conv2d (+ folded eval BatchNorm2d + activation) as one ``mit_conv_gemm`` launch.
+
+    weight: [Cout, Cin, kh, kw] (torch layout).  Input channels are zero-padded to a multiple
+    of 4 (``cin_pad``); the input tensor must then carry that many channels.
+    """
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride=1, padding=0,
+                 pad_mode: int = PAD_ZERO, bn=None, act: int = ACT_NONE, alpha: float = 0.0, device="cuda",
+                 out_scale: Optional[torch.Tensor] = None):
+        Cout, Cin, kh, kw = weight.shape
+        self.Cout, self.Cin_raw = Cout, Cin
+        self.Cin = _round_up(Cin, 4)
+        self.kh, self.kw = kh, kw
+        self.sy, self.sx = (stride, stride) if isinstance(stride, int) else stride
+        self.py, self.px = (padding, padding) if isinstance(padding, int) else padding
+        self.pad_mode = pad_mode
+        self.act, self.alpha = act, alpha
+        w = weight.detach().to(torch.float32)
+        if self.Cin != Cin:
+            w = torch.cat([w, torch.zeros(Cout, self.Cin - Cin, kh, kw)], dim=1)
+        w_kn = w.permute(2, 3, 1, 0).reshape(kh * kw * self.Cin, Cout)  # K = (ky, kx, ci)
+        self.w, self.Kp, self.Np = pack_weight_kn(w_kn, device)
+        self.taps = [(ky - self.py, kx - self.px, 0) for ky in range(kh) for kx in range(kw)]
+        scale = bias_t = None
+        if bn is not None:
+            scale, bias_t = fold_bn(*bn, conv_bias=bias)
+        elif bias is not None:
+            bias_t = bias.detach().to(torch.float32)
+        if out_scale is not None:  # e.g. ConvNeXt layer-scale gamma: gamma * (conv + b)
+            os_ = out_scale.detach().to(torch.float32).reshape(-1)
+            scale = os_ if scale is None else scale * os_
+            if bias_t is not None:
+                bias_t = bias_t * os_
+        self.scale = None if scale is None else scale.to(device).contiguous()
+        self.bias = None if bias_t is None else bias_t.to(device).contiguous()
+
+    def out_hw(self, H: int, W: int) -> Tuple[int, int]:
+        return ((H + 2 * self.py - self.kh) // self.sy + 1, (W + 2 * self.px - self.kw) // self.sx + 1)
+
+    def desc(self, x: torch.Tensor, out: torch.Tensor, pre: Optional[torch.Tensor] = None,
+             post: Optional[torch.Tensor] = None) -> MitConvGemm:
+        _check_nhwc(x, "Conv2d input")
+        _check_nhwc(out, "Conv2d output")
+        B, H, W, Cx = x.shape
+        if Cx != self.Cin:
+            raise ValueError(f"Conv2d: input has {Cx} channels, layer expects {self.Cin}")
+        Ho, Wo = self.out_hw(H, W)
+        if tuple(out.shape) != (B, Ho, Wo, self.Cout):
+            raise ValueError(f"Conv2d: output shape {tuple(out.shape)} != {(B, Ho, Wo, self.Cout)}")
+        for t, nm in ((pre, "pre"), (post, "post")):
+            if t is not None and tuple(t.shape) != tuple(out.shape):
+                raise ValueError(f"Conv2d: {nm} shape {tuple(t.shape)} != output {tuple(out.shape)}")
+        return conv_gemm_desc(
+            a=x, NB=B, Hi=H, Wi=W, Cin=self.Cin, a_strides=(x.stride(0), x.stride(1), x.stride(2)), Ho=Ho, Wo=Wo,
+            sy=self.sy, sx=self.sx, taps=self.taps, pad_mode=self.pad_mode, w=self.w, ldw=self.Np, Kw=self.Kp,
+            Nw=self.Np, N=self.Cout, c=tensor_map(out), pre=tensor_map(pre), post=tensor_map(post),
+            scale=self.scale, bias=self.bias, act=self.act, alpha=self.alpha)
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, pre: Optional[torch.Tensor] = None,
+                 post: Optional[torch.Tensor] = None, cfg: int = -1) -> torch.Tensor:
+        if out is None:
+            Ho, Wo = self.out_hw(x.shape[1], x.shape[2])
+            out = torch.empty(x.shape[0], Ho, Wo, self.Cout, dtype=torch.float32, device=x.device)
+        launch_conv_gemm(self.desc(x, out, pre, post), cfg)
+        return out
+
+
+class ConvTranspose2d:
+    """nn.ConvTranspose2d (+ folded BN + activation) as ``stride**2`` sub-pixel convolutions.
+
+    Output pixels of parity (py, px) are an ordinary stride-1 convolution of the input with the
+    kernel taps of matching parity; each class is one launch writing the strided output view
+    ``out[:, py::s, px::s]`` (no zero-stuffing, no scatter).  weight: [Cin, Cout, kh, kw].
+    Covers k3 s2 p1 op1 (inpainting_lama_mpe.py:587-589), k4 s2 p1 (ctd_utils/basemodel.py:20)
+    and k2 s2 (basemodel.py:93,96).
+    """
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride=2, padding=0,
+                 output_padding=0, bn=None, act: int = ACT_NONE, alpha: float = 0.0, device="cuda"):
+        Cin, Cout, kh, kw = weight.shape
+        if Cin % 4:
+            raise ValueError("ConvTranspose2d: Cin must be a multiple of 4")
+        self.Cin, self.Cout, self.k, self.s, self.p, self.op = Cin, Cout, (kh, kw), stride, padding, output_padding
+        self.act, self.alpha = act, alpha
+        w = weight.detach().to(torch.float32)
+        self.sub: List[Tuple[int, int, _Packed]] = []
+        s, p = stride, padding
+        for py in range(s):
+            kys = [ky for ky in range(kh) if (py + p - ky) % s == 0]
+            for px in range(s):
+                kxs = [kx for kx in range(kw) if (px + p - kx) % s == 0]
+                taps, blocks = [], []
+                for ky in kys:
+                    for kx in kxs:
+                        taps.append(((py + p - ky) // s, (px + p - kx) // s, 0))
+                        blocks.append(w[:, :, ky, kx])  # [Cin, Cout]
+                if not taps:
+                    raise ValueError("ConvTranspose2d: empty parity class (kernel smaller than stride)")
+                wk, Kp, Np = pack_weight_kn(torch.cat(blocks, dim=0), device)
+                self.sub.append((py, px, _Packed(wk, Kp, Np, taps)))
+        scale = bias_t = None
+        if bn is not None:
+            scale, bias_t = fold_bn(*bn, conv_bias=bias)
+        elif bias is not None:
+            bias_t = bias.detach().to(torch.float32)
+        self.scale = None if scale is None else scale.to(device).contiguous()
+        self.bias = None if bias_t is None else bias_t.to(device).contiguous()
+
+    def out_hw(self, H: int, W: int) -> Tuple[int, int]:
+        return ((H - 1) * self.s - 2 * self.p + self.k[0] + self.op, (W - 1) * self.s - 2 * self.p + self.k[1] + self.op)
+
+    def descs(self, x: torch.Tensor, out: torch.Tensor) -> List[MitConvGemm]:
+        _check_nhwc(x, "ConvTranspose2d input")
+        _check_nhwc(out, "ConvTranspose2d output")
+        B, H, W, Cx = x.shape
+        if Cx != self.Cin:
+            raise ValueError(f"ConvTranspose2d: input has {Cx} channels, layer expects {self.Cin}")
+        Ho, Wo = self.out_hw(H, W)
+        if tuple(out.shape) != (B, Ho, Wo, self.Cout):
+            raise ValueError(f"ConvTranspose2d: output shape {tuple(out.shape)} != {(B, Ho, Wo, self.Cout)}")
+        ds = []
+        for py, px, pk in self.sub:
+            ov = out[:, py::self.s, px::self.s]
+            if ov.shape[1] == 0 or ov.shape[2] == 0:
+                continue
+            ds.append(conv_gemm_desc(
+                a=x, NB=B, Hi=H, Wi=W, Cin=self.Cin, a_strides=(x.stride(0), x.stride(1), x.stride(2)),
+                Ho=ov.shape[1], Wo=ov.shape[2], sy=1, sx=1, taps=pk.taps, pad_mode=PAD_ZERO, w=pk.w, ldw=pk.Np,
+                Kw=pk.Kp, Nw=pk.Np, N=self.Cout, c=tensor_map(ov), scale=self.scale, bias=self.bias, act=self.act,
+                alpha=self.alpha))
+        return ds
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, cfg: int = -1) -> torch.Tensor:
+        if out is None:
+            Ho, Wo = self.out_hw(x.shape[1], x.shape[2])
+            out = torch.empty(x.shape[0], Ho, Wo, self.Cout, dtype=torch.float32, device=x.device)
+        for d in self.descs(x, out):
+            launch_conv_gemm(d, cfg)
+        return out
