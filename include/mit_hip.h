@@ -115,6 +115,35 @@ int mit_conv_gemm(const MitConvGemm *desc, void *stream);
 int mit_conv_gemm_cfg(const MitConvGemm *desc, int cfg, void *stream);
 const char *mit_conv_gemm_config_name(int cfg);
 
+/* LaMa inpainting stage: memory-bound pieces ----------------------------------------------
+ * Reference: manga_translator/inpainting/inpainting_lama_mpe.py. */
+
+/* u8 page [B,H,W,3] + u8 mask [B,H,W] -> fp32 NHWC [B,H,W,4] = (rgb/255*(1-m), m), m = (mask/255 >= 0.5).
+ * Replaces the host-side tensor prep of LamaMPEInpainter._infer :82-92 and the torch.cat of
+ * FFCResNetGenerator.forward :604. */
+int mit_lama_prep(const uint8_t *img_dev, const uint8_t *mask_dev, float *out_dev, int B, int H, int W, void *stream);
+
+/* Masked positional-encoding index maps on the 256x256 structure grid:
+ * hole = (INTER_AREA resize of the binary mask) > 0; relpos = clipped ring distance; direct = 4 direction bits.
+ * Replaces LamaFourier.load_masked_position_encoding :751-807 (cv2.resize + the cv2.filter2D loop on the CPU).
+ * ys/yc/yw (xs/xc/xw): DEVICE arrays describing the separable resize: destination row d averages source rows
+ * [ys[d], ys[d]+yc[d]) with weights yw[d*ymax + j] (doubles). */
+int mit_lama_mpe_index(const uint8_t *mask_dev, int B, int H, int W, const int *ys_dev, const int *yc_dev,
+                       const double *yw_dev, int ymax, const int *xs_dev, const int *xc_dev, const double *xw_dev,
+                       int xmax, uint8_t *hole_dev, uint8_t *relpos_dev, uint8_t *direct_dev, void *stream);
+
+/* x[B,H,W,64] += alpha5 * rel_pos_emb[rel] + alpha6 * (direct @ direct_emb), with the 256-grid maps
+ * nearest-resized through ymap[H] / xmap[W] (cv2.INTER_NEAREST :810-813) and zeroed outside the mask.
+ * Replaces MPE.forward :625-632 and the two adds of FFCResNetGenerator.forward :611-612. */
+int mit_lama_mpe_add(float *x_dev, const uint8_t *mask_dev, const uint8_t *relpos_dev, const uint8_t *direct_dev,
+                     const int *ymap_dev, const int *xmap_dev, const float *emb_dev, const float *dirw_dev, float alpha5,
+                     float alpha6, int B, int H, int W, void *stream);
+
+/* predicted fp32 (pixel stride pred_pixstride floats, 3 used) + page + mask -> inpainted u8 [B,H,W,3]:
+ * pred*m + (1-m)*img (:726), *255 truncated to u8 (:111), composited with the original through mask >= 127 (:59-60,117). */
+int mit_lama_post(const float *pred_dev, int64_t pred_pixstride, const uint8_t *img_dev, const uint8_t *mask_dev,
+                  uint8_t *out_dev, int B, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,361 @@
+"""LaMa-MPE / LaMa-large inpainting generator on the gfx950 engine.
+
+Same network as ``FFCResNetGenerator`` + ``MPE`` of the reference
+(/root/reference/manga_translator/inpainting/inpainting_lama_mpe.py:545-632,713-726), laid out for
+MI355X:
+
+* activations fp32 NHWC; the bottleneck state is ONE [B,h,w,512] tensor whose first 128 channels
+  are the local branch and last 384 the global branch, so ``convl2l(x_l) + convg2l(x_g)`` (:365) is a
+  single 3x3 conv over 512 input channels and torch.cat / ConcatTupleLayer (:535-542) cost nothing;
+* every BatchNorm is folded into the producing conv's epilogue, ReLU / sigmoid / residual adds too;
+* FourierUnit's rfftn / irfftn (:228,252) run as four dense DFT GEMMs on the same MFMA kernel
+  (W-axis real DFT, H-axis complex DFT and their inverses), with the re/im planes kept planar so the
+  384->384 spectral 1x1 conv reads them as two "taps" and no permute/stack/complex copy exists;
+* uint8 pages in, uint8 pages out: only bytes cross PCIe.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, PAD_REFLECT, PAD_ZERO, conv_gemm_desc, launch_conv_gemm, tensor_map
+
+LOCAL_C, GLOBAL_C, SPEC_C = 128, 384, 192
+MPE_S = 256
+
+
+def _bn(sd, prefix, eps=1e-5):
+    return (sd[prefix + ".weight"], sd[prefix + ".bias"], sd[prefix + ".running_mean"], sd[prefix + ".running_var"], eps)
+
+
+def _cat_bn(sd, p1, p2):
+    a, b = _bn(sd, p1), _bn(sd, p2)
+    return tuple(torch.cat([x, y]) for x, y in zip(a[:4], b[:4])) + (a[4],)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------
+# DFT matrices (float64 on the host, rounded once to fp32)
+# ------------------------------------------------------------------------------------------
+
+def dft_matrices(h: int, w: int):
+    """Dense real matrices of the ortho-normalised rfft2 / irfft2 over an [h, w] grid.
+
+    F1   [2*wk, wp]  : row (t,kw), col w     real->complex DFT along W (t=0 re, t=1 im), wp = w padded to 4
+    G2   [2h, 2h->pad4] : row (t',kh), col (t,h) complex DFT along H on planar re/im
+    G2i  [2h, 2h->pad4] : row (t,h), col (t',kh) inverse complex DFT along H
+    Fi   [w, 2*wk->pad4] : row w, col (t,kw)  complex->real inverse along W (Hermitian weights; the
+                       imaginary parts of the DC / Nyquist bins are ignored exactly like pocketfft's c2r)
+    """
+    wk = w // 2 + 1
+    wp = _round_up(w, 4)
+    kw = np.arange(wk)[:, None]
+    xs = np.arange(w)[None, :]
+    ang = 2.0 * np.pi * ((kw * xs) % w) / w
+    sw = 1.0 / math.sqrt(w)
+    F1 = np.zeros((2 * wk, wp), dtype=np.float64)
+    F1[:wk, :w] = np.cos(ang) * sw
+    F1[wk:, :w] = -np.sin(ang) * sw
+    kh = np.arange(h)[:, None]
+    ys = np.arange(h)[None, :]
+    angh = 2.0 * np.pi * ((kh * ys) % h) / h
+    sh = 1.0 / math.sqrt(h)
+    Gr, Gi = np.cos(angh) * sh, -np.sin(angh) * sh
+    k2p = _round_up(2 * h, 4)
+    G2 = np.zeros((2 * h, k2p), dtype=np.float64)
+    G2[:, :2 * h] = np.block([[Gr, -Gi], [Gi, Gr]])
+    Gri, Gii = np.cos(angh) * sh, np.sin(angh) * sh
+    G2i = np.zeros((2 * h, k2p), dtype=np.float64)
+    G2i[:, :2 * h] = np.block([[Gri, -Gii], [Gii, Gri]])
+    kp = _round_up(2 * wk, 4)
+    a = np.full(wk, 2.0)
+    a[0] = 1.0
+    if w % 2 == 0:
+        a[wk - 1] = 1.0
+    Fi = np.zeros((w, kp), dtype=np.float64)
+    Fi[:, :wk] = (np.cos(ang) * sw * a[:, None]).T
+    sin_t = np.sin(ang)
+    sin_t[0, :] = 0.0
+    if w % 2 == 0:
+        sin_t[wk - 1, :] = 0.0
+    Fi[:, wk:2 * wk] = (-sin_t * sw * a[:, None]).T
+    f32 = lambda m: torch.from_numpy(np.ascontiguousarray(m.astype(np.float32)))
+    return f32(F1), f32(G2), f32(G2i), f32(Fi)
+
+
+# ------------------------------------------------------------------------------------------
+# host tables for the MPE index kernels (same formulas as OpenCV's resize)
+# ------------------------------------------------------------------------------------------
+
+def _area_taps(n_src: int, n_dst: int):
+    """cv2.INTER_AREA taps per destination index (area mean when shrinking, the INTER_AREA flavour of
+    bilinear otherwise) -> (start[int32], count[int32], weights[float64, n_dst x maxtaps])."""
+    scale = n_src / n_dst
+    rows = []
+    for d in range(n_dst):
+        if n_dst <= n_src:
+            lo, hi = d * scale, (d + 1) * scale
+            s0, s1 = int(math.floor(lo)), min(int(math.ceil(hi)), n_src)
+            ws = [max(0.0, min(hi, s + 1) - max(lo, s)) / scale for s in range(s0, s1)]
+        else:
+            inv = n_dst / n_src
+            s0 = int(math.floor(d * scale))
+            f = (d + 1) - (s0 + 1) * inv
+            f = 0.0 if f <= 0 else f - math.floor(f)
+            if s0 >= n_src - 1:
+                s0, f = n_src - 1, 0.0
+            ws = [1.0 - f] + ([f] if f > 0 else [])
+        rows.append((s0, ws))
+    maxt = max(len(ws) for _, ws in rows)
+    start = np.array([s for s, _ in rows], dtype=np.int32)
+    cnt = np.array([len(ws) for _, ws in rows], dtype=np.int32)
+    wts = np.zeros((n_dst, maxt), dtype=np.float64)
+    for d, (_, ws) in enumerate(rows):
+        wts[d, :len(ws)] = ws
+    return start, cnt, wts, maxt
+
+
+def _nearest_map(n_dst: int, n_src: int) -> np.ndarray:
+    """cv2.INTER_NEAREST source index per destination index."""
+    return np.minimum(np.floor(np.arange(n_dst) * (n_src / n_dst)).astype(np.int64), n_src - 1).astype(np.int32)
+
+
+class _FFC:
+    """One FFC_BN_ACT of a res-block (:372-399): packed layers."""
+
+    def __init__(self, sd, p, device):
+        w_l = torch.cat([sd[p + ".ffc.convl2l.weight"], sd[p + ".ffc.convg2l.weight"]], dim=1)  # [128, 512, 3, 3]
+        self.to_l = ops.Conv2d(w_l, None, padding=1, pad_mode=PAD_REFLECT, bn=_bn(sd, p + ".bn_l"), act=ACT_RELU,
+                               device=device)
+        self.l2g = ops.Conv2d(sd[p + ".ffc.convl2g.weight"], None, padding=1, pad_mode=PAD_REFLECT, device=device)
+        st = p + ".ffc.convg2g"
+        self.st_in = ops.Conv2d(sd[st + ".conv1.0.weight"], None, bn=_bn(sd, st + ".conv1.1"), act=ACT_RELU, device=device)
+        # spectral 1x1 conv: reference channel index is c*2 + t (:229-231,245-246); ours is planar t*C + c
+        wf = sd[st + ".fu.conv_layer.weight"].reshape(SPEC_C, 2, SPEC_C, 2)  # [c_out, t_out, c_in, t_in]
+        wf = wf.permute(3, 2, 1, 0).reshape(2 * SPEC_C, 2 * SPEC_C)  # [(t_in, c_in), (t_out, c_out)]
+        self.fu_w, self.fu_Kp, self.fu_Np = ops.pack_weight_kn(wf, device)
+        g, b, m, v, eps = _bn(sd, st + ".fu.bn")
+        perm = lambda t: t.reshape(SPEC_C, 2).t().reshape(-1)
+        sc, bi = ops.fold_bn(perm(g), perm(b), perm(m), perm(v), eps)
+        self.fu_scale, self.fu_bias = sc.to(device), bi.to(device)
+        # conv2 (192->384) carries the global branch's BN + ReLU (+ pre = convl2g(x_l), + residual)
+        self.st_out = ops.Conv2d(sd[st + ".conv2.weight"], None, bn=_bn(sd, p + ".bn_g"), act=ACT_RELU, device=device)
+
+
+class LamaEngine:
+    """Batched LaMa generator. ``forward(img_u8[B,H,W,3], mask_u8[B,H,W]) -> u8 [B,H,W,3]`` (device tensors)."""
+
+    def __init__(self, gen_sd: Dict[str, torch.Tensor], mpe_sd: Optional[Dict[str, torch.Tensor]] = None,
+                 n_blocks: int = 9, device="cuda"):
+        self.device = torch.device(device)
+        self.n_blocks = n_blocks
+        sd, dev = gen_sd, self.device
+        self.stem = ops.Conv2d(sd["model.1.ffc.convl2l.weight"], None, padding=3, pad_mode=PAD_REFLECT,
+                               bn=_bn(sd, "model.1.bn_l"), act=ACT_RELU, device=dev)
+        self.down1 = ops.Conv2d(sd["model.2.ffc.convl2l.weight"], None, stride=2, padding=1, pad_mode=PAD_REFLECT,
+                                bn=_bn(sd, "model.2.bn_l"), act=ACT_RELU, device=dev)
+        self.down2 = ops.Conv2d(sd["model.3.ffc.convl2l.weight"], None, stride=2, padding=1, pad_mode=PAD_REFLECT,
+                                bn=_bn(sd, "model.3.bn_l"), act=ACT_RELU, device=dev)
+        w3 = torch.cat([sd["model.4.ffc.convl2l.weight"], sd["model.4.ffc.convl2g.weight"]], dim=0)  # 256 -> 128+384
+        self.down3 = ops.Conv2d(w3, None, stride=2, padding=1, pad_mode=PAD_REFLECT,
+                                bn=_cat_bn(sd, "model.4.bn_l", "model.4.bn_g"), act=ACT_RELU, device=dev)
+        self.blocks = [(_FFC(sd, f"model.{5 + i}.conv1", dev), _FFC(sd, f"model.{5 + i}.conv2", dev))
+                       for i in range(n_blocks)]
+        base = 5 + n_blocks + 1
+        self.ups = []
+        for i in range(3):
+            p = base + 3 * i
+            self.ups.append(ops.ConvTranspose2d(sd[f"model.{p}.weight"], sd[f"model.{p}.bias"], stride=2, padding=1,
+                                                output_padding=1, bn=_bn(sd, f"model.{p + 1}"), act=ACT_RELU, device=dev))
+        p = base + 10
+        self.out_conv = ops.Conv2d(sd[f"model.{p}.weight"], sd[f"model.{p}.bias"], padding=3, pad_mode=PAD_REFLECT,
+                                   act=ACT_SIGMOID, device=dev)
+        self.mpe = None
+        if mpe_sd is not None:
+            self.mpe = dict(emb=mpe_sd["rel_pos_emb.weight"].to(torch.float32).to(dev).contiguous(),
+                            dirw=mpe_sd["direct_emb.weight"].to(torch.float32).to(dev).contiguous(),
+                            alpha5=float(mpe_sd["alpha5"]), alpha6=float(mpe_sd["alpha6"]))
+        self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._dft: Dict[Tuple[int, int], Tuple[torch.Tensor, ...]] = {}
+        self._mpe_tabs: Dict[Tuple[int, int], dict] = {}
+
+    # -- workspace -------------------------------------------------------------------------
+    def _buf(self, name: str, *shape, dtype=torch.float32) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.empty(*shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def release_workspace(self):
+        self._ws.clear()
+
+    def _dft_mats(self, h, w):
+        k = (h, w)
+        if k not in self._dft:
+            self._dft[k] = tuple(m.to(self.device) for m in dft_matrices(h, w))
+        return self._dft[k]
+
+    def _mpe_tables(self, H, W):
+        k = (H, W)
+        if k not in self._mpe_tabs:
+            ys, yc, yw, ymax = _area_taps(H, MPE_S)
+            xs, xc, xw, xmax = _area_taps(W, MPE_S)
+            dev = self.device
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            self._mpe_tabs[k] = dict(ys=t(ys), yc=t(yc), yw=t(yw), ymax=ymax, xs=t(xs), xc=t(xc), xw=t(xw), xmax=xmax,
+                                     ymap=t(_nearest_map(H, MPE_S)), xmap=t(_nearest_map(W, MPE_S)))
+        return self._mpe_tabs[k]
+
+    # -- FourierUnit (:214-257) as DFT GEMMs ---------------------------------------------------
+    def _fourier_unit(self, ffc: _FFC, t1: torch.Tensor, t2: torch.Tensor):
+        """t2 = t1 + irfft2(relu(bn(conv1x1(rfft2(t1)))))   (x + fu(x), :305)."""
+        B, h, w, Cc = t1.shape
+        wk = w // 2 + 1
+        F1, G2, G2i, Fi = self._dft_mats(h, w)
+        plane = h * wk * Cc
+        Y = self._buf("fu_Y", B, 2, h, wk, Cc)
+        Zf = self._buf("fu_Z", B, 2, h, wk, Cc)
+        Z2 = self._buf("fu_Z2", B, 2, h, wk, Cc)
+        U = self._buf("fu_U", B, h, 2, wk, Cc)
+        one = [(0, 0, 0)]
+        # S1: real DFT along W.  rows (t,kw) = F1 @ t1[b,h] ([w] x [C]);  z = (b, h)
+        cm = ops.MitTensorMap()
+        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Y.data_ptr(), 2 * plane, wk * Cc, 0, plane, Cc
+        launch_conv_gemm(conv_gemm_desc(
+            a=F1, NB=1, Hi=2, Wi=wk, Cin=F1.shape[1], a_strides=(0, wk * F1.shape[1], F1.shape[1]), Ho=2, Wo=wk, sy=1,
+            sx=1, taps=one, pad_mode=PAD_ZERO, w=t1, ldw=Cc, Kw=w, Nw=Cc, N=Cc, c=cm, Z=B * h, zdiv=h,
+            w_zs=(h * w * Cc, w * Cc)))
+        # S2: complex DFT along H on planar re/im.  Z[b] = G2 @ Y[b] ([2h] x [wk*C])
+        cm = ops.MitTensorMap()
+        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Zf.data_ptr(), 0, 2 * plane, 0, 0, wk * Cc
+        launch_conv_gemm(conv_gemm_desc(
+            a=G2, NB=1, Hi=1, Wi=2 * h, Cin=G2.shape[1], a_strides=(0, 0, G2.shape[1]), Ho=1, Wo=2 * h, sy=1, sx=1, taps=one,
+            pad_mode=PAD_ZERO, w=Y, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
+            w_zs=(0, 2 * plane)))
+        # spectral 1x1 conv + BN + ReLU: two taps = re plane, im plane; planar output via the column split
+        cm = ops.MitTensorMap()
+        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Z2.data_ptr(), 0, 0, 2 * plane, wk * Cc, Cc
+        cm.nsplit, cm.nhi = Cc, plane
+        launch_conv_gemm(conv_gemm_desc(
+            a=Zf, NB=B, Hi=h, Wi=wk, Cin=Cc, a_strides=(2 * plane, wk * Cc, Cc), Ho=h, Wo=wk, sy=1, sx=1,
+            taps=[(0, 0, 0), (0, 0, plane)], pad_mode=PAD_ZERO, w=ffc.fu_w, ldw=ffc.fu_Np, Kw=ffc.fu_Kp, Nw=ffc.fu_Np,
+            N=2 * Cc, c=cm, scale=ffc.fu_scale, bias=ffc.fu_bias, act=ACT_RELU))
+        # S3: inverse complex DFT along H.  U[b,h,t] rows (t,h) = G2i @ Z2[b]
+        cm = ops.MitTensorMap()
+        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = U.data_ptr(), 0, 2 * plane, 0, wk * Cc, 2 * wk * Cc
+        launch_conv_gemm(conv_gemm_desc(
+            a=G2i, NB=1, Hi=2, Wi=h, Cin=G2i.shape[1], a_strides=(0, h * G2i.shape[1], G2i.shape[1]), Ho=2, Wo=h, sy=1, sx=1, taps=one,
+            pad_mode=PAD_ZERO, w=Z2, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
+            w_zs=(0, 2 * plane)))
+        # S4: complex->real inverse DFT along W, + t1.  t2[b,h] = Fi @ U[b,h] ([2wk] x [C]) + t1[b,h]
+        cm = ops.MitTensorMap()
+        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = t2.data_ptr(), 0, w * Cc, 0, 0, Cc
+        pm = ops.MitTensorMap()
+        pm.base, pm.zs1, pm.zs0, pm.bs, pm.ys, pm.xs = t1.data_ptr(), 0, w * Cc, 0, 0, Cc
+        launch_conv_gemm(conv_gemm_desc(
+            a=Fi, NB=1, Hi=1, Wi=w, Cin=Fi.shape[1], a_strides=(0, 0, Fi.shape[1]), Ho=1, Wo=w, sy=1, sx=1, taps=one,
+            pad_mode=PAD_ZERO, w=U, ldw=Cc, Kw=2 * wk, Nw=Cc, N=Cc, c=cm, post=pm, Z=B * h, zdiv=1 << 30,
+            w_zs=(0, 2 * wk * Cc)))
+
+    def _ffc(self, ffc: _FFC, x: torch.Tensor, out: torch.Tensor, residual: Optional[torch.Tensor]):
+        """FFC_BN_ACT.forward (:395-399 over :349-369) on the fused [B,h,w,512] state."""
+        B, h, w, _ = x.shape
+        x_l, x_g = x[..., :LOCAL_C], x[..., LOCAL_C:]
+        res_l = None if residual is None else residual[..., :LOCAL_C]
+        res_g = None if residual is None else residual[..., LOCAL_C:]
+        ffc.to_l(x, out=out[..., :LOCAL_C], post=res_l)  # convl2l(x_l) + convg2l(x_g) -> bn_l -> relu (+ id_l)
+        P = self._buf("ffc_P", B, h, w, GLOBAL_C)
+        ffc.l2g(x_l, out=P)  # convl2g(x_l), raw
+        t1 = self._buf("ffc_t1", B, h, w, SPEC_C)
+        t2 = self._buf("ffc_t2", B, h, w, SPEC_C)
+        ffc.st_in(x_g, out=t1)  # SpectralTransform.conv1 (:272-277)
+        self._fourier_unit(ffc, t1, t2)
+        ffc.st_out(t2, out=out[..., LOCAL_C:], pre=P, post=res_g)  # conv2(x + fu(x)) + convl2g -> bn_g -> relu (+ id_g)
+
+    # -- full generator ------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, img_u8: torch.Tensor, mask_u8: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """LamaFourier.__call__ (:713-726) + the tensor pre/post of _infer (:82-117) for pages whose
+        H, W are multiples of 8.  img_u8 [B,H,W,3] u8, mask_u8 [B,H,W] u8 (device) -> u8 [B,H,W,3]."""
+        if img_u8.dtype != torch.uint8 or mask_u8.dtype != torch.uint8:
+            raise TypeError("LamaEngine.forward expects uint8 page and mask tensors")
+        if img_u8.dim() != 4 or img_u8.shape[-1] != 3 or tuple(mask_u8.shape) != tuple(img_u8.shape[:3]):
+            raise ValueError(f"bad shapes: page {tuple(img_u8.shape)}, mask {tuple(mask_u8.shape)}")
+        B, H, W, _ = img_u8.shape
+        if H % 8 or W % 8:
+            raise ValueError("LamaEngine.forward: H and W must be multiples of 8 (the plugin resizes first, :67-79)")
+        img_u8, mask_u8 = img_u8.contiguous(), mask_u8.contiguous()
+        lib = _lib.load()
+        st = C.c_void_p(ops.current_stream())
+        x4 = self._buf("in4", B, H, W, 4)
+        _lib.check(lib.mit_lama_prep(img_u8.data_ptr(), mask_u8.data_ptr(), x4.data_ptr(), B, H, W, st), "mit_lama_prep")
+        s64 = self._buf("full64", B, H, W, 64)
+        self.stem(x4, out=s64)
+        if self.mpe is not None:
+            tb = self._mpe_tables(H, W)
+            hole = self._buf("mpe_hole", B, MPE_S, MPE_S, dtype=torch.uint8)
+            rel = self._buf("mpe_rel", B, MPE_S, MPE_S, dtype=torch.uint8)
+            dr = self._buf("mpe_dir", B, MPE_S, MPE_S, dtype=torch.uint8)
+            _lib.check(lib.mit_lama_mpe_index(mask_u8.data_ptr(), B, H, W, tb["ys"].data_ptr(), tb["yc"].data_ptr(),
+                                              tb["yw"].data_ptr(), tb["ymax"], tb["xs"].data_ptr(), tb["xc"].data_ptr(),
+                                              tb["xw"].data_ptr(), tb["xmax"], hole.data_ptr(), rel.data_ptr(),
+                                              dr.data_ptr(), st), "mit_lama_mpe_index")
+            _lib.check(lib.mit_lama_mpe_add(s64.data_ptr(), mask_u8.data_ptr(), rel.data_ptr(), dr.data_ptr(),
+                                            tb["ymap"].data_ptr(), tb["xmap"].data_ptr(), self.mpe["emb"].data_ptr(),
+                                            self.mpe["dirw"].data_ptr(), self.mpe["alpha5"], self.mpe["alpha6"], B, H, W,
+                                            st), "mit_lama_mpe_add")
+            if taps is not None:
+                taps["mpe_rel"], taps["mpe_dir"], taps["mpe_hole"] = rel.clone(), dr.clone(), hole.clone()
+        if taps is not None:
+            taps["stem"] = s64.clone()
+        d1 = self._buf("d1", B, H // 2, W // 2, 128)
+        self.down1(s64, out=d1)
+        d2 = self._buf("d2", B, H // 4, W // 4, 256)
+        self.down2(d1, out=d2)
+        h, w = H // 8, W // 8
+        X = self._buf("X", B, h, w, 512)
+        T = self._buf("Xtmp", B, h, w, 512)
+        self.down3(d2, out=X)
+        if taps is not None:
+            taps["down"] = X.clone()
+        for i, (c1, c2) in enumerate(self.blocks):  # FFCResnetBlock.forward :421-436
+            self._ffc(c1, X, T, None)
+            self._ffc(c2, T, X, X)  # in place: each element reads its own residual before it is overwritten
+            if taps is not None:
+                taps[f"block{i}"] = X.clone()
+        u1 = self._buf("d2", B, H // 4, W // 4, 256)
+        self.ups[0](X, out=u1)
+        u2 = self._buf("d1", B, H // 2, W // 2, 128)
+        self.ups[1](u1, out=u2)
+        u3 = self._buf("full64", B, H, W, 64)
+        self.ups[2](u2, out=u3)
+        pred = self._buf("pred", B, H, W, 3)
+        self.out_conv(u3, out=pred)
+        if taps is not None:
+            taps["pred"] = pred.clone()
+        out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=self.device)
+        _lib.check(lib.mit_lama_post(pred.data_ptr(), 3, img_u8.data_ptr(), mask_u8.data_ptr(), out.data_ptr(), B, H, W,
+                                     st), "mit_lama_post")
+        return out
+
+    # algorithmic FLOPs of one page (0.9706 MFLOP per input pixel for 9 blocks)
+    def flops_per_page(self, H: int, W: int) -> float:
+        px = H * W
+        conv = 2.0 * px * (49 * 4 * 64 + 49 * 64 * 3)  # stem + out
+        conv += 2.0 * (px / 4) * 9 * 64 * 128 + 2.0 * (px / 16) * 9 * 128 * 256 + 2.0 * (px / 64) * 9 * 256 * 512
+        per_ffc = 2.0 * (px / 64) * (9 * (128 * 128 + 384 * 128 + 128 * 384) + 384 * 192 + 192 * 384)
+        per_ffc += 2.0 * (px / 64) * ((W // 8 // 2 + 1) / (W // 8)) * 384 * 384
+        conv += per_ffc * 2 * self.n_blocks
+        conv += 2.0 * (px / 64) * 9 * 512 * 256 + 2.0 * (px / 16) * 9 * 256 * 128 + 2.0 * (px / 4) * 9 * 128 * 64
+        return conv

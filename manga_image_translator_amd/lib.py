@@ -78,6 +78,15 @@ SYMBOLS = {
     "mit_conv_gemm": (C.c_int, [C.POINTER(MitConvGemm), C.c_void_p]),
     "mit_conv_gemm_cfg": (C.c_int, [C.POINTER(MitConvGemm), C.c_int, C.c_void_p]),
     "mit_conv_gemm_config_name": (C.c_char_p, [C.c_int]),
+    "mit_lama_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mit_lama_mpe_index": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "mit_lama_mpe_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]),
+    "mit_lama_post": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE — loads the reference's own nn.Module files from /root/reference.
+
+Only usable where /root/reference exists (the build container).  It is used by
+``oracle/make_golden.py`` to generate the committed fixtures under ``tests/golden/`` and by
+the ``not gpu`` tests that validate the oracle restatements (``oracle/*.py``) against the
+real reference code.  Nothing in the product imports this.
+
+The reference package itself does not import here (colorama, cv2, the Rust wheel … are not
+installed), so the dense model files are loaded by path with stub modules for the missing
+third-party imports.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+from unittest import mock
+
+REF_ROOT = "/root/reference"
+PKG = os.path.join(REF_ROOT, "manga_translator")
+
+_loaded = {}
+
+
+def available() -> bool:
+    return os.path.isdir(PKG)
+
+
+def _stub_third_party():
+    for name in ["cv2", "colorama", "dotenv", "shapely", "shapely.geometry", "shapely.affinity", "pyclipper",
+                 "py3langid", "langcodes", "omegaconf", "torchvision", "torchvision.models", "torchvision.ops",
+                 "skimage", "kornia", "timm", "freetype", "pydensecrf", "pydensecrf.utils", "pydensecrf.densecrf",
+                 "requests"]:
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = mock.MagicMock()
+
+
+def _pkg(name: str):
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    return sys.modules[name]
+
+
+def _load(dotted: str, relpath: str):
+    if dotted in _loaded:
+        return _loaded[dotted]
+    spec = importlib.util.spec_from_file_location(dotted, os.path.join(PKG, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[dotted] = mod
+    spec.loader.exec_module(mod)
+    _loaded[dotted] = mod
+    return mod
+
+
+def _prepare():
+    if not available():
+        raise RuntimeError("/root/reference is not present on this machine")
+    _stub_third_party()
+    for p in ["manga_translator", "manga_translator.ocr", "manga_translator.inpainting", "manga_translator.detection",
+              "manga_translator.detection.ctd_utils", "manga_translator.detection.ctd_utils.utils",
+              "manga_translator.detection.ctd_utils.yolov5"]:
+        _pkg(p)
+    for name in ["manga_translator.config", "manga_translator.utils", "manga_translator.utils.generic",
+                 "manga_translator.utils.bubble"]:
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock()
+    # tiny stand-ins for the plugin base classes so the plugin classes in the same files define
+    for dotted, names in [("manga_translator.ocr.common", ["OfflineOCR", "CommonOCR"]),
+                          ("manga_translator.inpainting.common", ["OfflineInpainter", "CommonInpainter"]),
+                          ("manga_translator.detection.common", ["OfflineDetector", "CommonDetector"])]:
+        if dotted not in sys.modules:
+            m = types.ModuleType(dotted)
+            for n in names:
+                setattr(m, n, type(n, (), {}))
+            sys.modules[dotted] = m
+
+
+def lama():
+    """reference module manga_translator/inpainting/inpainting_lama_mpe.py"""
+    _prepare()
+    return _load("manga_translator.inpainting.inpainting_lama_mpe", "inpainting/inpainting_lama_mpe.py")
+
+
+def ocr48():
+    """reference module manga_translator/ocr/model_48px.py"""
+    _prepare()
+    _load("manga_translator.ocr.xpos_relative_position", "ocr/xpos_relative_position.py")
+    return _load("manga_translator.ocr.model_48px", "ocr/model_48px.py")
+
+
+def ctd():
+    """reference modules manga_translator/detection/ctd_utils/{basemodel,yolov5/*}.py -> (basemodel, yolo)"""
+    _prepare()
+    base = "manga_translator.detection.ctd_utils"
+    _load(base + ".utils.yolov5_utils", "detection/ctd_utils/utils/yolov5_utils.py")
+    _load(base + ".utils.weight_init", "detection/ctd_utils/utils/weight_init.py")
+    _load(base + ".yolov5.common", "detection/ctd_utils/yolov5/common.py")
+    yolo = _load(base + ".yolov5.yolo", "detection/ctd_utils/yolov5/yolo.py")
+    bm = _load(base + ".basemodel", "detection/ctd_utils/basemodel.py")
+    return bm, yolo

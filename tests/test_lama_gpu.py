@@ -1,0 +1,103 @@
+"""LaMa stage parity: HIP engine (through the C-ABI) vs the CPU oracle restatement of the reference.
+
+Tolerances (fp32 parity mode, exact-fp32 MFMA): the network is ~40-80 fp32 layers deep, so the
+sigmoid output is compared at 2e-4 absolute (observed ~1e-5); the uint8 page must be identical
+except where the oracle's pre-truncation value sits within 0.05 of an integer (then +-1 level).
+Integer maps (MPE ring / direction indices) must be bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_blocks, mpe, cuda, seed=0):
+    from manga_image_translator_amd import lama, lama_schema, synth
+
+    sd = synth.synth_state_dict(lama_schema.lama_generator_schema(n_blocks), seed=seed)
+    mpe_sd = synth.synth_state_dict(lama_schema.lama_mpe_schema(), seed=seed) if mpe else None
+    eng = lama.LamaEngine(sd, mpe_sd, n_blocks=n_blocks, device=cuda)
+    return sd, mpe_sd, eng
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def test_fourier_unit_parity(cuda):
+    from oracle import lama as OL
+
+    sd, _, eng = _setup(1, False, cuda)
+    g = torch.Generator().manual_seed(3)
+    for (B, h, w) in [(2, 8, 11), (1, 33, 34), (1, 16, 23)]:
+        t1 = torch.randn(B, h, w, 192, generator=g)
+        t2 = torch.empty(B, h, w, 192, device=cuda)
+        eng._fourier_unit(eng.blocks[0][0], t1.to(cuda), t2)
+        torch.cuda.synchronize()
+        x = _nchw(t1)
+        ref = x + OL.fourier_unit(x, sd, "model.5.conv1.ffc.convg2g.fu")
+        err = (_nchw(t2.cpu()) - ref).abs().max().item()
+        assert err < 5e-5, (B, h, w, err)
+
+
+@pytest.mark.parametrize("n_blocks,mpe,B,H,W", [(18, False, 2, 64, 88), (9, True, 1, 264, 272), (9, True, 2, 256, 320)])
+def test_lama_page_parity(cuda, n_blocks, mpe, B, H, W):
+    from manga_image_translator_amd import synth
+    from oracle import lama as OL
+
+    sd, mpe_sd, eng = _setup(n_blocks, mpe, cuda)
+    pages, masks = [], []
+    for i in range(B):
+        p, _, m = synth.synth_page(i, H, W, n_boxes=6)
+        pages.append(p)
+        masks.append(m)
+    masks[0][3, 5] = 127  # the mask==127 corner case of _infer :59-60 vs :86-87
+    img = torch.from_numpy(np.stack(pages)).to(cuda)
+    msk = torch.from_numpy(np.stack(masks)).to(cuda)
+    taps = {}
+    out = eng.forward(img, msk, taps=taps)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i in range(B):
+        otaps = {}
+        ref = OL.infer(sd, mpe_sd, pages[i], masks[i], n_blocks, otaps)
+        if mpe:
+            rel, _, direct = OL.load_masked_position_encoding((masks[i].astype(np.float32) / 255.0 >= 0.5).astype(np.float32))
+            ymap = np.minimum(np.floor(np.arange(H) * (256 / H)).astype(np.int64), 255)
+            xmap = np.minimum(np.floor(np.arange(W) * (256 / W)).astype(np.int64), 255)
+            got_rel = taps["mpe_rel"][i].cpu().numpy()[ymap][:, xmap]
+            got_dir = taps["mpe_dir"][i].cpu().numpy()[ymap][:, xmap]
+            inm = masks[i].astype(np.float32) / 255.0 >= 0.5
+            assert np.array_equal(np.where(inm, got_rel, 0), rel), "MPE ring index mismatch"
+            bits = (direct * np.array([1, 2, 4, 8])).sum(-1)
+            assert np.array_equal(np.where(inm, got_dir, 0), bits), "MPE direction bits mismatch"
+        stem_err = (_nchw(taps["stem"][i:i + 1].cpu()) - otaps["stem"]).abs().max().item()
+        assert stem_err < 2e-5, stem_err
+        last = n_blocks - 1
+        blk = torch.cat([otaps[f"block{last}_l"], otaps[f"block{last}_g"]], dim=1)
+        blk_err = (_nchw(taps[f"block{last}"][i:i + 1].cpu()) - blk).abs().max().item()
+        assert blk_err < 2e-4 * max(1.0, blk.abs().max().item()), blk_err
+        # predicted float image (sigmoid output, before composite)
+        m01 = torch.from_numpy((masks[i].astype(np.float32) / 255.0 >= 0.5).astype(np.float32))[None, None]
+        pred = _nchw(taps["pred"][i:i + 1].cpu())
+        comp = pred * m01 + (1 - m01) * otaps["out_float"]  # outside the mask the oracle float is the page itself
+        ferr = ((comp - otaps["out_float"]) * m01).abs().max().item()
+        assert ferr < 2e-4, ferr
+        # uint8 page
+        diff = out[i].astype(np.int32) - ref.astype(np.int32)
+        bad = np.argwhere(diff != 0)
+        if len(bad):
+            assert np.abs(diff).max() <= 1
+            of = (otaps["out_float"][0].permute(1, 2, 0).numpy() * 255.0)
+            frac = np.abs(of - np.round(of))
+            assert all(frac[tuple(b)] < 0.05 for b in bad), "uint8 mismatch away from a truncation boundary"
+            assert len(bad) < 1e-3 * diff.size
+
+
+def test_lama_rejects_bad_input(cuda):
+    _, _, eng = _setup(1, False, cuda)
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(1, 60, 64, 3, dtype=torch.uint8, device=cuda), torch.zeros(1, 60, 64, dtype=torch.uint8, device=cuda))
+    with pytest.raises(TypeError):
+        eng.forward(torch.zeros(1, 64, 64, 3, device=cuda), torch.zeros(1, 64, 64, dtype=torch.uint8, device=cuda))
