@@ -144,6 +144,29 @@ int mit_lama_mpe_add(float *x_dev, const uint8_t *mask_dev, const uint8_t *relpo
 int mit_lama_post(const float *pred_dev, int64_t pred_pixstride, const uint8_t *img_dev, const uint8_t *mask_dev,
                   uint8_t *out_dev, int B, int H, int W, void *stream);
 
+/* Text-detection stage (ctd): memory-bound pieces and NHWC helpers ---------------------------
+ * Reference: manga_translator/detection/ctd.py, ctd_utils/. */
+
+/* u8 pages [B,H,W,3] -> letterboxed fp32 NHWC [B,S,S,4] (rgb/255, 4th channel 0; bottom/right zero pad).
+ * Replaces preprocess_img (ctd.py:17-28) + letterbox (ctd_utils/utils/imgproc_utils.py:69-100, cv2.resize
+ * INTER_LINEAR + copyMakeBorder).  mode 0: no resize; 1: exact 2x shrink (OpenCV routes it to the 2x2 box
+ * mean); 2: OpenCV 11-bit fixed-point bilinear with per-axis DEVICE tables (source index, two coefficients). */
+int mit_ctd_prep(const uint8_t *img_dev, int B, int H, int W, int nh, int nw, int S, int mode, const int *yidx_dev,
+                 const short *ycoef_dev, const int *xidx_dev, const short *xcoef_dev, float *out_dev, void *stream);
+
+/* NHWC max-pool k x k, stride 1, pad k/2 — nn.MaxPool2d of SPPF (yolov5/common.py:181-197). Pixel strides in floats. */
+int mit_maxpool_nhwc(const float *in_dev, int64_t in_pixstride, float *out_dev, int64_t out_pixstride, int B, int H,
+                     int W, int C, int k, void *stream);
+/* NHWC 2x2/2 average pool — nn.AvgPool2d(2, 2) of double_conv_c3 (ctd_utils/basemodel.py:28-39). */
+int mit_avgpool2_nhwc(const float *in_dev, int64_t in_pixstride, float *out_dev, int64_t out_pixstride, int B, int Ho,
+                      int Wo, int C, void *stream);
+/* channel-slice copy between NHWC buffers (torch.cat inputs that need a second home, basemodel.py:62-68,102-103). */
+int mit_copy_channels(const float *in_dev, int64_t in_pixstride, float *out_dev, int64_t out_pixstride, int64_t npix,
+                      int C, void *stream);
+/* fp32 map -> u8. mode 0: (uint8)(v*255) truncation (postprocess_mask ctd.py:30-44); mode 1: v > thr
+ * (SegDetectorRepresenter.binarize, ctd_utils/utils/db_utils.py:75). */
+int mit_map_to_u8(const float *in_dev, uint8_t *out_dev, int64_t n, int mode, float thr, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

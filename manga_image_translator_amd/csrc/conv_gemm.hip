@@ -36,8 +36,8 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
     switch (act) {
         case MIT_ACT_RELU: return v > 0.f ? v : 0.f;
         case MIT_ACT_LEAKY: return v > 0.f ? v : v * alpha;
-        case MIT_ACT_SILU: return v / (1.f + __expf(-v));
-        case MIT_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case MIT_ACT_SILU: return v / (1.f + expf(-v));
+        case MIT_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case MIT_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         default: return v;
     }

@@ -1,0 +1,68 @@
+"""Text-detection (ctd) stage parity: HIP engine vs the CPU oracle restatement of TextDetBase.
+
+Float maps are compared at 1e-4 absolute (sigmoid outputs of a ~60-layer fp32 net; observed ~1e-6).
+The discrete results the reference derives from them must be identical except inside a stated
+margin: the shrink bitmap ``lines[:,0] > 0.3`` may differ only where the oracle value is within 1e-4
+of 0.3, the u8 mask only where oracle*255 is within 0.03 of an integer (then by one level); the
+test records how many pixels sit inside those margins.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctd_setup(cuda):
+    from manga_image_translator_amd import ctd, ctd_schema as S, synth
+
+    g = S.CTD_GAIN
+    ysd = synth.synth_state_dict(S.yolo_schema(), seed=0, gain=g)
+    ssd = synth.synth_state_dict(S.unet_head_schema(), seed=0, gain=g)
+    dsd = synth.synth_state_dict(S.db_head_schema(), seed=0, gain=g)
+    return ysd, ssd, dsd, ctd.CtdEngine(ysd, ssd, dsd, device=cuda)
+
+
+@pytest.mark.parametrize("H,W,B", [(512, 384, 2), (1024, 728, 1), (2048, 1456, 1), (600, 1000, 1)])
+def test_ctd_maps_parity(cuda, ctd_setup, H, W, B):
+    from manga_image_translator_amd import synth
+    from oracle import ctd as OC
+
+    ysd, ssd, dsd, eng = ctd_setup
+    pages = [synth.synth_page(i, H, W, n_boxes=8)[0] for i in range(B)]
+    taps = {}
+    mask_u8, lines, (dw, dh) = eng.forward(torch.from_numpy(np.stack(pages)).to(cuda), taps=taps)
+    bitmap = eng.shrink_bitmap(lines)
+    torch.cuda.synchronize()
+    mask_u8, lines, bitmap = mask_u8.cpu().numpy(), lines.cpu().numpy(), bitmap.cpu().numpy()
+    for i in range(B):
+        otaps = {}
+        ref_mask, ref_lines = OC.infer_maps(ysd, ssd, dsd, pages[i], otaps)
+        x_in, _, rdw, rdh = OC.preprocess_img(pages[i])
+        assert (rdw, rdh) == (dw, dh)
+        got_in = taps["input"][i].cpu().permute(2, 0, 1)[:3]
+        assert torch.equal(got_in, x_in[0]), "letterboxed network input differs"
+        for n in ("f160", "f80", "f40", "f20", "f3"):
+            e = (taps[n][i].cpu().permute(2, 0, 1) - otaps[n][0]).abs().max().item()
+            assert e < 1e-4 * max(1.0, otaps[n].abs().max().item()), (n, e)
+        assert ref_lines.shape[1:] == lines[i].shape
+        err = np.abs(lines[i] - ref_lines[0]).max()
+        assert err < 1e-4, err
+        ref_bitmap = ref_lines[0, 0] > 0.3
+        flips = bitmap[i].astype(bool) != ref_bitmap
+        margin = np.abs(ref_lines[0, 0] - 0.3) < 1e-4
+        assert not np.any(flips & ~margin), "shrink-bitmap flip outside the 1e-4 margin"
+        mdiff = mask_u8[i].astype(np.int32) - ref_mask.astype(np.int32)
+        assert np.abs(mdiff).max() <= 1
+        mf = taps["mask_f32"][i, :ref_mask.shape[0], :ref_mask.shape[1], 0].cpu().numpy() * 255.0
+        near = np.abs(mf - np.round(mf)) < 0.03
+        assert not np.any((mdiff != 0) & ~near), "u8 mask differs away from a truncation boundary"
+        print(f"page {i}: lines max err {err:.2e}; bitmap flips {int(flips.sum())} of {flips.size} "
+              f"({int(margin.sum())} px inside margin); mask u8 diffs {int((mdiff != 0).sum())}")
+
+
+def test_ctd_rejects_bad_input(cuda, ctd_setup):
+    eng = ctd_setup[3]
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(1, 64, 64, 4, dtype=torch.uint8, device=cuda))
