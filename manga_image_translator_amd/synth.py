@@ -63,6 +63,11 @@ def synth_state_dict(schema: Schema, seed: int = 0, gain: float = 1.0) -> Dict[s
             t = torch.full(shape, float(kind.split(":", 1)[1]))
         elif kind == "normal":
             t = torch.randn(shape, generator=g)
+        elif kind == "xpos_scale":  # XPOS.scale buffer (ocr/xpos_relative_position.py:50-52)
+            hd = shape[0] * 2
+            t = (torch.arange(0, hd, 2) + 0.4 * hd) / (1.4 * hd)
+        elif kind.startswith("tie:"):  # shares storage with an earlier entry (pred.weight = embd.weight, model_48px.py:536)
+            t = sd[kind.split(":", 1)[1]]
         else:
             raise ValueError(f"unknown schema kind {kind!r} for {name}")
         if mul:
