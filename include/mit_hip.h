@@ -167,6 +167,85 @@ int mit_copy_channels(const float *in_dev, int64_t in_pixstride, float *out_dev,
  * (SegDetectorRepresenter.binarize, ctd_utils/utils/db_utils.py:75). */
 int mit_map_to_u8(const float *in_dev, uint8_t *out_dev, int64_t n, int mode, float thr, void *stream);
 
+/* 48px OCR stage -----------------------------------------------------------------------------
+ * Reference: manga_translator/ocr/model_48px.py, ocr/xpos_relative_position.py. */
+
+/* XPOS tables, computed once on the host with the reference's own fp32 expressions
+ * (xpos_relative_position.py:9-16,54-59): cos_t/sin_t [imax][40] for index i = 0..imax-1;
+ * scale_t / iscale_t [2*pmax][40]: row (p + pmax) holds scale**(p/320) and its reciprocal. */
+typedef struct MitXposTables {
+    const float *cos_t, *sin_t, *scale_t, *iscale_t;
+    int32_t imax, pmax;
+} MitXposTables;
+
+/* A packed nn.Linear: w [Kp][ldw] (k-major), out = act((x @ w) * scale + bias); scale may be NULL. */
+typedef struct MitLinear {
+    const float *w, *scale, *bias;
+    int64_t ldw;
+    int32_t K, N, Kp, Np;
+} MitLinear;
+
+typedef struct MitOcrDecoderLayer {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ln3_w, *ln3_b;
+    MitLinear qkv;  /* self_attn q|k|v fused, N = 960; the q columns carry the head_dim**-0.5 scaling */
+    MitLinear out;  /* self_attn.out_proj */
+    MitLinear q2;   /* multihead_attn.q_proj (scaled) */
+    MitLinear out2; /* multihead_attn.out_proj */
+    MitLinear ff1, ff2;
+} MitOcrDecoderLayer;
+
+typedef struct MitOcr48Decoder {
+    MitOcrDecoderLayer layers[5];
+    const float *embd; /* [dict][320] */
+    MitLinear pred1;   /* + GELU */
+    MitLinear pred;    /* tied to embd, N = dict */
+    MitLinear color1;  /* 320 -> 64, ReLU */
+    MitLinear color_heads; /* 64 -> 10 = fg(3) | bg(3) | fg_ind(2) | bg_ind(2) */
+    MitXposTables xpos;
+    int32_t dict_size, _pad;
+} MitOcr48Decoder;
+
+typedef struct MitOcr48DecodeArgs {
+    int32_t N, L;               /* text lines; padded encoder-memory length */
+    const float *mem_k;         /* [5][N][L][320] cross-attention keys (k_proj + XPOS) per decoder layer */
+    const float *mem_v;         /* [5][N][L][320] */
+    const int32_t *mem_len;     /* [N] valid memory length (w+3)/4+2 (model_48px.py:684-688) */
+    int32_t max_seq_length;     /* T: decode steps (255 in the reference call, :120) */
+    int32_t start_tok, end_tok, max_finished, suppress_eos;
+    void *workspace;            /* device scratch of mit_ocr48_decode_workspace_bytes() */
+    int64_t workspace_bytes;
+    int32_t *res_tok;           /* [N][T+1] tokens incl. the start token */
+    int32_t *res_len;           /* [N] number of valid tokens in res_tok */
+    float *res_prob;            /* [N] exp(sum of log-probs) (:752) */
+    int32_t *res_row;           /* [N] beam row whose activation cache feeds the colour heads */
+    float *colors;              /* [N*5][T][12] colour-head outputs for every beam row (10 used) */
+    float *trace_logits;        /* optional [T][N*5][dict] raw logits (pred(pred1(decoded)), :713); NULL in production */
+    int32_t *trace_hist;        /* optional [T][N*5][T+1] beam tokens after each step */
+    int32_t steps_run;          /* out: steps executed */
+    int32_t _pad;
+} MitOcr48DecodeArgs;
+
+int mit_ocr_prep(const uint8_t *lines_dev, float *out_dev, int N, int H, int Wp, void *stream);
+/* depthwise k x k conv + per-channel scale/bias (ConvNeXtBlock.dwconv + norm, model_48px.py:195-196,205-206). w [k*k][C]. */
+int mit_dwconv_nhwc(const float *in_dev, const float *w_dev, const float *scale_dev, const float *bias_dev, float *out_dev,
+                    int B, int H, int W, int C, int k, void *stream);
+/* nn.LayerNorm over the last dim (transformer norm1/2/3). */
+int mit_layernorm(const float *in_dev, int64_t in_rowstride, const float *w_dev, const float *b_dev, float *out_dev,
+                  int64_t out_rowstride, int rows, int D, float eps, void *stream);
+/* XPOS.forward on [R, T, 4*80] (row / time strides in floats): index i0+t, centred position p0+t. */
+int mit_xpos_rotate(const float *in_dev, int64_t in_rs, int64_t in_ts, float *out_dev, int64_t out_rs, int64_t out_ts, int R,
+                    int T, int i0, int p0, int downscale, const MitXposTables *tables, void *stream);
+/* softmax(q k^T + key-padding mask) v for 4 heads x 80 (XposMultiheadAttention.forward :369-384); q already scaled and
+ * rotated, k rotated.  Row r reads keys/values of row r / kv_div; klen_dev (optional) = valid keys per kv row. */
+int mit_attention(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k_dev, int64_t k_rs, int64_t k_ts,
+                  const float *v_dev, int64_t v_rs, int64_t v_ts, float *out_dev, int64_t o_rs, int64_t o_ts,
+                  const int *klen_dev, int R, int Tq, int Tk, int kv_div, void *stream);
+/* The whole beam search of OCR.infer_beam_batch_tensor (:691-784) after the encoder, as one native call: per step
+ * embedding -> 5 decoder layers (KV cache instead of the reference's per-step K/V recomputation) -> pred1/pred ->
+ * log-softmax/top-5 -> beam bookkeeping, all on `stream`; synchronises the stream every few steps to test for early exit. */
+int64_t mit_ocr48_decode_workspace_bytes(int N, int T, int dict_size);
+int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,193 @@
+// ocr_decoder.hip — native beam-search decoder loop of the 48px OCR (OCR.infer_beam_batch_tensor,
+// manga_translator/ocr/model_48px.py:691-784).
+//
+// The reference runs ~75 tiny torch ops per step from Python and syncs to the host several times per
+// step (:741-772).  Here the whole loop is one C call: every step enqueues its kernels on the stream
+// from C++ (no Python, no per-step host sync), keeps a real K/V cache per layer (the reference
+// re-projects the whole history each step, :561-566 — identical values, since row r's history never
+// changes: the reference re-orders hypotheses but not caches, :730-735), and does the top-k / beam
+// bookkeeping on the device.  Finished samples stay in place (frozen results) instead of being
+// compacted away; the host polls a device counter every few steps for the early exit.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/mit_hip.h"
+#include "common.h"
+#include "ocr_kernels.h"
+
+namespace {
+
+constexpr int E = 320;
+constexpr int FF = 2048;
+
+struct Ws {
+    float *tgt, *nrm, *qkv, *krot, *qrot, *att, *q2, *ffh, *decoded, *p1, *logits, *vals, *logp, *cfeat;
+    int *idx, *hist, *done, *done_count;
+};
+
+inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
+int64_t carve(Ws *w, char *base, int N, int T, int D) {
+    const int64_t R = (int64_t)N * 5;
+    const int64_t Dp = (D + 3) / 4 * 4;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    float *tgt = (float *)take(R * E * 4);
+    float *nrm = (float *)take(R * E * 4);
+    float *qkv = (float *)take(5 * 3 * R * T * E * 4);
+    float *krot = (float *)take(R * T * E * 4);
+    float *qrot = (float *)take(R * E * 4);
+    float *att = (float *)take(R * E * 4);
+    float *q2 = (float *)take(R * E * 4);
+    float *ffh = (float *)take(R * FF * 4);
+    float *decoded = (float *)take(R * T * E * 4);
+    float *p1 = (float *)take(R * E * 4);
+    float *logits = (float *)take(R * Dp * 4);
+    float *vals = (float *)take(R * 5 * 4);
+    float *logp = (float *)take(2 * R * 4);
+    float *cfeat = (float *)take(R * T * 64 * 4);
+    int *idx = (int *)take(R * 5 * 4);
+    int *hist = (int *)take(2 * R * (T + 1) * 4);
+    int *done = (int *)take((int64_t)N * 4);
+    int *done_count = (int *)take(256);
+    if (w) *w = Ws{tgt, nrm, qkv, krot, qrot, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, idx, hist, done, done_count};
+    return off;
+}
+
+// C[M x N] = act((A[M x K] @ W) * scale + bias) + post, rows of A / C / post strided.
+int gemm(const MitLinear &lin, const float *A, int64_t lda, float *Cp, int64_t ldc, int M, int act, const float *post,
+         int64_t ldpost, hipStream_t s, int nsplit = 0, int64_t nhi = 0) {
+    MitConvGemm d;
+    memset(&d, 0, sizeof(d));
+    d.a = A;
+    d.a_xs = lda;
+    d.NB = 1; d.Hi = 1; d.Wi = M; d.Cin = lin.K;
+    d.Ho = 1; d.Wo = M; d.sy = 1; d.sx = 1;
+    d.ntaps = 1; d.pad_mode = MIT_PAD_ZERO;
+    d.w = lin.w; d.ldw = lin.ldw; d.Kw = lin.Kp; d.Nw = lin.Np;
+    d.N = lin.N; d.Z = 1; d.zdiv = 1;
+    d.c.base = Cp; d.c.xs = ldc; d.c.nsplit = nsplit; d.c.nhi = nhi;
+    if (post) {
+        d.post.base = const_cast<float *>(post);
+        d.post.xs = ldpost;
+    }
+    d.scale = lin.scale; d.bias = lin.bias; d.act = act;
+    return mit_conv_gemm(&d, s);
+}
+
+__global__ void fill_int_kernel(int *p, int64_t n, int v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void copy_hist_kernel(const int *src, int *dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+inline int neg_ceil_half(int n) { return -((n + 1) / 2); }  // python: -(n) // 2
+
+}  // namespace
+
+extern "C" int64_t mit_ocr48_decode_workspace_bytes(int N, int T, int dict_size) {
+    if (N <= 0 || T <= 0 || dict_size <= 0) return 0;
+    return carve(nullptr, nullptr, N, T, dict_size);
+}
+
+extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *a, void *stream) {
+    if (!dec || !a) return mit_set_error("mit_ocr48_decode: null argument");
+    const int N = a->N, L = a->L, T = a->max_seq_length, D = dec->dict_size;
+    if (N <= 0 || L <= 0 || T <= 0) return mit_set_error("mit_ocr48_decode: empty problem");
+    if (!a->mem_k || !a->mem_v || !a->mem_len || !a->workspace || !a->res_tok || !a->res_len || !a->res_prob || !a->res_row || !a->colors)
+        return mit_set_error("mit_ocr48_decode: null buffer");
+    if (a->workspace_bytes < carve(nullptr, nullptr, N, T, D)) return mit_set_error("mit_ocr48_decode: workspace too small");
+    if (T + 1 > dec->xpos.imax || (T + 1) / 2 + 1 >= dec->xpos.pmax) return mit_set_error("mit_ocr48_decode: XPOS tables too small for T");
+    hipStream_t s = (hipStream_t)stream;
+    Ws w;
+    carve(&w, (char *)a->workspace, N, T, D);
+    const int R = N * 5;
+    const int64_t Dp = (D + 3) / 4 * 4;
+    const int64_t TE = (int64_t)T * E;
+    const int hist_ld = T + 1;
+    int *hist[2] = {w.hist, w.hist + (int64_t)R * hist_ld};
+    float *logp[2] = {w.logp, w.logp + R};
+
+    hipLaunchKernelGGL(fill_int_kernel, dim3(64), dim3(256), 0, s, hist[0], (int64_t)2 * R * hist_ld, a->start_tok);
+    MIT_CHECK_HIP(hipMemsetAsync(w.done, 0, (size_t)N * 4, s));
+    MIT_CHECK_HIP(hipMemsetAsync(w.done_count, 0, 4, s));
+    MIT_CHECK_HIP(hipMemsetAsync(w.decoded, 0, (size_t)R * TE * 4, s));
+    MIT_CHECK_HIP(hipMemsetAsync(a->res_len, 0, (size_t)N * 4, s));
+
+    int cur = 0, steps = 0;
+    for (int step = 0; step < T; ++step) {
+        ocrk_embed(hist[cur] + step, hist_ld, dec->embd, w.tgt, R, E, s);
+        const int minpos = neg_ceil_half(step + 1);
+        for (int l = 0; l < 5; ++l) {
+            const MitOcrDecoderLayer &ly = dec->layers[l];
+            float *qc = w.qkv + (int64_t)(l * 3 + 0) * R * TE;
+            float *kc = w.qkv + (int64_t)(l * 3 + 1) * R * TE;
+            float *vc = w.qkv + (int64_t)(l * 3 + 2) * R * TE;
+            // self attention (:565)
+            ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, w.nrm, E, R, E, 1e-5f, s);
+            if (gemm(ly.qkv, w.nrm, E, qc + (int64_t)step * E, TE, R, MIT_ACT_NONE, nullptr, 0, s, E, (int64_t)R * TE)) return 1;
+            ocrk_xpos_rotate(qc + (int64_t)step * E, TE, E, w.qrot, E, E, R, 1, step, step + minpos, 0, dec->xpos, s);
+            ocrk_xpos_rotate(kc, TE, E, w.krot, TE, E, R, step + 1, 0, minpos, 1, dec->xpos, s);
+            ocrk_attention(w.qrot, E, E, w.krot, TE, E, vc, TE, E, w.att, E, E, nullptr, R, 1, step + 1, 1, s);
+            if (gemm(ly.out, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, s)) return 1;
+            // cross attention (:567)
+            ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, w.nrm, E, R, E, 1e-5f, s);
+            if (gemm(ly.q2, w.nrm, E, w.q2, E, R, MIT_ACT_NONE, nullptr, 0, s)) return 1;
+            ocrk_xpos_rotate(w.q2, E, E, w.qrot, E, E, R, 1, step, step + minpos, 0, dec->xpos, s);
+            const float *mk = a->mem_k + (int64_t)l * N * L * E;
+            const float *mv = a->mem_v + (int64_t)l * N * L * E;
+            ocrk_attention(w.qrot, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, w.att, E, E, a->mem_len, R, 1, L, 5, s);
+            if (gemm(ly.out2, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, s)) return 1;
+            // feed forward (:568)
+            ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, s);
+            if (gemm(ly.ff1, w.nrm, E, w.ffh, FF, R, MIT_ACT_RELU, nullptr, 0, s)) return 1;
+            if (l < 4) {
+                if (gemm(ly.ff2, w.ffh, FF, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, s)) return 1;
+            } else {  // last layer writes the step's output straight into the activation cache (:570)
+                if (gemm(ly.ff2, w.ffh, FF, w.decoded + (int64_t)step * E, TE, R, MIT_ACT_NONE, w.tgt, E, s)) return 1;
+            }
+        }
+        if (gemm(dec->pred1, w.decoded + (int64_t)step * E, TE, w.p1, E, R, MIT_ACT_GELU, nullptr, 0, s)) return 1;
+        if (gemm(dec->pred, w.p1, E, w.logits, Dp, R, MIT_ACT_NONE, nullptr, 0, s)) return 1;
+        if (a->trace_logits)
+            MIT_CHECK_HIP(hipMemcpy2DAsync(a->trace_logits + (int64_t)step * R * D, (size_t)D * 4, w.logits, (size_t)Dp * 4,
+                                           (size_t)D * 4, R, hipMemcpyDeviceToDevice, s));
+        ocrk_logsoftmax_top5(w.logits, Dp, R, D, a->suppress_eos ? a->end_tok : -1, w.vals, w.idx, nullptr, s);
+        if (step == 0) {
+            ocrk_beam_init(w.vals, w.idx, hist[cur], hist_ld, logp[cur], N, a->start_tok, s);
+        } else {
+            ocrk_beam_step(w.vals, w.idx, hist[cur], hist[cur ^ 1], hist_ld, logp[cur], logp[cur ^ 1], w.done, a->res_row,
+                           a->res_len, a->res_prob, a->res_tok, w.done_count, N, step, a->end_tok, a->max_finished, s);
+            cur ^= 1;
+        }
+        if (a->trace_hist)
+            MIT_CHECK_HIP(hipMemcpyAsync(a->trace_hist + (int64_t)step * R * hist_ld, hist[cur], (size_t)R * hist_ld * 4,
+                                         hipMemcpyDeviceToDevice, s));
+        MIT_CHECK_LAUNCH("mit_ocr48_decode");
+        steps = step + 1;
+        if (step >= 1 && (step % 4 == 3) && step + 1 < T) {  // early exit (:765-766) without a per-step sync
+            int dc = 0;
+            MIT_CHECK_HIP(hipMemcpyAsync(&dc, w.done_count, 4, hipMemcpyDeviceToHost, s));
+            MIT_CHECK_HIP(hipStreamSynchronize(s));
+            if (dc >= N) break;
+        }
+    }
+    ocrk_beam_finalize(hist[cur], hist_ld, logp[cur], w.done, a->res_row, a->res_len, a->res_prob, a->res_tok, N, steps + 1, s);
+    // colour heads over every beam row's activation cache (:789-799); the caller gathers rows res_row[n]
+    if (gemm(dec->color1, w.decoded, E, w.cfeat, 64, R * T, MIT_ACT_RELU, nullptr, 0, s)) return 1;
+    if (gemm(dec->color_heads, w.cfeat, 64, a->colors, 12, R * T, MIT_ACT_NONE, nullptr, 0, s)) return 1;
+    MIT_CHECK_LAUNCH("mit_ocr48_decode");
+    a->steps_run = steps;
+    return 0;
+}

@@ -1,0 +1,23 @@
+// ocr_kernels.h — internal launch helpers of ocr_kernels.hip used by the native decoder loop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mit_hip.h"
+
+void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
+                    int D, float eps, hipStream_t s);
+void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
+                      int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s);
+void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
+                    int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
+                    int kv_div, hipStream_t s);
+void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s);
+void ocrk_logsoftmax_top5(const float *logits, int64_t ld, int R, int D, int suppress_tok, float *vals, int *idx,
+                          float *logp_out, hipStream_t s);
+void ocrk_beam_init(const float *vals, const int *idx, int *hist, int hist_ld, float *logp, int N, int start_tok,
+                    hipStream_t s);
+void ocrk_beam_step(const float *vals, const int *idx, const int *hist_in, int *hist_out, int hist_ld, const float *logp_in,
+                    float *logp_out, int *done, int *res_row, int *res_len, float *res_prob, int *res_tok, int *done_count,
+                    int N, int step, int end_tok, int max_finished, hipStream_t s);
+void ocrk_beam_finalize(const int *hist, int hist_ld, const float *logp, int *done, int *res_row, int *res_len,
+                        float *res_prob, int *res_tok, int N, int len, hipStream_t s);

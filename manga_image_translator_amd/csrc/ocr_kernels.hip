@@ -1,0 +1,484 @@
+// ocr_kernels.hip — non-GEMM kernels of the 48px OCR stage (ConvNeXt backbone glue, XPOS
+// transformer pieces, beam-search bookkeeping).  All fp32; the dense projections run on
+// mit_conv_gemm.
+//
+// Reference: manga_translator/ocr/model_48px.py (ConvNeXtBlock :203-214, XposMultiheadAttention
+// :327-394, decoder_forward :548-572, infer_beam_batch_tensor :678-801) and
+// ocr/xpos_relative_position.py (:9-71).
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/mit_hip.h"
+#include "common.h"
+#include "ocr_kernels.h"
+
+namespace {
+
+inline int grid_for(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+
+// ---- u8 line crops [N,48,Wp,3] -> fp32 NHWC [N,48,Wp,4] = ((x - 127.5) / 127.5, 0) (:115) ----
+__global__ void ocr_prep_kernel(const uint8_t *__restrict__ in, float4 *__restrict__ out, int64_t npix) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < npix; i += stride) {
+        float4 v;
+        v.x = ((float)in[3 * i + 0] - 127.5f) / 127.5f;
+        v.y = ((float)in[3 * i + 1] - 127.5f) / 127.5f;
+        v.z = ((float)in[3 * i + 2] - 127.5f) / 127.5f;
+        v.w = 0.f;
+        out[i] = v;
+    }
+}
+
+// ---- depthwise k x k conv (stride 1, pad k/2) + per-channel scale/bias (conv bias + folded BN) ----
+// w layout [k*k][C]; 4 channels per thread.
+__global__ void dwconv_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ scale,
+                              const float *__restrict__ bias, float *__restrict__ out, int B, int H, int W, int C4, int k) {
+    const int64_t total = (int64_t)B * H * W * C4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int r = k / 2;
+    const int C = C4 * 4;
+    for (; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int x = (int)(p % W);
+        p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = y + ky - r;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = x + kx - r;
+                if (xx < 0 || xx >= W) continue;
+                const float4 v = *reinterpret_cast<const float4 *>(in + (((int64_t)b * H + yy) * W + xx) * C + c4 * 4);
+                const float4 ww = *reinterpret_cast<const float4 *>(w + (int64_t)(ky * k + kx) * C + c4 * 4);
+                acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y);
+                acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
+            }
+        }
+        const float4 s = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+        const float4 bb = *reinterpret_cast<const float4 *>(bias + c4 * 4);
+        float4 o;
+        o.x = acc.x * s.x + bb.x; o.y = acc.y * s.y + bb.y; o.z = acc.z * s.z + bb.z; o.w = acc.w * s.w + bb.w;
+        *reinterpret_cast<float4 *>(out + (((int64_t)b * H + y) * W + x) * C + c4 * 4) = o;
+    }
+}
+
+// ---- LayerNorm over the last dim (D <= 64*8), one wave per row ----
+__global__ void layernorm_kernel(const float *__restrict__ in, int64_t in_rs, const float *__restrict__ w,
+                                 const float *__restrict__ b, float *__restrict__ out, int64_t out_rs, int rows, int D,
+                                 float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *x = in + (int64_t)row * in_rs;
+    float v[8];
+    float sum = 0.f;
+    int n = 0;
+    for (int d = lane; d < D; d += 64) {
+        v[n] = x[d];
+        sum += v[n];
+        ++n;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)D;
+    float var = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float t = v[j] - mean;
+        var += t * t;
+    }
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)D + eps);
+    float *y = out + (int64_t)row * out_rs;
+    n = 0;
+    for (int d = lane; d < D; d += 64) {
+        y[d] = (v[n] - mean) * rstd * w[d] + b[d];
+        ++n;
+    }
+}
+
+// ---- XPOS rotation (xpos_relative_position.py:36-39,54-71) on [R, T, heads*80] ----
+// position index i = i0 + t selects the sin/cos row, p = p0 + t the scale row (centred positions).
+__global__ void xpos_rotate_kernel(const float *__restrict__ in, int64_t in_rs, int64_t in_ts, float *__restrict__ out,
+                                   int64_t out_rs, int64_t out_ts, int R, int T, int i0, int p0, int downscale,
+                                   const float *__restrict__ cosT, const float *__restrict__ sinT,
+                                   const float *__restrict__ scaleT, const float *__restrict__ iscaleT, int pmax) {
+    // one thread per (r, t, pair j of 160 pairs = 4 heads x 40)
+    const int64_t total = (int64_t)R * T * 160;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int pair = (int)(i % 160);
+        const int64_t rt = i / 160;
+        const int t = (int)(rt % T);
+        const int r = (int)(rt / T);
+        const int j = pair % 40;
+        const int ii = i0 + t, pp = p0 + t + pmax;
+        const float sc = downscale ? iscaleT[pp * 40 + j] : scaleT[pp * 40 + j];
+        const float c = cosT[ii * 40 + j] * sc;
+        const float s = sinT[ii * 40 + j] * sc;
+        const float2 x = *reinterpret_cast<const float2 *>(in + (int64_t)r * in_rs + (int64_t)t * in_ts + pair * 2);
+        float2 o;
+        o.x = x.x * c + (-x.y) * s;  // (x * cos) + (rotate_every_two(x) * sin)
+        o.y = x.y * c + x.x * s;
+        *reinterpret_cast<float2 *>(out + (int64_t)r * out_rs + (int64_t)t * out_ts + pair * 2) = o;
+    }
+}
+
+// ---- softmax(q k^T + key mask) v, 4 heads x 80, one wave per (query, head, row) ----
+__global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int64_t q_ts, const float *__restrict__ K,
+                                 int64_t k_rs, int64_t k_ts, const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
+                                 float *__restrict__ O, int64_t o_rs, int64_t o_ts, const int *__restrict__ klen, int Tk,
+                                 int kv_div) {
+    extern __shared__ float lds[];  // [80] q + [Tk] weights
+    float *qs = lds;
+    float *ws = lds + 80;
+    const int tq = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
+    const int lane = threadIdx.x;
+    const int kr = r / kv_div;
+    const float *q = Q + (int64_t)r * q_rs + (int64_t)tq * q_ts + h * 80;
+    for (int d = lane; d < 80; d += 64) qs[d] = q[d];
+    __syncthreads();
+    const int valid = klen ? min(klen[kr], Tk) : Tk;
+    const float *kb = K + (int64_t)kr * k_rs + h * 80;
+    float mx = -INFINITY;
+    for (int t = lane; t < Tk; t += 64) {
+        float dot = -INFINITY;
+        if (t < valid) {
+            const float4 *kp = reinterpret_cast<const float4 *>(kb + (int64_t)t * k_ts);
+            dot = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 20; ++d4) {
+                const float4 kv = kp[d4];
+                dot += qs[d4 * 4 + 0] * kv.x;
+                dot += qs[d4 * 4 + 1] * kv.y;
+                dot += qs[d4 * 4 + 2] * kv.z;
+                dot += qs[d4 * 4 + 3] * kv.w;
+            }
+        }
+        ws[t] = dot;
+        mx = fmaxf(mx, dot);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int t = lane; t < Tk; t += 64) {
+        const float e = expf(ws[t] - mx);
+        ws[t] = e;
+        sum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    const float *vb = V + (int64_t)kr * v_rs + h * 80;
+    float *ob = O + (int64_t)r * o_rs + (int64_t)tq * o_ts + h * 80;
+    for (int d = lane; d < 80; d += 64) {
+        float acc = 0.f;
+        for (int t = 0; t < valid; ++t) acc += (ws[t] * inv) * vb[(int64_t)t * v_ts + d];
+        ob[d] = acc;
+    }
+}
+
+// ---- embedding rows: out[r] = E[tok[r]] ----
+__global__ void embed_kernel(const int *__restrict__ tok, int64_t tok_stride, const float *__restrict__ E,
+                             float *__restrict__ out, int R, int D) {
+    const int64_t total = (int64_t)R * (D / 4);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int d4 = (int)(i % (D / 4));
+        const int r = (int)(i / (D / 4));
+        const int t = tok[(int64_t)r * tok_stride];
+        reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(E + (int64_t)t * D)[d4];
+    }
+}
+
+// ---- log_softmax + top-5 over the dictionary, one block per row ----
+// ties resolve to the lower index.
+__global__ __launch_bounds__(256) void logsoftmax_top5_kernel(const float *__restrict__ logits, int64_t ld, int D,
+                                                               int suppress_tok, float *__restrict__ vals,
+                                                               int *__restrict__ idx, float *__restrict__ logp_out) {
+    __shared__ float red[256];
+    __shared__ float cv[256 * 5];
+    __shared__ int ci[256 * 5];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float *x = logits + (int64_t)r * ld;
+    float tv[5];
+    int ti[5];
+    for (int j = 0; j < 5; ++j) {
+        tv[j] = -INFINITY;
+        ti[j] = 0x7fffffff;
+    }
+    float mx = -INFINITY;
+    for (int d = tid; d < D; d += 256) {
+        float v = x[d];
+        if (d == suppress_tok) v = -INFINITY;
+        mx = fmaxf(mx, v);
+        if (v > tv[4] || (v == tv[4] && d < ti[4])) {
+            int j = 4;
+            while (j > 0 && (v > tv[j - 1] || (v == tv[j - 1] && d < ti[j - 1]))) {
+                tv[j] = tv[j - 1];
+                ti[j] = ti[j - 1];
+                --j;
+            }
+            tv[j] = v;
+            ti[j] = d;
+        }
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        const float v = (d == suppress_tok) ? -INFINITY : x[d];
+        sum += expf(v - mx);
+    }
+    red[tid] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float lse = logf(red[0]);
+    if (logp_out) {
+        for (int d = tid; d < D; d += 256) {
+            const float v = (d == suppress_tok) ? -INFINITY : x[d];
+            logp_out[(int64_t)r * D + d] = (v - mx) - lse;
+        }
+    }
+    for (int j = 0; j < 5; ++j) {
+        cv[tid * 5 + j] = tv[j];
+        ci[tid * 5 + j] = ti[j];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float bv[5];
+        int bi[5];
+        for (int j = 0; j < 5; ++j) {
+            bv[j] = -INFINITY;
+            bi[j] = 0x7fffffff;
+        }
+        for (int c = 0; c < 256 * 5; ++c) {
+            const float v = cv[c];
+            const int d = ci[c];
+            if (d == 0x7fffffff) continue;
+            if (v > bv[4] || (v == bv[4] && d < bi[4])) {
+                int j = 4;
+                while (j > 0 && (v > bv[j - 1] || (v == bv[j - 1] && d < bi[j - 1]))) {
+                    bv[j] = bv[j - 1];
+                    bi[j] = bi[j - 1];
+                    --j;
+                }
+                bv[j] = v;
+                bi[j] = d;
+            }
+        }
+        for (int j = 0; j < 5; ++j) {
+            vals[r * 5 + j] = (bv[j] - mx) - lse;  // log_softmax value
+            idx[r * 5 + j] = bi[j];
+        }
+    }
+}
+
+// ---- beam bookkeeping: one thread per sample (25 candidates) ----
+// step 0 (:693-699): beam j of a sample takes the j-th best token of its (identical) row.
+__global__ void beam_init_kernel(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist,
+                                 int hist_ld, float *__restrict__ logp, int N, int start_tok) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    for (int j = 0; j < 5; ++j) {
+        const int row = n * 5 + j;
+        hist[(int64_t)row * hist_ld + 0] = start_tok;
+        hist[(int64_t)row * hist_ld + 1] = idx[(n * 5) * 5 + j];
+        logp[row] = vals[(n * 5) * 5 + j];
+    }
+}
+
+// steps >= 1 (:716-771). hist_in/out [R][hist_ld]: tokens 0..step valid on input, 0..step+1 on output.
+__global__ void beam_step_kernel(const float *__restrict__ vals, const int *__restrict__ idx,
+                                 const int *__restrict__ hist_in, int *__restrict__ hist_out, int hist_ld,
+                                 const float *__restrict__ logp_in, float *__restrict__ logp_out, int *__restrict__ done,
+                                 int *__restrict__ res_row, int *__restrict__ res_len, float *__restrict__ res_prob,
+                                 int *__restrict__ res_tok, int *__restrict__ done_count, int N, int step, int end_tok,
+                                 int max_finished) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float cl[25];
+    int ct[25];
+    for (int b = 0; b < 5; ++b) {
+        const int row = n * 5 + b;
+        const bool fin = hist_in[(int64_t)row * hist_ld + step] == end_tok;
+        for (int j = 0; j < 5; ++j) {
+            const float v = fin ? 0.f : vals[row * 5 + j];
+            ct[b * 5 + j] = fin ? end_tok : idx[row * 5 + j];
+            cl[b * 5 + j] = logp_in[row] + v;
+        }
+    }
+    int sel[5];
+    bool used[25];
+    for (int c = 0; c < 25; ++c) used[c] = false;
+    for (int k = 0; k < 5; ++k) {  // topk, descending, lower flat index first on ties
+        int best = -1;
+        for (int c = 0; c < 25; ++c)
+            if (!used[c] && (best < 0 || cl[c] > cl[best])) best = c;
+        used[best] = true;
+        sel[k] = best;
+    }
+    int fcount = 0;
+    for (int k = 0; k < 5; ++k) {
+        const int row = n * 5 + k;
+        const int src = n * 5 + sel[k] / 5;
+        for (int t = 0; t <= step; ++t) hist_out[(int64_t)row * hist_ld + t] = hist_in[(int64_t)src * hist_ld + t];
+        hist_out[(int64_t)row * hist_ld + step + 1] = ct[sel[k]];
+        logp_out[row] = cl[sel[k]];
+        fcount += ct[sel[k]] == end_tok;
+    }
+    if (!done[n] && fcount >= max_finished) {
+        done[n] = 1;
+        atomicAdd(done_count, 1);
+        const int row = n * 5 + 0;  // argmax of the (descending) top-k
+        res_row[n] = row;
+        res_len[n] = step + 2;
+        res_prob[n] = expf(cl[sel[0]]);
+        for (int t = 0; t <= step + 1; ++t) res_tok[(int64_t)n * hist_ld + t] = hist_out[(int64_t)row * hist_ld + t];
+    }
+}
+
+// fallback (:774-784): samples that never finished take the first row of their beam.
+__global__ void beam_finalize_kernel(const int *__restrict__ hist, int hist_ld, const float *__restrict__ logp,
+                                     int *__restrict__ done, int *__restrict__ res_row, int *__restrict__ res_len,
+                                     float *__restrict__ res_prob, int *__restrict__ res_tok, int N, int len) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N || done[n]) return;
+    const int row = n * 5;
+    res_row[n] = row;
+    res_len[n] = len;
+    res_prob[n] = expf(logp[row]);
+    for (int t = 0; t < len; ++t) res_tok[(int64_t)n * hist_ld + t] = hist[(int64_t)row * hist_ld + t];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// internal launch helpers (shared with ocr_decoder.hip) + C-ABI wrappers
+// ---------------------------------------------------------------------------------------------
+
+void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
+                    int D, float eps, hipStream_t s) {
+    const int waves = 4;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + waves - 1) / waves), dim3(64 * waves), 0, s, in, in_rs, w, b, out, out_rs,
+                       rows, D, eps);
+}
+
+void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
+                      int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s) {
+    const int64_t total = (int64_t)R * T * 160;
+    hipLaunchKernelGGL(xpos_rotate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, in_rs, in_ts, out, out_rs, out_ts, R,
+                       T, i0, p0, downscale, tb.cos_t, tb.sin_t, tb.scale_t, tb.iscale_t, tb.pmax);
+}
+
+void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
+                    int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
+                    int kv_div, hipStream_t s) {
+    const size_t smem = (80 + (size_t)Tk) * sizeof(float);
+    hipLaunchKernelGGL(attention_kernel, dim3(Tq, 4, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
+                       o_ts, klen, Tk, kv_div);
+}
+
+void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3(grid_for((int64_t)R * D / 4, 256)), dim3(256), 0, s, tok, tok_stride, E, out, R, D);
+}
+
+void ocrk_logsoftmax_top5(const float *logits, int64_t ld, int R, int D, int suppress_tok, float *vals, int *idx,
+                          float *logp_out, hipStream_t s) {
+    hipLaunchKernelGGL(logsoftmax_top5_kernel, dim3(R), dim3(256), 0, s, logits, ld, D, suppress_tok, vals, idx, logp_out);
+}
+
+void ocrk_beam_init(const float *vals, const int *idx, int *hist, int hist_ld, float *logp, int N, int start_tok,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(beam_init_kernel, dim3((N + 63) / 64), dim3(64), 0, s, vals, idx, hist, hist_ld, logp, N, start_tok);
+}
+
+void ocrk_beam_step(const float *vals, const int *idx, const int *hist_in, int *hist_out, int hist_ld, const float *logp_in,
+                    float *logp_out, int *done, int *res_row, int *res_len, float *res_prob, int *res_tok, int *done_count,
+                    int N, int step, int end_tok, int max_finished, hipStream_t s) {
+    hipLaunchKernelGGL(beam_step_kernel, dim3((N + 63) / 64), dim3(64), 0, s, vals, idx, hist_in, hist_out, hist_ld, logp_in,
+                       logp_out, done, res_row, res_len, res_prob, res_tok, done_count, N, step, end_tok, max_finished);
+}
+
+void ocrk_beam_finalize(const int *hist, int hist_ld, const float *logp, int *done, int *res_row, int *res_len,
+                        float *res_prob, int *res_tok, int N, int len, hipStream_t s) {
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, s, hist, hist_ld, logp, done, res_row, res_len,
+                       res_prob, res_tok, N, len);
+}
+
+extern "C" int mit_ocr_prep(const uint8_t *lines_dev, float *out_dev, int N, int H, int Wp, void *stream) {
+    if (!lines_dev || !out_dev) return mit_set_error("mit_ocr_prep: null pointer");
+    const int64_t npix = (int64_t)N * H * Wp;
+    hipLaunchKernelGGL(ocr_prep_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, lines_dev,
+                       reinterpret_cast<float4 *>(out_dev), npix);
+    MIT_CHECK_LAUNCH("mit_ocr_prep");
+    return 0;
+}
+
+extern "C" int mit_dwconv_nhwc(const float *in_dev, const float *w_dev, const float *scale_dev, const float *bias_dev,
+                               float *out_dev, int B, int H, int W, int C, int k, void *stream) {
+    if (!in_dev || !w_dev || !scale_dev || !bias_dev || !out_dev) return mit_set_error("mit_dwconv_nhwc: null pointer");
+    if ((C & 3) || !(k & 1)) return mit_set_error("mit_dwconv_nhwc: C %% 4 == 0 and odd k required");
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in_dev, w_dev, scale_dev,
+                       bias_dev, out_dev, B, H, W, C / 4, k);
+    MIT_CHECK_LAUNCH("mit_dwconv_nhwc");
+    return 0;
+}
+
+extern "C" int mit_layernorm(const float *in_dev, int64_t in_rowstride, const float *w_dev, const float *b_dev,
+                             float *out_dev, int64_t out_rowstride, int rows, int D, float eps, void *stream) {
+    if (!in_dev || !w_dev || !b_dev || !out_dev) return mit_set_error("mit_layernorm: null pointer");
+    if (D <= 0 || D > 512) return mit_set_error("mit_layernorm: D out of range");
+    if (rows <= 0) return 0;
+    ocrk_layernorm(in_dev, in_rowstride, w_dev, b_dev, out_dev, out_rowstride, rows, D, eps, (hipStream_t)stream);
+    MIT_CHECK_LAUNCH("mit_layernorm");
+    return 0;
+}
+
+static int check_tables(const MitXposTables *tb, int imax_needed, int pmin, int pmax_needed, const char *who) {
+    if (!tb || !tb->cos_t || !tb->sin_t || !tb->scale_t || !tb->iscale_t) return mit_set_error("%s: null XPOS tables", who);
+    if (imax_needed > tb->imax || pmin < -tb->pmax || pmax_needed >= tb->pmax)
+        return mit_set_error("%s: XPOS position out of table range", who);
+    return 0;
+}
+
+extern "C" int mit_xpos_rotate(const float *in_dev, int64_t in_rs, int64_t in_ts, float *out_dev, int64_t out_rs,
+                               int64_t out_ts, int R, int T, int i0, int p0, int downscale, const MitXposTables *tables,
+                               void *stream) {
+    if (!in_dev || !out_dev) return mit_set_error("mit_xpos_rotate: null pointer");
+    if (R <= 0 || T <= 0) return 0;
+    if (check_tables(tables, i0 + T, p0, p0 + T - 1, "mit_xpos_rotate")) return 1;
+    ocrk_xpos_rotate(in_dev, in_rs, in_ts, out_dev, out_rs, out_ts, R, T, i0, p0, downscale, *tables, (hipStream_t)stream);
+    MIT_CHECK_LAUNCH("mit_xpos_rotate");
+    return 0;
+}
+
+extern "C" int mit_attention(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k_dev, int64_t k_rs, int64_t k_ts,
+                             const float *v_dev, int64_t v_rs, int64_t v_ts, float *out_dev, int64_t o_rs, int64_t o_ts,
+                             const int *klen_dev, int R, int Tq, int Tk, int kv_div, void *stream) {
+    if (!q_dev || !k_dev || !v_dev || !out_dev) return mit_set_error("mit_attention: null pointer");
+    if (R <= 0 || Tq <= 0 || Tk <= 0 || kv_div <= 0) return mit_set_error("mit_attention: empty problem");
+    if (Tk > 8192 || R > 65535 || Tq > 65535) return mit_set_error("mit_attention: problem too large");
+    ocrk_attention(q_dev, q_rs, q_ts, k_dev, k_rs, k_ts, v_dev, v_rs, v_ts, out_dev, o_rs, o_ts, klen_dev, R, Tq, Tk, kv_div,
+                   (hipStream_t)stream);
+    MIT_CHECK_LAUNCH("mit_attention");
+    return 0;
+}

@@ -69,6 +69,37 @@ class MitConvGemm(C.Structure):
     ]
 
 
+class MitXposTables(C.Structure):
+    _fields_ = [("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("scale_t", C.c_void_p), ("iscale_t", C.c_void_p),
+                ("imax", C.c_int32), ("pmax", C.c_int32)]
+
+
+class MitLinear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("ldw", C.c_int64), ("K", C.c_int32),
+                ("N", C.c_int32), ("Kp", C.c_int32), ("Np", C.c_int32)]
+
+
+class MitOcrDecoderLayer(C.Structure):
+    _fields_ = [("ln1_w", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p),
+                ("ln3_w", C.c_void_p), ("ln3_b", C.c_void_p), ("qkv", MitLinear), ("out", MitLinear), ("q2", MitLinear),
+                ("out2", MitLinear), ("ff1", MitLinear), ("ff2", MitLinear)]
+
+
+class MitOcr48Decoder(C.Structure):
+    _fields_ = [("layers", MitOcrDecoderLayer * 5), ("embd", C.c_void_p), ("pred1", MitLinear), ("pred", MitLinear),
+                ("color1", MitLinear), ("color_heads", MitLinear), ("xpos", MitXposTables), ("dict_size", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class MitOcr48DecodeArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("mem_k", C.c_void_p), ("mem_v", C.c_void_p), ("mem_len", C.c_void_p),
+                ("max_seq_length", C.c_int32), ("start_tok", C.c_int32), ("end_tok", C.c_int32), ("max_finished", C.c_int32),
+                ("suppress_eos", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("res_tok", C.c_void_p), ("res_len", C.c_void_p), ("res_prob", C.c_void_p), ("res_row", C.c_void_p),
+                ("colors", C.c_void_p), ("trace_logits", C.c_void_p), ("trace_hist", C.c_void_p), ("steps_run", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
 # every symbol include/mit_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mit_last_error": (C.c_char_p, []),
@@ -93,6 +124,18 @@ SYMBOLS = {
                                     C.c_void_p]),
     "mit_copy_channels": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "mit_map_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "mit_ocr_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mit_dwconv_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_void_p]),
+    "mit_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                C.c_float, C.c_void_p]),
+    "mit_xpos_rotate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.POINTER(MitXposTables), C.c_void_p]),
+    "mit_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p]),
+    "mit_ocr48_decode_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "mit_ocr48_decode": (C.c_int, [C.POINTER(MitOcr48Decoder), C.POINTER(MitOcr48DecodeArgs), C.c_void_p]),
     "mit_lama_post": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p]),
 }

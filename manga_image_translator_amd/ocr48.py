@@ -1,0 +1,342 @@
+"""48px OCR (``--ocr 48px``) on the gfx950 engine: ConvNeXt backbone, XPOS encoder, native beam decoder.
+
+Same model as ``OCR`` of the reference (/root/reference/manga_translator/ocr/model_48px.py:496-801):
+  backbone (:216-276) -> 4 encoder layers (:543-546) -> beam search over 5 decoder layers (:678-801).
+
+MI355X layout
+* the backbone/encoder run per chunk exactly as the reference batches them (sorted by width, 16 lines,
+  zero-padded uint8 crops of width max(w)+7, :79-91) because the conv stack sees that padding;
+* the decoder does NOT: it only sees the encoder memory through a key mask, so the lines of ALL chunks
+  (and pages) handed to ``decode`` are decoded together in one native loop (mit_ocr48_decode) —
+  hundreds of beam rows per GEMM instead of 80;
+* BatchNorm folded into conv epilogues; dwconv + BN in one kernel; layer-scale gamma, GELU, ReLU and
+  residual adds in GEMM epilogues; q|k|v projections fused into one GEMM writing straight into the KV cache.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import ops
+from .lib import MitLinear, MitOcr48DecodeArgs, MitOcr48Decoder, MitXposTables
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, launch_conv_gemm, conv_gemm_desc, tensor_map
+
+EMBD, HEADS, HEAD_DIM, FF = 320, 4, 80, 2048
+XPOS_IMAX, XPOS_PMAX = 2048, 1024
+
+
+def _bn(sd, p, eps=1e-5):
+    return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"], eps)
+
+
+class Linear:
+    """nn.Linear as a packed [K, N] matrix on the device (+ optional per-column scale)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], device, col_scale: Optional[torch.Tensor] = None):
+        N, K = weight.shape
+        self.K, self.N = K, N
+        self.w, self.Kp, self.Np = ops.pack_weight_kn(weight.detach().to(torch.float32).t(), device)
+        b = None if bias is None else bias.detach().to(torch.float32)
+        sc = None
+        if col_scale is not None:
+            sc = col_scale.to(torch.float32)
+            b = None if b is None else b * sc
+        self.scale = None if sc is None else sc.to(device).contiguous()
+        self.bias = None if b is None else b.to(device).contiguous()
+
+    def c_struct(self) -> MitLinear:
+        m = MitLinear()
+        m.w, m.ldw, m.K, m.N, m.Kp, m.Np = self.w.data_ptr(), self.Np, self.K, self.N, self.Kp, self.Np
+        m.scale = None if self.scale is None else self.scale.data_ptr()
+        m.bias = None if self.bias is None else self.bias.data_ptr()
+        return m
+
+    def __call__(self, x: torch.Tensor, out: torch.Tensor, act: int = ACT_NONE, post: Optional[torch.Tensor] = None,
+                 nsplit: int = 0, nhi: int = 0):
+        """x [M, K] (row stride free), out [M, N] (or split columns), post [M, N]."""
+        M = x.shape[0]
+        cm = ops.MitTensorMap()
+        cm.base, cm.xs, cm.nsplit, cm.nhi = out.data_ptr(), out.stride(0), nsplit, nhi
+        pm = None
+        if post is not None:
+            pm = ops.MitTensorMap()
+            pm.base, pm.xs = post.data_ptr(), post.stride(0)
+        launch_conv_gemm(conv_gemm_desc(
+            a=x, NB=1, Hi=1, Wi=M, Cin=self.K, a_strides=(0, 0, x.stride(0)), Ho=1, Wo=M, sy=1, sx=1, taps=[(0, 0, 0)],
+            pad_mode=ops.PAD_ZERO, w=self.w, ldw=self.Np, Kw=self.Kp, Nw=self.Np, N=self.N, c=cm, post=pm, scale=self.scale,
+            bias=self.bias, act=act))
+        return out
+
+
+def xpos_tables(scale_vec: torch.Tensor, device):
+    """Tables for MitXposTables, computed with the reference's own fp32 expressions
+    (xpos_relative_position.py:9-16 fixed_pos_embedding, :54-57 scale ** (pos / scale_base), :66-67 1/scale)."""
+    sv = scale_vec.detach().to(torch.float32).cpu()
+    dim = sv.shape[0]
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, dim) / dim))
+    sinus = torch.einsum("i , j -> i j", torch.arange(0, XPOS_IMAX, dtype=torch.float), inv_freq).to(sv)
+    pos = torch.arange(-XPOS_PMAX, XPOS_PMAX, 1).to(sv).div(EMBD)[:, None]  # scale_base = embed_dim (model_48px.py:316)
+    scale = sv ** pos
+    t = dict(cos=torch.cos(sinus), sin=torch.sin(sinus), scale=scale, iscale=1 / scale)
+    return {k: v.contiguous().to(device) for k, v in t.items()}
+
+
+class _EncLayer:
+    def __init__(self, sd, p, device):
+        a = p + ".self_attn"
+        s = HEAD_DIM ** -0.5
+        wq, wk, wv = (sd[f"{a}.{n}_proj.weight"] for n in "qkv")
+        bq, bk, bv = (sd[f"{a}.{n}_proj.bias"] for n in "qkv")
+        col_scale = torch.cat([torch.full((EMBD,), s), torch.ones(2 * EMBD)])
+        self.qkv = Linear(torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0), device, col_scale)
+        self.out = Linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"], device)
+        self.ff1 = Linear(sd[p + ".linear1.weight"], sd[p + ".linear1.bias"], device)
+        self.ff2 = Linear(sd[p + ".linear2.weight"], sd[p + ".linear2.bias"], device)
+        self.ln = [(sd[f"{p}.norm{i}.weight"].float().to(device), sd[f"{p}.norm{i}.bias"].float().to(device)) for i in (1, 2)]
+
+
+class _Block:
+    """ConvNeXtBlock (:184-214)."""
+
+    def __init__(self, sd, p, dim, ks, device):
+        self.ks = ks
+        w = sd[p + ".dwconv.weight"].detach().float()  # [dim, 1, ks, ks]
+        self.dw_w = w.reshape(dim, ks * ks).t().contiguous().to(device)  # [ks*ks][dim]
+        sc, bi = ops.fold_bn(*_bn(sd, p + ".norm", 1e-6), conv_bias=sd[p + ".dwconv.bias"])
+        self.dw_scale, self.dw_bias = sc.to(device), bi.to(device)
+        self.pw1 = ops.Conv2d(sd[p + ".pwconv1.weight"], sd[p + ".pwconv1.bias"], act=ACT_GELU, device=device)
+        self.pw2 = ops.Conv2d(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], out_scale=sd[p + ".gamma"], device=device)
+
+
+class Ocr48Engine:
+    """encode(): u8 line crops of one chunk -> encoder memory; decode(): beam search over any number of lines."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], dict_size: int, device="cuda"):
+        self.device = dev = torch.device(device)
+        self.dict_size = dict_size
+        cbr = lambda p, i, s, pad: ops.Conv2d(sd[f"{p}.{i}.weight"], sd[f"{p}.{i}.bias"], stride=s, padding=pad,
+                                              bn=_bn(sd, f"{p}.{i + 1}"), act=ACT_RELU, device=dev)
+        b = "backbone."
+        self.stem = [cbr(b + "stem", 0, 1, 3), cbr(b + "stem", 3, 2, 0), cbr(b + "stem", 6, 1, 1)]
+        self.stages = []
+        for name, dim, n, ks in (("block1", 80, 4, 7), ("block2", 160, 12, 7), ("block3", 320, 10, 5), ("block4", 320, 8, 3)):
+            self.stages.append([_Block(sd, f"{b}{name}.{i}", dim, ks, dev) for i in range(n)])
+        self.downs = [cbr(b + "down1", 0, 2, 0), cbr(b + "down2", 0, (2, 1), 0), cbr(b + "down3", 0, (2, 1), 0),
+                      cbr(b + "down4", 0, 1, 0)]
+        self.enc = [_EncLayer(sd, f"encoders.{i}", dev) for i in range(4)]
+        self.tables = xpos_tables(sd["encoders.0.self_attn.xpos.scale"], dev)
+        self.xpos = MitXposTables()
+        self.xpos.cos_t, self.xpos.sin_t = self.tables["cos"].data_ptr(), self.tables["sin"].data_ptr()
+        self.xpos.scale_t, self.xpos.iscale_t = self.tables["scale"].data_ptr(), self.tables["iscale"].data_ptr()
+        self.xpos.imax, self.xpos.pmax = XPOS_IMAX, XPOS_PMAX
+        # ---- decoder weights (kept alive in self._keep) ----
+        self._keep: List = []
+        d = MitOcr48Decoder()
+        s = HEAD_DIM ** -0.5
+        self.mem_kv = []
+        for l in range(5):
+            p = f"decoders.{l}"
+            a, m = p + ".self_attn", p + ".multihead_attn"
+            col_scale = torch.cat([torch.full((EMBD,), s), torch.ones(2 * EMBD)])
+            lin = dict(
+                qkv=Linear(torch.cat([sd[f"{a}.{n}_proj.weight"] for n in "qkv"], 0),
+                           torch.cat([sd[f"{a}.{n}_proj.bias"] for n in "qkv"], 0), dev, col_scale),
+                out=Linear(sd[a + ".out_proj.weight"], sd[a + ".out_proj.bias"], dev),
+                q2=Linear(sd[m + ".q_proj.weight"], sd[m + ".q_proj.bias"], dev, torch.full((EMBD,), s)),
+                out2=Linear(sd[m + ".out_proj.weight"], sd[m + ".out_proj.bias"], dev),
+                ff1=Linear(sd[p + ".linear1.weight"], sd[p + ".linear1.bias"], dev),
+                ff2=Linear(sd[p + ".linear2.weight"], sd[p + ".linear2.bias"], dev))
+            self._keep.append(lin)
+            ly = d.layers[l]
+            for k, v in lin.items():
+                setattr(ly, k, v.c_struct())
+            for i in (1, 2, 3):
+                wt, bt = sd[f"{p}.norm{i}.weight"].float().to(dev), sd[f"{p}.norm{i}.bias"].float().to(dev)
+                self._keep += [wt, bt]
+                setattr(ly, f"ln{i}_w", wt.data_ptr())
+                setattr(ly, f"ln{i}_b", bt.data_ptr())
+            # cross-attention K|V projection of the encoder memory (done once per line at encode time)
+            self.mem_kv.append(Linear(torch.cat([sd[m + ".k_proj.weight"], sd[m + ".v_proj.weight"]], 0),
+                                      torch.cat([sd[m + ".k_proj.bias"], sd[m + ".v_proj.bias"]], 0), dev))
+        self.embd = sd["embd.weight"].detach().float().to(dev).contiguous()
+        self.pred1 = Linear(sd["pred1.0.weight"], sd["pred1.0.bias"], dev)
+        self.pred = Linear(sd["pred.weight"], sd["pred.bias"], dev)
+        self.color1 = Linear(sd["color_pred1.0.weight"], sd["color_pred1.0.bias"], dev)
+        heads = ("color_pred_fg", "color_pred_bg", "color_pred_fg_ind", "color_pred_bg_ind")
+        self.color_heads = Linear(torch.cat([sd[h + ".weight"] for h in heads], 0), torch.cat([sd[h + ".bias"] for h in heads], 0), dev)
+        d.embd = self.embd.data_ptr()
+        d.pred1, d.pred = self.pred1.c_struct(), self.pred.c_struct()
+        d.color1, d.color_heads = self.color1.c_struct(), self.color_heads.c_struct()
+        d.xpos = self.xpos
+        d.dict_size = dict_size
+        self.dec = d
+        self._ws: Dict[Tuple, torch.Tensor] = {}
+
+    def _buf(self, name, *shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.empty(*shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def release_workspace(self):
+        self._ws.clear()
+
+    # -- ConvNext_FeatureExtractor.forward (:262-276) -----------------------------------------
+    def _backbone(self, x: torch.Tensor, tag: str) -> torch.Tensor:
+        lib = _lib.load()
+        st = C.c_void_p(ops.current_stream())
+        for conv in self.stem:
+            x = conv(x, out=self._buf(f"{tag}.s{id(conv)}", x.shape[0], *conv.out_hw(x.shape[1], x.shape[2]), conv.Cout))
+        for si, (blocks, down) in enumerate(zip(self.stages, self.downs)):
+            B, H, W, Cc = x.shape
+            t = self._buf(f"{tag}.dw{si}", B, H, W, Cc)
+            h4 = self._buf(f"{tag}.h{si}", B, H, W, 4 * Cc)
+            for blk in blocks:
+                _lib.check(lib.mit_dwconv_nhwc(x.data_ptr(), blk.dw_w.data_ptr(), blk.dw_scale.data_ptr(), blk.dw_bias.data_ptr(),
+                                               t.data_ptr(), B, H, W, Cc, blk.ks, st), "mit_dwconv_nhwc")
+                blk.pw1(t, out=h4)
+                blk.pw2(h4, out=x, post=x)  # input + gamma * pwconv2(...), in place (:211-213)
+            x = down(x, out=self._buf(f"{tag}.d{si}", B, *down.out_hw(H, W), down.Cout))
+        return x
+
+    def _rotate(self, src, dst, R, T, i0, p0, downscale, src_rs, src_ts, dst_rs, dst_ts):
+        _lib.check(_lib.load().mit_xpos_rotate(src.data_ptr(), src_rs, src_ts, dst.data_ptr(), dst_rs, dst_ts, R, T, i0, p0,
+                                               int(downscale), C.byref(self.xpos), C.c_void_p(ops.current_stream())), "mit_xpos_rotate")
+
+    def _layernorm(self, x2d, w, b, out2d):
+        _lib.check(_lib.load().mit_layernorm(x2d.data_ptr(), x2d.stride(0), w.data_ptr(), b.data_ptr(), out2d.data_ptr(),
+                                             out2d.stride(0), x2d.shape[0], EMBD, 1e-5, C.c_void_p(ops.current_stream())), "mit_layernorm")
+
+    def _attention(self, q, k, v, out, klen, R, Tq, Tk, kv_div, strides):
+        (q_rs, q_ts), (k_rs, k_ts), (v_rs, v_ts), (o_rs, o_ts) = strides
+        _lib.check(_lib.load().mit_attention(q.data_ptr(), q_rs, q_ts, k.data_ptr(), k_rs, k_ts, v.data_ptr(), v_rs, v_ts,
+                                             out.data_ptr(), o_rs, o_ts, None if klen is None else klen.data_ptr(), R, Tq, Tk,
+                                             kv_div, C.c_void_p(ops.current_stream())), "mit_attention")
+
+    @torch.no_grad()
+    def encode(self, region_u8: torch.Tensor, widths: Sequence[int], taps: Optional[dict] = None):
+        """One reference chunk (:83-120 + :682-689): region_u8 [N,48,Wp,3] u8 (device), widths of the unpadded crops.
+
+        Returns (mem_k [5,N,L,320], mem_v [5,N,L,320], mem_len [N] int32, L): the per-decoder-layer cross-attention
+        keys (projected + XPOS-rotated for this chunk's length L) and values of the encoder memory."""
+        if region_u8.dtype != torch.uint8 or region_u8.dim() != 4 or region_u8.shape[1] != 48 or region_u8.shape[3] != 3:
+            raise ValueError(f"Ocr48Engine.encode expects u8 [N,48,Wp,3], got {region_u8.dtype} {tuple(region_u8.shape)}")
+        region_u8 = region_u8.contiguous()
+        N, _, Wp, _ = region_u8.shape
+        lib = _lib.load()
+        st = C.c_void_p(ops.current_stream())
+        tag = f"enc{N}x{Wp}"
+        x = self._buf(tag + ".in", N, 48, Wp, 4)
+        _lib.check(lib.mit_ocr_prep(region_u8.data_ptr(), x.data_ptr(), N, 48, Wp, st), "mit_ocr_prep")
+        feat = self._backbone(x, tag)  # [N,1,L,320]
+        L = feat.shape[2]
+        mem = feat.reshape(N * L, EMBD)  # 'N C 1 W -> N W C' is free in NHWC
+        if taps is not None:
+            taps["backbone"] = mem.reshape(N, L, EMBD).clone()
+        valid = torch.tensor([(w + 3) // 4 + 2 for w in widths], dtype=torch.int32)
+        klen = valid.clamp(max=L).to(self.device)
+        M = N * L
+        nrm = self._buf(tag + ".nrm", M, EMBD)
+        qkv = self._buf(tag + ".qkv", 3, M, EMBD)
+        qr = self._buf(tag + ".qr", M, EMBD)
+        kr = self._buf(tag + ".kr", M, EMBD)
+        att = self._buf(tag + ".att", M, EMBD)
+        ffh = self._buf(tag + ".ffh", M, FF)
+        minpos = -((L + 1) // 2)  # python: -(L) // 2
+        LE = L * EMBD
+        for ly in self.enc:  # transformer_encoder_forward (:278-292), norm_first
+            self._layernorm(mem, *ly.ln[0], nrm)
+            ly.qkv(nrm, qkv[0], nsplit=EMBD, nhi=M * EMBD)
+            self._rotate(qkv[0], qr, N, L, 0, minpos, False, LE, EMBD, LE, EMBD)
+            self._rotate(qkv[1], kr, N, L, 0, minpos, True, LE, EMBD, LE, EMBD)
+            self._attention(qr, kr, qkv[2], att, klen, N, L, L, 1, ((LE, EMBD),) * 4)
+            ly.out(att, mem, post=mem)
+            self._layernorm(mem, *ly.ln[1], nrm)
+            ly.ff1(nrm, ffh, act=ACT_RELU)
+            ly.ff2(ffh, mem, post=mem)
+        if taps is not None:
+            taps["memory"] = mem.reshape(N, L, EMBD).clone()
+        mem_k = torch.empty(5, N, L, EMBD, device=self.device)
+        mem_v = torch.empty(5, N, L, EMBD, device=self.device)
+        ktmp = self._buf(tag + ".ktmp", M, EMBD)
+        for l in range(5):
+            # one GEMM: K columns land in ktmp, V columns straight in mem_v[l] (column split with an arbitrary plane offset)
+            self.mem_kv[l](mem, ktmp, nsplit=EMBD, nhi=(mem_v[l].data_ptr() - ktmp.data_ptr()) // 4)
+            self._rotate(ktmp, mem_k[l], N, L, 0, minpos, True, LE, EMBD, LE, EMBD)
+        return mem_k, mem_v, klen, L
+
+    @torch.no_grad()
+    def decode(self, mem_k: torch.Tensor, mem_v: torch.Tensor, mem_len: torch.Tensor, max_seq_length: int = 255,
+               suppress_eos: bool = False, trace: bool = False):
+        """Beam search (:691-801) over N lines at once. mem_k/mem_v [5,N,L,320], mem_len [N] int32.
+
+        Returns a dict of device tensors: tokens [N,T+1] int32, length [N], prob [N], colors [N,T,10]
+        (+ trace_logits [T,N*5,dict], trace_hist when ``trace``)."""
+        _, N, L, _ = mem_k.shape
+        T = max_seq_length
+        lib = _lib.load()
+        nbytes = lib.mit_ocr48_decode_workspace_bytes(N, T, self.dict_size)
+        ws = self._buf("decode.ws", nbytes, dtype=torch.uint8)
+        dev = self.device
+        res_tok = torch.zeros(N, T + 1, dtype=torch.int32, device=dev)
+        res_len = torch.zeros(N, dtype=torch.int32, device=dev)
+        res_prob = torch.zeros(N, dtype=torch.float32, device=dev)
+        res_row = torch.zeros(N, dtype=torch.int32, device=dev)
+        colors = torch.empty(N * 5, T, 12, dtype=torch.float32, device=dev)
+        a = MitOcr48DecodeArgs()
+        a.N, a.L = N, L
+        a.mem_k, a.mem_v, a.mem_len = mem_k.contiguous().data_ptr(), mem_v.contiguous().data_ptr(), mem_len.data_ptr()
+        a.max_seq_length, a.start_tok, a.end_tok, a.max_finished, a.suppress_eos = T, 1, 2, 2, int(suppress_eos)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+        a.res_tok, a.res_len, a.res_prob, a.res_row, a.colors = (t.data_ptr() for t in (res_tok, res_len, res_prob, res_row, colors))
+        out = {}
+        if trace:
+            out["trace_logits"] = torch.zeros(T, N * 5, self.dict_size, device=dev)
+            out["trace_hist"] = torch.zeros(T, N * 5, T + 1, dtype=torch.int32, device=dev)
+            a.trace_logits, a.trace_hist = out["trace_logits"].data_ptr(), out["trace_hist"].data_ptr()
+        _lib.check(lib.mit_ocr48_decode(C.byref(self.dec), C.byref(a), C.c_void_p(ops.current_stream())), "mit_ocr48_decode")
+        sel = colors.reshape(N, 5, T, 12)[torch.arange(N, device=dev), (res_row.long() % 5)]
+        out.update(tokens=res_tok, length=res_len, prob=res_prob, colors=sel[..., :10], steps_run=a.steps_run)
+        return out
+
+    # -- host batching of Model48pxOCR._infer (:79-91) -----------------------------------------
+    @staticmethod
+    def make_chunks(region_imgs: List[np.ndarray], max_chunk_size: int = 16):
+        perm = sorted(range(len(region_imgs)), key=lambda i: region_imgs[i].shape[1])
+        for c in range(0, len(perm), max_chunk_size):
+            indices = perm[c:c + max_chunk_size]
+            widths = [region_imgs[i].shape[1] for i in indices]
+            max_width = 4 * (max(widths) + 7) // 4  # == max + 7, the reference's precedence quirk (:86)
+            region = np.zeros((len(indices), 48, max_width, 3), dtype=np.uint8)
+            for j, i in enumerate(indices):
+                region[j, :, :widths[j], :] = region_imgs[i]
+            yield indices, widths, region
+
+    @torch.no_grad()
+    def recognize(self, region_imgs: List[np.ndarray], max_seq_length: int = 255, suppress_eos: bool = False):
+        """All lines of one or more pages: per-chunk encode, one pooled decode. Results in the reference's chunk order."""
+        order, mks, mvs, lens = [], [], [], []
+        for indices, widths, region in self.make_chunks(region_imgs):
+            mk, mv, kl, L = self.encode(torch.from_numpy(region).to(self.device), widths)
+            order += indices
+            mks.append(mk)
+            mvs.append(mv)
+            lens.append(kl)
+        Lmax = max(m.shape[2] for m in mks)
+        pad = lambda m: m if m.shape[2] == Lmax else torch.cat([m, m.new_zeros(5, m.shape[1], Lmax - m.shape[2], EMBD)], 2)
+        mem_k, mem_v = torch.cat([pad(m) for m in mks], 1), torch.cat([pad(m) for m in mvs], 1)
+        out = self.decode(mem_k, mem_v, torch.cat(lens), max_seq_length, suppress_eos)
+        out["order"] = order
+        return out
+
+    @staticmethod
+    def backbone_flops(N: int, Wp: int) -> float:
+        """58.6 MFLOP per line x padded pixel column."""
+        return 58.6e6 * N * Wp
