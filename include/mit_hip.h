@@ -115,6 +115,19 @@ int mit_conv_gemm(const MitConvGemm *desc, void *stream);
 int mit_conv_gemm_cfg(const MitConvGemm *desc, int cfg, void *stream);
 const char *mit_conv_gemm_config_name(int cfg);
 
+/* kernel-time probe (measurement only; bench.py's roofline leg).  While enabled every mit_conv_gemm launch — from the
+ * host or from the native decoder loop — is bracketed by HIP events on its own stream; mit_prof_read synchronises those
+ * events and returns, per tile configuration, the launch count, the summed kernel time and the summed FLOPs
+ * (exec = 2*M*N*K*Z as launched; alg = the caller's figure given through mit_prof_tag_next for the next launch of
+ * this thread, else exec).  Nothing in the reference corresponds to it (the reference has no profiler hooks on this path). */
+typedef struct MitProfStat {
+    int64_t launches;
+    double ms, exec_flops, alg_flops;
+} MitProfStat;
+int mit_prof_enable(int on); /* clears the records; on != 0 starts recording */
+int mit_prof_tag_next(double alg_flops);
+int mit_prof_read(MitProfStat *stats, int max_cfgs, int *n_cfgs);
+
 /* LaMa inpainting stage: memory-bound pieces ----------------------------------------------
  * Reference: manga_translator/inpainting/inpainting_lama_mpe.py. */
 
@@ -225,6 +238,17 @@ typedef struct MitOcr48DecodeArgs {
     int32_t _pad;
 } MitOcr48DecodeArgs;
 
+/* One text line to rectify: cv2.warpPerspective of the page crop [y1:y1+ch, x1:x1+cw] to (dw, dh) with inverse map minv
+ * (row-major 3x3, destination -> crop coordinates), then ROTATE_90_COUNTERCLOCKWISE when vertical; the result lands in
+ * row out_row of the chunk tensor.  Replaces Quadrilateral.get_transformed_region (utils/generic.py:445-481). */
+typedef struct MitWarpLine {
+    double minv[9];
+    int32_t page, x1, y1, cw, ch, dw, dh, vertical, out_row, _pad;
+} MitWarpLine;
+/* pages u8 [P,H,W,3] -> chunk u8 [N,Hout,Wp,3], zero beyond each line's width (model_48px.py:83-91: np.zeros + copy).
+ * 8-bit bilinear with OpenCV's fixed-point rules (INTER_BITS 5, 15-bit weights), BORDER_CONSTANT 0. */
+int mit_ocr_warp_lines(const uint8_t *pages_dev, int H, int W, const MitWarpLine *lines_dev, int n_lines, uint8_t *out_dev,
+                       int Hout, int Wp, void *stream);
 int mit_ocr_prep(const uint8_t *lines_dev, float *out_dev, int N, int H, int Wp, void *stream);
 /* depthwise k x k conv + per-channel scale/bias (ConvNeXtBlock.dwconv + norm, model_48px.py:195-196,205-206). w [k*k][C]. */
 int mit_dwconv_nhwc(const float *in_dev, const float *w_dev, const float *scale_dev, const float *bias_dev, float *out_dev,

@@ -20,6 +20,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <vector>
 #include "../../include/mit_hip.h"
 #include "common.h"
 
@@ -325,7 +327,57 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     return 0;
 }
 
+// ---- kernel-time probe (mit_prof_*): HIP events around every launch while enabled ----
+struct ProbeRec {
+    hipEvent_t start, stop;
+    int cfg;
+    double exec_flops, alg_flops;
+};
+std::mutex g_probe_mu;
+bool g_probe_on = false;
+std::vector<ProbeRec> g_probe;
+thread_local double g_next_alg_flops = -1.0;
+
 }  // namespace
+
+extern "C" int mit_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    for (auto &r : g_probe) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    g_probe.clear();
+    g_probe_on = on != 0;
+    return 0;
+}
+
+extern "C" int mit_prof_tag_next(double alg_flops) {
+    g_next_alg_flops = alg_flops;
+    return 0;
+}
+
+extern "C" int mit_prof_read(MitProfStat *stats, int max_cfgs, int *n_cfgs) {
+    if (!stats || !n_cfgs) return mit_set_error("mit_prof_read: null");
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    const int n = max_cfgs < kNumCfgs ? max_cfgs : kNumCfgs;
+    for (int i = 0; i < n; ++i) {
+        stats[i].launches = 0;
+        stats[i].ms = stats[i].exec_flops = stats[i].alg_flops = 0.0;
+    }
+    for (auto &r : g_probe) {
+        MIT_CHECK_HIP(hipEventSynchronize(r.stop));
+        float ms = 0.f;
+        MIT_CHECK_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+        if (r.cfg < n) {
+            stats[r.cfg].launches += 1;
+            stats[r.cfg].ms += ms;
+            stats[r.cfg].exec_flops += r.exec_flops;
+            stats[r.cfg].alg_flops += r.alg_flops;
+        }
+    }
+    *n_cfgs = n;
+    return 0;
+}
 
 extern "C" const char *mit_conv_gemm_config_name(int cfg) {
     if (cfg < 0 || cfg >= kNumCfgs) return nullptr;
@@ -366,7 +418,24 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     const int Ktot = p.ntaps * p.Cin;
     const int KT = (Ktot + c.BK - 1) / c.BK;
     if ((int64_t)MT * NT > 0x7fffffffLL) return mit_set_error("mit_conv_gemm: grid too large");
-    c.launch(p, M, MT, NT, KT, reinterpret_cast<hipStream_t>(stream));
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    const double tagged = g_next_alg_flops;
+    g_next_alg_flops = -1.0;
+    if (g_probe_on) {
+        std::lock_guard<std::mutex> lk(g_probe_mu);
+        ProbeRec r;
+        MIT_CHECK_HIP(hipEventCreate(&r.start));
+        MIT_CHECK_HIP(hipEventCreate(&r.stop));
+        r.cfg = cfg;
+        r.exec_flops = 2.0 * (double)M * p.N * Ktot * p.Z;
+        r.alg_flops = tagged >= 0.0 ? tagged : r.exec_flops;
+        MIT_CHECK_HIP(hipEventRecord(r.start, hs));
+        c.launch(p, M, MT, NT, KT, hs);
+        MIT_CHECK_HIP(hipEventRecord(r.stop, hs));
+        g_probe.push_back(r);
+    } else {
+        c.launch(p, M, MT, NT, KT, hs);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mit_set_error("mit_conv_gemm: launch failed: %s", hipGetErrorString(e));
     return 0;

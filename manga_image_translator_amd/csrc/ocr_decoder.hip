@@ -176,7 +176,8 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
                                          hipMemcpyDeviceToDevice, s));
         MIT_CHECK_LAUNCH("mit_ocr48_decode");
         steps = step + 1;
-        if (step >= 1 && (step % 4 == 3) && step + 1 < T) {  // early exit (:765-766) without a per-step sync
+        if (!a->suppress_eos && step >= 1 && (step % 4 == 3) && step + 1 < T) {  // early exit (:765-766) without a per-step sync;
+            // with EOS suppressed no hypothesis can finish, so the loop stays fully asynchronous
             int dc = 0;
             MIT_CHECK_HIP(hipMemcpyAsync(&dc, w.done_count, 4, hipMemcpyDeviceToHost, s));
             MIT_CHECK_HIP(hipStreamSynchronize(s));

@@ -100,6 +100,16 @@ class MitOcr48DecodeArgs(C.Structure):
                 ("_pad", C.c_int32)]
 
 
+class MitProfStat(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("exec_flops", C.c_double), ("alg_flops", C.c_double)]
+
+
+class MitWarpLine(C.Structure):
+    _fields_ = [("minv", C.c_double * 9), ("page", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32), ("cw", C.c_int32),
+                ("ch", C.c_int32), ("dw", C.c_int32), ("dh", C.c_int32), ("vertical", C.c_int32), ("out_row", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
 # every symbol include/mit_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mit_last_error": (C.c_char_p, []),
@@ -109,6 +119,11 @@ SYMBOLS = {
     "mit_conv_gemm": (C.c_int, [C.POINTER(MitConvGemm), C.c_void_p]),
     "mit_conv_gemm_cfg": (C.c_int, [C.POINTER(MitConvGemm), C.c_int, C.c_void_p]),
     "mit_conv_gemm_config_name": (C.c_char_p, [C.c_int]),
+    "mit_prof_enable": (C.c_int, [C.c_int]),
+    "mit_prof_tag_next": (C.c_int, [C.c_double]),
+    "mit_prof_read": (C.c_int, [C.POINTER(MitProfStat), C.c_int, C.POINTER(C.c_int)]),
+    "mit_ocr_warp_lines": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_void_p]),
     "mit_lama_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_lama_mpe_index": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,

@@ -178,12 +178,15 @@ class Ocr48Engine:
         self._ws: Dict[Tuple, torch.Tensor] = {}
 
     def _buf(self, name, *shape, dtype=torch.float32):
-        key = (name, tuple(shape), dtype)
+        """Named workspace slab, grown to the largest request (chunk widths vary from call to call; all users are
+        ordered on one stream, so a slab can be re-viewed at a new shape by the next chunk)."""
+        n = max(int(math.prod(shape)), 1)
+        key = (name, dtype)
         t = self._ws.get(key)
-        if t is None:
-            t = torch.empty(*shape, dtype=dtype, device=self.device)
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=dtype, device=self.device)
             self._ws[key] = t
-        return t
+        return t[:n].view(*shape)
 
     def release_workspace(self):
         self._ws.clear()
@@ -192,8 +195,8 @@ class Ocr48Engine:
     def _backbone(self, x: torch.Tensor, tag: str) -> torch.Tensor:
         lib = _lib.load()
         st = C.c_void_p(ops.current_stream())
-        for conv in self.stem:
-            x = conv(x, out=self._buf(f"{tag}.s{id(conv)}", x.shape[0], *conv.out_hw(x.shape[1], x.shape[2]), conv.Cout))
+        for ci, conv in enumerate(self.stem):
+            x = conv(x, out=self._buf(f"{tag}.s{ci}", x.shape[0], *conv.out_hw(x.shape[1], x.shape[2]), conv.Cout))
         for si, (blocks, down) in enumerate(zip(self.stages, self.downs)):
             B, H, W, Cc = x.shape
             t = self._buf(f"{tag}.dw{si}", B, H, W, Cc)
@@ -220,8 +223,19 @@ class Ocr48Engine:
                                              out.data_ptr(), o_rs, o_ts, None if klen is None else klen.data_ptr(), R, Tq, Tk,
                                              kv_div, C.c_void_p(ops.current_stream())), "mit_attention")
 
+    @staticmethod
+    def memory_len(Wp: int) -> int:
+        """Backbone output length for a padded width Wp: the two k2 s2 convs floor it twice (:222-224,:237-239)."""
+        return (Wp // 2) // 2
+
+    @staticmethod
+    def valid_len(width: int, L: int) -> int:
+        """Unmasked memory positions of a line (:684-688)."""
+        return min((width + 3) // 4 + 2, L)
+
     @torch.no_grad()
-    def encode(self, region_u8: torch.Tensor, widths: Sequence[int], taps: Optional[dict] = None):
+    def encode(self, region_u8: torch.Tensor, widths: Sequence[int], taps: Optional[dict] = None,
+               klen: Optional[torch.Tensor] = None):
         """One reference chunk (:83-120 + :682-689): region_u8 [N,48,Wp,3] u8 (device), widths of the unpadded crops.
 
         Returns (mem_k [5,N,L,320], mem_v [5,N,L,320], mem_len [N] int32, L): the per-decoder-layer cross-attention
@@ -232,7 +246,7 @@ class Ocr48Engine:
         N, _, Wp, _ = region_u8.shape
         lib = _lib.load()
         st = C.c_void_p(ops.current_stream())
-        tag = f"enc{N}x{Wp}"
+        tag = "enc"
         x = self._buf(tag + ".in", N, 48, Wp, 4)
         _lib.check(lib.mit_ocr_prep(region_u8.data_ptr(), x.data_ptr(), N, 48, Wp, st), "mit_ocr_prep")
         feat = self._backbone(x, tag)  # [N,1,L,320]
@@ -240,8 +254,10 @@ class Ocr48Engine:
         mem = feat.reshape(N * L, EMBD)  # 'N C 1 W -> N W C' is free in NHWC
         if taps is not None:
             taps["backbone"] = mem.reshape(N, L, EMBD).clone()
-        valid = torch.tensor([(w + 3) // 4 + 2 for w in widths], dtype=torch.int32)
-        klen = valid.clamp(max=L).to(self.device)
+        if L != self.memory_len(Wp):
+            raise RuntimeError(f"backbone length {L} != memory_len({Wp})")
+        if klen is None:  # (a synchronous upload; batch callers pass a device tensor prepared up front)
+            klen = torch.tensor([self.valid_len(w, L) for w in widths], dtype=torch.int32).to(self.device)
         M = N * L
         nrm = self._buf(tag + ".nrm", M, EMBD)
         qkv = self._buf(tag + ".qkv", 3, M, EMBD)
@@ -334,6 +350,79 @@ class Ocr48Engine:
         mem_k, mem_v = torch.cat([pad(m) for m in mks], 1), torch.cat([pad(m) for m in mvs], 1)
         out = self.decode(mem_k, mem_v, torch.cat(lens), max_seq_length, suppress_eos)
         out["order"] = order
+        return out
+
+    @torch.no_grad()
+    def recognize_pages(self, pages_u8: torch.Tensor, quads_per_page, max_seq_length: int = 255, suppress_eos: bool = False,
+                        directions=None):
+        """Model48pxOCR._infer (:67-120) for a batch of pages resident on the device.
+
+        pages_u8 [P,H,W,3] u8; quads_per_page[p] = list of textline.Quadrilateral.  Each line is rectified on the GPU
+        (mit_ocr_warp_lines) straight into its chunk tensor — chunks are formed per page exactly as the reference does
+        (sorted by crop width, groups of 16, padded to max+7) — every chunk is encoded, and the lines of ALL pages are
+        decoded in one pooled beam search.  ``directions[p][i]`` overrides a line's own direction (the reference takes a
+        majority vote over merge-graph components, ocr/common.py:12-39).  Returns decode()'s dict plus ``order`` =
+        [(page, line)] in result-row order and ``widths``."""
+        from . import textline as TL
+        from .lib import MitWarpLine
+
+        if pages_u8.dtype != torch.uint8 or pages_u8.dim() != 4 or pages_u8.shape[-1] != 3:
+            raise ValueError(f"recognize_pages expects u8 [P,H,W,3], got {pages_u8.dtype} {tuple(pages_u8.shape)}")
+        pages_u8 = pages_u8.contiguous()
+        P, H, W, _ = pages_u8.shape
+        if len(quads_per_page) != P:
+            raise ValueError("one quad list per page expected")
+        chunks, order, all_widths, recs = [], [], [], []
+        for p, quads in enumerate(quads_per_page):
+            plans = [TL.warp_plan(q, (directions[p][i] if directions is not None else q.direction), H, W, 48)
+                     for i, q in enumerate(quads)]
+            for idx, ws, wp in TL.chunk_plan([pl.width for pl in plans]):
+                first = len(recs)
+                for row, i in enumerate(idx):
+                    pl = plans[i]
+                    r = MitWarpLine()
+                    r.minv[:] = pl.minv.reshape(-1).tolist()
+                    r.page, r.x1, r.y1, r.cw, r.ch, r.dw, r.dh = p, pl.x1, pl.y1, pl.cw, pl.ch, pl.dw, pl.dh
+                    r.vertical, r.out_row = int(pl.vertical), row
+                    recs.append(r)
+                    order.append((p, i))
+                all_widths += ws
+                chunks.append((first, len(idx), ws, wp))
+        if not recs:
+            return dict(order=[], widths=[], tokens=None)
+        arr = (MitWarpLine * len(recs))(*recs)
+        raw = bytes(arr)
+        klens = np.array([self.valid_len(w, self.memory_len(wp)) for _, _, ws, wp in chunks for w in ws], dtype=np.int32)
+        # one pinned staging buffer -> one asynchronous upload (a pageable copy would stall behind queued GPU work)
+        stage = torch.empty(len(raw) + klens.nbytes, dtype=torch.uint8, pin_memory=True)
+        stage[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        stage[len(raw):] = torch.from_numpy(klens.view(np.uint8))
+        table = stage.to(self.device, non_blocking=True)
+        lines_dev = table[:len(raw)]
+        klen_all = table[len(raw):].view(torch.int32)
+        lib = _lib.load()
+        st = C.c_void_p(ops.current_stream())
+        mks, mvs = [], []
+        rec_bytes = C.sizeof(MitWarpLine)
+        for first, n, ws, wp in chunks:
+            region = self._buf("region", n, 48, wp, 3, dtype=torch.uint8)
+            _lib.check(lib.mit_ocr_warp_lines(pages_u8.data_ptr(), H, W, lines_dev.data_ptr() + first * rec_bytes, n,
+                                              region.data_ptr(), 48, wp, st), "mit_ocr_warp_lines")
+            mk, mv, kl, L = self.encode(region, ws, klen=klen_all[first:first + n])
+            mks.append(mk)
+            mvs.append(mv)
+        Lmax = max(m.shape[2] for m in mks)
+        n_lines = len(recs)
+        mem_k = torch.zeros(5, n_lines, Lmax, EMBD, device=self.device)
+        mem_v = torch.zeros(5, n_lines, Lmax, EMBD, device=self.device)
+        r0 = 0
+        for mk, mv in zip(mks, mvs):
+            n, L = mk.shape[1], mk.shape[2]
+            mem_k[:, r0:r0 + n, :L].copy_(mk)
+            mem_v[:, r0:r0 + n, :L].copy_(mv)
+            r0 += n
+        out = self.decode(mem_k, mem_v, klen_all, max_seq_length, suppress_eos)
+        out["order"], out["widths"], out["_stage"] = order, all_widths, (stage, table)
         return out
 
     @staticmethod

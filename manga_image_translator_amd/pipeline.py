@@ -1,0 +1,122 @@
+"""The dense hot path of one page batch: detect (ctd) -> OCR (48px) -> inpaint (LaMa-MPE), all on one GPU.
+
+This is the batch-mode counterpart of the three ``_infer`` bodies the reference runs one page at a time
+(/root/reference/manga_translator/detection/ctd.py:129-179, ocr/model_48px.py:67-180,
+inpainting/inpainting_lama_mpe.py:56-118, driven by manga_translator.py:1491-1519).  Pages, quads and masks arrive as
+device-resident uint8 tensors and host-side ``Quadrilateral`` lists; only uint8 maps, token ids and a few floats per line
+leave the device.
+
+Everything is enqueued on the current HIP stream without intermediate synchronisation: the host's per-line planning
+for OCR overlaps the GPU's LaMa work of the same page group.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ctd, ctd_schema, lama, lama_schema, ocr48, ocr_schema, synth
+from .textline import Quadrilateral
+
+DICT_SIZE = 6004  # synthetic dictionary size; real runs take it from alphabet-all-v7.txt
+
+
+def synthetic_weights(seed: int = 0, lama_blocks: int = 9, dict_size: int = DICT_SIZE) -> Dict[str, Dict[str, torch.Tensor]]:
+    """Seeded random weights in the reference architectures' own state_dict layouts (no checkpoints exist offline)."""
+    g = ctd_schema.CTD_GAIN
+    w = {
+        "ctd.yolo": synth.synth_state_dict(ctd_schema.yolo_schema(), seed=seed, gain=g),
+        "ctd.seg": synth.synth_state_dict(ctd_schema.unet_head_schema(), seed=seed, gain=g),
+        "ctd.det": synth.synth_state_dict(ctd_schema.db_head_schema(), seed=seed, gain=g),
+        "ocr48": synth.synth_state_dict(ocr_schema.ocr48_schema(dict_size), seed=seed),
+        "lama.gen": synth.synth_state_dict(lama_schema.lama_generator_schema(lama_blocks), seed=seed),
+    }
+    if lama_blocks == 9:  # lama_mpe; lama_large (18 blocks) runs without MPE (inpainting_lama_mpe.py:132)
+        w["lama.mpe"] = synth.synth_state_dict(lama_schema.lama_mpe_schema(), seed=seed)
+    return w
+
+
+@dataclass
+class PageBatchResult:
+    """Device tensors produced by one ``PageEngine.run``."""
+    det_mask: torch.Tensor          # u8 [B, h, w]  postprocess_mask output before the resize to page size (ctd.py:30-44,152)
+    det_shrink: torch.Tensor        # u8 [B, h, w]  lines[:, 0] > 0.3 (db_utils.py:75), the representer's input bitmap
+    ocr_tokens: Optional[torch.Tensor]   # i32 [n_lines, T+1]
+    ocr_length: Optional[torch.Tensor]   # i32 [n_lines]
+    ocr_prob: Optional[torch.Tensor]     # f32 [n_lines]
+    ocr_colors: Optional[torch.Tensor]   # f32 [n_lines, T, 10]
+    ocr_order: List                      # [(page, line)] for every result row
+    inpainted: torch.Tensor         # u8 [B, H, W, 3]
+    keep: list = field(default_factory=list)  # staging buffers that must outlive the queued copies
+
+    def packed(self) -> torch.Tensor:
+        """All per-page results as one contiguous uint8 tensor (what the multi-GPU gather moves)."""
+        parts = [self.det_mask.reshape(-1), self.det_shrink.reshape(-1), self.inpainted.reshape(-1)]
+        if self.ocr_tokens is not None:
+            parts += [self.ocr_tokens.reshape(-1).view(torch.uint8), self.ocr_length.view(torch.uint8),
+                      self.ocr_prob.view(torch.uint8), self.ocr_colors.reshape(-1).view(torch.uint8)]
+        return torch.cat(parts)
+
+
+class PageEngine:
+    """Owns the three stage engines of one GPU."""
+
+    def __init__(self, weights: Dict[str, Dict[str, torch.Tensor]], device="cuda", lama_blocks: int = 9,
+                 dict_size: int = DICT_SIZE, ctd_mb: int = 8, lama_mb: int = 4, group: int = 8):
+        self.device = torch.device(device)
+        self.ctd = ctd.CtdEngine(weights["ctd.yolo"], weights["ctd.seg"], weights["ctd.det"], device=self.device)
+        self.ocr = ocr48.Ocr48Engine(weights["ocr48"], dict_size, device=self.device)
+        self.lama = lama.LamaEngine(weights["lama.gen"], weights.get("lama.mpe"), n_blocks=lama_blocks, device=self.device)
+        self.ctd_mb, self.lama_mb, self.group = ctd_mb, lama_mb, group
+
+    @torch.no_grad()
+    def run(self, pages_u8: torch.Tensor, quads_per_page: Sequence[Sequence[Quadrilateral]], masks_u8: torch.Tensor,
+            max_seq_length: int = 255, suppress_eos: bool = False, stages: Sequence[str] = ("detect", "ocr", "inpaint")
+            ) -> PageBatchResult:
+        """pages_u8 [B,H,W,3] u8, masks_u8 [B,H,W] u8 (0/255), both on the device; quads_per_page[b] = the page's text lines.
+
+        The stages are fed independently (detector: pages; OCR: pages + quads; inpainter: pages + masks) because the
+        reference's own stage coupling — contours, unclip, mask refinement — is host glue outside this path."""
+        B, H, W, _ = pages_u8.shape
+        nh, nw, dw, dh = self.ctd.letterbox_geometry(H, W)
+        S = ctd.INPUT_SIZE
+        dev = self.device
+        det_mask = torch.zeros(B, S - dh, S - dw, dtype=torch.uint8, device=dev)
+        det_shrink = torch.zeros(B, S - dh, S - dw, dtype=torch.uint8, device=dev)
+        inpainted = torch.empty(B, H, W, 3, dtype=torch.uint8, device=dev) if "inpaint" in stages else pages_u8
+        toks, lens, probs, cols, order, keep = [], [], [], [], [], []
+        for g0 in range(0, B, self.group):
+            g1 = min(B, g0 + self.group)
+            if "inpaint" in stages:  # GPU-heavy, host-light: queue it first so the host work below overlaps it
+                for i in range(g0, g1, self.lama_mb):
+                    j = min(g1, i + self.lama_mb)
+                    inpainted[i:j].copy_(self.lama.forward(pages_u8[i:j], masks_u8[i:j]))
+            if "detect" in stages:
+                for i in range(g0, g1, self.ctd_mb):
+                    j = min(g1, i + self.ctd_mb)
+                    m, lines, _ = self.ctd.forward(pages_u8[i:j])
+                    det_mask[i:j].copy_(m)
+                    det_shrink[i:j].copy_(self.ctd.shrink_bitmap(lines))
+            if "ocr" in stages:
+                r = self.ocr.recognize_pages(pages_u8[g0:g1], quads_per_page[g0:g1], max_seq_length, suppress_eos)
+                if r.get("tokens") is not None:
+                    toks.append(r["tokens"])
+                    lens.append(r["length"])
+                    probs.append(r["prob"])
+                    cols.append(r["colors"])
+                    order += [(g0 + p, i) for p, i in r["order"]]
+                    keep.append(r["_stage"])
+        cat = lambda xs: torch.cat(xs) if xs else None
+        return PageBatchResult(det_mask, det_shrink, cat(toks), cat(lens), cat(probs), cat(cols), order, inpainted, keep)
+
+    def flops_per_page(self, H: int, W: int, line_widths: Sequence[int], steps: int) -> Dict[str, float]:
+        """Algorithmic FLOPs of one page (SURVEY.md §8d conventions), per stage."""
+        ocr_bb = sum(58.6e6 * len(ws) * wp for ws, wp in line_widths)
+        return {"detect": self.ctd.flops_per_page(), "ocr_backbone": ocr_bb, "inpaint": self.lama.flops_per_page(H, W)}
+
+
+def quads_from_array(quads: np.ndarray) -> List[Quadrilateral]:
+    """int [K,4,2] corner arrays -> Quadrilateral objects."""
+    return [Quadrilateral(q) for q in np.asarray(quads)]

@@ -1,0 +1,136 @@
+"""Text-line rectification (mit_ocr_warp_lines) and the three-stage page pipeline vs the CPU oracle.
+
+Integer/byte work must be bit-exact: the rectified uint8 crops, the chunk packing, the detector's uint8 mask and
+thresholded bitmap (away from the stated fp32 margin), OCR token ids.  Floating point: OCR probabilities 1e-3 relative,
+LaMa uint8 output +-1 level only where the oracle's pre-truncation value is within 0.05 of an integer.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_quads(rng, H, W, n):
+    """Mix of axis-aligned, slightly rotated and perspective-skewed boxes, some touching the page border."""
+    quads = []
+    for k in range(n):
+        vertical = k % 2 == 0
+        bw, bh = (int(rng.integers(20, 40)), int(rng.integers(90, 200))) if vertical else (int(rng.integers(90, 200)), int(rng.integers(18, 40)))
+        x0, y0 = int(rng.integers(0, W - bw)), int(rng.integers(0, H - bh))
+        q = np.array([[x0, y0], [x0 + bw, y0], [x0 + bw, y0 + bh], [x0, y0 + bh]], dtype=np.int64)
+        if k % 3 == 1:  # rotate by a few degrees about the centre
+            a = np.deg2rad(rng.uniform(-8, 8))
+            c = q.mean(0)
+            R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+            q = np.rint((q - c) @ R.T + c).astype(np.int64)
+        elif k % 3 == 2:  # perspective-ish jitter
+            q = q + rng.integers(-4, 5, size=(4, 2))
+        if k == 0:
+            q[:, 0] -= q[:, 0].min()  # flush with the left border
+        quads.append(q)
+    return quads
+
+
+def test_warp_lines_bit_exact(cuda):
+    from manga_image_translator_amd import lib as L, ocr48, textline as TL
+    from oracle import textline as OT
+
+    rng = np.random.default_rng(5)
+    P, H, W = 2, 300, 420
+    pages = rng.integers(0, 256, size=(P, H, W, 3), dtype=np.uint8)
+    lib = L.load()
+    pages_dev = torch.from_numpy(pages).to(cuda)
+    for p in range(P):
+        quads = [TL.Quadrilateral(q) for q in _rand_quads(rng, H, W, 9)]
+        plans = [TL.warp_plan(q, q.direction, H, W) for q in quads]
+        for idx, ws, wp in TL.chunk_plan([pl.width for pl in plans], max_chunk_size=4):
+            recs = (L.MitWarpLine * len(idx))()
+            for row, i in enumerate(idx):
+                pl, r = plans[i], recs[row]
+                r.minv[:] = pl.minv.reshape(-1).tolist()
+                r.page, r.x1, r.y1, r.cw, r.ch, r.dw, r.dh, r.vertical, r.out_row = p, pl.x1, pl.y1, pl.cw, pl.ch, pl.dw, pl.dh, int(pl.vertical), row
+            rec_dev = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(cuda)
+            out = torch.full((len(idx), 48, wp, 3), 77, dtype=torch.uint8, device=cuda)
+            L.check(lib.mit_ocr_warp_lines(pages_dev.data_ptr(), H, W, rec_dev.data_ptr(), len(idx), out.data_ptr(), 48, wp, None))
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            for row, i in enumerate(idx):
+                q = quads[i]
+                ref = OT.get_transformed_region(pages[p], q.pts, q.direction, 48)
+                assert ref.shape == (48, ws[row], 3)
+                assert np.array_equal(got[row, :, :ws[row]], ref), f"page {p} line {i}: crop differs"
+                assert not got[row, :, ws[row]:].any(), "chunk padding must be zero"
+
+
+def test_recognize_pages_matches_host_chunking(cuda):
+    """recognize_pages (GPU warp + device chunk packing) == recognize() on oracle-made crops of the same lines."""
+    from manga_image_translator_amd import ocr48, ocr_schema, synth, textline as TL
+    from oracle import textline as OT
+
+    D = 97
+    eng = ocr48.Ocr48Engine(synth.synth_state_dict(ocr_schema.ocr48_schema(D)), D, device=cuda)
+    rng = np.random.default_rng(11)
+    H, W = 256, 384
+    page = rng.integers(0, 256, size=(1, H, W, 3), dtype=np.uint8)
+    quads = [TL.Quadrilateral(q) for q in _rand_quads(rng, H, W, 6)]
+    got = eng.recognize_pages(torch.from_numpy(page).to(cuda), [quads], max_seq_length=6, suppress_eos=True)
+    crops = [OT.get_transformed_region(page[0], q.pts, q.direction, 48) for q in quads]
+    ref = eng.recognize(crops, max_seq_length=6, suppress_eos=True)
+    torch.cuda.synchronize()
+    assert [i for _, i in got["order"]] == ref["order"]
+    assert torch.equal(got["tokens"].cpu(), ref["tokens"].cpu())
+    assert torch.allclose(got["prob"].cpu(), ref["prob"].cpu(), rtol=1e-5, atol=0)
+
+
+def test_page_pipeline_parity(cuda):
+    from manga_image_translator_amd import pipeline, synth
+    from oracle import ctd as OC, lama as OL, ocr48 as OO, textline as OT
+
+    D = 211
+    weights = pipeline.synthetic_weights(dict_size=D)
+    eng = pipeline.PageEngine(weights, device=cuda, dict_size=D, ctd_mb=2, lama_mb=2, group=2)
+    B, H, W, T = 3, 256, 192, 5
+    pages, quads, masks = zip(*[synth.synth_page(i, H, W, n_boxes=4) for i in range(B)])
+    qobjs = [pipeline.quads_from_array(q) for q in quads]
+    res = eng.run(torch.from_numpy(np.stack(pages)).to(cuda), qobjs, torch.from_numpy(np.stack(masks)).to(cuda),
+                  max_seq_length=T, suppress_eos=True)
+    torch.cuda.synchronize()
+    toks, probs = res.ocr_tokens.cpu().numpy(), res.ocr_prob.cpu().numpy()
+    row = 0
+    for b in range(B):
+        # detect: uint8 mask and thresholded bitmap
+        rmask, rlines = OC.infer_maps(weights["ctd.yolo"], weights["ctd.seg"], weights["ctd.det"], pages[b])
+        gm = res.det_mask[b].cpu().numpy()
+        assert gm.shape == rmask.shape
+        dm = gm.astype(np.int32) - rmask.astype(np.int32)
+        assert np.abs(dm).max() <= 1 and (dm != 0).mean() < 1e-2  # truncation of v*255 at an integer boundary
+        near = np.abs(rlines[0, 0] - 0.3) < 1e-4
+        gs = res.det_shrink[b].cpu().numpy().astype(bool)
+        assert np.array_equal(gs[~near], (rlines[0, 0] > 0.3)[~near]), "thresholded bitmap differs outside the 1e-4 margin"
+        # ocr: same crops, same chunks -> same tokens
+        crops = [OT.get_transformed_region(pages[b], q.pts, q.direction, 48) for q in qobjs[b]]
+        for indices, widths, img in OO.make_chunks(crops):
+            out = OO.infer_beam_batch_tensor(weights["ocr48"], img, widths, max_seq_length=T, suppress_eos=True)
+            for j, i in enumerate(indices):
+                assert res.ocr_order[row] == (b, i)
+                ref_tok = out[j][0].numpy()
+                n = int(res.ocr_length[row])
+                assert np.array_equal(toks[row, 1:n], ref_tok), (b, i, toks[row, :n], ref_tok)
+                assert abs(probs[row] - out[j][1]) <= 1e-3 * max(out[j][1], 1e-6) + 1e-7
+                row += 1
+        # inpaint
+        otaps = {}
+        ref = OL.infer(weights["lama.gen"], weights["lama.mpe"], pages[b], masks[b], 9, otaps)
+        diff = res.inpainted[b].cpu().numpy().astype(np.int32) - ref.astype(np.int32)
+        bad = np.argwhere(diff != 0)
+        if len(bad):
+            of = otaps["out_float"][0].permute(1, 2, 0).numpy() * 255.0
+            frac = np.abs(of - np.round(of))
+            assert np.abs(diff).max() <= 1 and all(frac[tuple(x)] < 0.05 for x in bad) and len(bad) < 1e-3 * diff.size
+    assert row == len(res.ocr_order)
+    # the packed gather payload covers every result tensor
+    assert res.packed().numel() == (res.det_mask.numel() + res.det_shrink.numel() + res.inpainted.numel()
+                                    + 4 * (res.ocr_tokens.numel() + res.ocr_length.numel() + res.ocr_prob.numel() + res.ocr_colors.numel()))
