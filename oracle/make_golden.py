@@ -1,0 +1,203 @@
+"""TEST INFRASTRUCTURE — generates the committed fixtures under tests/golden/ by running the REFERENCE's own code.
+
+Run in the build container (where /root/reference exists):   python -m oracle.make_golden
+
+The reference's tests hold no golden vectors for the dense path, so the pins are produced here by
+importing the reference's nn.Module / helper files by path (oracle/ref_import.py) and running them, fp32 on the CPU,
+on small seeded inputs with the seeded synthetic weights (manga_image_translator_amd/synth.py — the weights are
+regenerated from their seed wherever the fixtures are consumed, only inputs and outputs are stored).  Wherever the
+reference code calls OpenCV the call lands in ref_import.cv2_shim(), i.e. in the oracle's restatement of that
+primitive: what is pinned is the reference's Python + ATen path, not OpenCV's pixels.
+
+Fixtures (all small; each .npz also records the reference file whose code produced it):
+  lama_mpe.npz     LamaFourier(use_mpe=True).__call__  (inpainting_lama_mpe.py:713-726, :751-815)   64x72
+  lama_large.npz   LamaFourier(large_arch=True).__call__                                             48x40
+  ctd.npz          preprocess_img + TextDetBase.forward (ctd.py:17-28, ctd_utils/basemodel.py:234-238) 120x90 page
+  ocr48.npz        OCR.infer_beam_batch_tensor (ocr/model_48px.py:678-801) on 5 crops, dict 97, T = 9
+  textline.npz     sort_pnts / Quadrilateral / get_transformed_region (utils/generic.py:324-481) on 12 quads
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from manga_image_translator_amd import ctd_schema, lama_schema, ocr_schema, synth  # noqa: E402
+from oracle import ref_import as R  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+OCR_DICT = 97
+
+
+def build_ref_lama(n_blocks: int, mpe: bool):
+    L = R.lama()
+    L.cv2 = R.cv2_shim()
+    m = L.LamaFourier(build_discriminator=False, use_mpe=mpe, large_arch=(n_blocks == 18))
+    sd = synth.synth_state_dict(lama_schema.lama_generator_schema(n_blocks))
+    m.generator.load_state_dict(sd, strict=True)
+    mpe_sd = None
+    if mpe:
+        mpe_sd = synth.synth_state_dict(lama_schema.lama_mpe_schema())
+        m.mpe.load_state_dict(mpe_sd, strict=True)
+    return m.eval(), sd, mpe_sd
+
+
+def ref_lama_infer(m, image: np.ndarray, mask: np.ndarray):
+    """The tensor part of LamaMPEInpainter._infer (:82-117) around the reference model (no resize: H, W % 8 == 0)."""
+    img_t = torch.from_numpy(image).permute(2, 0, 1).unsqueeze(0).float() / 255.0
+    mask_t = torch.from_numpy(mask).unsqueeze(0).unsqueeze(0).float() / 255.0
+    mask_t[mask_t < 0.5] = 0
+    mask_t[mask_t >= 0.5] = 1
+    with torch.no_grad():
+        img_t = img_t * (1 - mask_t)
+        out = m(img_t, mask_t)
+    return out
+
+
+def golden_lama():
+    for name, nb, mpe, (H, W), seed in (("lama_mpe", 9, True, (64, 72), 3), ("lama_large", 18, False, (48, 40), 4)):
+        m, _, _ = build_ref_lama(nb, mpe)
+        page, _, mask = synth.synth_page(seed, H, W, n_boxes=3)
+        mask[5, 7] = 127
+        out = ref_lama_infer(m, page, mask)
+        extra = {}
+        if mpe:
+            mk = (mask.astype(np.float32) / 255.0 >= 0.5).astype(np.float32)
+            rel, ab, direct = m.load_masked_position_encoding(mk)
+            extra = dict(rel_pos=rel.astype(np.int32), direct=direct.astype(np.int8))
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), page=page, mask=mask, out_float=out.numpy(),
+                            n_blocks=nb, source="manga_translator/inpainting/inpainting_lama_mpe.py", **extra)
+        print(name, out.shape, float(out.mean()))
+
+
+def build_ref_ctd():
+    bm, yolo = R.ctd()
+    shim = R.cv2_shim()
+    g = ctd_schema.CTD_GAIN
+    ysd = synth.synth_state_dict(ctd_schema.yolo_schema(), gain=g)
+    ssd = synth.synth_state_dict(ctd_schema.unet_head_schema(), gain=g)
+    dsd = synth.synth_state_dict(ctd_schema.db_head_schema(), gain=g)
+    holder = torch.nn.Module()
+    holder.blk_det = yolo.load_yolov5_ckpt({"cfg": ctd_schema.YOLOV5S_CFG, "weights": ysd})
+    holder.text_seg = bm.UnetHead(act="leaky")
+    holder.text_seg.load_state_dict(ssd, strict=True)
+    holder.text_det = bm.DBHead(64, act="leaky")
+    holder.text_det.load_state_dict(dsd, strict=True)
+    holder.eval()
+    fwd = lambda x: bm.TextDetBase.forward(holder, x)
+    return fwd, shim, (ysd, ssd, dsd)
+
+
+def golden_ctd():
+    fwd, shim, _ = build_ref_ctd()
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "_ref_imgproc", os.path.join(R.PKG, "detection/ctd_utils/utils/imgproc_utils.py"))
+    ip = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ip)
+    ip.cv2 = shim
+    page = synth.synth_page(7, 120, 90, n_boxes=3)[0]
+    # preprocess_img (ctd.py:17-28) with the reference's own letterbox(); the BGR2RGB + [::-1] pair cancels
+    img_in, ratio, (dw, dh) = ip.letterbox(page, new_shape=(128, 128), auto=False, stride=64)
+    x = torch.from_numpy(np.ascontiguousarray(img_in.transpose(2, 0, 1))[None].astype(np.float32) / 255)
+    with torch.no_grad():
+        _, mask, lines = fwd(x)
+    np.savez_compressed(os.path.join(GOLDEN, "ctd.npz"), page=page, net_in=x.numpy(), mask=mask.numpy(), lines=lines.numpy(),
+                        dw=dw, dh=dh, source="manga_translator/detection/ctd_utils/basemodel.py + utils/imgproc_utils.py")
+    print("ctd", mask.shape, lines.shape, float(mask.mean()), float(lines.mean()), (dw, dh))
+
+
+def build_ref_ocr():
+    M = R.ocr48()
+    dictionary = [f"c{i}" for i in range(OCR_DICT)]
+    model = M.OCR(dictionary, 768)
+    sd = synth.synth_state_dict(ocr_schema.ocr48_schema(OCR_DICT))
+    model.load_state_dict(sd, strict=True)
+    return model.eval(), sd
+
+
+def golden_ocr():
+    model, _ = build_ref_ocr()
+    rng = np.random.default_rng(21)
+    widths = [41, 58, 90, 91, 133]
+    Wp = max(widths) + 7
+    region = np.zeros((len(widths), 48, Wp, 3), dtype=np.uint8)
+    for i, w in enumerate(widths):
+        region[i, :, :w] = rng.integers(0, 256, size=(48, w, 3), dtype=np.uint8)
+    img = ((torch.from_numpy(region).float() - 127.5) / 127.5).permute(0, 3, 1, 2).contiguous()
+    T = 9
+    with torch.no_grad():
+        res = model.infer_beam_batch_tensor(img, widths, beams_k=5, max_seq_length=T)
+        mem = model.backbone(img).squeeze(2).permute(0, 2, 1)
+    tok = np.zeros((len(widths), T + 1), dtype=np.int64)
+    ln = np.zeros(len(widths), dtype=np.int64)
+    prob = np.zeros(len(widths), dtype=np.float64)
+    cols = np.zeros((len(widths), T + 1, 10), dtype=np.float32)
+    for i, (idx, p, fg, bg, fgi, bgi) in enumerate(res):
+        n = len(idx)
+        tok[i, :n], ln[i], prob[i] = idx.numpy(), n, float(p)
+        cols[i, :n] = torch.cat([fg, bg, fgi, bgi], dim=-1).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "ocr48.npz"), region=region, widths=np.array(widths), T=T, tokens=tok, length=ln,
+                        prob=prob, colors=cols, backbone=mem.numpy(), dict_size=OCR_DICT,
+                        source="manga_translator/ocr/model_48px.py")
+    print("ocr48", tok[:, :6], ln, prob)
+
+
+def golden_textline():
+    G = R.generic()
+    G.cv2 = R.cv2_shim()
+    rng = np.random.default_rng(9)
+    H, W = 200, 260
+    img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    quads, sorted_pts, dirs, crops, ratios, fonts = [], [], [], [], [], []
+    for k in range(12):
+        vertical = k % 2 == 0
+        bw, bh = (int(rng.integers(14, 30)), int(rng.integers(60, 150))) if vertical else (int(rng.integers(60, 150)), int(rng.integers(12, 30)))
+        x0, y0 = int(rng.integers(0, W - bw)), int(rng.integers(0, H - bh))
+        q = np.array([[x0, y0], [x0 + bw, y0], [x0 + bw, y0 + bh], [x0, y0 + bh]], dtype=np.int64)
+        if k % 3 == 1:
+            a = np.deg2rad(rng.uniform(-9, 9))
+            c = q.mean(0)
+            q = np.rint((q - c) @ np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]).T + c).astype(np.int64)
+        elif k % 3 == 2:
+            q = q + rng.integers(-3, 4, size=(4, 2))
+        q = q[rng.permutation(4)]  # arbitrary corner order in, canonical order out
+        quad = G.Quadrilateral(q.copy(), "", 0)
+        region = quad.get_transformed_region(img, quad.direction, 48)
+        quads.append(q)
+        sorted_pts.append(np.asarray(quad.pts))
+        dirs.append(quad.direction)
+        ratios.append(quad.aspect_ratio)
+        fonts.append(quad.font_size)
+        crops.append(region)
+    wmax = max(c.shape[1] for c in crops)
+    packed = np.zeros((len(crops), 48, wmax, 3), dtype=np.uint8)
+    for i, c in enumerate(crops):
+        packed[i, :, :c.shape[1]] = c
+    np.savez_compressed(os.path.join(GOLDEN, "textline.npz"), image=img, quads=np.array(quads), sorted_pts=np.array(sorted_pts),
+                        direction=np.array(dirs), aspect_ratio=np.array(ratios), font_size=np.array(fonts),
+                        crops=packed, crop_width=np.array([c.shape[1] for c in crops]),
+                        source="manga_translator/utils/generic.py")
+    print("textline", dirs, [c.shape for c in crops][:4])
+
+
+def main():
+    if not R.available():
+        raise SystemExit("/root/reference is not present: fixtures can only be regenerated in the build container")
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    golden_textline()
+    golden_ocr()
+    golden_ctd()
+    golden_lama()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,3 +104,60 @@ def ctd():
     yolo = _load(base + ".yolov5.yolo", "detection/ctd_utils/yolov5/yolo.py")
     bm = _load(base + ".basemodel", "detection/ctd_utils/basemodel.py")
     return bm, yolo
+
+
+def generic():
+    """reference module manga_translator/utils/generic.py (sort_pnts, Quadrilateral, ...), loaded under a private
+    package name so the MagicMock standing in for ``manga_translator.utils`` elsewhere is untouched."""
+    _prepare()
+    if "_ref_utils" not in sys.modules:
+        pk = types.ModuleType("_ref_utils")
+        pk.__path__ = []
+        sys.modules["_ref_utils"] = pk
+    _load("_ref_utils.generic2", "utils/generic2.py")
+    return _load("_ref_utils.generic", "utils/generic.py")
+
+
+def cv2_shim():
+    """A stand-in ``cv2`` namespace built from the oracle's restatements of the few OpenCV calls on the path, so the
+    reference's OWN Python around those calls (letterbox, load_masked_position_encoding's ring loop,
+    get_transformed_region) can be executed here.  The primitives themselves stay "parity unpinned" (no real cv2)."""
+    import numpy as np
+
+    from . import ctd as OC, lama as OL, textline as OT
+
+    ns = types.SimpleNamespace()
+    ns.INTER_NEAREST, ns.INTER_LINEAR, ns.INTER_AREA = 0, 1, 3
+    ns.BORDER_CONSTANT, ns.RANSAC, ns.ROTATE_90_COUNTERCLOCKWISE = 0, 8, 2
+    ns.COLOR_BGR2RGB, ns.COLOR_RGB2BGR = 4, 4
+
+    def resize(src, dsize, interpolation=1, **_):
+        if interpolation == ns.INTER_AREA:
+            return OL.resize_area_u8(src, dsize)
+        if interpolation == ns.INTER_NEAREST:
+            return OL.resize_nearest(src, dsize)
+        if interpolation == ns.INTER_LINEAR:
+            return OC.resize_linear_u8(src, dsize)
+        raise NotImplementedError(interpolation)
+
+    def filter2D(src, ddepth, kernel):
+        p = np.pad(src, 1, mode="reflect")
+        h, w = src.shape
+        out = np.zeros_like(src)
+        for ky in range(3):
+            for kx in range(3):
+                out = out + kernel[ky, kx] * p[ky:ky + h, kx:kx + w]
+        return out
+
+    def copyMakeBorder(src, top, bottom, left, right, borderType, value=(0, 0, 0)):
+        out = np.zeros((src.shape[0] + top + bottom, src.shape[1] + left + right) + src.shape[2:], dtype=src.dtype)
+        out[...] = np.asarray(value, dtype=src.dtype)[:src.shape[2]] if src.ndim == 3 else value
+        out[top:top + src.shape[0], left:left + src.shape[1]] = src
+        return out
+
+    ns.resize, ns.filter2D, ns.copyMakeBorder = resize, filter2D, copyMakeBorder
+    ns.cvtColor = lambda src, code: src[..., ::-1]
+    ns.findHomography = lambda s, d, *a, **k: (OT.find_homography_4pt(s, d), None)
+    ns.warpPerspective = lambda img, M, dsize, **k: OT.warp_perspective_u8(img, M, dsize)
+    ns.rotate = lambda img, code: np.ascontiguousarray(np.rot90(img, 1))
+    return ns

@@ -1,0 +1,71 @@
+"""The C-ABI library: loads, exports every function include/mit_hip.h declares, and the ctypes mirror of every struct
+has the C compiler's size and field offsets (gcc compiles a probe against the real header).  No compute calls: those
+are the ``-m gpu`` tests."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mit_hip.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mit_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from manga_image_translator_amd import lib
+
+    handle = lib.load(build_if_missing=True)
+    names = _declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in mit_hip.h but not exported by libmit_hip.so"
+        assert n in lib.SYMBOLS, f"{n} has no ctypes prototype in lib.SYMBOLS"
+    assert set(lib.SYMBOLS) <= set(names), sorted(set(lib.SYMBOLS) - set(names))
+    assert handle.mit_abi_version() == lib.MIT_ABI_VERSION
+    assert handle.mit_conv_gemm_config_name(0) == b"128x128x16" and handle.mit_conv_gemm_config_name(99) is None
+
+
+def test_error_channel_without_gpu():
+    """Argument validation happens before any HIP call, so it is observable on a CPU-only box."""
+    from manga_image_translator_amd import lib
+
+    handle = lib.load()
+    assert handle.mit_conv_gemm(None, None) != 0
+    assert b"null descriptor" in handle.mit_last_error()
+    d = lib.MitConvGemm()
+    assert handle.mit_conv_gemm(C.byref(d), None) != 0
+    assert b"null operand" in handle.mit_last_error()
+    with pytest.raises(RuntimeError, match="null operand"):
+        lib.check(1, "probe")
+    assert handle.mit_ocr_warp_lines(None, 1, 1, None, 0, None, 48, 8, None) != 0
+
+
+def test_ctypes_structs_match_c_layout(tmp_path):
+    from manga_image_translator_amd import lib
+
+    structs = {"MitTensorMap": lib.MitTensorMap, "MitConvGemm": lib.MitConvGemm, "MitXposTables": lib.MitXposTables,
+               "MitLinear": lib.MitLinear, "MitOcrDecoderLayer": lib.MitOcrDecoderLayer, "MitOcr48Decoder": lib.MitOcr48Decoder,
+               "MitOcr48DecodeArgs": lib.MitOcr48DecodeArgs, "MitProfStat": lib.MitProfStat, "MitWarpLine": lib.MitWarpLine}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for name, st in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for fname, *_ in st._fields_:
+            lines.append(f'printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-std=c11", str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, st in structs.items():
+        assert int(out[name]) == C.sizeof(st), name
+        for fname, *_ in st._fields_:
+            assert int(out[f"{name}.{fname}"]) == getattr(st, fname).offset, f"{name}.{fname}"

@@ -1,0 +1,111 @@
+"""Host logic of the operators (no GPU): the descriptors built by ops.Conv2d / ops.ConvTranspose2d / fold_bn, evaluated by
+the numpy descriptor emulator (tests/_desc_emulator.py, the documented semantics of include/mit_hip.h), reproduce
+torch's conv2d / conv_transpose2d + eval BatchNorm + activation on the CPU.  The same descriptors are what the GPU
+kernel receives, so this pins packing, tap tables, padding modes, strided views and epilogue folding on their own."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _desc_emulator as EMU
+from manga_image_translator_amd import ops
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _bn_params(c, g):
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1,
+            torch.rand(c, generator=g) + 0.5, 1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,mode,act", [
+    (4, 8, 3, 1, 1, ops.PAD_REFLECT, ops.ACT_RELU), (8, 5, 3, 2, 1, ops.PAD_REFLECT, ops.ACT_NONE),
+    (3, 6, 7, 1, 3, ops.PAD_REFLECT, ops.ACT_SIGMOID), (3, 8, 6, 2, 2, ops.PAD_ZERO, ops.ACT_SILU),
+    (12, 7, 1, 1, 0, ops.PAD_ZERO, ops.ACT_LEAKY), (4, 4, (3, 1), (2, 1), 0, ops.PAD_ZERO, ops.ACT_GELU)])
+def test_conv2d_descriptor(cin, cout, k, s, p, mode, act):
+    g = torch.Generator().manual_seed(1)
+    kh, kw = (k, k) if isinstance(k, int) else k
+    w = torch.randn(cout, cin, kh, kw, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) * 0.1
+    bn = _bn_params(cout, g)
+    x = torch.randn(2, cin, 9, 11, generator=g)
+    layer = ops.Conv2d(w, b, stride=s, padding=p, pad_mode=mode, bn=bn, act=act, alpha=0.1, device="cpu")
+    xin = _nhwc(x)
+    if layer.Cin != cin:
+        xin = torch.cat([xin, torch.zeros(*xin.shape[:3], layer.Cin - cin)], dim=-1).contiguous()
+    Ho, Wo = layer.out_hw(9, 11)
+    out = torch.full((2, Ho, Wo, cout), float("nan"))
+    post = torch.randn(2, Ho, Wo, cout, generator=g)
+    EMU.run(layer.desc(xin, out, post=post))
+    pad = (p, p) if isinstance(p, int) else p
+    xp = F.pad(x, (pad[1], pad[1], pad[0], pad[0]), mode="reflect") if (mode == ops.PAD_REFLECT and max(pad) > 0) else x
+    ref = F.conv2d(xp, w, b, stride=s, padding=0 if mode == ops.PAD_REFLECT else p)
+    ref = F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, bn[4])
+    ref = {ops.ACT_RELU: torch.relu, ops.ACT_NONE: lambda v: v, ops.ACT_SIGMOID: torch.sigmoid, ops.ACT_SILU: F.silu,
+           ops.ACT_LEAKY: lambda v: F.leaky_relu(v, 0.1), ops.ACT_GELU: F.gelu}[act](ref)
+    ref = _nhwc(ref) + post
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5), (out - ref).abs().max()
+
+
+@pytest.mark.parametrize("k,s,p,op", [(3, 2, 1, 1), (4, 2, 1, 0), (2, 2, 0, 0)])
+def test_conv_transpose_subpixel_descriptors(k, s, p, op):
+    g = torch.Generator().manual_seed(2)
+    cin, cout = 8, 6
+    w = torch.randn(cin, cout, k, k, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) * 0.1
+    bn = _bn_params(cout, g)
+    x = torch.randn(2, cin, 5, 7, generator=g)
+    layer = ops.ConvTranspose2d(w, b, stride=s, padding=p, output_padding=op, bn=bn, act=ops.ACT_RELU, device="cpu")
+    Ho, Wo = layer.out_hw(5, 7)
+    big = torch.full((2, Ho, Wo, cout + 3), float("nan"))  # output is a channel slice of a wider (concat) buffer
+    out = big[..., 2:2 + cout]
+    xin = _nhwc(x)  # keep alive: descriptors hold raw pointers
+    for d in layer.descs(xin, out):
+        EMU.run(d)
+    ref = F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op)
+    ref = torch.relu(F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, bn[4]))
+    assert torch.allclose(out, _nhwc(ref), atol=2e-5, rtol=1e-5)
+    assert torch.isnan(big[..., :2]).all() and torch.isnan(big[..., 2 + cout:]).all(), "neighbouring channels untouched"
+
+
+def test_fold_bn_matches_batchnorm():
+    g = torch.Generator().manual_seed(3)
+    bn = _bn_params(16, g)
+    x = torch.randn(4, 16, 3, 3, generator=g)
+    cb = torch.randn(16, generator=g)
+    sc, bi = ops.fold_bn(*bn, conv_bias=cb)
+    ref = F.batch_norm(x + cb[None, :, None, None], bn[2], bn[3], bn[0], bn[1], False, 0.0, bn[4])
+    assert torch.allclose(x * sc[None, :, None, None] + bi[None, :, None, None], ref, atol=1e-5)
+
+
+def test_descriptor_validation_errors():
+    with pytest.raises(TypeError):
+        ops.tensor_map(torch.zeros(1, 2, 2, 4, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        ops.tensor_map(torch.zeros(1, 4, 2, 2).permute(0, 2, 3, 1)[..., ::2])
+    layer = ops.Conv2d(torch.zeros(4, 8, 1, 1), device="cpu")
+    with pytest.raises(ValueError):
+        layer.desc(torch.zeros(1, 2, 2, 4), torch.zeros(1, 2, 2, 4))
+    with pytest.raises(ValueError):
+        ops.ConvTranspose2d(torch.zeros(6, 4, 2, 2), device="cpu")
+
+
+def test_lama_dft_matrices_are_the_ortho_rfft2():
+    """The FourierUnit's rfftn/irfftn (inpainting_lama_mpe.py:228,252) as dense DFT matrices: F1/G2 reproduce
+    torch.fft.rfftn(norm='ortho') and G2i/Fi its inverse, for an odd and an even, non-power-of-two width."""
+    from manga_image_translator_amd.lama import dft_matrices
+
+    for h, w in ((8, 11), (6, 14)):
+        F1, G2, G2i, Fi = (m.double() for m in dft_matrices(h, w))
+        wk = w // 2 + 1
+        x = torch.randn(h, w, dtype=torch.float64, generator=torch.Generator().manual_seed(h * w))
+        Y = F1[:, :w] @ x.t()                     # [(t,kw), h]
+        Yre, Yim = Y[:wk].t(), Y[wk:].t()          # [h, wk]
+        Z = G2[:, :2 * h] @ torch.cat([Yre, Yim], 0)  # [(t',kh), wk]
+        ref = torch.fft.rfftn(x, dim=(-2, -1), norm="ortho")
+        assert torch.allclose(Z[:h], ref.real, atol=1e-6) and torch.allclose(Z[h:], ref.imag, atol=1e-6)
+        U = G2i[:, :2 * h] @ Z                     # [(t,h), wk]
+        back = torch.cat([U[:h], U[h:]], 1) @ Fi[:, :2 * wk].t()  # [h, w]
+        assert torch.allclose(back, x, atol=1e-6)

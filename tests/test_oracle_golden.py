@@ -1,0 +1,93 @@
+"""The CPU oracle vs the committed golden vectors (tests/golden/*.npz, produced by oracle/make_golden.py from the
+REFERENCE's own modules).  Runs anywhere (no /root/reference, no GPU).
+
+Tolerances: both sides are fp32 ATen on a CPU, but thread count / ISA may differ between the machine that made the
+fixture and this one, so floats are compared at 2e-5 absolute on O(1) activations (observed: bit-equal to 1e-6);
+integer outputs (MPE maps, token ids, canonical corner order, rectified crops) must be identical.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name,mpe", [("lama_mpe.npz", True), ("lama_large.npz", False)])
+def test_lama_oracle_matches_reference_fixture(name, mpe):
+    from manga_image_translator_amd import lama_schema, synth
+    from oracle import lama as OL
+
+    g = _load(name)
+    nb = int(g["n_blocks"])
+    sd = synth.synth_state_dict(lama_schema.lama_generator_schema(nb))
+    mpe_sd = synth.synth_state_dict(lama_schema.lama_mpe_schema()) if mpe else None
+    taps = {}
+    OL.infer(sd, mpe_sd, g["page"], g["mask"], nb, taps)
+    err = np.abs(taps["out_float"].numpy() - g["out_float"]).max()
+    assert err < 2e-5, err
+    if mpe:
+        mk = (g["mask"].astype(np.float32) / 255.0 >= 0.5).astype(np.float32)
+        rel, _, direct = OL.load_masked_position_encoding(mk)
+        assert np.array_equal(rel, g["rel_pos"]) and np.array_equal(direct, g["direct"])
+        assert rel.max() > 0 and direct.any()
+
+
+def test_ctd_oracle_matches_reference_fixture():
+    from manga_image_translator_amd import ctd_schema as S, synth
+    from oracle import ctd as OC
+
+    g = _load("ctd.npz")
+    gain = S.CTD_GAIN
+    ysd = synth.synth_state_dict(S.yolo_schema(), gain=gain)
+    ssd = synth.synth_state_dict(S.unet_head_schema(), gain=gain)
+    dsd = synth.synth_state_dict(S.db_head_schema(), gain=gain)
+    x, ratio, dw, dh = OC.preprocess_img(g["page"], input_size=(128, 128))
+    assert (dw, dh) == (int(g["dw"]), int(g["dh"]))
+    assert np.array_equal(x.numpy(), g["net_in"]), "letterbox / normalisation differs from the reference's preprocess"
+    with torch.no_grad():
+        mask, lines = OC.textdet_forward(ysd, ssd, dsd, x)
+    assert np.abs(mask.numpy() - g["mask"]).max() < 2e-5
+    assert np.abs(lines.numpy() - g["lines"]).max() < 2e-5
+    assert 0.02 < g["mask"].mean() < 0.98 and g["lines"].std() > 0.01  # the fixture is not a saturated constant
+
+
+def test_ocr_oracle_matches_reference_fixture():
+    from manga_image_translator_amd import ocr_schema, synth
+    from oracle import ocr48 as OO
+
+    g = _load("ocr48.npz")
+    D, T = int(g["dict_size"]), int(g["T"])
+    sd = synth.synth_state_dict(ocr_schema.ocr48_schema(D))
+    widths = g["widths"].tolist()
+    img = ((torch.from_numpy(g["region"]).float() - 127.5) / 127.5).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        bb = OO.backbone(sd, img).squeeze(2).permute(0, 2, 1).numpy()
+        res = OO.infer_beam_batch_tensor(sd, img, widths, max_seq_length=T)
+    assert np.abs(bb - g["backbone"]).max() < 2e-5 * max(1.0, np.abs(g["backbone"]).max())
+    for i, (idx, prob, fg, bg, fgi, bgi) in enumerate(res):
+        n = int(g["length"][i])
+        assert idx.tolist() == g["tokens"][i, :n].tolist()
+        assert abs(prob - g["prob"][i]) < 1e-4 * g["prob"][i]
+        col = torch.cat([fg, bg, fgi, bgi], dim=-1).numpy()
+        assert np.abs(col - g["colors"][i, :n]).max() < 1e-4
+
+
+def test_textline_oracle_matches_reference_fixture():
+    from oracle import textline as OT
+
+    g = _load("textline.npz")
+    for k in range(len(g["quads"])):
+        sp, vert = OT.sort_pnts(g["quads"][k])
+        assert np.array_equal(sp, g["sorted_pts"][k])
+        d = "v" if vert else "h"
+        assert d == str(g["direction"][k])
+        crop = OT.get_transformed_region(g["image"], sp, d, 48)
+        w = int(g["crop_width"][k])
+        assert crop.shape == (48, w, 3)
+        assert np.array_equal(crop, g["crops"][k, :, :w])
