@@ -1,0 +1,359 @@
+"""Drop-in detector / OCR / inpainter plugins: the reference's plugin interface over the gfx950 engine.
+
+Each class honours the contract of its reference counterpart:
+
+  HipComicTextDetector   <- ComicTextDetector   (/root/reference/manga_translator/detection/ctd.py:60-179)
+  HipModel48pxOCR        <- Model48pxOCR        (ocr/model_48px.py:25-180)
+  HipLamaMPEInpainter    <- LamaMPEInpainter    (inpainting/inpainting_lama_mpe.py:26-118)
+  HipLamaLargeInpainter  <- LamaLargeInpainter  (inpainting/inpainting_lama_mpe.py:121-136)
+
+Same lifecycle (``__init__`` touches no GPU; ``await load(device)`` / ``unload()`` / ``infer(...)``; infer before load
+raises), same ``_infer`` signatures, argument meaning and return types, errors as Python exceptions.  When the
+reference package is importable the classes derive from its ``OfflineDetector`` / ``OfflineOCR`` /
+``OfflineInpainter`` and ``register()`` adds them to ``DETECTORS`` / ``OCRS`` / ``INPAINTERS``;
+otherwise they derive from a minimal mirror of ``ModelWrapper`` (utils/inference.py:330-350) so the contract can be
+exercised stand-alone.  The OpenCV / pyclipper post-processing of the detector (contours -> boxes, mask refinement)
+is NOT part of the dense path: it is taken from the reference package when present, or injected by the caller.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import pipeline
+from .textline import Quadrilateral
+
+try:  # inside the reference's environment: be a real plugin
+    from manga_translator.detection.common import OfflineDetector as _DetBase  # type: ignore
+    from manga_translator.inpainting.common import OfflineInpainter as _InpBase  # type: ignore
+    from manga_translator.ocr.common import OfflineOCR as _OcrBase  # type: ignore
+    from manga_translator.utils import Quadrilateral as _RefQuadrilateral  # type: ignore
+
+    HAVE_REFERENCE = True
+except Exception:  # stand-alone: mirror the ModelWrapper lifecycle
+    HAVE_REFERENCE = False
+    _RefQuadrilateral = Quadrilateral
+
+    class _Wrapper:
+        """Mirror of ModelWrapper's load/unload/infer protocol (utils/inference.py:318-350)."""
+        _key = "hip"
+
+        def __init__(self, *args, **kwargs):
+            self._loaded = False
+
+        def is_loaded(self) -> bool:
+            return self._loaded
+
+        async def download(self):  # weights are handed over by the caller / found on disk; nothing to fetch offline
+            return None
+
+        async def load(self, device: str, *args, **kwargs):
+            if not self.is_loaded():
+                await self._load(*args, **kwargs, device=device)
+                self._loaded = True
+
+        async def unload(self):
+            if self.is_loaded():
+                await self._unload()
+                self._loaded = False
+
+        async def reload(self, device: str, *args, **kwargs):
+            await self.unload()
+            await self.load(*args, **kwargs, device=device)
+
+        async def infer(self, *args, **kwargs):
+            if not self.is_loaded():
+                raise Exception(f"{self._key}: Tried to forward pass without having loaded the model.")
+            return await self._infer(*args, **kwargs)
+
+    _DetBase = _InpBase = _OcrBase = _Wrapper
+
+
+def _gpu_device(device: str) -> torch.device:
+    """The reference passes 'cpu' | 'cuda' | 'mps' | 'xpu' (ROCm = 'cuda').  This backend has no CPU path."""
+    if not str(device).startswith("cuda"):
+        raise RuntimeError(f"the HIP backend runs on an MI355X only: device={device!r} (use --use-gpu)")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: the HIP backend has no CPU fallback")
+    return torch.device(device)
+
+
+class HipComicTextDetector(_DetBase):
+    """``--detector ctd`` on the HIP engine."""
+    _key = "ctd_hip"
+    _MODEL_MAPPING: Dict = {}
+
+    def __init__(self, *args, weights: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
+                 boxes_from_maps: Optional[Callable] = None, refine: Optional[Callable] = None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._weights, self._boxes, self._refine = weights, boxes_from_maps, refine
+        self.engine = None
+
+    async def _load(self, device: str, input_size=1024, **_):
+        from . import ctd
+
+        dev = _gpu_device(device)
+        w = self._weights or _load_ctd_checkpoint(self)
+        self.engine = ctd.CtdEngine(w["ctd.yolo"], w["ctd.seg"], w["ctd.det"], device=dev)
+        self.device, self.input_size = device, (input_size, input_size)
+
+    async def _unload(self):
+        self.engine = None
+
+    @torch.no_grad()
+    async def _infer(self, image: np.ndarray, detect_size: int, text_threshold: float, box_threshold: float,
+                     unclip_ratio: float, verbose: bool = False):
+        """-> (textlines, mask_refined u8 [H,W], None).  Like the reference, ignores detect_size / thresholds /
+        unclip_ratio (fixed 1024, 0.3, 0.6, 1.5: ctd.py:84,102,157)."""
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise ValueError(f"expected uint8 RGB [H,W,3], got {image.dtype} {image.shape}")
+        im_h, im_w = image.shape[:2]
+        page = torch.from_numpy(np.ascontiguousarray(image)).to(self.engine.device)[None]
+        mask_u8, lines, _ = self.engine.forward(page)
+        mask = mask_u8[0].cpu().numpy()           # postprocess_mask already applied on the GPU (ctd.py:30-44)
+        lines_map = lines.cpu().numpy()           # [1,2,h,w], cropped to the un-padded area (:152-153)
+        boxes_fn, refine_fn = self._boxes or _reference_boxes(), self._refine or _reference_refine()
+        boxes, scores = boxes_fn(lines_map, im_h, im_w)      # SegDetectorRepresenter(thresh=0.3) (:102,156)
+        keep = np.where(scores > 0.6)                        # box_thresh (:157-159)
+        boxes, scores = boxes[keep], scores[keep]
+        textlines = [_RefQuadrilateral(pts.astype(int), "", float(s)) for pts, s in zip(boxes, scores)]
+        return textlines, refine_fn(image, mask, textlines, im_h, im_w), None  # resize + refine_mask (:162,177)
+
+
+class HipModel48pxOCR(_OcrBase):
+    """``--ocr 48px`` on the HIP engine."""
+    _key = "48px_hip"
+    _MODEL_MAPPING: Dict = {}
+
+    def __init__(self, *args, weights: Optional[Dict[str, torch.Tensor]] = None, dictionary: Optional[Sequence[str]] = None,
+                 **kwargs):
+        super().__init__(*args, **kwargs)
+        self._weights, self.dictionary = weights, dictionary
+        self.engine = None
+
+    async def _load(self, device: str):
+        from . import ocr48
+
+        dev = _gpu_device(device)
+        if self._weights is None or self.dictionary is None:
+            self._weights, self.dictionary = _load_ocr_checkpoint(self)
+        self.engine = ocr48.Ocr48Engine(self._weights, len(self.dictionary), device=dev)
+        self.device = device
+
+    async def _unload(self):
+        self.engine = None
+
+    def _directions(self, textlines):
+        """(line, direction) in processing order.  With the reference present: its merge-graph majority vote
+        (ocr/common.py:12-39); stand-alone: each line's own direction."""
+        if HAVE_REFERENCE:
+            return list(self._generate_text_direction(textlines))
+        return [(q, q.direction) for q in textlines]
+
+    @torch.no_grad()
+    async def _infer(self, image: np.ndarray, textlines: List, config=None, verbose: bool = False, ignore_bubble: int = 0,
+                     max_seq_length: int = 255, suppress_eos: bool = False):
+        """Sets text / prob / fg_* / bg_* on the same Quadrilateral objects and returns those above the threshold,
+        in the reference's sorted-by-width chunk order (model_48px.py:67-180)."""
+        threshold = 0.2 if config is None or getattr(config, "prob", None) is None else config.prob
+        pairs = self._directions(textlines)
+        if not pairs:
+            return []
+        quads = [q for q, _ in pairs]
+        dirs = [[d for _, d in pairs]]
+        page = torch.from_numpy(np.ascontiguousarray(image)).to(self.engine.device)[None]
+        own = [Quadrilateral(np.asarray(q.pts)) for q in quads]  # geometry in this package's type
+        r = self.engine.recognize_pages(page, [own], max_seq_length=max_seq_length, suppress_eos=suppress_eos, directions=dirs)
+        toks, lens = r["tokens"].cpu().numpy(), r["length"].cpu().numpy()
+        probs, cols = r["prob"].cpu().numpy(), r["colors"].cpu().numpy()
+        out = []
+        for row, (_, i) in enumerate(r["order"]):
+            q, prob = quads[i], float(probs[row])
+            q.assigned_direction = dirs[0][i]
+            if prob < threshold:
+                continue
+            n = int(lens[row]) - 1                  # tokens after the start symbol
+            txt, fgc, bgc = decode_line(toks[row, 1:1 + n], cols[row, :n], self.dictionary)
+            q.text, q.prob = txt, prob
+            q.fg_r, q.fg_g, q.fg_b = fgc
+            q.bg_r, q.bg_g, q.bg_b = bgc
+            out.append(q)
+        return out
+
+
+def decode_line(token_ids: np.ndarray, colors: np.ndarray, dictionary: Sequence[str]) -> Tuple[str, Tuple[int, int, int], Tuple[int, int, int]]:
+    """Token ids + colour-head rows -> (text, fg rgb, bg rgb): model_48px.py:124-158 (AvgMeter means of int(c*255))."""
+    has_fg = colors[:, 7] > colors[:, 6]
+    has_bg = colors[:, 9] > colors[:, 8]
+    seq: List[str] = []
+    acc = [[0, 0] for _ in range(6)]  # sum, count for fr fg fb br bg bb
+
+    def add(k, v):
+        acc[k][0] += int(v * 255)
+        acc[k][1] += 1
+
+    for t, chid in enumerate(token_ids):
+        ch = dictionary[int(chid)]
+        if ch == "<S>":
+            continue
+        if ch == "</S>":
+            break
+        seq.append(" " if ch == "<SP>" else ch)
+        if has_fg[t]:
+            for k in range(3):
+                add(k, colors[t, k])
+        src = colors[t, 3:6] if has_bg[t] else colors[t, 0:3]
+        for k in range(3):
+            add(3 + k, src[k])
+    mean = [min(max(int(s / c) if c else 0, 0), 255) for s, c in acc]
+    return "".join(seq), tuple(mean[:3]), tuple(mean[3:])
+
+
+class HipLamaMPEInpainter(_InpBase):
+    """``--inpainter lama_mpe`` on the HIP engine."""
+    _key = "lama_mpe_hip"
+    _MODEL_MAPPING: Dict = {}
+    N_BLOCKS, USE_MPE, CKPT = 9, True, "inpainting_lama_mpe.ckpt"
+
+    def __init__(self, *args, weights: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
+                 resize: Optional[Callable] = None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._weights, self._resize = weights, resize
+        self.engine = None
+
+    async def _load(self, device: str):
+        from . import lama
+
+        dev = _gpu_device(device)
+        w = self._weights or _load_lama_checkpoint(self)
+        self.engine = lama.LamaEngine(w["lama.gen"], w.get("lama.mpe") if self.USE_MPE else None, n_blocks=self.N_BLOCKS,
+                                      device=dev)
+        self.device = device
+
+    async def _unload(self):
+        self.engine = None
+
+    @torch.no_grad()
+    async def _infer(self, image: np.ndarray, mask: np.ndarray, config=None, inpainting_size: int = 1024,
+                     verbose: bool = False) -> np.ndarray:
+        """image u8 [H,W,3], mask u8 [H,W] -> inpainted [H,W,3] (inpainting_lama_mpe.py:56-118).  Always fp32: the
+        reference's CPU path never autocasts (:93-95) and that is the parity target."""
+        if image.ndim != 3 or image.shape[2] != 3 or mask.shape != image.shape[:2]:
+            raise ValueError(f"bad shapes: image {image.shape}, mask {mask.shape}")
+        height, width = image.shape[:2]
+        img, msk = image, mask
+        scale = inpainting_size / max(height, width)
+        h, w = (height, width) if scale >= 1 else (int(round(height * scale)), int(round(width * scale)))
+        new_h, new_w = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+        resized = (new_h, new_w) != (height, width)
+        if resized:  # resize_keep_aspect + cv2.resize to a multiple of 8 (:65-79): OpenCV glue, outside the dense path
+            rs = self._resize or _reference_resize()
+            if (h, w) != (height, width):
+                img, msk = rs(img, (w, h), "keep_aspect"), rs(msk, (w, h), "keep_aspect")
+            if (new_h, new_w) != (h, w):
+                img, msk = rs(img, (new_w, new_h), "linear"), rs(msk, (new_w, new_h), "linear")
+        dev = self.engine.device
+        out = self.engine.forward(torch.from_numpy(np.ascontiguousarray(img)).to(dev)[None],
+                                  torch.from_numpy(np.ascontiguousarray(msk)).to(dev)[None])[0].cpu().numpy()
+        if not resized:
+            return out  # composite with the original page already done on the GPU (:117)
+        # the engine composited at the resized scale with the resized mask; the reference composites after resizing
+        # back, with the ORIGINAL mask thresholded at 127 (:59-61,114-117)
+        rs = self._resize or _reference_resize()
+        out = rs(out, (width, height), "linear")
+        m = (mask >= 127)[:, :, None]
+        return np.where(m, out, image)
+
+
+class HipLamaLargeInpainter(HipLamaMPEInpainter):
+    """``--inpainter lama_large``: 18 blocks, no MPE (inpainting_lama_mpe.py:121-136)."""
+    _key = "lama_large_hip"
+    N_BLOCKS, USE_MPE, CKPT = 18, False, "lama_large_512px.ckpt"
+
+
+# ---- pieces taken from the reference package when it is importable ---------------------------------------------
+
+def _reference_boxes():
+    if not HAVE_REFERENCE:
+        raise RuntimeError("box extraction needs the reference's SegDetectorRepresenter (OpenCV/pyclipper); pass boxes_from_maps=")
+    from manga_translator.detection.ctd_utils.utils.db_utils import SegDetectorRepresenter  # type: ignore
+
+    rep = SegDetectorRepresenter(thresh=0.3)
+
+    def fn(lines_map, im_h, im_w):
+        lines, scores = rep(None, lines_map, height=im_h, width=im_w)
+        return lines[0], scores[0]
+
+    return fn
+
+
+def _reference_refine():
+    if not HAVE_REFERENCE:
+        raise RuntimeError("mask refinement needs the reference's refine_mask (OpenCV); pass refine=")
+    import cv2  # type: ignore
+    from manga_translator.detection.ctd_utils.textmask import refine_mask  # type: ignore
+
+    def fn(image, mask, textlines, im_h, im_w):
+        mask = cv2.resize(mask, (im_w, im_h), interpolation=cv2.INTER_LINEAR)
+        return refine_mask(image, mask, textlines, refine_mode=None)
+
+    return fn
+
+
+def _reference_resize():
+    if not HAVE_REFERENCE:
+        raise RuntimeError("pages that need resizing (max side > inpainting_size or not a multiple of 8) need OpenCV; pass resize=")
+    import cv2  # type: ignore
+    from manga_translator.utils import resize_keep_aspect  # type: ignore
+
+    def fn(img, dsize, mode):
+        if mode == "keep_aspect":
+            return resize_keep_aspect(img, max(dsize))
+        return cv2.resize(img, dsize, interpolation=cv2.INTER_LINEAR)
+
+    return fn
+
+
+def _ckpt_path(plugin, name: str) -> str:
+    if hasattr(plugin, "_get_file_path"):
+        return plugin._get_file_path(name)
+    return os.path.join("models", name)
+
+
+def _load_ctd_checkpoint(plugin):
+    """comictextdetector.pt = {'blk_det': {'cfg','weights'}, 'text_seg', 'text_det'} (ctd_utils/basemodel.py:205-214)."""
+    ck = torch.load(_ckpt_path(plugin, "comictextdetector.pt"), map_location="cpu")
+    return {"ctd.yolo": ck["blk_det"]["weights"], "ctd.seg": ck["text_seg"], "ctd.det": ck["text_det"]}
+
+
+def _load_ocr_checkpoint(plugin):
+    with open(_ckpt_path(plugin, "alphabet-all-v7.txt"), "r", encoding="utf-8") as fp:
+        dictionary = [s[:-1] for s in fp.readlines()]
+    return torch.load(_ckpt_path(plugin, "ocr_ar_48px.ckpt"), map_location="cpu"), dictionary
+
+
+def _load_lama_checkpoint(plugin):
+    """{'gen_state_dict', 'str_state_dict'?} (inpainting_lama_mpe.py:818-825)."""
+    ck = torch.load(_ckpt_path(plugin, plugin.CKPT), map_location="cpu")
+    out = {"lama.gen": ck["gen_state_dict"]}
+    if "str_state_dict" in ck:
+        out["lama.mpe"] = ck["str_state_dict"]
+    return out
+
+
+def register() -> None:
+    """Add the HIP backends to the reference's registries (needs the reference package; INTEGRATION.md shows the
+    matching enum members)."""
+    if not HAVE_REFERENCE:
+        raise RuntimeError("manga_translator is not importable: nothing to register into")
+    from manga_translator.detection import DETECTORS  # type: ignore
+    from manga_translator.inpainting import INPAINTERS  # type: ignore
+    from manga_translator.ocr import OCRS  # type: ignore
+
+    DETECTORS["ctd_hip"] = HipComicTextDetector
+    OCRS["48px_hip"] = HipModel48pxOCR
+    INPAINTERS["lama_mpe_hip"] = HipLamaMPEInpainter
+    INPAINTERS["lama_large_hip"] = HipLamaLargeInpainter

@@ -134,3 +134,56 @@ def test_page_pipeline_parity(cuda):
     # the packed gather payload covers every result tensor
     assert res.packed().numel() == (res.det_mask.numel() + res.det_shrink.numel() + res.inpainted.numel()
                                     + 4 * (res.ocr_tokens.numel() + res.ocr_length.numel() + res.ocr_prob.numel() + res.ocr_colors.numel()))
+
+
+def test_plugins_end_to_end(cuda):
+    """The three drop-in plugins (load -> infer -> unload) return what the stage engines compute, in the reference's types."""
+    import asyncio
+
+    from manga_image_translator_amd import pipeline, plugins as P, synth, textline as TL
+    from oracle import lama as OL
+
+    run = lambda c: asyncio.new_event_loop().run_until_complete(c)
+    D = 64
+    weights = pipeline.synthetic_weights(dict_size=D)
+    dictionary = ["<PAD>", "<S>", "</S>", "<SP>"] + [chr(0x4E00 + i) for i in range(D - 4)]
+    H, W = 256, 192
+    page, quads, mask = synth.synth_page(2, H, W, n_boxes=4)
+
+    det = P.HipComicTextDetector(weights=weights,
+                                 boxes_from_maps=lambda lm, h, w: (np.array([[[1, 1], [40, 1], [40, 9], [1, 9]]]), np.array([0.9])),
+                                 refine=lambda img, m, tl, h, w: m)
+    run(det.load("cuda"))
+    tls, raw_mask, extra = run(det.infer(page, 1024, 0.5, 0.7, 2.3))
+    assert extra is None and len(tls) == 1 and tls[0].prob == pytest.approx(0.9)
+    assert raw_mask.dtype == np.uint8 and raw_mask.shape == (256, 192)  # letterbox of a 4:3 page to 1024: un-padded area / 4
+    run(det.unload())
+    assert not det.is_loaded()
+
+    ocr = P.HipModel48pxOCR(weights=weights["ocr48"], dictionary=dictionary)
+    run(ocr.load("cuda"))
+    lines = [TL.Quadrilateral(q) for q in quads]
+
+    class Cfg:
+        prob = 0.0
+
+    out = run(ocr.infer(page, lines, Cfg(), max_seq_length=6, suppress_eos=True))
+    assert len(out) == len(lines) and all(o in lines for o in out)  # same objects, mutated
+    assert all(isinstance(o.text, str) and len(o.text) <= 6 and 0 <= o.fg_r <= 255 and 0 <= o.bg_b <= 255 for o in out)
+    widths = [TL.warp_plan(q, q.direction, H, W).width for q in lines]
+    assert [lines.index(o) for o in out] == sorted(range(len(lines)), key=lambda i: widths[i])  # chunk order (:79,176)
+    Cfg.prob = 2.0
+    assert run(ocr.infer(page, lines, Cfg(), max_seq_length=6, suppress_eos=True)) == []  # everything below the threshold
+    run(ocr.unload())
+
+    inp = P.HipLamaMPEInpainter(weights=weights)
+    run(inp.load("cuda"))
+    got = run(inp.infer(page, mask, None, 2048))
+    ref = OL.infer(weights["lama.gen"], weights["lama.mpe"], page, mask, 9)
+    assert got.shape == page.shape and got.dtype == np.uint8
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    assert np.array_equal(got[mask < 127], page[mask < 127])  # outside the mask the page is returned untouched
+    with pytest.raises(RuntimeError, match="need OpenCV"):
+        run(inp.infer(page[:250], mask[:250], None, 2048))   # 250 rows: needs the cv2 resize hook
+    run(inp.unload())

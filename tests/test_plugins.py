@@ -1,0 +1,82 @@
+"""Plugin contract without a GPU: lifecycle, device handling, error behaviour, and the OCR result
+decoding (model_48px.py:121-175) against a line-by-line restatement that uses the reference's AvgMeter arithmetic."""
+import asyncio
+
+import numpy as np
+import pytest
+
+from manga_image_translator_amd import plugins as P
+
+
+def run(coro):
+    return asyncio.new_event_loop().run_until_complete(coro)
+
+
+@pytest.mark.parametrize("cls", [P.HipComicTextDetector, P.HipModel48pxOCR, P.HipLamaMPEInpainter, P.HipLamaLargeInpainter])
+def test_lifecycle_and_device_errors(cls):
+    p = cls()                                   # constructed with no arguments, touches no GPU
+    assert not p.is_loaded()
+    with pytest.raises(Exception, match="without having loaded"):
+        run(p.infer(np.zeros((8, 8, 3), np.uint8)))
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        run(p.load("cpu"))                      # the reference passes 'cpu' without --use-gpu: no CPU fallback here
+    assert not p.is_loaded()
+    run(p.unload())                             # unloading an unloaded plugin is a no-op, like ModelWrapper.unload
+
+
+def test_variants():
+    assert (P.HipLamaMPEInpainter.N_BLOCKS, P.HipLamaMPEInpainter.USE_MPE) == (9, True)
+    assert (P.HipLamaLargeInpainter.N_BLOCKS, P.HipLamaLargeInpainter.USE_MPE) == (18, False)
+    if not P.HAVE_REFERENCE:
+        with pytest.raises(RuntimeError):
+            P.register()
+
+
+def _ref_decode(tokens, fg_pred, bg_pred, fg_ind, bg_ind, dictionary):
+    """model_48px.py:124-158 verbatim in structure (AvgMeter = running sum / count)."""
+    class Avg:
+        def __init__(self):
+            self.s, self.c = 0, 0
+
+        def __call__(self, v=None):
+            if v is not None:
+                self.s += v
+                self.c += 1
+            return self.s / self.c if self.c > 0 else 0
+
+    has_fg, has_bg = fg_ind[:, 1] > fg_ind[:, 0], bg_ind[:, 1] > bg_ind[:, 0]
+    m = [Avg() for _ in range(6)]
+    seq = []
+    for chid, cf, cb, hf, hb in zip(tokens, fg_pred, bg_pred, has_fg, has_bg):
+        ch = dictionary[chid]
+        if ch == "<S>":
+            continue
+        if ch == "</S>":
+            break
+        if ch == "<SP>":
+            ch = " "
+        seq.append(ch)
+        if hf:
+            for k in range(3):
+                m[k](int(cf[k] * 255))
+        src = cb if hb else cf
+        for k in range(3):
+            m[3 + k](int(src[k] * 255))
+    vals = [min(max(int(x()), 0), 255) for x in m]
+    return "".join(seq), tuple(vals[:3]), tuple(vals[3:])
+
+
+def test_decode_line_matches_reference_logic():
+    rng = np.random.default_rng(0)
+    dictionary = ["<PAD>", "<S>", "</S>", "<SP>"] + [chr(0x3041 + i) for i in range(60)]
+    for trial in range(50):
+        n = int(rng.integers(1, 12))
+        toks = rng.integers(3, len(dictionary), size=n)
+        if trial % 3 == 0:
+            toks[rng.integers(0, n)] = 2          # an </S> in the middle stops the line
+        if trial % 5 == 0:
+            toks[0] = 1
+        cols = rng.normal(0.5, 0.6, size=(n, 10)).astype(np.float32)  # out-of-range colours exercise the clamps
+        got = P.decode_line(toks, cols, dictionary)
+        ref = _ref_decode(toks, cols[:, 0:3], cols[:, 3:6], cols[:, 6:8], cols[:, 8:10], dictionary)
+        assert got == ref
