@@ -45,6 +45,64 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
     }
 }
 
+// ---- epilogue shared by both kernels: row offsets computed once per row, shared through LDS ----
+template <int BM, int TM, int TN>
+__device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM][TN], float *smem, const int M, const int m0,
+                                         const int n0, const int wm0, const int wn0, const int z1, const int z0,
+                                         const int HoWo) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    RowOff *rowoff = reinterpret_cast<RowOff *>(smem);  // BM entries (<= A/B staging area)
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        RowOff ro = {-1, 0, 0};
+        if (m < M) {
+            const int nb = m / HoWo;
+            const int rem = m - nb * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            ro.c = z1 * p.c.zs1 + z0 * p.c.zs0 + (int64_t)nb * p.c.bs + (int64_t)oy * p.c.ys + (int64_t)ox * p.c.xs;
+            ro.pre = z1 * p.pre.zs1 + z0 * p.pre.zs0 + (int64_t)nb * p.pre.bs + (int64_t)oy * p.pre.ys +
+                     (int64_t)ox * p.pre.xs;
+            ro.post = z1 * p.post.zs1 + z0 * p.post.zs0 + (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys +
+                      (int64_t)ox * p.post.xs;
+        }
+        rowoff[r] = ro;
+    }
+    __syncthreads();
+
+    const bool has_pre = p.pre.base != nullptr;
+    const bool has_post = p.post.base != nullptr;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + li;
+        if (n >= p.N) continue;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float bi = p.bias ? p.bias[n] : 0.f;
+        int64_t ncol_c = n, ncol_pre = n, ncol_post = n;
+        if (p.c.nsplit) ncol_c = (int64_t)(n / p.c.nsplit) * p.c.nhi + (n % p.c.nsplit);
+        if (has_pre && p.pre.nsplit) ncol_pre = (int64_t)(n / p.pre.nsplit) * p.pre.nhi + (n % p.pre.nsplit);
+        if (has_post && p.post.nsplit) ncol_post = (int64_t)(n / p.post.nsplit) * p.post.nhi + (n % p.post.nsplit);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const RowOff ro = rowoff[row];
+                if (ro.c < 0) continue;
+                float v = acc[mi][ni][r];
+                if (has_pre) v += p.pre.base[ro.pre + ncol_pre];
+                v = v * sc + bi;
+                v = apply_act(v, p.act, p.act_alpha);
+                if (has_post) v += p.post.base[ro.post + ncol_post];
+                p.c.base[ro.c + ncol_c] = v;
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, const int M, const int MT,
                                                           const int NT, const int KT) {
@@ -230,61 +288,197 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, con
         __syncthreads();
     }
 
-    // ---- epilogue: row offsets computed once per row, shared through LDS ----
-    RowOff *rowoff = reinterpret_cast<RowOff *>(smem);  // BM entries (<= A/B staging area)
-    for (int r = tid; r < BM; r += 256) {
+    epilogue<BM, TM, TN>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+}
+
+// ---- fast path: Cin % BK == 0, so every K-tile lies inside ONE tap ----------------------------
+// The gather geometry (reflect / zero padding, strides, tap offsets) is evaluated once per block
+// into an LDS table rowtab[tap][row] of 32-bit element offsets (-1 = contributes zeros); the K
+// loop then costs one ds_read_b32 + one 64-bit add per 16-byte load, the tap index and channel
+// offset are wave-uniform scalars, and the next k-step's fragments are read from LDS while the
+// current step's MFMAs issue.  Same tiling, LDS images, accumulation order and epilogue as the
+// generic kernel, so results are bitwise identical to it.
+constexpr int FAST_MAX_TAPS = 16;
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const MitConvGemm p, const int M, const int MT,
+                                                               const int NT, const int KT) {
+    constexpr int WM = BM / WAVES_M;
+    constexpr int WN = BN / WAVES_N;
+    constexpr int TM = WM / 32;
+    constexpr int TN = WN / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    constexpr int KQ = BK / 4;
+    constexpr int A_ITERS = BM * KQ / 256;
+    constexpr int A_MSTEP = 256 / KQ;
+    constexpr int NQ = BN / 4;
+    constexpr int B_ITERS = BK * NQ / 256;
+    constexpr int B_KSTEP = 256 / NQ;
+    static_assert(A_ITERS >= 1 && (BM * KQ) % 256 == 0, "A tile must fill the workgroup");
+    static_assert(B_ITERS >= 1 && (BK * NQ) % 256 == 0, "B tile must fill the workgroup");
+    constexpr int LDA = BM + (BK == 16 ? 2 : 1);
+    constexpr int LDB = BN + 4;
+    constexpr int A_TILE = BK * LDA;
+    constexpr int B_TILE = BK * LDB;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;
+    float *Bs = smem + 2 * A_TILE;
+    int *rowtab = reinterpret_cast<int *>(smem + 2 * A_TILE + 2 * B_TILE);  // [ntaps][BM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+
+    const int nwg = MT * NT;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / NT, nt = bid - mt * NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.y;
+    const int z1 = z / p.zdiv, z0 = z - z1 * p.zdiv;
+    const int HoWo = p.Ho * p.Wo;
+
+    const float *__restrict__ a_base = p.a + z1 * p.a_zs1 + z0 * p.a_zs0;
+    const float *__restrict__ w_base = p.w + z1 * p.w_zs1 + z0 * p.w_zs0;
+
+    // ---- gather table ----
+    for (int idx = tid; idx < p.ntaps * BM; idx += 256) {
+        const int t = idx / BM, r = idx - t * BM;
         const int m = m0 + r;
-        RowOff ro = {-1, 0, 0};
+        int off = -1;
         if (m < M) {
             const int nb = m / HoWo;
             const int rem = m - nb * HoWo;
             const int oy = rem / p.Wo;
             const int ox = rem - oy * p.Wo;
-            ro.c = z1 * p.c.zs1 + z0 * p.c.zs0 + (int64_t)nb * p.c.bs + (int64_t)oy * p.c.ys + (int64_t)ox * p.c.xs;
-            ro.pre = z1 * p.pre.zs1 + z0 * p.pre.zs0 + (int64_t)nb * p.pre.bs + (int64_t)oy * p.pre.ys +
-                     (int64_t)ox * p.pre.xs;
-            ro.post = z1 * p.post.zs1 + z0 * p.post.zs0 + (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys +
-                      (int64_t)ox * p.post.xs;
+            int iy = oy * p.sy + p.tap_dy[t];
+            int ix = ox * p.sx + p.tap_dx[t];
+            bool ok = true;
+            if (p.pad_mode == MIT_PAD_REFLECT) {
+                iy = iy < 0 ? -iy : (iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy);
+                ix = ix < 0 ? -ix : (ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix);
+            } else {
+                ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            }
+            if (ok) off = (int)((int64_t)nb * p.a_bs + (int64_t)iy * p.a_ys + (int64_t)ix * p.a_xs + p.tap_off[t]);
         }
-        rowoff[r] = ro;
+        rowtab[idx] = off;
     }
+
+    const int aq = tid % KQ;
+    const int am = tid / KQ;
+    const int bn4 = tid % NQ;
+    const int bk = tid / NQ;
+    const bool b_ncol_ok = (n0 + bn4 * 4) < p.Nw;
+    const float *__restrict__ a_thr = a_base + aq * 4;
+    const float *__restrict__ w_thr = w_base + n0 + bn4 * 4;
+
+    f32x4 a_reg[A_ITERS];
+    f32x4 b_reg[B_ITERS];
+
+    __syncthreads();  // rowtab visible
+
+    // (tap, ci0) of the tile being loaded: wave-uniform, advanced incrementally
+    int ld_tap = 0, ld_ci0 = 0;
+    auto load_tile = [&](int kt) {
+        const int *rt = rowtab + ld_tap * BM + am;
+        const float *ak = a_thr + ld_ci0;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int off = rt[i * A_MSTEP];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (off >= 0) v = *reinterpret_cast<const f32x4 *>(ak + off);
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int k = kt * BK + bk + i * B_KSTEP;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ncol_ok && k < p.Kw) v = *reinterpret_cast<const f32x4 *>(w_thr + (int64_t)k * p.ldw);
+            b_reg[i] = v;
+        }
+        ld_ci0 += BK;
+        if (ld_ci0 >= p.Cin) {
+            ld_ci0 = 0;
+            ++ld_tap;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float *as = As + buf * A_TILE;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int ml = am + i * A_MSTEP;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) as[(aq * 4 + j) * LDA + ml] = a_reg[i][j];
+        }
+        float *bs = Bs + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int kl = bk + i * B_KSTEP;
+            *reinterpret_cast<f32x4 *>(bs + kl * LDB + bn4 * 4) = b_reg[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int wm0 = (wave / WAVES_N) * WM;
+    const int wn0 = (wave % WAVES_N) * WN;
+
+    load_tile(0);
+    store_tile(0);
     __syncthreads();
 
-    const bool has_pre = p.pre.base != nullptr;
-    const bool has_post = p.post.base != nullptr;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float *as = As + cur * A_TILE + lh * LDA + wm0 + li;
+        const float *bs = Bs + cur * B_TILE + lh * LDB + wn0 + li;
+        float af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int n = n0 + wn0 + ni * 32 + li;
-        if (n >= p.N) continue;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float bi = p.bias ? p.bias[n] : 0.f;
-        int64_t ncol_c = n, ncol_pre = n, ncol_post = n;
-        if (p.c.nsplit) ncol_c = (int64_t)(n / p.c.nsplit) * p.c.nhi + (n % p.c.nsplit);
-        if (has_pre && p.pre.nsplit) ncol_pre = (int64_t)(n / p.pre.nsplit) * p.pre.nhi + (n % p.pre.nsplit);
-        if (has_post && p.post.nsplit) ncol_post = (int64_t)(n / p.post.nsplit) * p.post.nhi + (n % p.post.nsplit);
+        for (int mi = 0; mi < TM; ++mi) af[0][mi] = as[mi * 32];
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
+        for (int ni = 0; ni < TN; ++ni) bf[0][ni] = bs[ni * 32];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const RowOff ro = rowoff[row];
-                if (ro.c < 0) continue;
-                float v = acc[mi][ni][r];
-                if (has_pre) v += p.pre.base[ro.pre + ncol_pre];
-                v = v * sc + bi;
-                v = apply_act(v, p.act, p.act_alpha);
-                if (has_post) v += p.post.base[ro.post + ncol_post];
-                p.c.base[ro.c + ncol_c] = v;
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int c = ks & 1;
+            if (ks + 1 < BK / 2) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) af[c ^ 1][mi] = as[(2 * ks + 2) * LDA + mi * 32];
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bf[c ^ 1][ni] = bs[(2 * ks + 2) * LDB + ni * 32];
             }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][mi], bf[c][ni], acc[mi][ni], 0, 0, 0);
         }
+        if (kt + 1 < KT) store_tile(cur ^ 1);
+        __syncthreads();
     }
+
+    epilogue<BM, TM, TN>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
 }
 
 struct CfgEntry {
     const char *name;
     int BM, BN, BK;
     void (*launch)(const MitConvGemm &, int M, int MT, int NT, int KT, hipStream_t);
-    size_t smem;
+    int fast;  // 1: conv_gemm_fast_kernel (needs fast_eligible())
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -300,11 +494,36 @@ template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 void launch_cfg(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
     dim3 grid(MT * NT, p.Z, 1);
     size_t smem = smem_bytes<BM, BN, BK, WAVES_M, WAVES_N>();
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N>), grid, dim3(256), smem, s, p, M, MT, NT, KT);
+    auto kern = conv_gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
+    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set && smem > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
+    constexpr int LDA = BM + (BK == 16 ? 2 : 1);
+    constexpr int LDB = BN + 4;
+    size_t staging = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + (size_t)FAST_MAX_TAPS * BM * sizeof(int);
+    size_t rows = (size_t)BM * sizeof(RowOff);
+    size_t smem = staging > rows ? staging : rows;
+    auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
+    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set && smem > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    dim3 grid(MT * NT, p.Z, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 
 #define CFG(BM, BN, BK, WM_, WN_) \
     { #BM "x" #BN "x" #BK, BM, BN, BK, launch_cfg<BM, BN, BK, WM_, WN_>, 0 }
+#define FCFG(BM, BN, BK, WM_, WN_) \
+    { "fast" #BM "x" #BN "x" #BK, BM, BN, BK, launch_fast<BM, BN, BK, WM_, WN_>, 1 }
 
 const CfgEntry kCfgs[] = {
     CFG(128, 128, 16, 2, 2),  // 0: general
@@ -314,17 +533,38 @@ const CfgEntry kCfgs[] = {
     CFG(128, 128, 32, 2, 2),  // 4: Cin % 32 == 0, full 128-B lines per pixel
     CFG(256, 64, 16, 4, 1),   // 5
     CFG(64, 64, 16, 2, 2),    // 6: small problems
+    FCFG(128, 128, 16, 2, 2),  // 7
+    FCFG(128, 128, 32, 2, 2),  // 8
+    FCFG(128, 64, 16, 2, 2),   // 9
+    FCFG(256, 64, 16, 4, 1),   // 10
+    FCFG(256, 128, 16, 2, 2),  // 11
+    FCFG(128, 64, 32, 2, 2),   // 12
+    FCFG(256, 64, 32, 4, 1),   // 13
 };
+
+// fast kernel preconditions: whole K-tiles inside one tap, table fits, 32-bit element offsets
+bool fast_eligible(const MitConvGemm &p, int BK) {
+    if (p.Cin % BK || p.ntaps > FAST_MAX_TAPS) return false;
+    int64_t maxoff = (int64_t)(p.NB - 1) * p.a_bs + (int64_t)(p.Hi - 1) * p.a_ys + (int64_t)(p.Wi - 1) * p.a_xs + p.Cin;
+    int64_t minoff = 0;
+    if (p.a_bs < 0 || p.a_ys < 0 || p.a_xs < 0) return false;
+    int tmax = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+        if (p.tap_off[t] < 0) return false;
+        if (p.tap_off[t] > tmax) tmax = p.tap_off[t];
+    }
+    (void)minoff;
+    return maxoff + tmax < 0x7fffffffLL;
+}
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 int pick_cfg(const MitConvGemm &p, int64_t M) {
-    // measured on MI355X (scripts/bench_conv.py): 128x128x16 is the best general tile
-    // (3 waves/SIMD); the 256-row tiles run 1 wave/SIMD and lose ~20 %.
+    // measured on MI355X (scripts/bench_conv.py)
+    const bool f16 = fast_eligible(p, 16);
     if (p.N <= 32) return 2;
-    if (p.N <= 64) return 1;
     const int rem = p.N % 128;
-    if (rem != 0 && rem <= 64) return 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
-    return 0;
+    if (p.N <= 64 || (rem != 0 && rem <= 64)) return f16 ? 9 : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
+    return f16 ? 7 : 0;
 }
 
 // ---- kernel-time probe (mit_prof_*): HIP events around every launch while enabled ----
@@ -412,6 +652,8 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     if (cfg < 0) cfg = pick_cfg(p, M64);
     if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
     const CfgEntry &c = kCfgs[cfg];
+    if (c.fast && !fast_eligible(p, c.BK))
+        return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% %d == 0, <= %d taps and 32-bit element offsets", c.name, c.BK, FAST_MAX_TAPS);
     const int M = (int)M64;
     const int MT = (M + c.BM - 1) / c.BM;
     const int NT = (p.N + c.BN - 1) / c.BN;

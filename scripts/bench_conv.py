@@ -1,4 +1,7 @@
-"""Micro-benchmark of mit_conv_gemm on the LaMa/ctd conv shapes (GPU box only)."""
+"""Micro-benchmark of mit_conv_gemm tile configurations on the LaMa / OCR / ctd conv shapes (GPU box only).
+
+Interleaved rounds inside one process (guide §5.4 rule 24); every configuration's output is checked bit-for-bit against
+configuration 0 (same k-ordered accumulation)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,49 +9,72 @@ from manga_image_translator_amd import ops, lib
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", "4"))
+WIDE = [0, 4, 7, 8, 11]
+NARROW = [1, 5, 9, 10, 12, 13]
 SHAPES = [
-    # name, Cin, Cout, H, W, k, s, p, mode
-    ("g2l 384->128 3x3", 384, 128, 256, 182, 3, 1, 1, ops.PAD_REFLECT),
-    ("l2g 128->384 3x3", 128, 384, 256, 182, 3, 1, 1, ops.PAD_REFLECT),
-    ("l2l 128->128 3x3", 128, 128, 256, 182, 3, 1, 1, ops.PAD_REFLECT),
-    ("fused 512->128 3x3", 512, 128, 256, 182, 3, 1, 1, ops.PAD_REFLECT),
-    ("st1 384->192 1x1", 384, 192, 256, 182, 1, 1, 0, ops.PAD_ZERO),
-    ("fu 384->384 1x1 (256x92)", 384, 384, 256, 92, 1, 1, 0, ops.PAD_ZERO),
-    ("st2 192->384 1x1", 192, 384, 256, 182, 1, 1, 0, ops.PAD_ZERO),
-    ("down 64->128 3x3 s2", 64, 128, 2048, 1456, 3, 2, 1, ops.PAD_REFLECT),
-    ("stem 4->64 7x7", 4, 64, 2048, 1456, 7, 1, 3, ops.PAD_REFLECT),
-    ("out 64->3 7x7", 64, 3, 2048, 1456, 7, 1, 3, ops.PAD_REFLECT),
+    # name, Cin, Cout, H, W, k, s, p, mode, batch, cfgs
+    ("lama fused 512->128 3x3", 512, 128, 256, 182, 3, 1, 1, ops.PAD_REFLECT, B, WIDE),
+    ("lama l2g 128->384 3x3", 128, 384, 256, 182, 3, 1, 1, ops.PAD_REFLECT, B, WIDE),
+    ("lama st1 384->192 1x1", 384, 192, 256, 182, 1, 1, 0, ops.PAD_ZERO, B, NARROW + [0, 7]),
+    ("lama st2 192->384 1x1", 192, 384, 256, 182, 1, 1, 0, ops.PAD_ZERO, B, WIDE),
+    ("lama down2 128->256 3x3 s2", 128, 256, 1024, 728, 3, 2, 1, ops.PAD_REFLECT, B, WIDE),
+    ("lama down1 64->128 3x3 s2", 64, 128, 2048, 1456, 3, 2, 1, ops.PAD_REFLECT, 1, WIDE),
+    ("lama stem 4->64 7x7", 4, 64, 2048, 1456, 7, 1, 3, ops.PAD_REFLECT, 1, [1, 5]),
+    ("ocr pw1 320->1280 (16x6x128)", 320, 1280, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
+    ("ocr pw2 1280->320 (16x6x128)", 1280, 320, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, NARROW + [0, 7]),
+    ("ocr pw1 160->640 (16x12x128)", 160, 640, 192, 128, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
+    ("ocr pw2 640->160 (16x12x128)", 640, 160, 192, 128, 1, 1, 0, ops.PAD_ZERO, 1, NARROW + [0, 7]),
+    ("ctd 3x3 128->128 @128^2 x8", 128, 128, 128, 128, 3, 1, 1, ops.PAD_ZERO, 8, WIDE),
+    ("ctd 1x1 512->256 @64^2 x8", 512, 256, 64, 64, 1, 1, 0, ops.PAD_ZERO, 8, WIDE),
 ]
-cfgs = [int(c) for c in os.environ.get("CFGS", "-1,0,3,4").split(",")]
+only = os.environ.get("ONLY")
+ROUNDS = int(os.environ.get("ROUNDS", "3"))
 res = []
-for name, Cin, Cout, H, W, k, s, p, mode in SHAPES:
-    b = B if H <= 512 else 1
+L = lib.load()
+for name, Cin, Cout, H, W, k, s, p, mode, b, cfgs in SHAPES:
+    if only and only not in name:
+        continue
     w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
     layer = ops.Conv2d(w, None, stride=s, padding=p, pad_mode=mode, act=ops.ACT_RELU, device=dev)
     x = torch.randn(b, H, W, layer.Cin, device=dev)
     Ho, Wo = layer.out_hw(H, W)
-    out = torch.empty(b, Ho, Wo, Cout, device=dev)
     flops = 2.0 * b * Ho * Wo * Cout * Cin * k * k
-    for cfg in cfgs:
-        if cfg == 4 and Cin % 32:
-            continue
+    ref = None
+    times = {c: [] for c in cfgs}
+    ok = {}
+    for c in cfgs:
+        out = torch.zeros(b, Ho, Wo, Cout, device=dev)
         try:
-            for _ in range(2):
-                layer(x, out=out, cfg=cfg)
+            layer(x, out=out, cfg=c)
             torch.cuda.synchronize()
+        except Exception as ex:
+            ok[c] = f"FAILED {ex}"
+            continue
+        if ref is None:
+            ref = out.clone()
+            ok[c] = "ref"
+        else:
+            ok[c] = "bit-equal" if torch.equal(out, ref) else f"DIFF {(out - ref).abs().max().item():.3e}"
+    out = torch.empty(b, Ho, Wo, Cout, device=dev)
+    for r in range(ROUNDS):
+        for c in cfgs:
+            if ok[c].startswith("FAILED"):
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 5
+            n = 3
             e0.record()
             for _ in range(n):
-                layer(x, out=out, cfg=cfg)
+                layer(x, out=out, cfg=c)
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / n
-            tf = flops / ms / 1e9
-            cname = "auto" if cfg < 0 else lib.load().mit_conv_gemm_config_name(cfg).decode()
-            print(f"{name:28s} B={b} cfg={cname:12s} {ms:8.3f} ms  {tf:7.1f} TFLOP/s", flush=True)
-            res.append(dict(name=name, B=b, cfg=cname, ms=ms, tflops=tf))
-        except Exception as ex:
-            print(name, cfg, "FAILED", ex)
+            times[c].append(e0.elapsed_time(e1) / n)
+    for c in cfgs:
+        if not times[c]:
+            print(f"{name:32s} cfg={c} {ok[c]}")
+            continue
+        ms = sorted(times[c])[len(times[c]) // 2]
+        cname = L.mit_conv_gemm_config_name(c).decode()
+        print(f"{name:32s} B={b} {cname:16s} {ms:8.3f} ms {flops / ms / 1e9:7.1f} TF  ({ok[c]})", flush=True)
+        res.append(dict(name=name, B=b, cfg=cname, ms=ms, tflops=flops / ms / 1e9, check=ok[c]))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/bench_conv.json", "w"), indent=1)

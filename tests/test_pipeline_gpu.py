@@ -156,7 +156,7 @@ def test_plugins_end_to_end(cuda):
     run(det.load("cuda"))
     tls, raw_mask, extra = run(det.infer(page, 1024, 0.5, 0.7, 2.3))
     assert extra is None and len(tls) == 1 and tls[0].prob == pytest.approx(0.9)
-    assert raw_mask.dtype == np.uint8 and raw_mask.shape == (256, 192)  # letterbox of a 4:3 page to 1024: un-padded area / 4
+    assert raw_mask.dtype == np.uint8 and raw_mask.shape == (1024, 768)  # un-padded letterbox area (the injected refine hook skips the resize back)
     run(det.unload())
     assert not det.is_loaded()
 
