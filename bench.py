@@ -10,7 +10,8 @@ gathers the per-page results of every step (inside the timed region).  Prints ON
 
 Extra legs (outside the timed region):
   * roofline  — one instrumented pass with HIP events around every conv_gemm launch (the C-ABI's mit_prof_* probe);
-                the dominant kernel is conv_gemm_kernel<128,128,16,2,2>, MFMA-bound, priced against the fp32 matrix peak.
+                the dominant kernel (the conv_gemm tile configuration with the most GPU time) is MFMA-bound and priced
+                against the fp32 matrix peak.
   * cpu_baseline — the oracle (CPU restatement of the reference modules, same ATen ops, fp32) timed on the host cores
                 on a bounded sample (one page through all three stages), rank 0 at N = 1 only.
 """
@@ -34,7 +35,6 @@ H, W = 2048, 1456
 N_BOXES = 32
 DECODE_STEPS = 32          # fixed decode length with EOS suppressed (random weights never emit EOS)
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no xf32 on gfx950
-DOMINANT_CFG = 0           # conv_gemm_kernel<128,128,16,2,2>
 
 
 def parse():
@@ -79,9 +79,9 @@ def roofline_leg(engine, pages, quads, masks, stages, n_probe):
     L.check(lib.mit_prof_enable(1), "mit_prof_enable")
     engine.run(pages[:n], quads[:n], masks[:n], max_seq_length=DECODE_STEPS, suppress_eos=True, stages=stages)
     torch.cuda.synchronize()
-    stats = (L.MitProfStat * 16)()
+    stats = (L.MitProfStat * 32)()
     ncfg = C.c_int(0)
-    L.check(lib.mit_prof_read(stats, 16, C.byref(ncfg)), "mit_prof_read")
+    L.check(lib.mit_prof_read(stats, 32, C.byref(ncfg)), "mit_prof_read")
     L.check(lib.mit_prof_enable(0), "mit_prof_enable")
     per_cfg = {}
     for i in range(ncfg.value):
@@ -90,11 +90,15 @@ def roofline_leg(engine, pages, quads, masks, stages, n_probe):
             per_cfg[lib.mit_conv_gemm_config_name(i).decode()] = dict(
                 launches=int(s.launches), ms=round(s.ms, 3), alg_tflops=round(s.alg_flops / (s.ms * 1e-3) / 1e12, 2),
                 exec_tflops=round(s.exec_flops / (s.ms * 1e-3) / 1e12, 2))
-    d = stats[DOMINANT_CFG]
+    dom = max(range(ncfg.value), key=lambda i: stats[i].ms)  # the tile configuration with the most GPU time
+    d = stats[dom]
     if not d.launches:
         return None, per_cfg
+    cname = lib.mit_conv_gemm_config_name(dom).decode()
+    tile = cname.replace("fast", "").split("w")[0].replace("x", ",")
+    kernel = ("conv_gemm_fast_kernel<%s,...>" if cname.startswith("fast") else "conv_gemm_kernel<%s,...>") % tile
     achieved = d.alg_flops / (d.ms * 1e-3) / 1e12
-    roof = dict(bound="mfma", kernel="conv_gemm_kernel<128,128,16,2,2>", achieved=round(achieved, 2),
+    roof = dict(bound="mfma", kernel=kernel, tile_config=cname, achieved=round(achieved, 2),
                 peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None,
                 launches=int(d.launches), avg_launch_us=round(d.ms * 1e3 / d.launches, 2),
                 alg_gflop_per_launch=round(d.alg_flops / d.launches / 1e9, 3),

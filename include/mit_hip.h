@@ -115,6 +115,15 @@ int mit_conv_gemm(const MitConvGemm *desc, void *stream);
 int mit_conv_gemm_cfg(const MitConvGemm *desc, int cfg, void *stream);
 const char *mit_conv_gemm_config_name(int cfg);
 
+/* k x k (3, 5, 7) stride-1 "same" convolution with 1..4 output channels on the fp32 VALU (an MFMA tile would idle 29 of
+ * its 32 columns): out[b,y,x,n] = act(sum in[b,y+dy,x+dx,c] * w4[(ky*k+kx)*Cin + c][n] + bias[n]).  in: NHWC with pixel
+ * stride in_pixstride floats (Cin % 16 == 0 channels used); w4: [k*k][Cin][4] (output channel padded to 4, zeros beyond
+ * Cout); out: pixel stride out_pixstride, Cout floats written.  Replaces ReflectionPad2d(3) + Conv2d(64, 3, 7) + sigmoid at the
+ * end of FFCResNetGenerator (inpainting_lama_mpe.py:597-600). */
+int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *w4_dev, const float *bias_dev, float *out_dev,
+                        int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k, int pad_mode, int act,
+                        float act_alpha, void *stream);
+
 /* kernel-time probe (measurement only; bench.py's roofline leg).  While enabled every mit_conv_gemm launch — from the
  * host or from the native decoder loop — is bracketed by HIP events on its own stream; mit_prof_read synchronises those
  * events and returns, per tile configuration, the launch count, the summed kernel time and the summed FLOPs
@@ -253,6 +262,16 @@ int mit_ocr_prep(const uint8_t *lines_dev, float *out_dev, int N, int H, int Wp,
 /* depthwise k x k conv + per-channel scale/bias (ConvNeXtBlock.dwconv + norm, model_48px.py:195-196,205-206). w [k*k][C]. */
 int mit_dwconv_nhwc(const float *in_dev, const float *w_dev, const float *scale_dev, const float *bias_dev, float *out_dev,
                     int B, int H, int W, int C, int k, void *stream);
+/* Ragged variant: nsegs images [B_s,H_s,W_s,C] stored back to back along the pixel axis (the OCR chunks of a page group,
+ * whose padded widths differ, model_48px.py:83-86).  Segment s starts at pixel pixel_start; group_start = running count of
+ * (image row, 4-column group) work items = sum over earlier segments of B*H*ceil(W/4); total_groups = that sum over all. */
+typedef struct MitRaggedSeg {
+    int64_t pixel_start, group_start;
+    int32_t B, H, W, _pad;
+} MitRaggedSeg;
+int mit_dwconv_nhwc_ragged(const float *in_dev, const float *w_dev, const float *scale_dev, const float *bias_dev,
+                           float *out_dev, const MitRaggedSeg *segs_dev, int nsegs, int64_t total_groups, int C, int k,
+                           void *stream);
 /* nn.LayerNorm over the last dim (transformer norm1/2/3). */
 int mit_layernorm(const float *in_dev, int64_t in_rowstride, const float *w_dev, const float *b_dev, float *out_dev,
                   int64_t out_rowstride, int rows, int D, float eps, void *stream);

@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, con
 // generic kernel, so results are bitwise identical to it.
 constexpr int FAST_MAX_TAPS = 16;
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const MitConvGemm p, const int M, const int MT,
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConvGemm p, const int M, const int MT,
                                                                const int NT, const int KT) {
     constexpr int WM = BM / WAVES_M;
     constexpr int WN = BN / WAVES_N;
@@ -503,14 +503,14 @@ void launch_cfg(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW>
 void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
     constexpr int LDA = BM + (BK == 16 ? 2 : 1);
     constexpr int LDB = BN + 4;
-    size_t staging = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + (size_t)FAST_MAX_TAPS * BM * sizeof(int);
+    size_t staging = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + (size_t)p.ntaps * BM * sizeof(int);
     size_t rows = (size_t)BM * sizeof(RowOff);
     size_t smem = staging > rows ? staging : rows;
-    auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
+    auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW>;
     static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && smem > 64 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -523,7 +523,9 @@ void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
 #define CFG(BM, BN, BK, WM_, WN_) \
     { #BM "x" #BN "x" #BK, BM, BN, BK, launch_cfg<BM, BN, BK, WM_, WN_>, 0 }
 #define FCFG(BM, BN, BK, WM_, WN_) \
-    { "fast" #BM "x" #BN "x" #BK, BM, BN, BK, launch_fast<BM, BN, BK, WM_, WN_>, 1 }
+    { "fast" #BM "x" #BN "x" #BK, BM, BN, BK, launch_fast<BM, BN, BK, WM_, WN_, 1>, 1 }
+#define FCFGW(BM, BN, BK, WM_, WN_, MINW) \
+    { "fast" #BM "x" #BN "x" #BK "w" #MINW, BM, BN, BK, launch_fast<BM, BN, BK, WM_, WN_, MINW>, 1 }
 
 const CfgEntry kCfgs[] = {
     CFG(128, 128, 16, 2, 2),  // 0: general
@@ -540,6 +542,9 @@ const CfgEntry kCfgs[] = {
     FCFG(256, 128, 16, 2, 2),  // 11
     FCFG(128, 64, 32, 2, 2),   // 12
     FCFG(256, 64, 32, 4, 1),   // 13
+    FCFGW(128, 128, 16, 2, 2, 4),  // 14: <= 128 registers, 4 workgroups per CU
+    FCFGW(128, 128, 16, 4, 1, 4),  // 15: wave tile 32 x 128
+    FCFGW(128, 128, 16, 1, 4, 4),  // 16: wave tile 128 x 32
 };
 
 // fast kernel preconditions: whole K-tiles inside one tap, table fits, 32-bit element offsets
@@ -564,7 +569,7 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     if (p.N <= 32) return 2;
     const int rem = p.N % 128;
     if (p.N <= 64 || (rem != 0 && rem <= 64)) return f16 ? 9 : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
-    return f16 ? 7 : 0;
+    return f16 ? 16 : 0;  // 4 waves of 128 x 32, <= 128 registers: 4 workgroups per CU (+3-7 % over the 2 x 2 layout)
 }
 
 // ---- kernel-time probe (mit_prof_*): HIP events around every launch while enabled ----

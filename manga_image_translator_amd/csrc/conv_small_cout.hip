@@ -1,0 +1,116 @@
+// conv_small_cout.hip — k x k stride-1 convolution with <= 4 output channels (LaMa's 7x7 64->3 output conv).
+//
+// An implicit-GEMM tile would waste its N dimension on such a layer (32 MFMA columns for 3 channels: 598 GFLOP
+// executed per 2048x1456 page for 56 GFLOP of work, 7.4 ms).  Here every thread owns one output pixel and all
+// (<= 4) output channels on the fp32 VALU: the input halo tile is staged through LDS in 16-channel slices laid out
+// [c4][y][x] so that the 32 threads of a row read consecutive float4 (conflict-free ds_read_b128), and the weights
+// are wave-uniform, i.e. scalar loads feeding v_fma_f32 from SGPRs.  Accumulation order: channel slice, tap (ky, kx),
+// channel — a single fmaf chain per output, like the MFMA kernel's (k order differs: slice-major instead of tap-major).
+//
+// Reference op: FFCResNetGenerator.model[-2:] = ReflectionPad2d(3) + Conv2d(64, 3, 7) + sigmoid
+// (manga_translator/inpainting/inpainting_lama_mpe.py:597-600).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mit_hip.h"
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TW = 32, TH = 8, CCH = 16;
+
+__device__ __forceinline__ float act_fn(float v, int act, float alpha) {
+    switch (act) {
+        case MIT_ACT_RELU: return v > 0.f ? v : 0.f;
+        case MIT_ACT_LEAKY: return v > 0.f ? v : v * alpha;
+        case MIT_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__restrict__ in, int64_t in_pix, const f32x4 *__restrict__ w4,
+                                                               const float *__restrict__ bias, float *__restrict__ out,
+                                                               int64_t out_pix, int H, int W, int Cin, int Cout, int reflect,
+                                                               int act, float alpha) {
+    constexpr int R = K / 2;
+    constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
+    __shared__ f32x4 tile[CCH / 4][HH_][HW_];
+    const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
+    const float *ib = in + (int64_t)b * H * W * in_pix;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < Cin; c0 += CCH) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < (CCH / 4) * HH_ * HW_; i += 256) {
+            const int q = i % (CCH / 4);
+            const int p = i / (CCH / 4);
+            const int px = p % HW_, py = p / HW_;
+            int yy = y0 + py - R, xx = x0 + px - R;
+            bool ok = true;
+            if (reflect) {
+                yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+                xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+                ok = yy >= 0 && yy < H && xx >= 0 && xx < W;  // far outside the image (tile overhang): unused
+            } else {
+                ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4 *>(ib + ((int64_t)yy * W + xx) * in_pix + c0 + q * 4);
+            tile[q][py][px] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x4 *wt = w4 + (int64_t)(ky * K + kx) * Cin + c0;  // wave-uniform -> scalar loads
+#pragma unroll
+                for (int q = 0; q < CCH / 4; ++q) {
+                    const f32x4 v = tile[q][ty + ky][tx + kx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 ww = wt[q * 4 + e];
+                        acc.x = fmaf(v[e], ww.x, acc.x);
+                        acc.y = fmaf(v[e], ww.y, acc.y);
+                        acc.z = fmaf(v[e], ww.z, acc.z);
+                        acc.w = fmaf(v[e], ww.w, acc.w);
+                    }
+                }
+            }
+        }
+    }
+    const int x = x0 + tx, y = y0 + ty;
+    if (x < W && y < H) {
+        float *o = out + (((int64_t)b * H + y) * W + x) * out_pix;
+        for (int n = 0; n < Cout; ++n) o[n] = act_fn(acc[n] + (bias ? bias[n] : 0.f), act, alpha);
+    }
+}
+
+}  // namespace
+
+extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *w4_dev, const float *bias_dev,
+                                   float *out_dev, int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k,
+                                   int pad_mode, int act, float act_alpha, void *stream) {
+    if (!in_dev || !w4_dev || !out_dev) return mit_set_error("mit_conv_small_cout: null pointer");
+    if (Cout < 1 || Cout > 4) return mit_set_error("mit_conv_small_cout: 1 <= Cout <= 4 required (got %d)", Cout);
+    if (Cin <= 0 || (Cin % CCH)) return mit_set_error("mit_conv_small_cout: Cin must be a multiple of %d (got %d)", CCH, Cin);
+    if (B <= 0 || H <= 0 || W <= 0 || B > 65535) return mit_set_error("mit_conv_small_cout: bad size");
+    if ((in_pixstride & 3) || (reinterpret_cast<uintptr_t>(in_dev) & 15) || (reinterpret_cast<uintptr_t>(w4_dev) & 15))
+        return mit_set_error("mit_conv_small_cout: input pixels and weights must be 16-byte aligned");
+    if (pad_mode == MIT_PAD_REFLECT && (k / 2 >= H || k / 2 >= W)) return mit_set_error("mit_conv_small_cout: reflect pad larger than input");
+    dim3 grid(mit_div_up(W, TW), mit_div_up(H, TH), B), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w4_dev);
+    const int refl = pad_mode == MIT_PAD_REFLECT;
+    switch (k) {
+        case 3: hipLaunchKernelGGL(conv_small_cout_kernel<3>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+        case 5: hipLaunchKernelGGL(conv_small_cout_kernel<5>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+        case 7: hipLaunchKernelGGL(conv_small_cout_kernel<7>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+        default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
+    }
+    MIT_CHECK_LAUNCH("mit_conv_small_cout");
+    return 0;
+}

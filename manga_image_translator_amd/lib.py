@@ -110,6 +110,11 @@ class MitWarpLine(C.Structure):
                 ("_pad", C.c_int32)]
 
 
+class MitRaggedSeg(C.Structure):
+    _fields_ = [("pixel_start", C.c_int64), ("group_start", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
 # every symbol include/mit_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mit_last_error": (C.c_char_p, []),
@@ -119,6 +124,8 @@ SYMBOLS = {
     "mit_conv_gemm": (C.c_int, [C.POINTER(MitConvGemm), C.c_void_p]),
     "mit_conv_gemm_cfg": (C.c_int, [C.POINTER(MitConvGemm), C.c_int, C.c_void_p]),
     "mit_conv_gemm_config_name": (C.c_char_p, [C.c_int]),
+    "mit_conv_small_cout": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "mit_prof_enable": (C.c_int, [C.c_int]),
     "mit_prof_tag_next": (C.c_int, [C.c_double]),
     "mit_prof_read": (C.c_int, [C.POINTER(MitProfStat), C.c_int, C.POINTER(C.c_int)]),
@@ -142,6 +149,8 @@ SYMBOLS = {
     "mit_ocr_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_dwconv_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p]),
+    "mit_dwconv_nhwc_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mit_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                 C.c_float, C.c_void_p]),
     "mit_xpos_rotate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,

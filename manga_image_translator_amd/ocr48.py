@@ -209,6 +209,136 @@ class Ocr48Engine:
             x = down(x, out=self._buf(f"{tag}.d{si}", B, *down.out_hw(H, W), down.Cout))
         return x
 
+    # -- page-group path: all chunks of a group share every row-wise op ------------------------------------------
+    def _cat_views(self, name, shapes, C_):
+        """One slab holding [N,H,W,C_] images back to back; returns (flat [rows, C_], per-chunk 4-D views, row starts)."""
+        rows = [n * h * w for n, h, w in shapes]
+        starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+        flat = self._buf(name, int(starts[-1]), C_)
+        views = [flat[starts[i]:starts[i + 1]].view(n, h, w, C_) for i, (n, h, w) in enumerate(shapes)]
+        return flat, views, starts
+
+    def _ragged_table(self, shapes, starts, stage_tabs):
+        from .lib import MitRaggedSeg
+
+        segs = (MitRaggedSeg * len(shapes))()
+        g = 0
+        for i, (n, h, w) in enumerate(shapes):
+            segs[i].pixel_start, segs[i].group_start, segs[i].B, segs[i].H, segs[i].W = int(starts[i]), g, n, h, w
+            g += n * h * ((w + 3) // 4)
+        stage_tabs.append((bytes(segs), g))
+
+    @torch.no_grad()
+    def encode_group(self, regions: Sequence[torch.Tensor], klen_all: torch.Tensor, Lmax: int, mem_k: Optional[torch.Tensor] = None,
+                     mem_v: Optional[torch.Tensor] = None, first_lines: Optional[Sequence[int]] = None):
+        """Backbone + encoder + cross-attention K/V for several chunks at once.
+
+        regions[c] u8 [N_c,48,Wp_c,3] (device); klen_all int32 (device), indexed by pooled line number: chunk c owns
+        lines [first_lines[c], first_lines[c] + N_c) (default: back to back from 0) of the pooled outputs
+        mem_k / mem_v [5, n_lines, Lmax, 320] (allocated here when not given).  Every row-wise operator (the
+        pointwise convs = 96 % of the backbone FLOPs, LayerNorm, all Linear layers) runs ONCE over the rows of all
+        chunks; only the spatial ops (stem / downsampling convs, XPOS rotation, attention) are launched per chunk and
+        the depthwise conv through its ragged form.  Row results do not depend on which other rows share a launch, so
+        this is bitwise identical to encode() chunk by chunk.  Returns (mem_k, mem_v, keep) when it allocated the pooled
+        tensors, else the staging buffers to keep alive."""
+        lib = _lib.load()
+        st = C.c_void_p(ops.current_stream())
+        nc = len(regions)
+        Ns = [int(r.shape[0]) for r in regions]
+        Wps = [int(r.shape[2]) for r in regions]
+        # ---- stem, per chunk (7x7 s1, 2x2 s2, 3x3 s1) ----
+        sh0 = [(n, 48, wp) for n, wp in zip(Ns, Wps)]
+        _, x_in, _ = self._cat_views("g.in", sh0, 4)
+        for r, xi in zip(regions, x_in):
+            _lib.check(lib.mit_ocr_prep(r.contiguous().data_ptr(), xi.data_ptr(), xi.shape[0], 48, xi.shape[2], st), "mit_ocr_prep")
+        cur, cur_sh = x_in, sh0
+        for ci, conv in enumerate(self.stem):
+            sh = [(n, *conv.out_hw(h, w)) for n, h, w in cur_sh]
+            flat, views, starts = self._cat_views(f"g.s{ci}", sh, conv.Cout)
+            for xi, oi in zip(cur, views):
+                conv(xi, out=oi)
+            cur, cur_sh = views, sh
+        # ---- ragged tables for the four stages (uploaded in one pinned copy) ----
+        stage_shapes, tabs = [], []
+        sh = cur_sh
+        for down in self.downs:
+            stage_shapes.append(sh)
+            rows = [n * h * w for n, h, w in sh]
+            self._ragged_table(sh, np.concatenate([[0], np.cumsum(rows)]), tabs)
+            sh = [(n, *down.out_hw(h, w)) for n, h, w in sh]
+        blob = b"".join(t for t, _ in tabs)
+        stage = torch.empty(len(blob), dtype=torch.uint8, pin_memory=True)
+        stage.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        tab_dev = stage.to(self.device, non_blocking=True)
+        tab_off = np.concatenate([[0], np.cumsum([len(t) for t, _ in tabs])])
+        # ---- ConvNeXt stages ----
+        for si, (blocks, down) in enumerate(zip(self.stages, self.downs)):
+            sh = stage_shapes[si]
+            Cc = cur[0].shape[3]
+            rows = sum(n * h * w for n, h, w in sh)
+            x_flat = flat  # slab holding `cur`
+            t_flat = self._buf(f"g.dw{si}", rows, Cc)
+            h_flat = self._buf(f"g.h{si}", rows, 4 * Cc)
+            x4, t4, h4 = x_flat.view(1, 1, rows, Cc), t_flat.view(1, 1, rows, Cc), h_flat.view(1, 1, rows, 4 * Cc)
+            for blk in blocks:
+                _lib.check(lib.mit_dwconv_nhwc_ragged(x_flat.data_ptr(), blk.dw_w.data_ptr(), blk.dw_scale.data_ptr(),
+                                                      blk.dw_bias.data_ptr(), t_flat.data_ptr(),
+                                                      tab_dev.data_ptr() + int(tab_off[si]), nc, tabs[si][1], Cc, blk.ks, st),
+                           "mit_dwconv_nhwc_ragged")
+                blk.pw1(t4, out=h4)
+                blk.pw2(h4, out=x4, post=x4)
+            nsh = [(n, *down.out_hw(h, w)) for n, h, w in sh]
+            flat, views, starts = self._cat_views(f"g.d{si}", nsh, down.Cout)
+            for xi, oi in zip(cur, views):
+                down(xi, out=oi)
+            cur, cur_sh = views, nsh
+        # ---- transformer encoder over the concatenated memory [sum N_c * L_c, 320] ----
+        Ls = [w for _, _, w in cur_sh]
+        for wp, L in zip(Wps, Ls):
+            if L != self.memory_len(wp):
+                raise RuntimeError(f"backbone length {L} != memory_len({wp})")
+        mem = flat
+        M = mem.shape[0]
+        nrm = self._buf("g.nrm", M, EMBD)
+        qkv = self._buf("g.qkv", 3, M, EMBD)
+        qr = self._buf("g.qr", M, EMBD)
+        kr = self._buf("g.kr", M, EMBD)
+        att = self._buf("g.att", M, EMBD)
+        ffh = self._buf("g.ffh", M, FF)
+        row0 = starts  # first memory row of each chunk
+        own = mem_k is None
+        if first_lines is None:
+            first_lines = np.concatenate([[0], np.cumsum(Ns)])[:-1].tolist()
+        line0 = [int(f) for f in first_lines]
+        for ly in self.enc:
+            self._layernorm(mem, *ly.ln[0], nrm)
+            ly.qkv(nrm, qkv[0], nsplit=EMBD, nhi=M * EMBD)
+            for c in range(nc):
+                N, L = Ns[c], Ls[c]
+                a, b = int(row0[c]), int(row0[c + 1])
+                minpos, LE = -((L + 1) // 2), L * EMBD
+                self._rotate(qkv[0][a:b], qr[a:b], N, L, 0, minpos, False, LE, EMBD, LE, EMBD)
+                self._rotate(qkv[1][a:b], kr[a:b], N, L, 0, minpos, True, LE, EMBD, LE, EMBD)
+                self._attention(qr[a:b], kr[a:b], qkv[2][a:b], att[a:b], klen_all[line0[c]:line0[c] + N], N, L, L, 1,
+                                ((LE, EMBD),) * 4)
+            ly.out(att, mem, post=mem)
+            self._layernorm(mem, *ly.ln[1], nrm)
+            ly.ff1(nrm, ffh, act=ACT_RELU)
+            ly.ff2(ffh, mem, post=mem)
+        # ---- cross-attention keys / values of the five decoder layers, pooled and padded to Lmax ----
+        if own:
+            mem_k, mem_v = self.alloc_memory(sum(Ns), Lmax)
+        ktmp = self._buf("g.ktmp", M, EMBD)
+        vtmp = self._buf("g.vtmp", M, EMBD)
+        for l in range(5):
+            self.mem_kv[l](mem, ktmp, nsplit=EMBD, nhi=(vtmp.data_ptr() - ktmp.data_ptr()) // 4)
+            for c in range(nc):
+                N, L = Ns[c], Ls[c]
+                a, b, l0 = int(row0[c]), int(row0[c + 1]), int(line0[c])
+                self._rotate(ktmp[a:b], mem_k[l, l0:l0 + N], N, L, 0, -((L + 1) // 2), True, L * EMBD, EMBD, Lmax * EMBD, EMBD)
+                mem_v[l, l0:l0 + N, :L].copy_(vtmp[a:b].view(N, L, EMBD))
+        return (mem_k, mem_v, (stage, tab_dev)) if own else (stage, tab_dev)
+
     def _rotate(self, src, dst, R, T, i0, p0, downscale, src_rs, src_ts, dst_rs, dst_ts):
         _lib.check(_lib.load().mit_xpos_rotate(src.data_ptr(), src_rs, src_ts, dst.data_ptr(), dst_rs, dst_ts, R, T, i0, p0,
                                                int(downscale), C.byref(self.xpos), C.c_void_p(ops.current_stream())), "mit_xpos_rotate")
@@ -352,78 +482,97 @@ class Ocr48Engine:
         out["order"] = order
         return out
 
+    # -- Model48pxOCR._infer (:67-120) for a batch of device-resident pages ----------------------------------------
+    def plan_pages(self, quads_per_page, H: int, W: int, directions=None):
+        """Host planning for ``recognize_pages``: per page, rectification geometry of every line (textline.warp_plans) and
+        the reference's chunking (sorted by crop width, groups of 16, padded to max+7, model_48px.py:79-86).
+
+        Returns a dict: ``records`` (WARP_LINE_DTYPE, one per line, ordered chunk by chunk), ``chunks``
+        [(first_record, n_lines, widths, padded_width, page)], ``order`` [(page, line)] per record, ``klens`` int32, ``Lmax``."""
+        from . import textline as TL
+
+        recs, chunks, order, klens = [], [], [], []
+        n = 0
+        for p, quads in enumerate(quads_per_page):
+            dirs = [q.direction for q in quads] if directions is None else list(directions[p])
+            rec = TL.warp_plans(quads, dirs, H, W, 48)
+            rec["page"] = p
+            widths = np.where(rec["vertical"] != 0, rec["dh"], rec["dw"])
+            for idx, ws, wp in TL.chunk_plan(widths.tolist()):
+                r = rec[idx].copy()
+                r["out_row"] = np.arange(len(idx))
+                recs.append(r)
+                order += [(p, i) for i in idx]
+                L = self.memory_len(wp)
+                klens += [self.valid_len(w, L) for w in ws]
+                chunks.append((n, len(idx), ws, wp, p))
+                n += len(idx)
+        records = np.concatenate(recs) if recs else np.zeros(0, dtype=TL.WARP_LINE_DTYPE)
+        Lmax = max((self.memory_len(c[3]) for c in chunks), default=0)
+        return dict(records=records, chunks=chunks, order=order, klens=np.asarray(klens, dtype=np.int32), Lmax=Lmax, H=H, W=W)
+
+    def upload_plan(self, plan):
+        """One pinned staging buffer -> one asynchronous upload of the line records and key lengths (a pageable copy would
+        stall behind queued GPU work).  Adds ``lines_dev`` / ``klen_dev`` / ``_keep`` to the plan."""
+        raw = plan["records"].tobytes()
+        kb = plan["klens"].tobytes()
+        stage = torch.empty(len(raw) + len(kb), dtype=torch.uint8, pin_memory=True)
+        stage.copy_(torch.frombuffer(bytearray(raw + kb), dtype=torch.uint8))
+        table = stage.to(self.device, non_blocking=True)
+        plan["lines_dev"], plan["klen_dev"] = table[:len(raw)], table[len(raw):].view(torch.int32)
+        plan["_keep"] = [stage, table]
+        return plan
+
+    @torch.no_grad()
+    def encode_planned(self, pages_u8: torch.Tensor, plan, chunk_ids: Sequence[int], mem_k: torch.Tensor, mem_v: torch.Tensor):
+        """Rectify (mit_ocr_warp_lines) and encode the given chunks of an uploaded plan; their cross-attention K/V land in
+        rows [first_record, first_record + n) of the pooled ``mem_k`` / ``mem_v`` [5, n_lines, Lmax, 320]."""
+        if not chunk_ids:
+            return
+        lib = _lib.load()
+        st = C.c_void_p(ops.current_stream())
+        H, W = plan["H"], plan["W"]
+        rec_bytes = plan["records"].dtype.itemsize
+        regions = []
+        for ci in chunk_ids:
+            first, n, ws, wp, _ = plan["chunks"][ci]
+            region = torch.empty(n, 48, wp, 3, dtype=torch.uint8, device=self.device)
+            _lib.check(lib.mit_ocr_warp_lines(pages_u8.data_ptr(), H, W, plan["lines_dev"].data_ptr() + first * rec_bytes, n,
+                                              region.data_ptr(), 48, wp, st), "mit_ocr_warp_lines")
+            regions.append(region)
+        firsts = [plan["chunks"][ci][0] for ci in chunk_ids]
+        keep = self.encode_group(regions, plan["klen_dev"], mem_k.shape[2], mem_k, mem_v, firsts)
+        plan["_keep"].append(keep)
+
     @torch.no_grad()
     def recognize_pages(self, pages_u8: torch.Tensor, quads_per_page, max_seq_length: int = 255, suppress_eos: bool = False,
-                        directions=None):
-        """Model48pxOCR._infer (:67-120) for a batch of pages resident on the device.
-
-        pages_u8 [P,H,W,3] u8; quads_per_page[p] = list of textline.Quadrilateral.  Each line is rectified on the GPU
-        (mit_ocr_warp_lines) straight into its chunk tensor — chunks are formed per page exactly as the reference does
-        (sorted by crop width, groups of 16, padded to max+7) — every chunk is encoded, and the lines of ALL pages are
-        decoded in one pooled beam search.  ``directions[p][i]`` overrides a line's own direction (the reference takes a
-        majority vote over merge-graph components, ocr/common.py:12-39).  Returns decode()'s dict plus ``order`` =
-        [(page, line)] in result-row order and ``widths``."""
-        from . import textline as TL
-        from .lib import MitWarpLine
-
+                        directions=None, group_pages: int = 8):
+        """pages_u8 [P,H,W,3] u8 (device); quads_per_page[p] = list of textline.Quadrilateral.  Each line is rectified on
+        the GPU straight into its chunk tensor, chunks are encoded ``group_pages`` pages at a time (row-wise operators over
+        all their chunks at once), and the lines of ALL pages are decoded in one pooled beam search.  ``directions[p][i]``
+        overrides a line's own direction (the reference takes a majority vote over merge-graph components,
+        ocr/common.py:12-39).  Returns decode()'s dict plus ``order`` = [(page, line)] in result-row order."""
         if pages_u8.dtype != torch.uint8 or pages_u8.dim() != 4 or pages_u8.shape[-1] != 3:
             raise ValueError(f"recognize_pages expects u8 [P,H,W,3], got {pages_u8.dtype} {tuple(pages_u8.shape)}")
         pages_u8 = pages_u8.contiguous()
         P, H, W, _ = pages_u8.shape
         if len(quads_per_page) != P:
             raise ValueError("one quad list per page expected")
-        chunks, order, all_widths, recs = [], [], [], []
-        for p, quads in enumerate(quads_per_page):
-            plans = [TL.warp_plan(q, (directions[p][i] if directions is not None else q.direction), H, W, 48)
-                     for i, q in enumerate(quads)]
-            for idx, ws, wp in TL.chunk_plan([pl.width for pl in plans]):
-                first = len(recs)
-                for row, i in enumerate(idx):
-                    pl = plans[i]
-                    r = MitWarpLine()
-                    r.minv[:] = pl.minv.reshape(-1).tolist()
-                    r.page, r.x1, r.y1, r.cw, r.ch, r.dw, r.dh = p, pl.x1, pl.y1, pl.cw, pl.ch, pl.dw, pl.dh
-                    r.vertical, r.out_row = int(pl.vertical), row
-                    recs.append(r)
-                    order.append((p, i))
-                all_widths += ws
-                chunks.append((first, len(idx), ws, wp))
-        if not recs:
-            return dict(order=[], widths=[], tokens=None)
-        arr = (MitWarpLine * len(recs))(*recs)
-        raw = bytes(arr)
-        klens = np.array([self.valid_len(w, self.memory_len(wp)) for _, _, ws, wp in chunks for w in ws], dtype=np.int32)
-        # one pinned staging buffer -> one asynchronous upload (a pageable copy would stall behind queued GPU work)
-        stage = torch.empty(len(raw) + klens.nbytes, dtype=torch.uint8, pin_memory=True)
-        stage[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-        stage[len(raw):] = torch.from_numpy(klens.view(np.uint8))
-        table = stage.to(self.device, non_blocking=True)
-        lines_dev = table[:len(raw)]
-        klen_all = table[len(raw):].view(torch.int32)
-        lib = _lib.load()
-        st = C.c_void_p(ops.current_stream())
-        mks, mvs = [], []
-        rec_bytes = C.sizeof(MitWarpLine)
-        for first, n, ws, wp in chunks:
-            region = self._buf("region", n, 48, wp, 3, dtype=torch.uint8)
-            _lib.check(lib.mit_ocr_warp_lines(pages_u8.data_ptr(), H, W, lines_dev.data_ptr() + first * rec_bytes, n,
-                                              region.data_ptr(), 48, wp, st), "mit_ocr_warp_lines")
-            mk, mv, kl, L = self.encode(region, ws, klen=klen_all[first:first + n])
-            mks.append(mk)
-            mvs.append(mv)
-        Lmax = max(m.shape[2] for m in mks)
-        n_lines = len(recs)
-        mem_k = torch.zeros(5, n_lines, Lmax, EMBD, device=self.device)
-        mem_v = torch.zeros(5, n_lines, Lmax, EMBD, device=self.device)
-        r0 = 0
-        for mk, mv in zip(mks, mvs):
-            n, L = mk.shape[1], mk.shape[2]
-            mem_k[:, r0:r0 + n, :L].copy_(mk)
-            mem_v[:, r0:r0 + n, :L].copy_(mv)
-            r0 += n
-        out = self.decode(mem_k, mem_v, klen_all, max_seq_length, suppress_eos)
-        out["order"], out["widths"], out["_stage"] = order, all_widths, (stage, table)
+        plan = self.upload_plan(self.plan_pages(quads_per_page, H, W, directions))
+        n_lines = len(plan["order"])
+        if n_lines == 0:
+            return dict(order=[], tokens=None)
+        mem_k, mem_v = self.alloc_memory(n_lines, plan["Lmax"])
+        for p0 in range(0, P, group_pages):
+            ids = [i for i, c in enumerate(plan["chunks"]) if p0 <= c[4] < p0 + group_pages]
+            self.encode_planned(pages_u8, plan, ids, mem_k, mem_v)
+        out = self.decode(mem_k, mem_v, plan["klen_dev"], max_seq_length, suppress_eos)
+        out["order"], out["_stage"] = plan["order"], plan["_keep"]
         return out
+
+    def alloc_memory(self, n_lines: int, Lmax: int):
+        """Zeroed pooled cross-attention K / V [5, n_lines, Lmax, 320] (positions beyond a line's memory stay zero and masked)."""
+        return (torch.zeros(5, n_lines, Lmax, EMBD, device=self.device), torch.zeros(5, n_lines, Lmax, EMBD, device=self.device))
 
     @staticmethod
     def backbone_flops(N: int, Wp: int) -> float:

@@ -22,7 +22,7 @@ from .lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "ACT_LEAKY", "ACT_SILU", "ACT_SIGMOID", "ACT_GELU", "PAD_ZERO", "PAD_REFLECT",
-    "Conv2d", "ConvTranspose2d", "fold_bn", "conv_gemm_desc", "launch_conv_gemm", "current_stream",
+    "Conv2d", "ConvSmallCout", "ConvTranspose2d", "fold_bn", "conv_gemm_desc", "launch_conv_gemm", "current_stream",
 ]
 
 
@@ -196,6 +196,38 @@ class Conv2d:
             Ho, Wo = self.out_hw(x.shape[1], x.shape[2])
             out = torch.empty(x.shape[0], Ho, Wo, self.Cout, dtype=torch.float32, device=x.device)
         launch_conv_gemm(self.desc(x, out, pre, post), cfg)
+        return out
+
+
+class ConvSmallCout:
+    """k x k stride-1 "same" conv with <= 4 output channels (+ bias + activation) on ``mit_conv_small_cout``.
+
+    weight [Cout, Cin, k, k]; used for LaMa's 7x7 64->3 output conv (inpainting_lama_mpe.py:597-600)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, pad_mode: int = PAD_ZERO,
+                 act: int = ACT_NONE, alpha: float = 0.0, device="cuda"):
+        Cout, Cin, kh, kw = weight.shape
+        if kh != kw or kh not in (3, 5, 7) or Cout > 4 or Cin % 16:
+            raise ValueError(f"ConvSmallCout: unsupported shape {tuple(weight.shape)}")
+        self.Cout, self.Cin, self.k, self.pad_mode, self.act, self.alpha = Cout, Cin, kh, pad_mode, act, alpha
+        w4 = torch.zeros(kh * kw, Cin, 4, dtype=torch.float32)
+        w4[:, :, :Cout] = weight.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(kh * kw, Cin, Cout)
+        self.w4 = w4.to(device).contiguous()
+        self.bias = None if bias is None else bias.detach().to(torch.float32).to(device).contiguous()
+
+    def __call__(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        _check_nhwc(x, "ConvSmallCout input")
+        _check_nhwc(out, "ConvSmallCout output")
+        B, H, W, Cx = x.shape
+        if Cx < self.Cin or tuple(out.shape[:3]) != (B, H, W) or out.shape[3] < self.Cout:
+            raise ValueError(f"ConvSmallCout: bad shapes {tuple(x.shape)} -> {tuple(out.shape)}")
+        if not (x.stride(2) * W == x.stride(1) and x.stride(1) * H == x.stride(0) and out.stride(2) * W == out.stride(1)
+                and out.stride(1) * H == out.stride(0)):
+            raise ValueError("ConvSmallCout: pixel-dense tensors required")
+        lib = _lib.load()
+        _lib.check(lib.mit_conv_small_cout(x.data_ptr(), x.stride(2), self.w4.data_ptr(), _ptr(self.bias), out.data_ptr(),
+                                           out.stride(2), B, H, W, self.Cin, self.Cout, self.k, self.pad_mode, self.act,
+                                           self.alpha, C.c_void_p(current_stream())), "mit_conv_small_cout")
         return out
 
 

@@ -9,21 +9,25 @@ from manga_image_translator_amd import ops, lib
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", "4"))
-WIDE = [0, 4, 7, 8, 11]
-NARROW = [1, 5, 9, 10, 12, 13]
+WIDE = [int(c) for c in os.environ.get('WIDE', '7,14,15,16').split(',')]
+NARROW = [int(c) for c in os.environ.get('NARROW', '9,7,14').split(',')]
 SHAPES = [
     # name, Cin, Cout, H, W, k, s, p, mode, batch, cfgs
     ("lama fused 512->128 3x3", 512, 128, 256, 182, 3, 1, 1, ops.PAD_REFLECT, B, WIDE),
     ("lama l2g 128->384 3x3", 128, 384, 256, 182, 3, 1, 1, ops.PAD_REFLECT, B, WIDE),
-    ("lama st1 384->192 1x1", 384, 192, 256, 182, 1, 1, 0, ops.PAD_ZERO, B, NARROW + [0, 7]),
+    ("lama st1 384->192 1x1", 384, 192, 256, 182, 1, 1, 0, ops.PAD_ZERO, B, NARROW),
     ("lama st2 192->384 1x1", 192, 384, 256, 182, 1, 1, 0, ops.PAD_ZERO, B, WIDE),
     ("lama down2 128->256 3x3 s2", 128, 256, 1024, 728, 3, 2, 1, ops.PAD_REFLECT, B, WIDE),
     ("lama down1 64->128 3x3 s2", 64, 128, 2048, 1456, 3, 2, 1, ops.PAD_REFLECT, 1, WIDE),
     ("lama stem 4->64 7x7", 4, 64, 2048, 1456, 7, 1, 3, ops.PAD_REFLECT, 1, [1, 5]),
+    ("ocr grp pw1 80->320 (1.2M rows)", 80, 320, 1200, 1024, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
+    ("ocr grp pw2 320->80 (1.2M rows)", 320, 80, 1200, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
+    ("ocr grp pw2 1280->320 (150k rows)", 1280, 320, 150, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
+    ("ocr grp pw2 640->160 (300k rows)", 640, 160, 300, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr pw1 320->1280 (16x6x128)", 320, 1280, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
-    ("ocr pw2 1280->320 (16x6x128)", 1280, 320, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, NARROW + [0, 7]),
+    ("ocr pw2 1280->320 (16x6x128)", 1280, 320, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr pw1 160->640 (16x12x128)", 160, 640, 192, 128, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
-    ("ocr pw2 640->160 (16x12x128)", 640, 160, 192, 128, 1, 1, 0, ops.PAD_ZERO, 1, NARROW + [0, 7]),
+    ("ocr pw2 640->160 (16x12x128)", 640, 160, 192, 128, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ctd 3x3 128->128 @128^2 x8", 128, 128, 128, 128, 3, 1, 1, ops.PAD_ZERO, 8, WIDE),
     ("ctd 1x1 512->256 @64^2 x8", 512, 256, 64, 64, 1, 1, 0, ops.PAD_ZERO, 8, WIDE),
 ]

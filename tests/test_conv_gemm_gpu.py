@@ -169,3 +169,32 @@ def test_bad_descriptor_raises(cuda):
     d.Cin = 6
     with pytest.raises(RuntimeError, match="Cin"):
         ops.launch_conv_gemm(d)
+
+
+@pytest.mark.parametrize("cout,cin,k,mode,act", [(3, 64, 7, "reflect", "sigmoid"), (1, 16, 3, "zero", "relu"), (4, 32, 5, "reflect", "none")])
+def test_conv_small_cout(cuda, cout, cin, k, mode, act):
+    """mit_conv_small_cout (VALU direct conv for <= 4 output channels) vs torch conv2d on the CPU; sizes that are not
+    multiples of the 32x8 tile exercise the overhang, reflect padding at every border."""
+    import torch.nn.functional as F
+
+    from manga_image_translator_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    B, H, W = 2, 19, 45
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, cin, H, W, generator=g)
+    layer = ops.ConvSmallCout(w, b, pad_mode=ops.PAD_REFLECT if mode == "reflect" else ops.PAD_ZERO,
+                              act={"sigmoid": ops.ACT_SIGMOID, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}[act], device=cuda)
+    wide = torch.full((B, H, W, cout + 2), 7.0, device=cuda)  # output is a channel slice: neighbours must stay untouched
+    out = wide[..., :cout]
+    layer(x.permute(0, 2, 3, 1).contiguous().to(cuda), out=out)
+    torch.cuda.synchronize()
+    r = k // 2
+    xp = F.pad(x, (r, r, r, r), mode="reflect") if mode == "reflect" else F.pad(x, (r, r, r, r))
+    ref = F.conv2d(xp, w, b)
+    ref = {"sigmoid": torch.sigmoid, "relu": torch.relu, "none": lambda v: v}[act](ref).permute(0, 2, 3, 1)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    assert (wide[..., cout:] == 7.0).all()
+    with pytest.raises(ValueError):
+        ops.ConvSmallCout(torch.zeros(5, 16, 3, 3), device=cuda)

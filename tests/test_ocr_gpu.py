@@ -110,3 +110,25 @@ def test_pooled_decode_equals_per_chunk(cuda, ocr_setup):
         assert torch.equal(o["tokens"].cpu(), toks[pos:pos + len(ws)])
         pos += len(ws)
     assert pooled["order"] == sorted(range(20), key=lambda i: crops[i].shape[1])
+
+
+def test_group_encode_equals_per_chunk(cuda, ocr_setup):
+    """encode_group (row-wise ops over all chunks at once, ragged depthwise conv) is bitwise the per-chunk encode()."""
+    sd, D, eng = ocr_setup
+    crops = _crops([40 + 13 * i for i in range(21)], seed=9)  # 2 chunks: 16 + 5 lines, different padded widths
+    chunks = list(eng.make_chunks(crops))
+    regions = [torch.from_numpy(r).to(cuda) for _, _, r in chunks]
+    Ls = [eng.memory_len(r.shape[2]) for r in regions]
+    Lmax = max(Ls)
+    klens = torch.tensor([eng.valid_len(w, L) for (_, ws, _), L in zip(chunks, Ls) for w in ws], dtype=torch.int32, device=cuda)
+    gk, gv, _ = eng.encode_group(regions, klens, Lmax)
+    gk, gv = gk.clone(), gv.clone()
+    l0 = 0
+    for (_, ws, _), reg, L in zip(chunks, regions, Ls):
+        mk, mv, kl, L1 = eng.encode(reg, ws)
+        torch.cuda.synchronize()
+        n = len(ws)
+        assert L1 == L and torch.equal(kl, klens[l0:l0 + n])
+        assert torch.equal(gk[:, l0:l0 + n, :L], mk) and torch.equal(gv[:, l0:l0 + n, :L], mv)
+        assert not gk[:, l0:l0 + n, L:].any() and not gv[:, l0:l0 + n, L:].any()  # zero padding up to Lmax
+        l0 += n
