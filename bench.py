@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--pages", type=int, default=64, help="pages per GPU per step (BASELINE config 3: 64)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pages generated per rank (cycled)")
     ap.add_argument("--stages", default="detect,ocr,inpaint")
-    ap.add_argument("--lama-mb", type=int, default=4)
+    ap.add_argument("--lama-mb", type=int, default=8)
     ap.add_argument("--ctd-mb", type=int, default=8)
     ap.add_argument("--group", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -140,6 +140,15 @@ int mit_prof_read(MitProfStat *stats, int max_cfgs, int *n_cfgs);
 /* LaMa inpainting stage: memory-bound pieces ----------------------------------------------
  * Reference: manga_translator/inpainting/inpainting_lama_mpe.py. */
 
+/* Complex FFT of length h (power of two <= 512) along the row axis of planar re/im data, ncols independent columns (column
+ * stride 1), B batches: element (b, t, r, c) at base + b*bs + t*ts + r*hs + c with t = 0 (re) / 1 (im).
+ * out[k] = scale * sum_r in[r] * exp(-/+ 2 pi i k r / h) (inverse != 0: +).  twiddle_dev: h/2 (cos, sin) pairs of 2 pi k / h.
+ * In-place (in == out with equal strides) is allowed.  The H-axis half of torch.fft.rfftn / irfftn(norm='ortho') in
+ * FourierUnit.forward (inpainting_lama_mpe.py:228,252); the W axis stays a dense DFT on mit_conv_gemm. */
+int mit_fft_cols(const float *in_dev, int64_t in_bs, int64_t in_ts, int64_t in_hs, float *out_dev, int64_t out_bs,
+                 int64_t out_ts, int64_t out_hs, const float *twiddle_dev, int B, int h, int64_t ncols, int inverse, float scale,
+                 void *stream);
+
 /* u8 page [B,H,W,3] + u8 mask [B,H,W] -> fp32 NHWC [B,H,W,4] = (rgb/255*(1-m), m), m = (mask/255 >= 0.5).
  * Replaces the host-side tensor prep of LamaMPEInpainter._infer :82-92 and the torch.cat of
  * FFCResNetGenerator.forward :604. */

@@ -155,8 +155,9 @@ class LamaEngine:
     """Batched LaMa generator. ``forward(img_u8[B,H,W,3], mask_u8[B,H,W]) -> u8 [B,H,W,3]`` (device tensors)."""
 
     def __init__(self, gen_sd: Dict[str, torch.Tensor], mpe_sd: Optional[Dict[str, torch.Tensor]] = None,
-                 n_blocks: int = 9, device="cuda"):
+                 n_blocks: int = 9, device="cuda", fft_h: bool = True):
         self.device = torch.device(device)
+        self.fft_h = fft_h  # False: keep the H-axis transform on the dense DFT GEMM (for A/B comparison)
         self.n_blocks = n_blocks
         sd, dev = gen_sd, self.device
         self.stem = ops.Conv2d(sd["model.1.ffc.convl2l.weight"], None, padding=3, pad_mode=PAD_REFLECT,
@@ -185,6 +186,7 @@ class LamaEngine:
                             dirw=mpe_sd["direct_emb.weight"].to(torch.float32).to(dev).contiguous(),
                             alpha5=float(mpe_sd["alpha5"]), alpha6=float(mpe_sd["alpha6"]))
         self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._tw: Dict[int, torch.Tensor] = {}
         self._dft: Dict[Tuple[int, int], Tuple[torch.Tensor, ...]] = {}
         self._mpe_tabs: Dict[Tuple[int, int], dict] = {}
 
@@ -205,6 +207,19 @@ class LamaEngine:
         if k not in self._dft:
             self._dft[k] = tuple(m.to(self.device) for m in dft_matrices(h, w))
         return self._dft[k]
+
+    def _twiddles(self, h):
+        """(cos, sin)(2 pi k / h), k < h/2, rounded once from float64 — the table mit_fft_cols consumes."""
+        if h not in self._tw:
+            ang = 2.0 * np.pi * np.arange(h // 2) / h
+            self._tw[h] = torch.from_numpy(np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)).to(self.device).contiguous()
+        return self._tw[h]
+
+    def _fft_h(self, src, dst, dst_strides, B, h, ncols, plane, inverse):
+        """H-axis complex FFT on planar re/im [B,2,h,ncols] (src) -> dst with (batch, plane, row) strides ``dst_strides``."""
+        _lib.check(_lib.load().mit_fft_cols(src.data_ptr(), 2 * plane, plane, ncols, dst.data_ptr(), *dst_strides,
+                                            self._twiddles(h).data_ptr(), B, h, ncols, int(inverse), 1.0 / math.sqrt(h),
+                                            C.c_void_p(ops.current_stream())), "mit_fft_cols")
 
     def _mpe_tables(self, H, W):
         k = (H, W)
@@ -241,14 +256,19 @@ class LamaEngine:
             a=F1, NB=1, Hi=2, Wi=wk, Cin=F1.shape[1], a_strides=(0, wk * F1.shape[1], F1.shape[1]), Ho=2, Wo=wk, sy=1,
             sx=1, taps=one, pad_mode=PAD_ZERO, w=t1, ldw=Cc, Kw=w, Nw=Cc, N=Cc, c=cm, Z=B * h, zdiv=h,
             w_zs=(h * w * Cc, w * Cc)))
-        # S2: complex DFT along H on planar re/im.  Z[b] = G2 @ Y[b] ([2h] x [wk*C])
-        cm = ops.MitTensorMap()
-        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Zf.data_ptr(), 0, 2 * plane, 0, 0, wk * Cc
-        tag()
-        launch_conv_gemm(conv_gemm_desc(
-            a=G2, NB=1, Hi=1, Wi=2 * h, Cin=G2.shape[1], a_strides=(0, 0, G2.shape[1]), Ho=1, Wo=2 * h, sy=1, sx=1, taps=one,
-            pad_mode=PAD_ZERO, w=Y, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
-            w_zs=(0, 2 * plane)))
+        # S2: complex DFT along H on planar re/im: LDS-butterfly FFT when h is a power of two (H/8 = 256 for the BASELINE
+        # page), else the dense [2h x 2h] DFT GEMM  Z[b] = G2 @ Y[b]
+        use_fft = h >= 2 and (h & (h - 1)) == 0 and h <= 512 and self.fft_h
+        if use_fft:
+            self._fft_h(Y, Zf, (2 * plane, plane, wk * Cc), B, h, wk * Cc, plane, False)
+        else:
+            cm = ops.MitTensorMap()
+            cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Zf.data_ptr(), 0, 2 * plane, 0, 0, wk * Cc
+            tag()
+            launch_conv_gemm(conv_gemm_desc(
+                a=G2, NB=1, Hi=1, Wi=2 * h, Cin=G2.shape[1], a_strides=(0, 0, G2.shape[1]), Ho=1, Wo=2 * h, sy=1, sx=1, taps=one,
+                pad_mode=PAD_ZERO, w=Y, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
+                w_zs=(0, 2 * plane)))
         # spectral 1x1 conv + BN + ReLU: two taps = re plane, im plane; planar output via the column split
         cm = ops.MitTensorMap()
         cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Z2.data_ptr(), 0, 0, 2 * plane, wk * Cc, Cc
@@ -258,13 +278,16 @@ class LamaEngine:
             taps=[(0, 0, 0), (0, 0, plane)], pad_mode=PAD_ZERO, w=ffc.fu_w, ldw=ffc.fu_Np, Kw=ffc.fu_Kp, Nw=ffc.fu_Np,
             N=2 * Cc, c=cm, scale=ffc.fu_scale, bias=ffc.fu_bias, act=ACT_RELU))
         # S3: inverse complex DFT along H.  U[b,h,t] rows (t,h) = G2i @ Z2[b]
-        cm = ops.MitTensorMap()
-        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = U.data_ptr(), 0, 2 * plane, 0, wk * Cc, 2 * wk * Cc
-        tag()
-        launch_conv_gemm(conv_gemm_desc(
-            a=G2i, NB=1, Hi=2, Wi=h, Cin=G2i.shape[1], a_strides=(0, h * G2i.shape[1], G2i.shape[1]), Ho=2, Wo=h, sy=1, sx=1, taps=one,
-            pad_mode=PAD_ZERO, w=Z2, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
-            w_zs=(0, 2 * plane)))
+        if use_fft:
+            self._fft_h(Z2, U, (2 * plane, wk * Cc, 2 * wk * Cc), B, h, wk * Cc, plane, True)
+        else:
+            cm = ops.MitTensorMap()
+            cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = U.data_ptr(), 0, 2 * plane, 0, wk * Cc, 2 * wk * Cc
+            tag()
+            launch_conv_gemm(conv_gemm_desc(
+                a=G2i, NB=1, Hi=2, Wi=h, Cin=G2i.shape[1], a_strides=(0, h * G2i.shape[1], G2i.shape[1]), Ho=2, Wo=h, sy=1, sx=1, taps=one,
+                pad_mode=PAD_ZERO, w=Z2, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
+                w_zs=(0, 2 * plane)))
         # S4: complex->real inverse DFT along W, + t1.  t2[b,h] = Fi @ U[b,h] ([2wk] x [C]) + t1[b,h]
         cm = ops.MitTensorMap()
         cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = t2.data_ptr(), 0, w * Cc, 0, 0, Cc

@@ -101,3 +101,27 @@ def test_lama_rejects_bad_input(cuda):
         eng.forward(torch.zeros(1, 60, 64, 3, dtype=torch.uint8, device=cuda), torch.zeros(1, 60, 64, dtype=torch.uint8, device=cuda))
     with pytest.raises(TypeError):
         eng.forward(torch.zeros(1, 64, 64, 3, device=cuda), torch.zeros(1, 64, 64, dtype=torch.uint8, device=cuda))
+
+
+def test_fft_h_matches_dft_gemm_at_page_size(cuda):
+    """FourierUnit at the BASELINE page's spectral size (256 x 182, 192 ch): the LDS-butterfly H-axis FFT and the dense
+    DFT-GEMM path agree to fp32 round-off, and both match torch.fft (the reference's rfftn/irfftn) through the oracle."""
+    from manga_image_translator_amd import lama, lama_schema, synth
+    from oracle import lama as OL
+
+    sd = synth.synth_state_dict(lama_schema.lama_generator_schema(1))
+    g = torch.Generator().manual_seed(11)
+    t1 = torch.randn(1, 256, 182, 192, generator=g)
+    outs = []
+    for fft_h in (True, False):
+        eng = lama.LamaEngine(sd, None, n_blocks=1, device=cuda, fft_h=fft_h)
+        t2 = torch.empty(1, 256, 182, 192, device=cuda)
+        eng._fourier_unit(eng.blocks[0][0], t1.to(cuda), t2)
+        torch.cuda.synchronize()
+        outs.append(t2.cpu())
+    x = _nchw(t1)
+    ref = _nchw((x + OL.fourier_unit(x, sd, "model.5.conv1.ffc.convg2g.fu")).permute(0, 2, 3, 1))
+    scale = ref.abs().max().item()
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5 * scale
+    for o in outs:
+        assert (_nchw(o) - ref).abs().max().item() < 5e-5 * scale
