@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--group", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--probe-pages", type=int, default=8)
+    ap.add_argument("--probe-pages", type=int, default=0, help="pages in the instrumented pass (0 = a whole step)")
     return ap.parse_args()
 
 
@@ -74,7 +74,7 @@ def roofline_leg(engine, pages, quads, masks, stages, n_probe):
     from manga_image_translator_amd import lib as L
 
     lib = L.load()
-    n = min(n_probe, pages.shape[0])
+    n = pages.shape[0] if n_probe <= 0 else min(n_probe, pages.shape[0])  # a whole step by default: same launch mix as the timed steps
     torch.cuda.synchronize()
     L.check(lib.mit_prof_enable(1), "mit_prof_enable")
     engine.run(pages[:n], quads[:n], masks[:n], max_seq_length=DECODE_STEPS, suppress_eos=True, stages=stages)

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, con
 // generic kernel, so results are bitwise identical to it.
 constexpr int FAST_MAX_TAPS = 16;
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int ROT = 0>
 __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConvGemm p, const int M, const int MT,
                                                                const int NT, const int KT) {
     constexpr int WM = BM / WAVES_M;
@@ -440,11 +440,17 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
 
     load_tile(0);
     store_tile(0);
+    if (ROT && KT > 1) load_tile(1);  // stays in registers across the barrier
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
+        if (ROT) {  // tile kt+1 (loaded during the previous iteration) -> LDS right after the barrier, then fetch kt+2
+            if (kt + 1 < KT) store_tile(cur ^ 1);
+            if (kt + 2 < KT) load_tile(kt + 2);
+        } else if (kt + 1 < KT) {
+            load_tile(kt + 1);
+        }
         const float *as = As + cur * A_TILE + lh * LDA + wm0 + li;
         const float *bs = Bs + cur * B_TILE + lh * LDB + wn0 + li;
         float af[2][TM], bf[2][TN];
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
                 for (int ni = 0; ni < TN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][mi], bf[c][ni], acc[mi][ni], 0, 0, 0);
         }
-        if (kt + 1 < KT) store_tile(cur ^ 1);
+        if (!ROT && kt + 1 < KT) store_tile(cur ^ 1);
         __syncthreads();
     }
 
@@ -503,14 +509,14 @@ void launch_cfg(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int ROT = 0>
 void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
     constexpr int LDA = BM + (BK == 16 ? 2 : 1);
     constexpr int LDB = BN + 4;
     size_t staging = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + (size_t)p.ntaps * BM * sizeof(int);
     size_t rows = (size_t)BM * sizeof(RowOff);
     size_t smem = staging > rows ? staging : rows;
-    auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW>;
+    auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, ROT>;
     static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && smem > 64 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -545,6 +551,9 @@ const CfgEntry kCfgs[] = {
     FCFGW(128, 128, 16, 2, 2, 4),  // 14: <= 128 registers, 4 workgroups per CU
     FCFGW(128, 128, 16, 4, 1, 4),  // 15: wave tile 32 x 128
     FCFGW(128, 128, 16, 1, 4, 4),  // 16: wave tile 128 x 32
+    {"fast128x128x16w4r", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 1>, 1},  // 17: 16 with the write-after-barrier rotation
+    {"fast128x64x16r", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 1, 1>, 1},       // 18: 9 with the rotation
+    {"fast128x128x16w4rb", 128, 128, 16, launch_fast<128, 128, 16, 2, 2, 4, 1>, 1}, // 19: 14 with the rotation
 };
 
 // fast kernel preconditions: whole K-tiles inside one tap, table fits, 32-bit element offsets

@@ -13,11 +13,14 @@
 #include "../../include/mit_hip.h"
 #include "common.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int CT = 32;     // columns per workgroup
 constexpr int TG = 8;      // thread groups (rows in flight) per column: 256 threads = 32 x 8
 
+template <int ROWS>  // rows per thread in the load / store passes = h / 32
 __global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__ in, int64_t in_bs, int64_t in_ts, int64_t in_hs,
                                                         float *__restrict__ out, int64_t out_bs, int64_t out_ts, int64_t out_hs,
                                                         const float2 *__restrict__ tw, int h, int logh, int64_t ncols,
@@ -25,31 +28,55 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *re = lds;               // [h][CT]
     float *im = lds + h * CT;
-    const int col = threadIdx.x & (CT - 1), g = threadIdx.x / CT;
-    const int64_t c0 = (int64_t)blockIdx.x * CT + col;
-    const bool live = c0 < ncols;
-    const float *ib = in + (int64_t)blockIdx.y * in_bs + c0;
-    float *ob = out + (int64_t)blockIdx.y * out_bs + c0;
-    // load with bit-reversed row index (decimation in time)
-    for (int r = g; r < h; r += TG) {
-        const int rr = __brev((unsigned)r) >> (32 - logh);
-        float a = 0.f, b = 0.f;
-        if (live) {
-            a = ib[(int64_t)r * in_hs];
-            b = ib[in_ts + (int64_t)r * in_hs];
+    float2 *tws = reinterpret_cast<float2 *>(lds + 2 * h * CT);  // [h/2]
+    const int64_t cb = (int64_t)blockIdx.x * CT;
+    const float *ib = in + (int64_t)blockIdx.y * in_bs + cb;
+    float *ob = out + (int64_t)blockIdx.y * out_bs + cb;
+    // ---- load: thread (cq, rg) fetches 4 adjacent columns of rows rg, rg+32, ...: a wave covers 8 rows x 128 B per
+    // instruction and all 2*ROWS loads are in flight together; rows go to their bit-reversed LDS slot (decimation in time)
+    const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    const bool vec_ok = cb + cq * 4 + 3 < ncols;
+    f32x4 va[ROWS], vb[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int r = rg + 32 * i;
+        va[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        vb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < h) {
+            const float *pa = ib + (int64_t)r * in_hs + cq * 4;
+            if (vec_ok) {
+                va[i] = *reinterpret_cast<const f32x4 *>(pa);
+                vb[i] = *reinterpret_cast<const f32x4 *>(pa + in_ts);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (cb + cq * 4 + e < ncols) {
+                        va[i][e] = pa[e];
+                        vb[i][e] = pa[in_ts + e];
+                    }
+            }
         }
-        re[rr * CT + col] = a;
-        im[rr * CT + col] = b;
+    }
+    for (int k = threadIdx.x; k < (h >> 1); k += 256) tws[k] = tw[k];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int r = rg + 32 * i;
+        if (r < h) {
+            const int rr = __brev((unsigned)r) >> (32 - logh);
+            *reinterpret_cast<f32x4 *>(re + rr * CT + cq * 4) = va[i];
+            *reinterpret_cast<f32x4 *>(im + rr * CT + cq * 4) = vb[i];
+        }
     }
     __syncthreads();
-    const int nb = h >> 1;  // butterflies per column
+    // ---- butterflies: thread (col, g); the 32 lanes of a half-wave sit on 32 consecutive banks ----
+    const int col = threadIdx.x & (CT - 1), g = threadIdx.x / CT;
+    const int nb = h >> 1;
     for (int s = 0; s < logh; ++s) {
         const int half = 1 << s;
         const int tstep = nb >> s;  // twiddle index stride: k * h / (2 * half)
         for (int j = g; j < nb; j += TG) {
             const int k = j & (half - 1);
             const int i0 = ((j >> s) << (s + 1)) + k, i1 = i0 + half;
-            const float2 w = tw[k * tstep];  // (cos, sin) of 2 pi k tstep / h
+            const float2 w = tws[k * tstep];  // (cos, sin) of 2 pi k tstep / h
             const float wr = w.x, wi = inverse ? w.y : -w.y;
             const float xr = re[i1 * CT + col], xi = im[i1 * CT + col];
             const float tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
@@ -61,10 +88,25 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__
         }
         __syncthreads();
     }
-    if (live) {
-        for (int r = g; r < h; r += TG) {
-            ob[(int64_t)r * out_hs] = re[r * CT + col] * scale;
-            ob[out_ts + (int64_t)r * out_hs] = im[r * CT + col] * scale;
+    // ---- store (same mapping as the load) ----
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int r = rg + 32 * i;
+        if (r >= h) continue;
+        f32x4 a = *reinterpret_cast<const f32x4 *>(re + r * CT + cq * 4);
+        f32x4 b = *reinterpret_cast<const f32x4 *>(im + r * CT + cq * 4);
+        a *= scale;
+        b *= scale;
+        float *po = ob + (int64_t)r * out_hs + cq * 4;
+        if (vec_ok) {
+            *reinterpret_cast<f32x4 *>(po) = a;
+            *reinterpret_cast<f32x4 *>(po + out_ts) = b;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (cb + cq * 4 + e < ncols) {
+                    po[e] = a[e];
+                    po[out_ts + e] = b[e];
+                }
         }
     }
 }
@@ -79,15 +121,30 @@ extern "C" int mit_fft_cols(const float *in_dev, int64_t in_bs, int64_t in_ts, i
     if (B <= 0 || B > 65535 || ncols <= 0) return mit_set_error("mit_fft_cols: bad size");
     int logh = 0;
     while ((1 << logh) < h) ++logh;
-    const size_t smem = (size_t)2 * h * CT * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && smem > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if ((ncols & 3) || (in_ts & 3) || (in_hs & 3) || (in_bs & 3) || (out_ts & 3) || (out_hs & 3) || (out_bs & 3) ||
+        (reinterpret_cast<uintptr_t>(in_dev) & 15) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
+        return mit_set_error("mit_fft_cols: column count, strides and bases must be multiples of 4 floats");
+    const size_t smem = (size_t)2 * h * CT * sizeof(float) + (size_t)(h / 2) * sizeof(float2);
     dim3 grid(mit_div_up(ncols, CT), B), block(256);
-    hipLaunchKernelGGL(fft_cols_kernel, grid, block, smem, reinterpret_cast<hipStream_t>(stream), in_dev, in_bs, in_ts, in_hs, out_dev,
-                       out_bs, out_ts, out_hs, reinterpret_cast<const float2 *>(twiddle_dev), h, logh, ncols, inverse, scale);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float2 *tw2 = reinterpret_cast<const float2 *>(twiddle_dev);
+#define MIT_FFT_LAUNCH(ROWS)                                                                                                   \
+    do {                                                                                                                       \
+        auto kern = fft_cols_kernel<ROWS>;                                                                                     \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set && smem > 64 * 1024) {                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(kern, grid, block, smem, st, in_dev, in_bs, in_ts, in_hs, out_dev, out_bs, out_ts, out_hs, tw2, h, logh, \
+                           ncols, inverse, scale);                                                                            \
+    } while (0)
+    if (h <= 32) MIT_FFT_LAUNCH(1);
+    else if (h <= 64) MIT_FFT_LAUNCH(2);
+    else if (h <= 128) MIT_FFT_LAUNCH(4);
+    else if (h <= 256) MIT_FFT_LAUNCH(8);
+    else MIT_FFT_LAUNCH(16);
+#undef MIT_FFT_LAUNCH
     MIT_CHECK_LAUNCH("mit_fft_cols");
     return 0;
 }

@@ -74,3 +74,31 @@ def test_chunk_plan_matches_reference_batching():
         ref = [(idx, ws, int(t.shape[3])) for idx, ws, t in OO.make_chunks(crops)]
         assert TL.chunk_plan(widths) == ref
     assert TL.chunk_plan([]) == []
+
+
+def test_batched_plans_equal_per_line_plans():
+    """textline.warp_plans (one batched 8x8 solve per page) gives bit-identical records to warp_plan line by line."""
+    H, W = G["image"].shape[:2]
+    quads = [TL.Quadrilateral(q) for q in G["quads"]]
+    dirs = [q.direction for q in quads]
+    dirs[0] = "h" if dirs[0] == "v" else "v"  # an overridden direction (majority vote of a merge-graph component)
+    rec = TL.warp_plans(quads, dirs, H, W)
+    assert rec.dtype.itemsize == 112
+    for r, q, d in zip(rec, quads, dirs):
+        pl = TL.warp_plan(q, d, H, W)
+        assert (r["x1"], r["y1"], r["cw"], r["ch"], r["dw"], r["dh"], bool(r["vertical"])) == (pl.x1, pl.y1, pl.cw, pl.ch, pl.dw, pl.dh, pl.vertical)
+        assert np.array_equal(r["minv"].reshape(3, 3), pl.minv)
+        assert q.assigned_direction == d
+    assert len(TL.warp_plans([], [], H, W)) == 0
+    with pytest.raises(ValueError):
+        TL.warp_plans(quads[:1], ["x"], H, W)
+
+
+def test_warp_record_layout_matches_c_struct():
+    import ctypes as C
+
+    from manga_image_translator_amd import lib
+
+    assert TL.WARP_LINE_DTYPE.itemsize == C.sizeof(lib.MitWarpLine)
+    for name, *_ in lib.MitWarpLine._fields_:
+        assert TL.WARP_LINE_DTYPE.fields[name][1] == getattr(lib.MitWarpLine, name).offset, name
