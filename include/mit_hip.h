@@ -195,8 +195,12 @@ int mit_avgpool2_nhwc(const float *in_dev, int64_t in_pixstride, float *out_dev,
 int mit_copy_channels(const float *in_dev, int64_t in_pixstride, float *out_dev, int64_t out_pixstride, int64_t npix,
                       int C, void *stream);
 /* fp32 map -> u8. mode 0: (uint8)(v*255) truncation (postprocess_mask ctd.py:30-44); mode 1: v > thr
- * (SegDetectorRepresenter.binarize, ctd_utils/utils/db_utils.py:75). */
+ * (SegDetectorRepresenter.binarize, ctd_utils/utils/db_utils.py:75); mode 2: (uint8)(clip(v,0,1)*255)
+ * (ESRGANUpscalerPytorch._infer, upscaling/esrgan_pytorch.py:545). */
 int mit_map_to_u8(const float *in_dev, uint8_t *out_dev, int64_t n, int mode, float thr, void *stream);
+
+/* out = a * x + y over n floats (n % 4 == 0): RRDB.forward's ``out * 0.2 + x`` (upscaling/esrgan_pytorch.py:112). */
+int mit_axpy(float *out_dev, float a, const float *x_dev, const float *y_dev, int64_t n, void *stream);
 
 /* 48px OCR stage -----------------------------------------------------------------------------
  * Reference: manga_translator/ocr/model_48px.py, ocr/xpos_relative_position.py. */

@@ -127,17 +127,43 @@ __global__ void copy_channels_kernel(const float *__restrict__ in, int64_t in_ps
     }
 }
 
-// ---- fp32 map -> u8: mode 0 = (uint8)(v*255) truncation (postprocess_mask ctd.py:41-44), mode 1 = v > thr ----
+// ---- fp32 map -> u8: mode 0 = (uint8)(v*255) truncation (postprocess_mask ctd.py:41-44), mode 1 = v > thr,
+//      mode 2 = (uint8)(clip(v, 0, 1) * 255) (ESRGANUpscalerPytorch._infer, upscaling/esrgan_pytorch.py:545) ----
 __global__ void map_to_u8_kernel(const float *__restrict__ in, uint8_t *__restrict__ out, int64_t n, int mode, float thr) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         const float v = in[i];
-        out[i] = mode == 0 ? (uint8_t)(int)(v * 255.0f) : (uint8_t)(v > thr ? 1 : 0);
+        if (mode == 0) out[i] = (uint8_t)(int)(v * 255.0f);
+        else if (mode == 1) out[i] = (uint8_t)(v > thr ? 1 : 0);
+        else out[i] = (uint8_t)(int)(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);
+    }
+}
+
+// ---- out = a * x + y, elementwise float4 (RRDB's residual scaling, upscaling/esrgan_pytorch.py:112) ----
+__global__ void axpy_kernel(float4 *__restrict__ out, float a, const float4 *__restrict__ x, const float4 *__restrict__ y, int64_t n4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const float4 xv = x[i], yv = y[i];
+        float4 o;
+        o.x = xv.x * a + yv.x; o.y = xv.y * a + yv.y; o.z = xv.z * a + yv.z; o.w = xv.w * a + yv.w;
+        out[i] = o;
     }
 }
 
 }  // namespace
+
+extern "C" int mit_axpy(float *out_dev, float a, const float *x_dev, const float *y_dev, int64_t n, void *stream) {
+    if (!out_dev || !x_dev || !y_dev) return mit_set_error("mit_axpy: null pointer");
+    if ((n & 3) || ((reinterpret_cast<uintptr_t>(out_dev) | reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(y_dev)) & 15))
+        return mit_set_error("mit_axpy: n %% 4 == 0 and 16-byte aligned pointers required");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4 *>(out_dev), a,
+                       reinterpret_cast<const float4 *>(x_dev), reinterpret_cast<const float4 *>(y_dev), n / 4);
+    MIT_CHECK_LAUNCH("mit_axpy");
+    return 0;
+}
 
 extern "C" int mit_ctd_prep(const uint8_t *img_dev, int B, int H, int W, int nh, int nw, int S, int mode,
                             const int *yidx_dev, const short *ycoef_dev, const int *xidx_dev, const short *xcoef_dev,

@@ -22,7 +22,7 @@ from .lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "ACT_LEAKY", "ACT_SILU", "ACT_SIGMOID", "ACT_GELU", "PAD_ZERO", "PAD_REFLECT",
-    "Conv2d", "ConvSmallCout", "ConvTranspose2d", "fold_bn", "conv_gemm_desc", "launch_conv_gemm", "current_stream",
+    "Conv2d", "ConvSmallCout", "ConvTranspose2d", "UpsampleConv2d", "fold_bn", "conv_gemm_desc", "launch_conv_gemm", "current_stream",
 ]
 
 
@@ -228,6 +228,58 @@ class ConvSmallCout:
         _lib.check(lib.mit_conv_small_cout(x.data_ptr(), x.stride(2), self.w4.data_ptr(), _ptr(self.bias), out.data_ptr(),
                                            out.stride(2), B, H, W, self.Cin, self.Cout, self.k, self.pad_mode, self.act,
                                            self.alpha, C.c_void_p(current_stream())), "mit_conv_small_cout")
+        return out
+
+
+class UpsampleConv2d:
+    """``Upsample(scale_factor=2, mode='nearest')`` followed by a 3x3 zero-padded conv (+ bias + activation) WITHOUT the
+    upsampled tensor: output pixels of parity (a, b) are a 2x2 convolution of the low-resolution input whose weights are
+    the sums of the 3x3 taps that land on the same source pixel (ESRGAN's upconv_block, upscaling/esrgan_pytorch.py:317-324).
+    2.25x fewer MACs and no 4x-sized intermediate; each parity class is one launch writing ``out[:, a::2, b::2]``.
+    The tap merge adds weights before multiplying, so results differ from conv(upsample(x)) by fp32 round-off only."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE, alpha: float = 0.0,
+                 device="cuda"):
+        Cout, Cin, kh, kw = weight.shape
+        if (kh, kw) != (3, 3) or Cin % 4:
+            raise ValueError("UpsampleConv2d: 3x3 kernels with Cin % 4 == 0 only")
+        self.Cin, self.Cout, self.act, self.alpha = Cin, Cout, act, alpha
+        w = weight.detach().to(torch.float64)
+        # source offset of tap k for output parity a: floor((a + k - 1) / 2)  ->  a=0: (-1, 0, 0), a=1: (0, 0, 1)
+        groups = {0: {-1: [0], 0: [1, 2]}, 1: {0: [0, 1], 1: [2]}}
+        self.sub: List[Tuple[int, int, _Packed]] = []
+        for a in (0, 1):
+            for b in (0, 1):
+                taps, blocks = [], []
+                for dy, kys in groups[a].items():
+                    for dx, kxs in groups[b].items():
+                        wsum = sum(w[:, :, ky, kx] for ky in kys for kx in kxs)  # [Cout, Cin]
+                        taps.append((dy, dx, 0))
+                        blocks.append(wsum.t().to(torch.float32))  # [Cin, Cout]
+                wk, Kp, Np = pack_weight_kn(torch.cat(blocks, dim=0), device)
+                self.sub.append((a, b, _Packed(wk, Kp, Np, taps)))
+        self.bias = None if bias is None else bias.detach().to(torch.float32).to(device).contiguous()
+
+    def descs(self, x: torch.Tensor, out: torch.Tensor) -> List[MitConvGemm]:
+        _check_nhwc(x, "UpsampleConv2d input")
+        _check_nhwc(out, "UpsampleConv2d output")
+        B, H, W, Cx = x.shape
+        if Cx != self.Cin or tuple(out.shape) != (B, 2 * H, 2 * W, self.Cout):
+            raise ValueError(f"UpsampleConv2d: bad shapes {tuple(x.shape)} -> {tuple(out.shape)}")
+        ds = []
+        for a, b, pk in self.sub:
+            ov = out[:, a::2, b::2]
+            ds.append(conv_gemm_desc(
+                a=x, NB=B, Hi=H, Wi=W, Cin=self.Cin, a_strides=(x.stride(0), x.stride(1), x.stride(2)), Ho=H, Wo=W, sy=1, sx=1,
+                taps=pk.taps, pad_mode=PAD_ZERO, w=pk.w, ldw=pk.Np, Kw=pk.Kp, Nw=pk.Np, N=self.Cout, c=tensor_map(ov),
+                bias=self.bias, act=self.act, alpha=self.alpha))
+        return ds
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, cfg: int = -1) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(x.shape[0], 2 * x.shape[1], 2 * x.shape[2], self.Cout, dtype=torch.float32, device=x.device)
+        for d in self.descs(x, out):
+            launch_conv_gemm(d, cfg)
         return out
 
 

@@ -6,6 +6,7 @@ Each class honours the contract of its reference counterpart:
   HipModel48pxOCR        <- Model48pxOCR        (ocr/model_48px.py:25-180)
   HipLamaMPEInpainter    <- LamaMPEInpainter    (inpainting/inpainting_lama_mpe.py:26-118)
   HipLamaLargeInpainter  <- LamaLargeInpainter  (inpainting/inpainting_lama_mpe.py:121-136)
+  HipESRGANUpscaler      <- ESRGANUpscalerPytorch (upscaling/esrgan_pytorch.py:512-549)
 
 Same lifecycle (``__init__`` touches no GPU; ``await load(device)`` / ``unload()`` / ``infer(...)``; infer before load
 raises), same ``_infer`` signatures, argument meaning and return types, errors as Python exceptions.  When the
@@ -30,6 +31,7 @@ try:  # inside the reference's environment: be a real plugin
     from manga_translator.detection.common import OfflineDetector as _DetBase  # type: ignore
     from manga_translator.inpainting.common import OfflineInpainter as _InpBase  # type: ignore
     from manga_translator.ocr.common import OfflineOCR as _OcrBase  # type: ignore
+    from manga_translator.upscaling.common import OfflineUpscaler as _UpBase  # type: ignore
     from manga_translator.utils import Quadrilateral as _RefQuadrilateral  # type: ignore
 
     HAVE_REFERENCE = True
@@ -69,7 +71,7 @@ except Exception:  # stand-alone: mirror the ModelWrapper lifecycle
                 raise Exception(f"{self._key}: Tried to forward pass without having loaded the model.")
             return await self._infer(*args, **kwargs)
 
-    _DetBase = _InpBase = _OcrBase = _Wrapper
+    _DetBase = _InpBase = _OcrBase = _UpBase = _Wrapper
 
 
 def _gpu_device(device: str) -> torch.device:
@@ -274,6 +276,45 @@ class HipLamaLargeInpainter(HipLamaMPEInpainter):
     N_BLOCKS, USE_MPE, CKPT = 18, False, "lama_large_512px.ckpt"
 
 
+class HipESRGANUpscaler(_UpBase):
+    """``--upscaler 4xultrasharp`` (RRDBNet 4x) on the HIP engine."""
+    _key = "4xultrasharp_hip"
+    _MODEL_MAPPING: Dict = {}
+    _VALID_UPSCALE_RATIOS = [2, 3, 4]
+
+    def __init__(self, *args, weights: Optional[Dict[str, torch.Tensor]] = None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._weights = weights
+        self.engine = None
+
+    async def _load(self, device: str):
+        from . import esrgan
+
+        dev = _gpu_device(device)
+        sd = self._weights or torch.load(_ckpt_path(self, "4xESRGAN.pth"), map_location="cpu")
+        nb = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("model.1.sub.") and ".RDB" in k)  # infer_params (:470-509)
+        self.engine = esrgan.EsrganEngine(sd, nb=nb, device=dev)
+        self.device = device
+
+    async def _unload(self):
+        self.engine = None
+
+    @torch.no_grad()
+    async def _infer(self, image_batch: List, upscale_ratio: float) -> List:
+        """List[PIL.Image] -> List[PIL.Image]: 4x on the GPU, then PIL's bilinear resize by ratio/4 (esrgan_pytorch.py:537-549)."""
+        from PIL import Image
+
+        assert upscale_ratio <= 4
+        ratio = upscale_ratio / 4
+        out = []
+        for img in image_batch:  # pages of a batch may differ in size: one launch sequence per page
+            rgb = np.ascontiguousarray(np.array(img.convert("RGB")))
+            up = self.engine.forward(torch.from_numpy(rgb).to(self.engine.device)[None])[0].cpu().numpy()
+            im = Image.fromarray(up)
+            out.append(im.resize(size=(int(round(im.size[0] * ratio)), int(round(im.size[1] * ratio))), resample=Image.Resampling.BILINEAR))
+        return out
+
+
 # ---- pieces taken from the reference package when it is importable ---------------------------------------------
 
 def _reference_boxes():
@@ -357,3 +398,6 @@ def register() -> None:
     OCRS["48px_hip"] = HipModel48pxOCR
     INPAINTERS["lama_mpe_hip"] = HipLamaMPEInpainter
     INPAINTERS["lama_large_hip"] = HipLamaLargeInpainter
+    from manga_translator.upscaling import UPSCALERS  # type: ignore
+
+    UPSCALERS["4xultrasharp_hip"] = HipESRGANUpscaler

@@ -14,6 +14,7 @@ Fixtures (all small; each .npz also records the reference file whose code produc
   lama_large.npz   LamaFourier(large_arch=True).__call__                                             48x40
   ctd.npz          preprocess_img + TextDetBase.forward (ctd.py:17-28, ctd_utils/basemodel.py:234-238) 120x90 page
   ocr48.npz        OCR.infer_beam_batch_tensor (ocr/model_48px.py:678-801) on 5 crops, dict 97, T = 9
+  esrgan.npz       RRDBNet.forward + the tensor part of ESRGANUpscalerPytorch._infer (upscaling/esrgan_pytorch.py:67-75,537-546), nb = 2, 40x56 page
   textline.npz     sort_pnts / Quadrilateral / get_transformed_region (utils/generic.py:324-481) on 12 quads
 """
 from __future__ import annotations
@@ -188,6 +189,29 @@ def golden_textline():
     print("textline", dirs, [c.shape for c in crops][:4])
 
 
+def build_ref_esrgan(nb: int):
+    from manga_image_translator_amd import esrgan_schema
+
+    E = R.esrgan()
+    net = E.RRDBNet(in_nc=3, out_nc=3, nf=64, nb=nb, upscale=4, plus=False)
+    sd = synth.synth_state_dict(esrgan_schema.rrdbnet_schema(nb))
+    net.load_state_dict(sd, strict=True)
+    return net.eval(), sd
+
+
+def golden_esrgan():
+    nb = 2
+    net, _ = build_ref_esrgan(nb)
+    page = synth.synth_page(11, 40, 56, n_boxes=2)[0]
+    x = torch.from_numpy(page[:, :, ::-1].copy()).float().div(255.0).permute(2, 0, 1).unsqueeze(0)  # _infer :541
+    with torch.no_grad():
+        y = net(x)
+    out = (y[0].clip(0, 1).permute(1, 2, 0).numpy()[:, :, ::-1].copy() * 255.0).astype(np.uint8)  # :545
+    np.savez_compressed(os.path.join(GOLDEN, "esrgan.npz"), page=page, out_float=y.numpy(), out_u8=out, nb=nb,
+                        source="manga_translator/upscaling/esrgan_pytorch.py")
+    print("esrgan", y.shape, float(y.mean()), float(y.std()))
+
+
 def main():
     if not R.available():
         raise SystemExit("/root/reference is not present: fixtures can only be regenerated in the build container")
@@ -197,6 +221,7 @@ def main():
     golden_ocr()
     golden_ctd()
     golden_lama()
+    golden_esrgan()
 
 
 if __name__ == "__main__":

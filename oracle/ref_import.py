@@ -161,3 +161,14 @@ def cv2_shim():
     ns.warpPerspective = lambda img, M, dsize, **k: OT.warp_perspective_u8(img, M, dsize)
     ns.rotate = lambda img, code: np.ascontiguousarray(np.rot90(img, 1))
     return ns
+
+
+def esrgan():
+    """reference module manga_translator/upscaling/esrgan_pytorch.py (RRDBNet)"""
+    _prepare()
+    _pkg("manga_translator.upscaling")
+    if "manga_translator.upscaling.common" not in sys.modules:
+        m = types.ModuleType("manga_translator.upscaling.common")
+        m.OfflineUpscaler = type("OfflineUpscaler", (), {})
+        sys.modules["manga_translator.upscaling.common"] = m
+    return _load("manga_translator.upscaling.esrgan_pytorch", "upscaling/esrgan_pytorch.py")

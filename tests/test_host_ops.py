@@ -109,3 +109,22 @@ def test_lama_dft_matrices_are_the_ortho_rfft2():
         U = G2i[:, :2 * h] @ Z                     # [(t,h), wk]
         back = torch.cat([U[:h], U[h:]], 1) @ Fi[:, :2 * wk].t()  # [h, w]
         assert torch.allclose(back, x, atol=1e-6)
+
+
+def test_upsample_conv_parity_descriptors():
+    """ops.UpsampleConv2d (nearest x2 + 3x3 conv as four merged 2x2 parity convs on the low-res input) vs
+    conv2d(interpolate(x)) — ESRGAN's upconv_block (upscaling/esrgan_pytorch.py:317-324)."""
+    g = torch.Generator().manual_seed(4)
+    cin, cout = 8, 6
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(2, cin, 5, 7, generator=g)
+    layer = ops.UpsampleConv2d(w, b, act=ops.ACT_LEAKY, alpha=0.2, device="cpu")
+    xin = _nhwc(x)
+    out = torch.full((2, 10, 14, cout), float("nan"))
+    for d in layer.descs(xin, out):
+        EMU.run(d)
+    ref = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1), 0.2)
+    assert torch.allclose(out, _nhwc(ref), atol=2e-5, rtol=1e-5), (out - _nhwc(ref)).abs().max()
+    with pytest.raises(ValueError):
+        ops.UpsampleConv2d(torch.zeros(4, 4, 5, 5), device="cpu")

@@ -91,3 +91,20 @@ def test_textline_oracle_matches_reference_fixture():
         w = int(g["crop_width"][k])
         assert crop.shape == (48, w, 3)
         assert np.array_equal(crop, g["crops"][k, :, :w])
+
+
+def test_esrgan_oracle_matches_reference_fixture():
+    from manga_image_translator_amd import esrgan_schema, synth
+    from oracle import esrgan as OE
+
+    g = _load("esrgan.npz")
+    nb = int(g["nb"])
+    sd = synth.synth_state_dict(esrgan_schema.rrdbnet_schema(nb))
+    x = torch.from_numpy(g["page"][:, :, ::-1].copy()).float().div(255.0).permute(2, 0, 1).unsqueeze(0)
+    with torch.no_grad():
+        y = OE.rrdbnet_forward(sd, x, nb)
+    assert np.abs(y.numpy() - g["out_float"]).max() < 2e-5
+    out = OE.infer(sd, g["page"], nb)
+    d = np.abs(out.astype(np.int32) - g["out_u8"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3  # identical up to a x255 truncation boundary
+    assert 0.05 < (g["out_u8"] == 0).mean() < 0.95 and len(np.unique(g["out_u8"])) > 100  # not a saturated constant

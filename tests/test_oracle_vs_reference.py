@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("gen,files", [("golden_textline", ["textline.npz"]), ("golden_ocr", ["ocr48.npz"]),
-                                       ("golden_ctd", ["ctd.npz"]), ("golden_lama", ["lama_mpe.npz", "lama_large.npz"])])
+                                       ("golden_ctd", ["ctd.npz"]), ("golden_lama", ["lama_mpe.npz", "lama_large.npz"]), ("golden_esrgan", ["esrgan.npz"])])
 def test_fixture_regenerates(tmp_path, monkeypatch, gen, files):
     from oracle import make_golden as MG
 
@@ -54,3 +54,7 @@ def test_schemas_match_reference_modules():
     check(ctd_schema.unet_head_schema(), bm.UnetHead(act="leaky").state_dict())
     check(ctd_schema.db_head_schema(), bm.DBHead(64, act="leaky").state_dict())
     check(ctd_schema.yolo_schema(), yolo.Model(ctd_schema.YOLOV5S_CFG).state_dict())
+    from manga_image_translator_amd import esrgan_schema
+
+    net, _ = MG.build_ref_esrgan(3)
+    check(esrgan_schema.rrdbnet_schema(3), net.state_dict())

@@ -12,12 +12,13 @@ def run(coro):
     return asyncio.new_event_loop().run_until_complete(coro)
 
 
-@pytest.mark.parametrize("cls", [P.HipComicTextDetector, P.HipModel48pxOCR, P.HipLamaMPEInpainter, P.HipLamaLargeInpainter])
+@pytest.mark.parametrize("cls", [P.HipComicTextDetector, P.HipModel48pxOCR, P.HipLamaMPEInpainter, P.HipLamaLargeInpainter,
+                                 P.HipESRGANUpscaler])
 def test_lifecycle_and_device_errors(cls):
     p = cls()                                   # constructed with no arguments, touches no GPU
     assert not p.is_loaded()
     with pytest.raises(Exception, match="without having loaded"):
-        run(p.infer(np.zeros((8, 8, 3), np.uint8)))
+        run(p.infer(np.zeros((8, 8, 3), np.uint8), 2))
     with pytest.raises(RuntimeError, match="MI355X only"):
         run(p.load("cpu"))                      # the reference passes 'cpu' without --use-gpu: no CPU fallback here
     assert not p.is_loaded()
