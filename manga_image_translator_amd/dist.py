@@ -32,8 +32,8 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise the default process group when WORLD_SIZE > 1 (env:// rendezvous). Returns (rank, world, local_rank)."""
     rank, world, local = env_world()
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # MIT_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
+            backend = os.environ.get("MIT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -104,6 +104,8 @@ def gather_pages(packed: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
         return packed.unsqueeze(0)
     world, rank = dist.get_world_size(), dist.get_rank()
     packed = packed.contiguous()
+    if dist.get_backend() != "nccl" and packed.is_cuda:  # gloo rehearsal: stage through host memory
+        packed = packed.cpu()
     if rank == dst:
         out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
         dist.gather(packed, list(out.unbind(0)), dst=dst)
