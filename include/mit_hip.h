@@ -296,6 +296,25 @@ int mit_xpos_rotate(const float *in_dev, int64_t in_rs, int64_t in_ts, float *ou
 int mit_attention(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k_dev, int64_t k_rs, int64_t k_ts,
                   const float *v_dev, int64_t v_rs, int64_t v_ts, float *out_dev, int64_t o_rs, int64_t o_ts,
                   const int *klen_dev, int R, int Tq, int Tk, int kv_div, void *stream);
+/* Same with an explicit head layout (heads x head_dim contiguous in the feature axis): 8 x 40 for the 48px_ctc encoder's
+ * nn.MultiheadAttention (model_48px_ctc.py:216-217,259-265; q already scaled by head_dim**-0.5, PE already added to q/k). */
+int mit_attention_heads(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k_dev, int64_t k_rs, int64_t k_ts,
+                        const float *v_dev, int64_t v_rs, int64_t v_ts, float *out_dev, int64_t o_rs, int64_t o_ts,
+                        const int *klen_dev, int R, int Tq, int Tk, int kv_div, int heads, int head_dim, void *stream);
+/* nn.AvgPool2d(kernel, stride, padding) with count_include_pad=True on NHWC fp32 — the FAN backbone's pools
+ * (model_48px_ctc.py:291,297,303: 2/2/0 twice, then kernel 2, stride (2,1), padding (0,1)). out [B,Ho,Wo,C] dense. */
+int mit_avgpool_nhwc(const float *in_dev, float *out_dev, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                     int pw, void *stream);
+/* y = relu?(x * scale[c] + bias[c]) per pixel: eval BatchNorm2d (+ ReLU) that cannot ride in a conv epilogue because its
+ * input also feeds a residual (pre-activation BasicBlock.forward, model_48px_ctc.py:389-403). */
+int mit_affine_act_nhwc(const float *in_dev, int64_t in_pixstride, const float *scale_dev, const float *bias_dev, float *out_dev,
+                        int64_t out_pixstride, int64_t npix, int C, int relu, void *stream);
+/* x <- gelu(x) (erf form) over n floats: the nn.GELU of char_pred_norm (model_48px_ctc.py:435). */
+int mit_gelu_inplace(float *x_dev, int64_t n, void *stream);
+/* log_softmax over D columns + the 5 largest (value, index) per row, ties to the lower index; suppress_tok < 0: none.
+ * Row r: vals_dev[5r..], idx_dev[5r..].  decode_ctc_top1's log_softmax + max (model_48px_ctc.py:477-478) uses entry 0. */
+int mit_logsoftmax_top5(const float *logits_dev, int64_t ld, int R, int D, int suppress_tok, float *vals_dev, int *idx_dev,
+                        void *stream);
 /* The whole beam search of OCR.infer_beam_batch_tensor (:691-784) after the encoder, as one native call: per step
  * embedding -> 5 decoder layers (KV cache instead of the reference's per-step K/V recomputation) -> pred1/pred ->
  * log-softmax/top-5 -> beam bookkeeping, all on `stream`; synchronises the stream every few steps to test for early exit. */

@@ -10,7 +10,7 @@ void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out,
                       int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s);
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
-                    int kv_div, hipStream_t s);
+                    int kv_div, hipStream_t s, int heads = 4, int head_dim = 80);
 void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s);
 void ocrk_logsoftmax_top5(const float *logits, int64_t ld, int R, int D, int suppress_tok, float *vals, int *idx,
                           float *logp_out, hipStream_t s);

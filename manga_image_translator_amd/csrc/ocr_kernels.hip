@@ -147,6 +147,69 @@ __global__ __launch_bounds__(256) void dwconv_ragged_kernel(const float *__restr
     }
 }
 
+// ---- general NHWC average pool (count_include_pad = True, the nn.AvgPool2d default): the FAN backbone's
+// AvgPool2d(2, stride=(2, 1), padding=(0, 1)) (ocr/model_48px_ctc.py:303) ----
+__global__ void avgpool_general_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int H, int W, int C4, int Ho,
+                                       int Wo, int kh, int kw, int sh, int sw, int ph, int pw) {
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int C = C4 * 4;
+    const float inv = 1.0f / (float)(kh * kw);
+    for (; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int x = (int)(p % Wo);
+        p /= Wo;
+        const int y = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < kh; ++ky) {
+            const int yy = y * sh + ky - ph;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < kw; ++kx) {
+                const int xx = x * sw + kx - pw;
+                if (xx < 0 || xx >= W) continue;
+                acc += *reinterpret_cast<const f32x4_t *>(in + (((int64_t)b * H + yy) * W + xx) * C + c4 * 4);
+            }
+        }
+        *reinterpret_cast<f32x4_t *>(out + (((int64_t)b * Ho + y) * Wo + x) * C + c4 * 4) = acc * inv;
+    }
+}
+
+// ---- y = act(x * scale[c] + bias[c]) over NHWC pixels: the pre-activation BatchNorm + ReLU of the FAN BasicBlock
+// (model_48px_ctc.py:392-394), whose input also feeds the residual and therefore cannot be folded into a conv ----
+__global__ void affine_act_kernel(const float *__restrict__ in, int64_t in_pix, const float *__restrict__ scale,
+                                  const float *__restrict__ bias, float *__restrict__ out, int64_t out_pix, int64_t npix, int C4,
+                                  int relu) {
+    const int64_t total = npix * C4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        const int64_t p = i / C4;
+        const f32x4_t v = *reinterpret_cast<const f32x4_t *>(in + p * in_pix + c4 * 4);
+        const f32x4_t s = *reinterpret_cast<const f32x4_t *>(scale + c4 * 4);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t *>(bias + c4 * 4);
+        f32x4_t o;
+        o.x = v.x * s.x + b.x; o.y = v.y * s.y + b.y; o.z = v.z * s.z + b.z; o.w = v.w * s.w + b.w;
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<f32x4_t *>(out + p * out_pix + c4 * 4) = o;
+    }
+}
+
+// ---- x <- gelu(x), erf form ----
+__global__ void gelu_kernel(float *__restrict__ x, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float v = x[i];
+        x[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    }
+}
+
 // ---- LayerNorm over the last dim (D <= 64*8), one wave per row ----
 __global__ void layernorm_kernel(const float *__restrict__ in, int64_t in_rs, const float *__restrict__ w,
                                  const float *__restrict__ b, float *__restrict__ out, int64_t out_rs, int rows, int D,
@@ -208,30 +271,30 @@ __global__ void xpos_rotate_kernel(const float *__restrict__ in, int64_t in_rs, 
     }
 }
 
-// ---- softmax(q k^T + key mask) v, 4 heads x 80, one wave per (query, head, row) ----
+// ---- softmax(q k^T + key mask) v, gridDim.y heads x HD (4 x 80 for the 48px model, 8 x 40 for 48px_ctc), one wave per
+// (query, head, row) ----
 __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int64_t q_ts, const float *__restrict__ K,
                                  int64_t k_rs, int64_t k_ts, const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
                                  float *__restrict__ O, int64_t o_rs, int64_t o_ts, const int *__restrict__ klen, int Tk,
-                                 int kv_div) {
-    extern __shared__ float lds[];  // [80] q + [Tk] weights
+                                 int kv_div, int HD) {
+    extern __shared__ float lds[];  // [HD] q + [Tk] weights
     float *qs = lds;
-    float *ws = lds + 80;
+    float *ws = lds + HD;
     const int tq = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
     const int lane = threadIdx.x;
     const int kr = r / kv_div;
-    const float *q = Q + (int64_t)r * q_rs + (int64_t)tq * q_ts + h * 80;
-    for (int d = lane; d < 80; d += 64) qs[d] = q[d];
+    const float *q = Q + (int64_t)r * q_rs + (int64_t)tq * q_ts + h * HD;
+    for (int d = lane; d < HD; d += 64) qs[d] = q[d];
     __syncthreads();
     const int valid = klen ? min(klen[kr], Tk) : Tk;
-    const float *kb = K + (int64_t)kr * k_rs + h * 80;
+    const float *kb = K + (int64_t)kr * k_rs + h * HD;
     float mx = -INFINITY;
     for (int t = lane; t < Tk; t += 64) {
         float dot = -INFINITY;
         if (t < valid) {
             const float4 *kp = reinterpret_cast<const float4 *>(kb + (int64_t)t * k_ts);
             dot = 0.f;
-#pragma unroll
-            for (int d4 = 0; d4 < 20; ++d4) {
+            for (int d4 = 0; d4 < HD / 4; ++d4) {
                 const float4 kv = kp[d4];
                 dot += qs[d4 * 4 + 0] * kv.x;
                 dot += qs[d4 * 4 + 1] * kv.y;
@@ -252,9 +315,9 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     __syncthreads();
     const float inv = 1.0f / sum;
-    const float *vb = V + (int64_t)kr * v_rs + h * 80;
-    float *ob = O + (int64_t)r * o_rs + (int64_t)tq * o_ts + h * 80;
-    for (int d = lane; d < 80; d += 64) {
+    const float *vb = V + (int64_t)kr * v_rs + h * HD;
+    float *ob = O + (int64_t)r * o_rs + (int64_t)tq * o_ts + h * HD;
+    for (int d = lane; d < HD; d += 64) {
         float acc = 0.f;
         for (int t = 0; t < valid; ++t) acc += (ws[t] * inv) * vb[(int64_t)t * v_ts + d];
         ob[d] = acc;
@@ -466,10 +529,10 @@ void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out,
 
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
-                    int kv_div, hipStream_t s) {
-    const size_t smem = (80 + (size_t)Tk) * sizeof(float);
-    hipLaunchKernelGGL(attention_kernel, dim3(Tq, 4, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
-                       o_ts, klen, Tk, kv_div);
+                    int kv_div, hipStream_t s, int heads, int head_dim) {
+    const size_t smem = ((size_t)head_dim + (size_t)Tk) * sizeof(float);
+    hipLaunchKernelGGL(attention_kernel, dim3(Tq, heads, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
+                       o_ts, klen, Tk, kv_div, head_dim);
 }
 
 void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s) {
@@ -537,6 +600,62 @@ extern "C" int mit_dwconv_nhwc_ragged(const float *in_dev, const float *w_dev, c
         default: return mit_set_error("mit_dwconv_nhwc_ragged: k must be 3, 5 or 7 (got %d)", k);
     }
     MIT_CHECK_LAUNCH("mit_dwconv_nhwc_ragged");
+    return 0;
+}
+
+extern "C" int mit_attention_heads(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k_dev, int64_t k_rs, int64_t k_ts,
+                                   const float *v_dev, int64_t v_rs, int64_t v_ts, float *out_dev, int64_t o_rs, int64_t o_ts,
+                                   const int *klen_dev, int R, int Tq, int Tk, int kv_div, int heads, int head_dim, void *stream) {
+    if (!q_dev || !k_dev || !v_dev || !out_dev) return mit_set_error("mit_attention_heads: null pointer");
+    if (R <= 0 || Tq <= 0 || Tk <= 0 || kv_div <= 0) return mit_set_error("mit_attention_heads: empty problem");
+    if (Tk > 8192 || R > 65535 || Tq > 65535) return mit_set_error("mit_attention_heads: problem too large");
+    if (heads <= 0 || heads > 64 || head_dim <= 0 || (head_dim & 3) || head_dim > 256)
+        return mit_set_error("mit_attention_heads: heads in [1, 64], head_dim a multiple of 4 up to 256");
+    ocrk_attention(q_dev, q_rs, q_ts, k_dev, k_rs, k_ts, v_dev, v_rs, v_ts, out_dev, o_rs, o_ts, klen_dev, R, Tq, Tk, kv_div,
+                   (hipStream_t)stream, heads, head_dim);
+    MIT_CHECK_LAUNCH("mit_attention_heads");
+    return 0;
+}
+
+extern "C" int mit_avgpool_nhwc(const float *in_dev, float *out_dev, int B, int H, int W, int C, int kh, int kw, int sh, int sw,
+                                int ph, int pw, void *stream) {
+    if (!in_dev || !out_dev) return mit_set_error("mit_avgpool_nhwc: null pointer");
+    if ((C & 3) || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || 2 * ph > kh || 2 * pw > kw)
+        return mit_set_error("mit_avgpool_nhwc: bad geometry (C %% 4 == 0, pad <= kernel / 2)");
+    const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    if (B <= 0 || Ho <= 0 || Wo <= 0) return mit_set_error("mit_avgpool_nhwc: empty output");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(avgpool_general_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev, B, H, W,
+                       C / 4, Ho, Wo, kh, kw, sh, sw, ph, pw);
+    MIT_CHECK_LAUNCH("mit_avgpool_nhwc");
+    return 0;
+}
+
+extern "C" int mit_affine_act_nhwc(const float *in_dev, int64_t in_pixstride, const float *scale_dev, const float *bias_dev,
+                                   float *out_dev, int64_t out_pixstride, int64_t npix, int C, int relu, void *stream) {
+    if (!in_dev || !scale_dev || !bias_dev || !out_dev) return mit_set_error("mit_affine_act_nhwc: null pointer");
+    if ((C & 3) || (in_pixstride & 3) || (out_pixstride & 3)) return mit_set_error("mit_affine_act_nhwc: C and pixel strides must be multiples of 4");
+    if (npix <= 0) return 0;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(npix * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, in_dev, in_pixstride,
+                       scale_dev, bias_dev, out_dev, out_pixstride, npix, C / 4, relu);
+    MIT_CHECK_LAUNCH("mit_affine_act_nhwc");
+    return 0;
+}
+
+extern "C" int mit_logsoftmax_top5(const float *logits_dev, int64_t ld, int R, int D, int suppress_tok, float *vals_dev, int *idx_dev,
+                                   void *stream) {
+    if (!logits_dev || !vals_dev || !idx_dev) return mit_set_error("mit_logsoftmax_top5: null pointer");
+    if (R <= 0 || D < 5) return mit_set_error("mit_logsoftmax_top5: need R > 0 and D >= 5");
+    ocrk_logsoftmax_top5(logits_dev, ld, R, D, suppress_tok, vals_dev, idx_dev, nullptr, (hipStream_t)stream);
+    MIT_CHECK_LAUNCH("mit_logsoftmax_top5");
+    return 0;
+}
+
+extern "C" int mit_gelu_inplace(float *x_dev, int64_t n, void *stream) {
+    if (!x_dev) return mit_set_error("mit_gelu_inplace: null pointer");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gelu_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x_dev, n);
+    MIT_CHECK_LAUNCH("mit_gelu_inplace");
     return 0;
 }
 

@@ -161,6 +161,15 @@ SYMBOLS = {
     "mit_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                 C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p]),
+    "mit_attention_heads": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    "mit_avgpool_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p]),
+    "mit_affine_act_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                      C.c_int, C.c_void_p]),
+    "mit_gelu_inplace": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "mit_logsoftmax_top5": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mit_ocr48_decode_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "mit_ocr48_decode": (C.c_int, [C.POINTER(MitOcr48Decoder), C.POINTER(MitOcr48DecodeArgs), C.c_void_p]),
     "mit_lama_post": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

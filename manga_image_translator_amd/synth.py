@@ -66,6 +66,14 @@ def synth_state_dict(schema: Schema, seed: int = 0, gain: float = 1.0) -> Dict[s
         elif kind == "xpos_scale":  # XPOS.scale buffer (ocr/xpos_relative_position.py:50-52)
             hd = shape[0] * 2
             t = (torch.arange(0, hd, 2) + 0.4 * hd) / (1.4 * hd)
+        elif kind == "sinus_pe":  # PositionalEncoding.pe buffer (ocr/model_48px_ctc.py:163-174), [1, max_len, d_model]
+            _, max_len, d_model = shape
+            pe = torch.zeros(max_len, d_model)
+            position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+            div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+            pe[:, 0::2] = torch.sin(position * div_term)
+            pe[:, 1::2] = torch.cos(position * div_term)
+            t = pe.unsqueeze(0)
         elif kind.startswith("tie:"):  # shares storage with an earlier entry (pred.weight = embd.weight, model_48px.py:536)
             t = sd[kind.split(":", 1)[1]]
         else:

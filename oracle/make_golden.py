@@ -14,6 +14,7 @@ Fixtures (all small; each .npz also records the reference file whose code produc
   lama_large.npz   LamaFourier(large_arch=True).__call__                                             48x40
   ctd.npz          preprocess_img + TextDetBase.forward (ctd.py:17-28, ctd_utils/basemodel.py:234-238) 120x90 page
   ocr48.npz        OCR.infer_beam_batch_tensor (ocr/model_48px.py:678-801) on 5 crops, dict 97, T = 9
+  ocr_ctc.npz      OCR.forward + OCR.decode (ocr/model_48px_ctc.py:463-494) on 3 crops padded to max_w+7+128, dict 97
   esrgan.npz       RRDBNet.forward + the tensor part of ESRGANUpscalerPytorch._infer (upscaling/esrgan_pytorch.py:67-75,537-546), nb = 2, 40x56 page
   textline.npz     sort_pnts / Quadrilateral / get_transformed_region (utils/generic.py:324-481) on 12 quads
 """
@@ -189,6 +190,41 @@ def golden_textline():
     print("textline", dirs, [c.shape for c in crops][:4])
 
 
+def build_ref_ocr_ctc():
+    from manga_image_translator_amd import ocr_ctc_schema
+
+    M = R.ocr_ctc()
+    model = M.OCR([f"c{i}" for i in range(OCR_DICT)], 768)
+    sd = synth.synth_state_dict(ocr_ctc_schema.ocr_ctc_schema(OCR_DICT), gain=ocr_ctc_schema.CTC_GAIN)
+    model.load_state_dict(sd, strict=True)
+    return model.eval(), sd
+
+
+def golden_ocr_ctc():
+    model, _ = build_ref_ocr_ctc()
+    rng = np.random.default_rng(33)
+    widths = [37, 64, 101]
+    Wp = max(widths) + 7 + 128  # model_48px_ctc.py:84
+    region = np.zeros((len(widths), 48, Wp, 3), dtype=np.uint8)
+    for i, w in enumerate(widths):
+        region[i, :, :w] = rng.integers(0, 256, size=(48, w, 3), dtype=np.uint8)
+    img = ((torch.from_numpy(region).float() - 127.5) / 127.5).permute(0, 3, 1, 2).contiguous()
+    with torch.inference_mode():
+        logits, colors = model(img)
+        texts = model.decode(img, widths, 0)
+    T = logits.shape[1]
+    nmax = max(1, max(len(t) for t in texts))
+    ids = np.full((len(widths), nmax), -1, dtype=np.int64)
+    vals = np.zeros((len(widths), nmax, 7), dtype=np.float32)
+    for i, line in enumerate(texts):
+        for j, item in enumerate(line):
+            ids[i, j] = int(item[0])
+            vals[i, j] = [float(v) for v in item[1:]]
+    np.savez_compressed(os.path.join(GOLDEN, "ocr_ctc.npz"), region=region, widths=np.array(widths), logits=logits.numpy(),
+                        colors=colors.numpy(), ids=ids, vals=vals, dict_size=OCR_DICT, source="manga_translator/ocr/model_48px_ctc.py")
+    print("ocr_ctc", logits.shape, T, [len(t) for t in texts], float(logits.std()))
+
+
 def build_ref_esrgan(nb: int):
     from manga_image_translator_amd import esrgan_schema
 
@@ -222,6 +258,7 @@ def main():
     golden_ctd()
     golden_lama()
     golden_esrgan()
+    golden_ocr_ctc()
 
 
 if __name__ == "__main__":

@@ -94,6 +94,12 @@ def ocr48():
     return _load("manga_translator.ocr.model_48px", "ocr/model_48px.py")
 
 
+def ocr_ctc():
+    """reference module manga_translator/ocr/model_48px_ctc.py"""
+    _prepare()
+    return _load("manga_translator.ocr.model_48px_ctc", "ocr/model_48px_ctc.py")
+
+
 def ctd():
     """reference modules manga_translator/detection/ctd_utils/{basemodel,yolov5/*}.py -> (basemodel, yolo)"""
     _prepare()

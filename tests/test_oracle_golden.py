@@ -108,3 +108,25 @@ def test_esrgan_oracle_matches_reference_fixture():
     d = np.abs(out.astype(np.int32) - g["out_u8"].astype(np.int32))
     assert d.max() <= 1 and (d != 0).mean() < 1e-3  # identical up to a x255 truncation boundary
     assert 0.05 < (g["out_u8"] == 0).mean() < 0.95 and len(np.unique(g["out_u8"])) > 100  # not a saturated constant
+
+
+def test_ocr_ctc_oracle_matches_reference_fixture():
+    from manga_image_translator_amd import ocr_ctc_schema as S, synth
+    from oracle import ocr_ctc as OC
+
+    g = _load("ocr_ctc.npz")
+    sd = synth.synth_state_dict(S.ocr_ctc_schema(int(g["dict_size"])), gain=S.CTC_GAIN)
+    img = ((torch.from_numpy(g["region"]).float() - 127.5) / 127.5).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        logits, colors = OC.forward(sd, img)
+    assert np.abs(logits.numpy() - g["logits"]).max() < 5e-5 * np.abs(g["logits"]).max()
+    assert np.abs(colors.numpy() - g["colors"]).max() < 5e-5 * max(1.0, np.abs(g["colors"]).max())
+    dec = OC.decode_ctc_top1(logits, colors)
+    for i, line in enumerate(dec):
+        n = int((g["ids"][i] >= 0).sum())
+        assert [t[0] for t in line] == g["ids"][i, :n].tolist() and n >= 5
+        assert np.allclose(np.array([t[1:] for t in line]), g["vals"][i, :n], atol=1e-4)
+    # chunk geometry (model_48px_ctc.py:84)
+    crops = [g["region"][i, :, :w] for i, w in enumerate(g["widths"])]
+    idx, ws, t = next(OC.make_chunks(crops))
+    assert t.shape[3] == max(ws) + 7 + 128 == g["region"].shape[2]

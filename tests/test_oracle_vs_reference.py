@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("gen,files", [("golden_textline", ["textline.npz"]), ("golden_ocr", ["ocr48.npz"]),
-                                       ("golden_ctd", ["ctd.npz"]), ("golden_lama", ["lama_mpe.npz", "lama_large.npz"]), ("golden_esrgan", ["esrgan.npz"])])
+                                       ("golden_ctd", ["ctd.npz"]), ("golden_lama", ["lama_mpe.npz", "lama_large.npz"]), ("golden_esrgan", ["esrgan.npz"]), ("golden_ocr_ctc", ["ocr_ctc.npz"])])
 def test_fixture_regenerates(tmp_path, monkeypatch, gen, files):
     from oracle import make_golden as MG
 
@@ -56,5 +56,9 @@ def test_schemas_match_reference_modules():
     check(ctd_schema.yolo_schema(), yolo.Model(ctd_schema.YOLOV5S_CFG).state_dict())
     from manga_image_translator_amd import esrgan_schema
 
+    from manga_image_translator_amd import ocr_ctc_schema
+
+    ctc, _ = MG.build_ref_ocr_ctc()
+    check(ocr_ctc_schema.ocr_ctc_schema(MG.OCR_DICT), ctc.state_dict())
     net, _ = MG.build_ref_esrgan(3)
     check(esrgan_schema.rrdbnet_schema(3), net.state_dict())
