@@ -91,7 +91,7 @@ class OcrCtcEngine:
             col_scale = torch.cat([torch.full((EMBD,), s), torch.ones(2 * EMBD)])  # F.multi_head_attention scales q
             qkv = Linear(w, b, dev, col_scale)
             # (x + pe) @ W_qk = x @ W_qk + pe @ W_qk: the second term is a [T, 960] table (zero for the v columns)
-            pe = sd[q + ".pe.pe"][0].double()                                   # [2048, 320]
+            pe = _sinus_pe(2048, EMBD).double()  # recomputed like the reference, which drops the checkpoint's pe.pe (:45-48)
             pew = torch.zeros(pe.shape[0], 3 * EMBD, dtype=torch.float64)
             pew[:, :2 * EMBD] = pe @ w[:2 * EMBD].double().t()
             self.enc.append(dict(
@@ -262,6 +262,18 @@ class OcrCtcEngine:
             for j, i in enumerate(indices):
                 region[j, :, :widths[j], :] = region_imgs[i]
             yield indices, widths, region
+
+
+def _sinus_pe(max_len: int, d_model: int) -> torch.Tensor:
+    """PositionalEncoding.pe (model_48px_ctc.py:163-174), fp32 like the reference."""
+    import math
+
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
 
 
 def _gelu_inplace(x2d: torch.Tensor) -> None:

@@ -4,6 +4,7 @@ Each class honours the contract of its reference counterpart:
 
   HipComicTextDetector   <- ComicTextDetector   (/root/reference/manga_translator/detection/ctd.py:60-179)
   HipModel48pxOCR        <- Model48pxOCR        (ocr/model_48px.py:25-180)
+  HipModel48pxCTCOCR     <- Model48pxCTCOCR     (ocr/model_48px_ctc.py:30-160)
   HipLamaMPEInpainter    <- LamaMPEInpainter    (inpainting/inpainting_lama_mpe.py:26-118)
   HipLamaLargeInpainter  <- LamaLargeInpainter  (inpainting/inpainting_lama_mpe.py:121-136)
   HipESRGANUpscaler      <- ESRGANUpscalerPytorch (upscaling/esrgan_pytorch.py:512-549)
@@ -184,6 +185,87 @@ class HipModel48pxOCR(_OcrBase):
             q.bg_r, q.bg_g, q.bg_b = bgc
             out.append(q)
         return out
+
+
+class HipModel48pxCTCOCR(HipModel48pxOCR):
+    """``--ocr 48px_ctc`` on the HIP engine (ocr/model_48px_ctc.py:62-160)."""
+    _key = "48px_ctc_hip"
+
+    async def _load(self, device: str):
+        from . import ocr_ctc
+
+        dev = _gpu_device(device)
+        if self._weights is None or self.dictionary is None:
+            self._weights, self.dictionary = _load_ocr_ctc_checkpoint(self)
+        self.engine = ocr_ctc.OcrCtcEngine(self._weights, len(self.dictionary), device=dev)
+        self.device = device
+
+    @torch.no_grad()
+    async def _infer(self, image: np.ndarray, textlines: List, config=None, verbose: bool = False):
+        """Same contract as the 48px plugin; chunks are padded to max_w + 7 + 128 (:84), the line probability is
+        exp(mean log-prob) against a 0.5 default threshold (:66,:124), colours average over non-space characters (:116-123).
+        The bubble filter (``config.ignore_bubble``, an OpenCV heuristic, :91-93) is not applied."""
+        import ctypes as C
+
+        from . import lib as _lib, ops, textline as TL
+
+        threshold = 0.5 if config is None or getattr(config, "prob", None) is None else config.prob
+        pairs = self._directions(textlines)
+        if not pairs:
+            return []
+        quads = [q for q, _ in pairs]
+        dirs = [d for _, d in pairs]
+        H, W = image.shape[:2]
+        dev = self.engine.device
+        page = torch.from_numpy(np.ascontiguousarray(image)).to(dev)[None]
+        own = [Quadrilateral(np.asarray(q.pts)) for q in quads]
+        rec = TL.warp_plans(own, dirs, H, W, 48)
+        widths = np.where(rec["vertical"] != 0, rec["dh"], rec["dw"]).tolist()
+        lib = _lib.load()
+        out = []
+        for idx, ws, wp in TL.chunk_plan(widths):
+            wp += 128
+            r = rec[idx].copy()
+            r["out_row"] = np.arange(len(idx))
+            lines_dev = torch.frombuffer(bytearray(r.tobytes()), dtype=torch.uint8).to(dev)
+            region = torch.empty(len(idx), 48, wp, 3, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mit_ocr_warp_lines(page.data_ptr(), H, W, lines_dev.data_ptr(), len(idx), region.data_ptr(), 48, wp,
+                                              C.c_void_p(ops.current_stream())), "mit_ocr_warp_lines")
+            logits, colors = self.engine.forward(region)
+            for j, line in enumerate(self.engine.decode(logits, colors, 0)):
+                q = quads[idx[j]]
+                q.assigned_direction = dirs[idx[j]]
+                res = decode_ctc_line(line, self.dictionary)
+                if res is None or res[1] < threshold:
+                    continue
+                q.text, q.prob = res[0], res[1]
+                q.fg_r, q.fg_g, q.fg_b = res[2]
+                q.bg_r, q.bg_g, q.bg_b = res[3]
+                out.append(q)
+        return out
+
+
+def decode_ctc_line(line, dictionary: Sequence[str]):
+    """[(char id, log-prob, fr, fg, fb, br, bg, bb)] -> (text, prob, fg rgb, bg rgb) or None for an empty line:
+    model_48px_ctc.py:105-134 (AvgMeter means; colours only over non-space characters; prob = exp(mean log-prob))."""
+    if not line:
+        return None
+    chars, lp_sum = [], 0.0
+    acc = [0] * 6
+    n_col = 0
+    for chid, logprob, *cols in line:
+        ch = dictionary[int(chid)]
+        if ch == "<SP>":
+            ch = " "
+        chars.append(ch)
+        lp_sum += logprob
+        if ch != " ":
+            for k in range(6):
+                acc[k] += int(cols[k] * 255)
+            n_col += 1
+    prob = float(np.exp(lp_sum / len(line)))
+    mean = [int(a / n_col) if n_col else 0 for a in acc]
+    return "".join(chars), prob, tuple(mean[:3]), tuple(mean[3:])
 
 
 def decode_line(token_ids: np.ndarray, colors: np.ndarray, dictionary: Sequence[str]) -> Tuple[str, Tuple[int, int, int], Tuple[int, int, int]]:
@@ -376,6 +458,14 @@ def _load_ocr_checkpoint(plugin):
     return torch.load(_ckpt_path(plugin, "ocr_ar_48px.ckpt"), map_location="cpu"), dictionary
 
 
+def _load_ocr_ctc_checkpoint(plugin):
+    """ocr-ctc.ckpt + alphabet-all-v5.txt (model_48px_ctc.py:19-28,40-52)."""
+    with open(_ckpt_path(plugin, "alphabet-all-v5.txt"), "r", encoding="utf-8") as fp:
+        dictionary = [s[:-1] for s in fp.readlines()]
+    sd = torch.load(_ckpt_path(plugin, "ocr-ctc.ckpt"), map_location="cpu")
+    return sd.get("model", sd), dictionary
+
+
 def _load_lama_checkpoint(plugin):
     """{'gen_state_dict', 'str_state_dict'?} (inpainting_lama_mpe.py:818-825)."""
     ck = torch.load(_ckpt_path(plugin, plugin.CKPT), map_location="cpu")
@@ -396,6 +486,7 @@ def register() -> None:
 
     DETECTORS["ctd_hip"] = HipComicTextDetector
     OCRS["48px_hip"] = HipModel48pxOCR
+    OCRS["48px_ctc_hip"] = HipModel48pxCTCOCR
     INPAINTERS["lama_mpe_hip"] = HipLamaMPEInpainter
     INPAINTERS["lama_large_hip"] = HipLamaLargeInpainter
     from manga_translator.upscaling import UPSCALERS  # type: ignore

@@ -60,3 +60,28 @@ def test_ocr_ctc_decode_collapse_rules(cuda):
     assert [[t[0] for t in l] for l in got] == [[3, 3, 5, 7], [4, 4, 9, 1]] == [[t[0] for t in l] for l in ref]
     for gl, rl in zip(got, ref):
         assert np.allclose(np.array([t[1:] for t in gl]), np.array([t[1:] for t in rl]), atol=1e-5)
+
+
+def test_ocr_ctc_plugin(cuda):
+    import asyncio
+
+    from manga_image_translator_amd import ocr_ctc_schema as S, plugins as P, synth, textline as TL
+
+    run = lambda c: asyncio.new_event_loop().run_until_complete(c)
+    D = 64
+    dictionary = ["<PAD>", "<S>", "</S>", "<SP>"] + [chr(0x3041 + i) for i in range(D - 4)]
+    ocr = P.HipModel48pxCTCOCR(weights=synth.synth_state_dict(S.ocr_ctc_schema(D), gain=S.CTC_GAIN), dictionary=dictionary)
+    run(ocr.load("cuda"))
+    page, quads, _ = synth.synth_page(3, 256, 320, n_boxes=5)
+    lines = [TL.Quadrilateral(q) for q in quads]
+
+    class Cfg:
+        prob = 0.0
+        ignore_bubble = 0
+
+    out = run(ocr.infer(page, lines, Cfg()))
+    assert 1 <= len(out) <= len(lines) and all(o in lines for o in out)
+    assert all(isinstance(o.text, str) and len(o.text) >= 1 and 0.0 < o.prob <= 1.0 and 0 <= o.fg_r <= 255 for o in out)
+    Cfg.prob = 1.1
+    assert run(ocr.infer(page, lines, Cfg())) == []
+    run(ocr.unload())

@@ -12,7 +12,7 @@ def run(coro):
     return asyncio.new_event_loop().run_until_complete(coro)
 
 
-@pytest.mark.parametrize("cls", [P.HipComicTextDetector, P.HipModel48pxOCR, P.HipLamaMPEInpainter, P.HipLamaLargeInpainter,
+@pytest.mark.parametrize("cls", [P.HipComicTextDetector, P.HipModel48pxOCR, P.HipModel48pxCTCOCR, P.HipLamaMPEInpainter, P.HipLamaLargeInpainter,
                                  P.HipESRGANUpscaler])
 def test_lifecycle_and_device_errors(cls):
     p = cls()                                   # constructed with no arguments, touches no GPU
@@ -81,3 +81,14 @@ def test_decode_line_matches_reference_logic():
         got = P.decode_line(toks, cols, dictionary)
         ref = _ref_decode(toks, cols[:, 0:3], cols[:, 3:6], cols[:, 6:8], cols[:, 8:10], dictionary)
         assert got == ref
+
+
+def test_decode_ctc_line_matches_reference_logic():
+    """model_48px_ctc.py:105-134: mean log-prob -> prob, colours averaged over non-space characters only."""
+    dictionary = ["<PAD>", "<S>", "</S>", "<SP>", "a", "b", "c"]
+    line = [(4, -0.1, 0.2, 0.4, 0.6, 0.9, 0.8, 0.7), (3, -0.5, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0), (6, -0.3, 0.4, 0.0, 1.0, 0.1, 0.2, 0.3)]
+    txt, prob, fg, bg = P.decode_ctc_line(line, dictionary)
+    assert txt == "a c" and prob == pytest.approx(np.exp((-0.1 - 0.5 - 0.3) / 3))
+    assert fg == (int((int(0.2 * 255) + int(0.4 * 255)) / 2), int((int(0.4 * 255) + 0) / 2), int((int(0.6 * 255) + 255) / 2))
+    assert bg == (int((int(0.9 * 255) + int(0.1 * 255)) / 2), int((int(0.8 * 255) + int(0.2 * 255)) / 2), int((int(0.7 * 255) + int(0.3 * 255)) / 2))
+    assert P.decode_ctc_line([], dictionary) is None
