@@ -39,6 +39,9 @@ enum MitAct {
     MIT_ACT_SIGMOID = 4, /* nn.Sigmoid          (basemodel.py:52,107,136; lama generator :599-600)   */
     MIT_ACT_GELU = 5     /* nn.GELU (erf)       (model_48px.py:199,534)                              */
 };
+/* OR-ed into MitConvGemm.act: the ``post`` operand is added BEFORE the activation, act(v*scale + bias + post) — the
+ * ``out += identity; relu(out)`` of torchvision's BasicBlock (default detector backbone, default_utils/DBNet_resnet34.py:76). */
+#define MIT_ACT_POST_FIRST 0x100
 
 enum MitPad {
     MIT_PAD_ZERO = 0,    /* nn.Conv2d default                                   */
@@ -65,7 +68,7 @@ typedef struct MitTensorMap {
  *   A[z][m,t,ci] = a[z1*a_zs1 + z0*a_zs0 + nb*a_bs + iy*a_ys + ix*a_xs + tap_off[t] + ci]
  *        iy = oy*sy + tap_dy[t], ix = ox*sx + tap_dx[t]; outside [0,Hi)x[0,Wi): zero or reflect
  *   W[z][k][n]   = w[z1*w_zs1 + z0*w_zs0 + k*ldw + n]          (rows k >= Kw, cols n >= Nw read as 0)
- *   epilogue(v)  = act( (v + pre[..]) * scale[n] + bias[n] ) + post[..]
+ *   epilogue(v)  = act( (v + pre[..]) * scale[n] + bias[n] ) + post[..]      (MIT_ACT_POST_FIRST: post joins inside act)
  *
  * Replaces (with BatchNorm folded into scale/bias by the packer):
  *   nn.Conv2d / nn.ConvTranspose2d (as stride-parity sub-convolutions) / nn.Linear calls in
@@ -188,6 +191,9 @@ int mit_ctd_prep(const uint8_t *img_dev, int B, int H, int W, int nh, int nw, in
 /* NHWC max-pool k x k, stride 1, pad k/2 — nn.MaxPool2d of SPPF (yolov5/common.py:181-197). Pixel strides in floats. */
 int mit_maxpool_nhwc(const float *in_dev, int64_t in_pixstride, float *out_dev, int64_t out_pixstride, int B, int H,
                      int W, int C, int k, void *stream);
+/* NHWC max-pool k x k, stride s, pad p (implicit -inf padding): torchvision ResNet's MaxPool2d(3, 2, 1)
+ * (default detector, default_utils/DBNet_resnet34.py:104).  out [B,Ho,Wo,C] dense. */
+int mit_maxpool2d_nhwc(const float *in_dev, float *out_dev, int B, int H, int W, int C, int k, int s, int p, void *stream);
 /* NHWC 2x2/2 average pool — nn.AvgPool2d(2, 2) of double_conv_c3 (ctd_utils/basemodel.py:28-39). */
 int mit_avgpool2_nhwc(const float *in_dev, int64_t in_pixstride, float *out_dev, int64_t out_pixstride, int B, int Ho,
                       int Wo, int C, void *stream);
@@ -309,6 +315,11 @@ int mit_avgpool_nhwc(const float *in_dev, float *out_dev, int B, int H, int W, i
  * input also feeds a residual (pre-activation BasicBlock.forward, model_48px_ctc.py:389-403). */
 int mit_affine_act_nhwc(const float *in_dev, int64_t in_pixstride, const float *scale_dev, const float *bias_dev, float *out_dev,
                         int64_t out_pixstride, int64_t npix, int C, int relu, void *stream);
+/* u8 RGB [npix,3] -> fp32 [npix,4] (4th channel 0).  mode 0: (x-127.5)/127.5 (model_48px.py:115); mode 1: x/127.5 - 1
+ * (det_batch_forward_default, detection/default.py:19); mode 2: x/255.  Each is the reference's own fp32 expression. */
+int mit_u8_to_f32_nhwc4(const uint8_t *in_dev, float *out_dev, int64_t npix, int mode, void *stream);
+/* x <- sigmoid(x): the ``db.sigmoid()`` that det_batch_forward_default applies on top of DBHead's output (default.py:23). */
+int mit_sigmoid_inplace(float *x_dev, int64_t n, void *stream);
 /* x <- gelu(x) (erf form) over n floats: the nn.GELU of char_pred_norm (model_48px_ctc.py:435). */
 int mit_gelu_inplace(float *x_dev, int64_t n, void *stream);
 /* log_softmax over D columns + the 5 largest (value, index) per row, ties to the lower index; suppress_tok < 0: none.

@@ -75,6 +75,8 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
 
     const bool has_pre = p.pre.base != nullptr;
     const bool has_post = p.post.base != nullptr;
+    const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;  // residual joins before the activation (ResNet BasicBlock)
+    const int act = p.act & 0xff;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int n = n0 + wn0 + ni * 32 + li;
@@ -95,8 +97,9 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
                 float v = acc[mi][ni][r];
                 if (has_pre) v += p.pre.base[ro.pre + ncol_pre];
                 v = v * sc + bi;
-                v = apply_act(v, p.act, p.act_alpha);
-                if (has_post) v += p.post.base[ro.post + ncol_post];
+                if (has_post && post_first) v += p.post.base[ro.post + ncol_post];
+                v = apply_act(v, act, p.act_alpha);
+                if (has_post && !post_first) v += p.post.base[ro.post + ncol_post];
                 p.c.base[ro.c + ncol_c] = v;
             }
         }

@@ -140,6 +140,35 @@ __global__ void map_to_u8_kernel(const float *__restrict__ in, uint8_t *__restri
     }
 }
 
+// ---- NHWC max-pool k x k, stride s, pad p (-inf padding) ----
+__global__ void maxpool2d_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int H, int W, int C4, int Ho, int Wo,
+                                 int k, int s, int p) {
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int C = C4 * 4;
+    for (; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        int64_t q = i / C4;
+        const int x = (int)(q % Wo);
+        q /= Wo;
+        const int y = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        float4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = y * s + ky - p;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = x * s + kx - p;
+                if (xx < 0 || xx >= W) continue;
+                const float4 v = *reinterpret_cast<const float4 *>(in + (((int64_t)b * H + yy) * W + xx) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4 *>(out + (((int64_t)b * Ho + y) * Wo + x) * C + c4 * 4) = m;
+    }
+}
+
 // ---- out = a * x + y, elementwise float4 (RRDB's residual scaling, upscaling/esrgan_pytorch.py:112) ----
 __global__ void axpy_kernel(float4 *__restrict__ out, float a, const float4 *__restrict__ x, const float4 *__restrict__ y, int64_t n4) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,6 +182,18 @@ __global__ void axpy_kernel(float4 *__restrict__ out, float a, const float4 *__r
 }
 
 }  // namespace
+
+extern "C" int mit_maxpool2d_nhwc(const float *in_dev, float *out_dev, int B, int H, int W, int C, int k, int s, int p, void *stream) {
+    if (!in_dev || !out_dev) return mit_set_error("mit_maxpool2d_nhwc: null pointer");
+    if ((C & 3) || k <= 0 || s <= 0 || p < 0 || 2 * p > k) return mit_set_error("mit_maxpool2d_nhwc: bad geometry");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    if (B <= 0 || Ho <= 0 || Wo <= 0) return mit_set_error("mit_maxpool2d_nhwc: empty output");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool2d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev, B, H, W, C / 4,
+                       Ho, Wo, k, s, p);
+    MIT_CHECK_LAUNCH("mit_maxpool2d_nhwc");
+    return 0;
+}
 
 extern "C" int mit_axpy(float *out_dev, float a, const float *x_dev, const float *y_dev, int64_t n, void *stream) {
     if (!out_dev || !x_dev || !y_dev) return mit_set_error("mit_axpy: null pointer");

@@ -200,6 +200,29 @@ __global__ void affine_act_kernel(const float *__restrict__ in, int64_t in_pix, 
     }
 }
 
+// ---- u8 RGB pixels -> fp32 NHWC4 (4th channel 0).  mode 0: (x - 127.5) / 127.5 (model_48px.py:115); mode 1: x / 127.5 - 1
+// (det_batch_forward_default, detection/default.py:19); mode 2: x / 255.  The three forms differ in their fp32 rounding. ----
+__global__ void u8_to_f32_kernel(const uint8_t *__restrict__ in, float4 *__restrict__ out, int64_t npix, int mode) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < npix; i += stride) {
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = (float)in[3 * i + c];
+            v[c] = mode == 0 ? (x - 127.5f) / 127.5f : (mode == 1 ? x / 127.5f - 1.0f : x / 255.0f);
+        }
+        out[i] = float4{v[0], v[1], v[2], 0.f};
+    }
+}
+
+// ---- x <- sigmoid(x) ----
+__global__ void sigmoid_kernel(float *__restrict__ x, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) x[i] = 1.f / (1.f + expf(-x[i]));
+}
+
 // ---- x <- gelu(x), erf form ----
 __global__ void gelu_kernel(float *__restrict__ x, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -648,6 +671,24 @@ extern "C" int mit_logsoftmax_top5(const float *logits_dev, int64_t ld, int R, i
     if (R <= 0 || D < 5) return mit_set_error("mit_logsoftmax_top5: need R > 0 and D >= 5");
     ocrk_logsoftmax_top5(logits_dev, ld, R, D, suppress_tok, vals_dev, idx_dev, nullptr, (hipStream_t)stream);
     MIT_CHECK_LAUNCH("mit_logsoftmax_top5");
+    return 0;
+}
+
+extern "C" int mit_u8_to_f32_nhwc4(const uint8_t *in_dev, float *out_dev, int64_t npix, int mode, void *stream) {
+    if (!in_dev || !out_dev) return mit_set_error("mit_u8_to_f32_nhwc4: null pointer");
+    if (mode < 0 || mode > 2) return mit_set_error("mit_u8_to_f32_nhwc4: bad mode %d", mode);
+    if (npix <= 0) return 0;
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, in_dev,
+                       reinterpret_cast<float4 *>(out_dev), npix, mode);
+    MIT_CHECK_LAUNCH("mit_u8_to_f32_nhwc4");
+    return 0;
+}
+
+extern "C" int mit_sigmoid_inplace(float *x_dev, int64_t n, void *stream) {
+    if (!x_dev) return mit_set_error("mit_sigmoid_inplace: null pointer");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x_dev, n);
+    MIT_CHECK_LAUNCH("mit_sigmoid_inplace");
     return 0;
 }
 

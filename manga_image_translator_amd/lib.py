@@ -12,6 +12,7 @@ MIT_MAX_TAPS = 64
 MIT_ABI_VERSION = 1
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
+ACT_POST_FIRST = 0x100
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 
@@ -144,6 +145,8 @@ SYMBOLS = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mit_maxpool_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]),
+    "mit_maxpool2d_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p]),
     "mit_avgpool2_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p]),
     "mit_copy_channels": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
@@ -168,6 +171,8 @@ SYMBOLS = {
                                    C.c_int, C.c_int, C.c_void_p]),
     "mit_affine_act_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                       C.c_int, C.c_void_p]),
+    "mit_u8_to_f32_nhwc4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "mit_sigmoid_inplace": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "mit_gelu_inplace": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "mit_logsoftmax_top5": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mit_ocr48_decode_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

@@ -17,11 +17,11 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import lib as _lib
-from .lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, MIT_MAX_TAPS, PAD_REFLECT,
+from .lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_POST_FIRST, ACT_RELU, ACT_SIGMOID, ACT_SILU, MIT_MAX_TAPS, PAD_REFLECT,
                   PAD_ZERO, MitConvGemm, MitTensorMap)
 
 __all__ = [
-    "ACT_NONE", "ACT_RELU", "ACT_LEAKY", "ACT_SILU", "ACT_SIGMOID", "ACT_GELU", "PAD_ZERO", "PAD_REFLECT",
+    "ACT_NONE", "ACT_RELU", "ACT_LEAKY", "ACT_SILU", "ACT_SIGMOID", "ACT_GELU", "ACT_POST_FIRST", "PAD_ZERO", "PAD_REFLECT",
     "Conv2d", "ConvSmallCout", "ConvTranspose2d", "UpsampleConv2d", "fold_bn", "conv_gemm_desc", "launch_conv_gemm", "current_stream",
 ]
 

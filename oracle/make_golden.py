@@ -15,6 +15,7 @@ Fixtures (all small; each .npz also records the reference file whose code produc
   ctd.npz          preprocess_img + TextDetBase.forward (ctd.py:17-28, ctd_utils/basemodel.py:234-238) 120x90 page
   ocr48.npz        OCR.infer_beam_batch_tensor (ocr/model_48px.py:678-801) on 5 crops, dict 97, T = 9
   ocr_ctc.npz      OCR.forward + OCR.decode (ocr/model_48px_ctc.py:463-494) on 3 crops padded to max_w+7+128, dict 97
+  dbnet.npz        TextDetection.forward + sigmoid (detection/default_utils/DBNet_resnet34.py:98-125, default.py:15-25) on a 256x256 page (fp16 maps + fp32 crops)
   esrgan.npz       RRDBNet.forward + the tensor part of ESRGANUpscalerPytorch._infer (upscaling/esrgan_pytorch.py:67-75,537-546), nb = 2, 40x56 page
   textline.npz     sort_pnts / Quadrilateral / get_transformed_region (utils/generic.py:324-481) on 12 quads
 """
@@ -225,6 +226,29 @@ def golden_ocr_ctc():
     print("ocr_ctc", logits.shape, T, [len(t) for t in texts], float(logits.std()))
 
 
+def build_ref_dbnet():
+    from manga_image_translator_amd import dbnet_schema
+
+    M = R.dbnet()
+    net = M.TextDetection()
+    sd = synth.synth_state_dict(dbnet_schema.text_detection_schema(), gain=1.2)
+    net.load_state_dict(sd, strict=True)
+    return net.eval(), sd
+
+
+def golden_dbnet():
+    net, _ = build_ref_dbnet()
+    page = synth.synth_page(13, 256, 256, n_boxes=3)[0]
+    x = torch.from_numpy(page[None].astype(np.float32) / 127.5 - 1.0).permute(0, 3, 1, 2).contiguous()  # default.py:19
+    with torch.no_grad():
+        db, mask = net(x)
+    np.savez_compressed(os.path.join(GOLDEN, "dbnet.npz"), page=page, db=db.sigmoid().numpy().astype(np.float16),
+                        db_logit_stats=np.array([float(db[:, 0].mean()), float(db[:, 0].std())]),
+                        mask=mask.numpy().astype(np.float16), db_f32_crop=db.sigmoid().numpy()[:, :, 96:160, 96:160],
+                        mask_f32_crop=mask.numpy()[:, :, 32:96, 32:96], source="manga_translator/detection/default_utils/DBNet_resnet34.py")
+    print("dbnet", db.shape, mask.shape, float(db.sigmoid().mean()), float(db.sigmoid().std()), float(mask.mean()), float(mask.std()))
+
+
 def build_ref_esrgan(nb: int):
     from manga_image_translator_amd import esrgan_schema
 
@@ -259,6 +283,7 @@ def main():
     golden_lama()
     golden_esrgan()
     golden_ocr_ctc()
+    golden_dbnet()
 
 
 if __name__ == "__main__":

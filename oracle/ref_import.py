@@ -169,6 +169,20 @@ def cv2_shim():
     return ns
 
 
+def dbnet():
+    """reference module manga_translator/detection/default_utils/DBNet_resnet34.py (TextDetection) with the oracle's
+    restated ResNet-34 standing in for the absent ``torchvision.models.resnet34``."""
+    _prepare()
+    from . import dbnet as _odb
+
+    tv = types.ModuleType("torchvision.models")
+    tv.resnet34 = _odb.resnet34
+    sys.modules["torchvision.models"] = tv
+    _pkg("manga_translator.detection.default_utils")
+    _load("manga_translator.detection.default_utils.DBHead", "detection/default_utils/DBHead.py")
+    return _load("manga_translator.detection.default_utils.DBNet_resnet34", "detection/default_utils/DBNet_resnet34.py")
+
+
 def esrgan():
     """reference module manga_translator/upscaling/esrgan_pytorch.py (RRDBNet)"""
     _prepare()

@@ -66,9 +66,15 @@ def run(d):
         if d.pre.base:
             off = _map_offsets(d.pre, z1, z0, nb, oy, ox, n)
             acc += _view(d.pre.base, off.max() + 1)[off]
-        v = _act(acc * scale[None, :] + bias[None, :], d.act, d.act_alpha)
+        v = acc * scale[None, :] + bias[None, :]
+        post = None
         if d.post.base:
             off = _map_offsets(d.post, z1, z0, nb, oy, ox, n)
-            v = v + _view(d.post.base, off.max() + 1)[off]
+            post = _view(d.post.base, off.max() + 1)[off]
+        if post is not None and (d.act & 0x100):
+            v = v + post
+        v = _act(v, d.act & 0xff, d.act_alpha)
+        if post is not None and not (d.act & 0x100):
+            v = v + post
         off = _map_offsets(d.c, z1, z0, nb, oy, ox, n)
         _view(d.c.base, off.max() + 1)[off] = v.astype(np.float32)

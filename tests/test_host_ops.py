@@ -128,3 +128,18 @@ def test_upsample_conv_parity_descriptors():
     assert torch.allclose(out, _nhwc(ref), atol=2e-5, rtol=1e-5), (out - _nhwc(ref)).abs().max()
     with pytest.raises(ValueError):
         ops.UpsampleConv2d(torch.zeros(4, 4, 5, 5), device="cpu")
+
+
+def test_post_before_activation_epilogue():
+    """MIT_ACT_POST_FIRST: relu(bn(conv) + identity) — torchvision BasicBlock's tail — in one descriptor."""
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(8, 8, 3, 3, generator=g) * 0.2
+    bn = _bn_params(8, g)
+    x = torch.randn(1, 8, 6, 5, generator=g)
+    idt = torch.randn(1, 8, 6, 5, generator=g)
+    layer = ops.Conv2d(w, None, padding=1, bn=bn, act=ops.ACT_RELU | ops.ACT_POST_FIRST, device="cpu")
+    xin, pin = _nhwc(x), _nhwc(idt)
+    out = torch.empty(1, 6, 5, 8)
+    EMU.run(layer.desc(xin, out, post=pin))
+    ref = torch.relu(F.batch_norm(F.conv2d(x, w, padding=1), bn[2], bn[3], bn[0], bn[1], False, 0.0, bn[4]) + idt)
+    assert torch.allclose(out, _nhwc(ref), atol=2e-5)

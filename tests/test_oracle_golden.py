@@ -130,3 +130,16 @@ def test_ocr_ctc_oracle_matches_reference_fixture():
     crops = [g["region"][i, :, :w] for i, w in enumerate(g["widths"])]
     idx, ws, t = next(OC.make_chunks(crops))
     assert t.shape[3] == max(ws) + 7 + 128 == g["region"].shape[2]
+
+
+def test_dbnet_oracle_matches_reference_fixture():
+    from manga_image_translator_amd import dbnet_schema, synth
+    from oracle import dbnet as OD
+
+    g = _load("dbnet.npz")
+    sd = synth.synth_state_dict(dbnet_schema.text_detection_schema(), gain=1.2)
+    db, mask = OD.det_batch_forward(sd, g["page"][None])
+    assert np.abs(db[:, :, 96:160, 96:160] - g["db_f32_crop"]).max() < 2e-5
+    assert np.abs(mask[:, :, 32:96, 32:96] - g["mask_f32_crop"]).max() < 2e-5
+    assert np.abs(db - g["db"].astype(np.float32)).max() < 1e-3 and np.abs(mask - g["mask"].astype(np.float32)).max() < 1e-3  # fp16 maps
+    assert g["db"].astype(np.float32).std() > 0.1 and g["mask"].astype(np.float32).std() > 0.1
