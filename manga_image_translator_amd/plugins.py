@@ -3,6 +3,7 @@
 Each class honours the contract of its reference counterpart:
 
   HipComicTextDetector   <- ComicTextDetector   (/root/reference/manga_translator/detection/ctd.py:60-179)
+  HipDefaultDetector     <- DefaultDetector     (detection/default.py:27-103)
   HipModel48pxOCR        <- Model48pxOCR        (ocr/model_48px.py:25-180)
   HipModel48pxCTCOCR     <- Model48pxCTCOCR     (ocr/model_48px_ctc.py:30-160)
   HipLamaMPEInpainter    <- LamaMPEInpainter    (inpainting/inpainting_lama_mpe.py:26-118)
@@ -124,6 +125,61 @@ class HipComicTextDetector(_DetBase):
         boxes, scores = boxes[keep], scores[keep]
         textlines = [_RefQuadrilateral(pts.astype(int), "", float(s)) for pts, s in zip(boxes, scores)]
         return textlines, refine_fn(image, mask, textlines, im_h, im_w), None  # resize + refine_mask (:162,177)
+
+
+class HipDefaultDetector(_DetBase):
+    """``--detector default`` (DBNet on ResNet-34) on the HIP engine."""
+    _key = "default_hip"
+    _MODEL_MAPPING: Dict = {}
+
+    def __init__(self, *args, weights: Optional[Dict[str, torch.Tensor]] = None, preprocess: Optional[Callable] = None,
+                 boxes_from_maps: Optional[Callable] = None, resize2x: Optional[Callable] = None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._weights, self._pre, self._boxes, self._resize2x = weights, preprocess, boxes_from_maps, resize2x
+        self.engine = None
+
+    async def _load(self, device: str):
+        from . import dbnet
+
+        dev = _gpu_device(device)
+        sd = self._weights
+        if sd is None:
+            ck = torch.load(_ckpt_path(self, "detect-20241225.ckpt"), map_location="cpu")
+            sd = ck["model"] if "model" in ck else ck
+        self.engine = dbnet.DbnetEngine(sd, device=dev)
+        self.device = device
+
+    async def _unload(self):
+        self.engine = None
+
+    @torch.no_grad()
+    async def _infer(self, image: np.ndarray, detect_size: int, text_threshold: float, box_threshold: float,
+                     unclip_ratio: float, verbose: bool = False):
+        """-> (textlines, raw_mask u8 [H,W], None) (default.py:56-103, the non-rearranged branch).  The OpenCV glue —
+        bilateralFilter + resize_aspect_ratio (:62), SegDetectorRepresenter (:73-77), the x2 mask resize (:89) — comes from
+        the reference package or from the injected callables; the network runs on the GPU."""
+        pre = self._pre or _reference_default_preprocess()
+        boxes_fn = self._boxes or _reference_default_boxes()
+        resize2x = self._resize2x or _reference_resize2x()
+        img_resized, target_ratio, pad_w, pad_h = pre(image, detect_size)
+        ratio = 1 / target_ratio
+        h, w = img_resized.shape[:2]
+        db, mask = self.engine.forward(torch.from_numpy(np.ascontiguousarray(img_resized)).to(self.engine.device)[None])
+        db, mask = db.cpu().numpy(), mask[0].cpu().numpy()
+        boxes, scores = boxes_fn(db, h, w, text_threshold, box_threshold, unclip_ratio)
+        if boxes.size == 0:
+            polys, scores = [], []
+        else:
+            idx = boxes.reshape(boxes.shape[0], -1).sum(axis=1) > 0
+            polys = (boxes[idx].astype(np.float64) * ratio).astype(np.int64)  # adjustResultCoordinates with ratio_net = 1 (:83)
+        textlines = [_RefQuadrilateral(pts.astype(int), "", float(s)) for pts, s in zip(polys, scores)]
+        textlines = [q for q in textlines if q.area > 16]
+        mask_resized = resize2x(mask)
+        if pad_h > 0:
+            mask_resized = mask_resized[:-pad_h, :]
+        elif pad_w > 0:
+            mask_resized = mask_resized[:, :-pad_w]
+        return textlines, np.clip(mask_resized * 255, 0, 255).astype(np.uint8), None
 
 
 class HipModel48pxOCR(_OcrBase):
@@ -426,6 +482,41 @@ def _reference_refine():
     return fn
 
 
+def _reference_default_preprocess():
+    if not HAVE_REFERENCE:
+        raise RuntimeError("the default detector's bilateral filter + resize need OpenCV; pass preprocess=")
+    import cv2  # type: ignore
+    from manga_translator.detection.default_utils import imgproc  # type: ignore
+
+    def fn(image, detect_size):
+        img, ratio, _, pad_w, pad_h = imgproc.resize_aspect_ratio(cv2.bilateralFilter(image, 17, 80, 80), detect_size,
+                                                                  cv2.INTER_LINEAR, mag_ratio=1)
+        return img, ratio, pad_w, pad_h
+
+    return fn
+
+
+def _reference_default_boxes():
+    if not HAVE_REFERENCE:
+        raise RuntimeError("box extraction needs the reference's dbnet_utils.SegDetectorRepresenter; pass boxes_from_maps=")
+    from manga_translator.detection.default_utils import dbnet_utils  # type: ignore
+
+    def fn(db, h, w, text_threshold, box_threshold, unclip_ratio):
+        det = dbnet_utils.SegDetectorRepresenter(text_threshold, box_threshold, unclip_ratio=unclip_ratio)
+        boxes, scores = det({"shape": [(h, w)]}, db)
+        return boxes[0], scores[0]
+
+    return fn
+
+
+def _reference_resize2x():
+    if not HAVE_REFERENCE:
+        raise RuntimeError("the x2 mask resize needs OpenCV; pass resize2x=")
+    import cv2  # type: ignore
+
+    return lambda m: cv2.resize(m, (m.shape[1] * 2, m.shape[0] * 2), interpolation=cv2.INTER_LINEAR)
+
+
 def _reference_resize():
     if not HAVE_REFERENCE:
         raise RuntimeError("pages that need resizing (max side > inpainting_size or not a multiple of 8) need OpenCV; pass resize=")
@@ -485,6 +576,7 @@ def register() -> None:
     from manga_translator.ocr import OCRS  # type: ignore
 
     DETECTORS["ctd_hip"] = HipComicTextDetector
+    DETECTORS["default_hip"] = HipDefaultDetector
     OCRS["48px_hip"] = HipModel48pxOCR
     OCRS["48px_ctc_hip"] = HipModel48pxCTCOCR
     INPAINTERS["lama_mpe_hip"] = HipLamaMPEInpainter

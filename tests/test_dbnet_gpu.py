@@ -35,3 +35,35 @@ def test_dbnet_rejects_bad_input(cuda):
     eng = dbnet.DbnetEngine(synth.synth_state_dict(dbnet_schema.text_detection_schema(), gain=1.2), device=cuda)
     with pytest.raises(ValueError):
         eng.forward(torch.zeros(1, 200, 256, 3, dtype=torch.uint8, device=cuda))
+
+
+def test_default_detector_plugin(cuda):
+    import asyncio
+
+    from manga_image_translator_amd import dbnet_schema, plugins as P, synth
+    from oracle import dbnet as OD
+
+    run = lambda c: asyncio.new_event_loop().run_until_complete(c)
+    sd = synth.synth_state_dict(dbnet_schema.text_detection_schema(), gain=1.2)
+    page = synth.synth_page(8, 256, 200, n_boxes=3)[0]
+    seen = {}
+
+    def pre(image, detect_size):  # stands in for bilateralFilter + resize_aspect_ratio: pad 200 -> 256 columns
+        canvas = np.zeros((256, 256, 3), np.uint8)
+        canvas[:, :200] = image
+        return canvas, 1.0, 56, 0
+
+    def boxes(db, h, w, tt, bt, ur):
+        seen["db"] = db
+        return np.array([[[10, 10], [90, 10], [90, 40], [10, 40]]]), np.array([0.8])
+
+    det = P.HipDefaultDetector(weights=sd, preprocess=pre, boxes_from_maps=boxes, resize2x=lambda m: np.repeat(np.repeat(m, 2, 0), 2, 1))
+    run(det.load("cuda"))
+    tls, raw_mask, extra = run(det.infer(page, 256, 0.5, 0.7, 2.3))
+    assert extra is None and len(tls) == 1 and raw_mask.dtype == np.uint8 and raw_mask.shape == (256, 200)
+    canvas, *_ = pre(page, 256)
+    rdb, rmask = OD.det_batch_forward(sd, canvas[None])
+    assert np.abs(seen["db"] - rdb).max() < 2e-4
+    ref_mask = np.clip(np.repeat(np.repeat(rmask[0, 0], 2, 0), 2, 1)[:, :-56] * 255, 0, 255).astype(np.uint8)
+    assert np.abs(raw_mask.astype(int) - ref_mask.astype(int)).max() <= 1
+    run(det.unload())

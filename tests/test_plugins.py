@@ -12,7 +12,7 @@ def run(coro):
     return asyncio.new_event_loop().run_until_complete(coro)
 
 
-@pytest.mark.parametrize("cls", [P.HipComicTextDetector, P.HipModel48pxOCR, P.HipModel48pxCTCOCR, P.HipLamaMPEInpainter, P.HipLamaLargeInpainter,
+@pytest.mark.parametrize("cls", [P.HipComicTextDetector, P.HipDefaultDetector, P.HipModel48pxOCR, P.HipModel48pxCTCOCR, P.HipLamaMPEInpainter, P.HipLamaLargeInpainter,
                                  P.HipESRGANUpscaler])
 def test_lifecycle_and_device_errors(cls):
     p = cls()                                   # constructed with no arguments, touches no GPU
