@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--lama-mb", type=int, default=8)
     ap.add_argument("--ctd-mb", type=int, default=8)
     ap.add_argument("--group", type=int, default=8)
+    ap.add_argument("--overlap", action="store_true", help="two streams: detector + OCR beside LaMa (+8 %% pages/s; per-kernel roofline numbers then include the stretch of concurrent kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--probe-pages", type=int, default=0, help="pages in the instrumented pass (0 = a whole step)")
@@ -162,7 +163,8 @@ def main():
     L.load(build_if_missing=False)
     weights = pipeline.synthetic_weights() if rank == 0 else None
     weights = D.broadcast_weights(weights)          # RCCL broadcast of one flat arena at load
-    engine = pipeline.PageEngine(weights, device=device, ctd_mb=args.ctd_mb, lama_mb=args.lama_mb, group=args.group)
+    engine = pipeline.PageEngine(weights, device=device, ctd_mb=args.ctd_mb, lama_mb=args.lama_mb, group=args.group,
+                                 overlap=args.overlap)
     pages, quads, masks, host_inputs = make_inputs(args.pages, args.distinct, rank, device)
 
     gather_state = {"on": world > 1, "note": None}
@@ -207,6 +209,7 @@ def main():
                                    "random-init weights of the reference architectures",
                        "pages_per_gpu": args.pages, "distinct_pages": min(args.distinct, args.pages), "stages": list(stages),
                        "microbatch": {"ctd": args.ctd_mb, "lama": args.lama_mb, "ocr_group": args.group},
+                       "streams": 2 if args.overlap else 1,
                        "parallelism": f"pages sharded one block per GPU x{world}; RCCL weight broadcast + result gather"},
             "roofline": roof, "cpu_baseline": cpu, "conv_gemm_by_tile": per_cfg,
         }

@@ -6,8 +6,8 @@ inpainting/inpainting_lama_mpe.py:56-118, driven by manga_translator.py:1491-151
 device-resident uint8 tensors and host-side ``Quadrilateral`` lists; only uint8 maps, token ids and a few floats per line
 leave the device.
 
-Everything is enqueued on the current HIP stream without intermediate synchronisation; OCR lines of the whole batch are
-decoded in one pooled beam search.
+Nothing synchronises with the host; OCR lines of the whole batch are decoded in one pooled beam search.  Optionally
+(``overlap=True``) LaMa runs on the caller's stream and detector + OCR on a side stream that joins at the end.
 """
 from __future__ import annotations
 
@@ -64,12 +64,13 @@ class PageEngine:
     """Owns the three stage engines of one GPU."""
 
     def __init__(self, weights: Dict[str, Dict[str, torch.Tensor]], device="cuda", lama_blocks: int = 9,
-                 dict_size: int = DICT_SIZE, ctd_mb: int = 8, lama_mb: int = 8, group: int = 8):
+                 dict_size: int = DICT_SIZE, ctd_mb: int = 8, lama_mb: int = 8, group: int = 8, overlap: bool = False):
         self.device = torch.device(device)
         self.ctd = ctd.CtdEngine(weights["ctd.yolo"], weights["ctd.seg"], weights["ctd.det"], device=self.device)
         self.ocr = ocr48.Ocr48Engine(weights["ocr48"], dict_size, device=self.device)
         self.lama = lama.LamaEngine(weights["lama.gen"], weights.get("lama.mpe"), n_blocks=lama_blocks, device=self.device)
         self.ctd_mb, self.lama_mb, self.group = ctd_mb, lama_mb, group
+        self.overlap, self._side = overlap, None
 
     @torch.no_grad()
     def run(self, pages_u8: torch.Tensor, quads_per_page: Sequence[Sequence[Quadrilateral]], masks_u8: torch.Tensor,
@@ -86,34 +87,55 @@ class PageEngine:
         det_mask = torch.zeros(B, S - dh, S - dw, dtype=torch.uint8, device=dev)
         det_shrink = torch.zeros(B, S - dh, S - dw, dtype=torch.uint8, device=dev)
         inpainted = torch.empty(B, H, W, 3, dtype=torch.uint8, device=dev) if "inpaint" in stages else pages_u8
+        # overlap=True: two HIP streams — LaMa (long MFMA kernels with quantised tails) on the caller's stream, detector + OCR
+        # (many short kernels) on a side stream, so the short kernels fill the CUs the big launches leave idle (+8 % pages/s
+        # measured).  The stages share no buffers (separate engines / workspaces; pages and masks are read-only), so no
+        # ordering is needed until the join.  Off by default: concurrent kernels stretch each other's durations, which makes
+        # per-kernel roofline numbers meaningless (bench.py --overlap turns it on).
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap and "inpaint" in stages and len(stages) > 1 else main
+        side.wait_stream(main)
         ocr_plan = None
-        if "ocr" in stages:  # host planning for every page up front (vectorised, ~1.5 ms per page), one table upload
-            ocr_plan = self.ocr.upload_plan(self.ocr.plan_pages(quads_per_page, H, W))
-            if len(ocr_plan["order"]) == 0:
-                ocr_plan = None
-            else:
-                mem_k, mem_v = self.ocr.alloc_memory(len(ocr_plan["order"]), ocr_plan["Lmax"])
+        with torch.cuda.stream(side):
+            if "ocr" in stages:  # host planning for every page up front (vectorised, ~1.5 ms per page), one table upload
+                ocr_plan = self.ocr.upload_plan(self.ocr.plan_pages(quads_per_page, H, W))
+                if len(ocr_plan["order"]) == 0:
+                    ocr_plan = None
+                else:
+                    mem_k, mem_v = self.ocr.alloc_memory(len(ocr_plan["order"]), ocr_plan["Lmax"])
+        r = None
         for g0 in range(0, B, self.group):
             g1 = min(B, g0 + self.group)
             if "inpaint" in stages:
                 for i in range(g0, g1, self.lama_mb):
                     j = min(g1, i + self.lama_mb)
                     inpainted[i:j].copy_(self.lama.forward(pages_u8[i:j], masks_u8[i:j]))
-            if "detect" in stages:
-                for i in range(g0, g1, self.ctd_mb):
-                    j = min(g1, i + self.ctd_mb)
-                    m, lines, _ = self.ctd.forward(pages_u8[i:j])
-                    det_mask[i:j].copy_(m)
-                    det_shrink[i:j].copy_(self.ctd.shrink_bitmap(lines))
-            if ocr_plan is not None:  # backbone + encoder of this group's chunks; their K/V land in the pooled memory
-                ids = [i for i, c in enumerate(ocr_plan["chunks"]) if g0 <= c[4] < g1]
-                self.ocr.encode_planned(pages_u8, ocr_plan, ids, mem_k, mem_v)
-        if ocr_plan is None:
+            with torch.cuda.stream(side):
+                if "detect" in stages:
+                    for i in range(g0, g1, self.ctd_mb):
+                        j = min(g1, i + self.ctd_mb)
+                        m, lines, _ = self.ctd.forward(pages_u8[i:j])
+                        det_mask[i:j].copy_(m)
+                        det_shrink[i:j].copy_(self.ctd.shrink_bitmap(lines))
+                if ocr_plan is not None:  # backbone + encoder of this group's chunks; their K/V land in the pooled memory
+                    ids = [i for i, c in enumerate(ocr_plan["chunks"]) if g0 <= c[4] < g1]
+                    self.ocr.encode_planned(pages_u8, ocr_plan, ids, mem_k, mem_v)
+        if ocr_plan is not None:
+            with torch.cuda.stream(side):
+                # one beam search over the lines of the whole batch: decode GEMMs see 5 x n_lines rows instead of 5 x 16
+                r = self.ocr.decode(mem_k, mem_v, ocr_plan["klen_dev"], max_seq_length, suppress_eos)
+        main.wait_stream(side)
+        if r is None:
             return PageBatchResult(det_mask, det_shrink, None, None, None, None, [], inpainted, [])
-        # one beam search over the lines of the whole batch: decode GEMMs see 5 x n_lines rows instead of 5 x 16
-        r = self.ocr.decode(mem_k, mem_v, ocr_plan["klen_dev"], max_seq_length, suppress_eos)
+        for t in (r["tokens"], r["length"], r["prob"], r["colors"]):
+            t.record_stream(main)  # allocated on the side stream, consumed by the caller on the main one
         return PageBatchResult(det_mask, det_shrink, r["tokens"], r["length"], r["prob"], r["colors"], ocr_plan["order"], inpainted,
-                               ocr_plan["_keep"])
+                               ocr_plan["_keep"] + [mem_k, mem_v])
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def flops_per_page(self, H: int, W: int, line_widths: Sequence[int], steps: int) -> Dict[str, float]:
         """Algorithmic FLOPs of one page (SURVEY.md §8d conventions), per stage."""
