@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pages generated per rank (cycled)")
     ap.add_argument("--stages", default="detect,ocr,inpaint")
     ap.add_argument("--lama-mb", type=int, default=8)
-    ap.add_argument("--ctd-mb", type=int, default=8)
-    ap.add_argument("--group", type=int, default=8)
+    ap.add_argument("--ctd-mb", type=int, default=16)
+    ap.add_argument("--group", type=int, default=16)
     ap.add_argument("--overlap", action="store_true", help="two streams: detector + OCR beside LaMa (+8 %% pages/s; per-kernel roofline numbers then include the stretch of concurrent kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

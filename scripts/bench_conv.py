@@ -24,6 +24,8 @@ SHAPES = [
     ("ocr grp pw2 320->80 (1.2M rows)", 320, 80, 1200, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr grp pw2 1280->320 (150k rows)", 1280, 320, 150, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr grp pw2 640->160 (300k rows)", 640, 160, 300, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
+    ("ocr grp pw1 160->640 (722k rows)", 160, 640, 705, 1024, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
+    ("ocr grp pw2 640->160 (722k rows)", 640, 160, 705, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr pw1 320->1280 (16x6x128)", 320, 1280, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
     ("ocr pw2 1280->320 (16x6x128)", 1280, 320, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr pw1 160->640 (16x12x128)", 160, 640, 192, 128, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
@@ -33,13 +35,14 @@ SHAPES = [
 ]
 only = os.environ.get("ONLY")
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
+ACT = {"relu": ops.ACT_RELU, "gelu": ops.ACT_GELU, "none": ops.ACT_NONE, "silu": ops.ACT_SILU}[os.environ.get("ACT", "relu")]
 res = []
 L = lib.load()
 for name, Cin, Cout, H, W, k, s, p, mode, b, cfgs in SHAPES:
     if only and only not in name:
         continue
     w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
-    layer = ops.Conv2d(w, None, stride=s, padding=p, pad_mode=mode, act=ops.ACT_RELU, device=dev)
+    layer = ops.Conv2d(w, None, stride=s, padding=p, pad_mode=mode, act=ACT, device=dev)
     x = torch.randn(b, H, W, layer.Cin, device=dev)
     Ho, Wo = layer.out_hw(H, W)
     flops = 2.0 * b * Ho * Wo * Cout * Cin * k * k
