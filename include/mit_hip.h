@@ -208,6 +208,21 @@ int mit_map_to_u8(const float *in_dev, uint8_t *out_dev, int64_t n, int mode, fl
 /* out = a * x + y over n floats (n % 4 == 0): RRDB.forward's ``out * 0.2 + x`` (upscaling/esrgan_pytorch.py:112). */
 int mit_axpy(float *out_dev, float a, const float *x_dev, const float *y_dev, int64_t n, void *stream);
 
+/* Host-side (CPU) detector post-processing: thresholded bitmap -> contours -> min-area boxes -> score -> unclip -> boxes.
+ * pred: f32 [H,W] probability map (host), bitmap: u8 [H,W] (pred > thresh, host).  Every contour (outer and hole borders,
+ * last-found first, at most max_candidates) yields one slot of boxes_out [n,4,2] (int64 x,y scaled to dest_w x dest_h,
+ * rounded, clipped; corner order tl,tr,br,bl, or starting at the smallest x+y when roll_start) and scores_out [n]; skipped
+ * contours leave zeros (the callers filter on score / non-zero boxes like the reference).  Replaces
+ * SegDetectorRepresenter.boxes_from_bitmap of ctd_utils/utils/db_utils.py:127-171 (min_sside 2, box_thresh 0,
+ * min_sside_out 0, roll_start 0, unclip 1.5) and default_utils/dbnet_utils.py:97-144 (min_sside 3, box_thresh, min_sside_out 5,
+ * roll_start 1), i.e. cv2.findContours/minAreaRect/boxPoints/fillPoly/mean + pyclipper JT_ROUND offset + shapely area/length.
+ * boxes_out / scores_out must hold max_candidates slots. */
+int mit_boxes_from_bitmap(const float *pred, const uint8_t *bitmap, int H, int W, int dest_w, int dest_h, int max_candidates,
+                          float unclip_ratio, float min_sside, float box_thresh, float min_sside_out, int roll_start,
+                          int64_t *boxes_out, float *scores_out, int *n_out);
+/* Number of contours / border points cv2.findContours(RETR_LIST) would trace in a 0/1 bitmap (diagnostics, tests). */
+int mit_find_contours_count(const uint8_t *bitmap, int H, int W, int *n_contours, int64_t *n_points);
+
 /* 48px OCR stage -----------------------------------------------------------------------------
  * Reference: manga_translator/ocr/model_48px.py, ocr/xpos_relative_position.py. */
 

@@ -1,0 +1,392 @@
+// hostglue.hip — host-side (CPU, no kernels) geometry the detectors need between the dense network and the text lines:
+// threshold bitmap -> contours -> min-area rectangles -> score -> "unclip" (polygon offset) -> boxes.
+//
+// Native restatement of what the reference does through OpenCV + pyclipper + shapely in
+//   SegDetectorRepresenter.boxes_from_bitmap / get_mini_boxes / box_score_fast / unclip
+//   (manga_translator/detection/ctd_utils/utils/db_utils.py:127-216 and default_utils/dbnet_utils.py:97-190).
+// None of those libraries is available where this repo is built or tested, so each primitive follows the published
+// algorithm of the library routine the reference calls (PARITY UNPINNED against the real libraries):
+//   cv2.findContours(RETR_LIST, CHAIN_APPROX_SIMPLE)  Suzuki-Abe border following (outer + hole borders); contours are
+//                                                     returned last-found-first like OpenCV's list mode; all border
+//                                                     points are kept (CHAIN_APPROX_SIMPLE only drops collinear points,
+//                                                     which changes neither the hull, the filled region nor min/max)
+//   cv2.minAreaRect + cv2.boxPoints                   convex hull + rotating calipers over hull edges
+//   cv2.fillPoly + cv2.mean(mask)                     even-odd scanline fill at pixel centres + the outline pixels
+//   pyclipper offset, JT_ROUND, ET_CLOSEDPOLYGON      ClipperOffset::DoOffset / OffsetPoint / DoRound (arc tolerance 0.25),
+//                                                     integer coordinates (pyclipper truncates the float box)
+//   shapely Polygon.area / .length                    shoelace area, perimeter
+// It lives in the C-ABI library so the plugins need no Python-level OpenCV stand-in on the per-page path.
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../../include/mit_hip.h"
+#include "common.h"
+
+namespace {
+
+struct Pt { int x, y; };
+struct Pd { double x, y; };
+
+// ---- Suzuki-Abe border following on a 0/1 image with a one-pixel zero frame ----
+void find_contours(const uint8_t *bitmap, int H, int W, std::vector<std::vector<Pt>> &out) {
+    const int Wp = W + 2, Hp = H + 2;
+    std::vector<int> f((size_t)Wp * Hp, 0);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) f[(size_t)(y + 1) * Wp + x + 1] = bitmap[(size_t)y * W + x] ? 1 : 0;
+    // 8-neighbourhood in clockwise order starting east (image coordinates, y down): E, SE, S, SW, W, NW, N, NE
+    static const int dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    static const int dy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    auto dir_of = [&](int fx, int fy, int tx, int ty) {
+        for (int d = 0; d < 8; ++d)
+            if (fx + dx[d] == tx && fy + dy[d] == ty) return d;
+        return -1;
+    };
+    int nbd = 1;
+    for (int i = 1; i <= H; ++i) {
+        for (int j = 1; j <= W; ++j) {
+            const int v = f[(size_t)i * Wp + j];
+            if (v == 0) continue;
+            int i2, j2;
+            if (v == 1 && f[(size_t)i * Wp + j - 1] == 0) {  // outer border start
+                i2 = i;
+                j2 = j - 1;
+            } else if (v >= 1 && f[(size_t)i * Wp + j + 1] == 0) {  // hole border start
+                i2 = i;
+                j2 = j + 1;
+            } else {
+                continue;
+            }
+            ++nbd;
+            std::vector<Pt> contour;
+            // (3.1) clockwise search around (i, j) starting from (i2, j2)
+            int start = dir_of(j, i, j2, i2);
+            int found = -1;
+            for (int s = 0; s < 8; ++s) {
+                const int d = (start + s) & 7;
+                if (f[(size_t)(i + dy[d]) * Wp + j + dx[d]] != 0) {
+                    found = d;
+                    break;
+                }
+            }
+            if (found < 0) {  // isolated pixel
+                f[(size_t)i * Wp + j] = -nbd;
+                contour.push_back({j - 1, i - 1});
+                out.push_back(contour);
+                continue;
+            }
+            const int i1 = i + dy[found], j1 = j + dx[found];
+            int pi = i1, pj = j1;  // (i2, j2) := (i1, j1)
+            int ci = i, cj = j;    // (i3, j3) := (i, j)
+            for (;;) {
+                // (3.3) counter-clockwise search around (ci, cj) starting after (pi, pj)
+                const int from = dir_of(cj, ci, pj, pi);
+                int nd = -1;
+                bool east_zero_examined = false;
+                for (int s = 1; s <= 8; ++s) {
+                    const int d = (from - s + 16) & 7;  // counter-clockwise = decreasing index in the clockwise table
+                    if (f[(size_t)(ci + dy[d]) * Wp + cj + dx[d]] != 0) {
+                        nd = d;
+                        break;
+                    }
+                    if (d == 0) east_zero_examined = true;  // pixel (ci, cj + 1) was examined and is 0
+                }
+                contour.push_back({cj - 1, ci - 1});
+                // (3.4)
+                int &cur = f[(size_t)ci * Wp + cj];
+                if (east_zero_examined) cur = -nbd;
+                else if (cur == 1) cur = nbd;
+                const int ni = ci + dy[nd], nj = cj + dx[nd];
+                // (3.5)
+                if (ni == i && nj == j && ci == i1 && cj == j1) break;
+                pi = ci;
+                pj = cj;
+                ci = ni;
+                cj = nj;
+            }
+            out.push_back(contour);
+        }
+    }
+    std::reverse(out.begin(), out.end());  // OpenCV's list mode hands back the last-found contour first
+}
+
+// ---- convex hull (monotone chain) ----
+double cross(const Pd &o, const Pd &a, const Pd &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); }
+
+std::vector<Pd> convex_hull(std::vector<Pd> p) {
+    std::sort(p.begin(), p.end(), [](const Pd &a, const Pd &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+    p.erase(std::unique(p.begin(), p.end(), [](const Pd &a, const Pd &b) { return a.x == b.x && a.y == b.y; }), p.end());
+    const int n = (int)p.size();
+    if (n < 3) return p;
+    std::vector<Pd> h(2 * n);
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        while (k >= 2 && cross(h[k - 2], h[k - 1], p[i]) <= 0) --k;
+        h[k++] = p[i];
+    }
+    for (int i = n - 2, t = k + 1; i >= 0; --i) {
+        while (k >= t && cross(h[k - 2], h[k - 1], p[i]) <= 0) --k;
+        h[k++] = p[i];
+    }
+    h.resize(k - 1);
+    return h;
+}
+
+// ---- minAreaRect + boxPoints: 4 corners (float32 like cv2.boxPoints) and the short side ----
+void min_area_rect(const std::vector<Pd> &pts, float box[4][2], float *sside) {
+    std::vector<Pd> h = convex_hull(pts);
+    const int n = (int)h.size();
+    if (n == 0) {
+        memset(box, 0, sizeof(float) * 8);
+        *sside = 0;
+        return;
+    }
+    if (n == 1) {
+        for (int i = 0; i < 4; ++i) box[i][0] = (float)h[0].x, box[i][1] = (float)h[0].y;
+        *sside = 0;
+        return;
+    }
+    double best = -1, bux = 1, buy = 0, bmin_u = 0, bmax_u = 0, bmin_v = 0, bmax_v = 0;
+    const int edges = n == 2 ? 1 : n;
+    for (int e = 0; e < edges; ++e) {
+        const Pd &a = h[e], &b = h[(e + 1) % n];
+        double ux = b.x - a.x, uy = b.y - a.y;
+        const double len = sqrt(ux * ux + uy * uy);
+        if (len == 0) continue;
+        ux /= len;
+        uy /= len;
+        double mnu = 1e300, mxu = -1e300, mnv = 1e300, mxv = -1e300;
+        for (const Pd &q : h) {
+            const double u = q.x * ux + q.y * uy, v = -q.x * uy + q.y * ux;
+            mnu = std::min(mnu, u);
+            mxu = std::max(mxu, u);
+            mnv = std::min(mnv, v);
+            mxv = std::max(mxv, v);
+        }
+        const double area = (mxu - mnu) * (mxv - mnv);
+        if (best < 0 || area < best) {
+            best = area;
+            bux = ux;
+            buy = uy;
+            bmin_u = mnu, bmax_u = mxu, bmin_v = mnv, bmax_v = mxv;
+        }
+    }
+    const double us[4] = {bmin_u, bmax_u, bmax_u, bmin_u}, vs[4] = {bmin_v, bmin_v, bmax_v, bmax_v};
+    for (int i = 0; i < 4; ++i) {
+        box[i][0] = (float)(us[i] * bux - vs[i] * buy);
+        box[i][1] = (float)(us[i] * buy + vs[i] * bux);
+    }
+    *sside = (float)std::min(bmax_u - bmin_u, bmax_v - bmin_v);
+}
+
+// get_mini_boxes' point order (db_utils.py:175-196): sort by x, then [tl, tr, br, bl]
+void mini_box_order(float box[4][2]) {
+    int idx[4] = {0, 1, 2, 3};
+    std::stable_sort(idx, idx + 4, [&](int a, int b) { return box[a][0] < box[b][0]; });
+    float p[4][2];
+    for (int i = 0; i < 4; ++i) p[i][0] = box[idx[i]][0], p[i][1] = box[idx[i]][1];
+    int i1, i4, i2, i3;
+    if (p[1][1] > p[0][1]) i1 = 0, i4 = 1; else i1 = 1, i4 = 0;
+    if (p[3][1] > p[2][1]) i2 = 2, i3 = 3; else i2 = 3, i3 = 2;
+    const int order[4] = {i1, i2, i3, i4};
+    float r[4][2];
+    for (int i = 0; i < 4; ++i) r[i][0] = p[order[i]][0], r[i][1] = p[order[i]][1];
+    memcpy(box, r, sizeof(r));
+}
+
+// ---- box_score_fast: mean of pred over fillPoly(contour) (outline pixels + even-odd interior) ----
+double polygon_mean(const float *pred, int H, int W, const std::vector<Pt> &poly) {
+    int xmin = INT32_MAX, xmax = INT32_MIN, ymin = INT32_MAX, ymax = INT32_MIN;
+    for (const Pt &p : poly) {
+        xmin = std::min(xmin, p.x), xmax = std::max(xmax, p.x);
+        ymin = std::min(ymin, p.y), ymax = std::max(ymax, p.y);
+    }
+    xmin = std::max(0, std::min(xmin, W - 1)), xmax = std::max(0, std::min(xmax, W - 1));
+    ymin = std::max(0, std::min(ymin, H - 1)), ymax = std::max(0, std::min(ymax, H - 1));
+    const int mw = xmax - xmin + 1, mh = ymax - ymin + 1;
+    std::vector<uint8_t> mask((size_t)mw * mh, 0);
+    const int n = (int)poly.size();
+    auto set = [&](int x, int y) {
+        x -= xmin, y -= ymin;
+        if (x >= 0 && x < mw && y >= 0 && y < mh) mask[(size_t)y * mw + x] = 1;
+    };
+    // outline: straight pixel runs between consecutive vertices (contour steps are 8-connected unit moves or their runs)
+    for (int i = 0; i < n; ++i) {
+        Pt a = poly[i], b = poly[(i + 1) % n];
+        int sx = (b.x > a.x) - (b.x < a.x), sy = (b.y > a.y) - (b.y < a.y);
+        int adx = abs(b.x - a.x), ady = abs(b.y - a.y);
+        if (adx == ady || adx == 0 || ady == 0) {
+            int steps = std::max(adx, ady);
+            for (int s = 0; s <= steps; ++s) set(a.x + s * sx, a.y + s * sy);
+        } else {  // general segment (offset polygons are never scored, but keep the routine total): Bresenham
+            int x = a.x, y = a.y, err = adx - ady;
+            for (;;) {
+                set(x, y);
+                if (x == b.x && y == b.y) break;
+                const int e2 = 2 * err;
+                if (e2 > -ady) err -= ady, x += sx;
+                if (e2 < adx) err += adx, y += sy;
+            }
+        }
+    }
+    // interior: even-odd rule sampled at pixel centres
+    std::vector<double> xs;
+    for (int y = ymin; y <= ymax; ++y) {
+        xs.clear();
+        const double yc = y;
+        for (int i = 0; i < n; ++i) {
+            const Pt a = poly[i], b = poly[(i + 1) % n];
+            if ((a.y <= yc && b.y > yc) || (b.y <= yc && a.y > yc)) xs.push_back(a.x + (yc - a.y) * (double)(b.x - a.x) / (double)(b.y - a.y));
+        }
+        std::sort(xs.begin(), xs.end());
+        for (size_t k = 0; k + 1 < xs.size(); k += 2)
+            for (int x = (int)ceil(xs[k]); x <= (int)floor(xs[k + 1]); ++x) set(x, y);
+    }
+    double sum = 0;
+    int64_t cnt = 0;
+    for (int y = 0; y < mh; ++y)
+        for (int x = 0; x < mw; ++x)
+            if (mask[(size_t)y * mw + x]) sum += pred[(size_t)(y + ymin) * W + x + xmin], ++cnt;
+    return cnt ? sum / (double)cnt : 0.0;
+}
+
+// ---- pyclipper offset of a closed polygon, JT_ROUND (ClipperOffset::DoOffset / OffsetPoint / DoRound) ----
+int64_t cround(double v) { return (int64_t)(v < 0 ? v - 0.5 : v + 0.5); }
+
+void clipper_offset_round(const float box[4][2], double delta, std::vector<Pd> &out) {
+    struct IP { int64_t x, y; };
+    std::vector<IP> path;
+    for (int i = 0; i < 4; ++i) {
+        IP p = {(int64_t)box[i][0], (int64_t)box[i][1]};  // pyclipper truncates float coordinates to integers
+        if (path.empty() || path.back().x != p.x || path.back().y != p.y) path.push_back(p);
+    }
+    while (path.size() > 1 && path.front().x == path.back().x && path.front().y == path.back().y) path.pop_back();
+    const int n = (int)path.size();
+    out.clear();
+    if (n < 3 || delta <= 0) return;
+    double area = 0;
+    for (int i = 0; i < n; ++i) {
+        const IP &a = path[i], &b = path[(i + 1) % n];
+        area += (double)a.x * b.y - (double)b.x * a.y;
+    }
+    if (area < 0) std::reverse(path.begin(), path.end());  // FixOrientations
+    const double two_pi = 6.283185307179586476925286766559, pi = 3.141592653589793238;
+    const double def_arc_tolerance = 0.25;
+    double y = def_arc_tolerance;  // ArcTolerance = 0.25 (pyclipper default)
+    if (y > fabs(delta) * def_arc_tolerance) y = fabs(delta) * def_arc_tolerance;
+    double steps = pi / acos(1 - y / fabs(delta));
+    if (steps > fabs(delta) * pi) steps = fabs(delta) * pi;
+    const double m_sin = sin(two_pi / steps), m_cos = cos(two_pi / steps), steps_per_rad = steps / two_pi;
+    std::vector<Pd> normals(n);
+    for (int i = 0; i < n; ++i) {
+        const IP &a = path[i], &b = path[(i + 1) % n];
+        double ddx = (double)(b.x - a.x), ddy = (double)(b.y - a.y);
+        const double f = 1.0 / sqrt(ddx * ddx + ddy * ddy);
+        normals[i] = {ddy * f, -ddx * f};
+    }
+    int k = n - 1;
+    for (int j = 0; j < n; ++j) {
+        double sinA = normals[k].x * normals[j].y - normals[j].x * normals[k].y;
+        const IP &pt = path[j];
+        auto add = [&](double nx, double ny) { out.push_back({(double)cround(pt.x + nx * delta), (double)cround(pt.y + ny * delta)}); };
+        if (fabs(sinA * delta) < 1.0) {
+            const double cosA = normals[k].x * normals[j].x + normals[j].y * normals[k].y;
+            if (cosA > 0) {
+                add(normals[k].x, normals[k].y);
+                k = j;
+                continue;
+            }
+        } else if (sinA > 1.0) sinA = 1.0;
+        else if (sinA < -1.0) sinA = -1.0;
+        if (sinA * delta < 0) {
+            add(normals[k].x, normals[k].y);
+            out.push_back({(double)pt.x, (double)pt.y});
+            add(normals[j].x, normals[j].y);
+        } else {  // DoRound
+            const double a = atan2(sinA, normals[k].x * normals[j].x + normals[k].y * normals[j].y);
+            const int st = std::max((int)cround(steps_per_rad * fabs(a)), 1);
+            double X = normals[k].x, Y = normals[k].y, X2;
+            for (int i = 0; i < st; ++i) {
+                add(X, Y);
+                X2 = X;
+                X = X * m_cos - m_sin * Y;
+                Y = X2 * m_sin + Y * m_cos;
+            }
+            add(normals[j].x, normals[j].y);
+        }
+        k = j;
+    }
+}
+
+}  // namespace
+
+extern "C" int mit_boxes_from_bitmap(const float *pred, const uint8_t *bitmap, int H, int W, int dest_w, int dest_h, int max_candidates,
+                                     float unclip_ratio, float min_sside, float box_thresh, float min_sside_out, int roll_start,
+                                     int64_t *boxes_out, float *scores_out, int *n_out) {
+    if (!pred || !bitmap || !boxes_out || !scores_out || !n_out) return mit_set_error("mit_boxes_from_bitmap: null pointer");
+    if (H <= 0 || W <= 0 || max_candidates <= 0) return mit_set_error("mit_boxes_from_bitmap: bad size");
+    std::vector<std::vector<Pt>> contours;
+    find_contours(bitmap, H, W, contours);
+    const int n = (int)std::min<size_t>(contours.size(), (size_t)max_candidates);
+    memset(boxes_out, 0, sizeof(int64_t) * 8 * (size_t)n);
+    memset(scores_out, 0, sizeof(float) * (size_t)n);
+    for (int idx = 0; idx < n; ++idx) {
+        const std::vector<Pt> &c = contours[idx];
+        std::vector<Pd> pts(c.size());
+        for (size_t i = 0; i < c.size(); ++i) pts[i] = {(double)c[i].x, (double)c[i].y};
+        float box[4][2], sside;
+        min_area_rect(pts, box, &sside);
+        mini_box_order(box);
+        if (sside < min_sside) continue;
+        const double score = polygon_mean(pred, H, W, c);
+        if (box_thresh > score) continue;
+        // unclip: shapely area / length of the float box, Clipper round offset, min-area rectangle of the result
+        double area = 0, length = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int j = (i + 1) & 3;
+            area += (double)box[i][0] * box[j][1] - (double)box[j][0] * box[i][1];
+            length += hypot((double)box[j][0] - box[i][0], (double)box[j][1] - box[i][1]);
+        }
+        area = fabs(area) * 0.5;
+        if (length <= 0) continue;
+        std::vector<Pd> expanded;
+        clipper_offset_round(box, area * unclip_ratio / length, expanded);
+        if (expanded.empty()) continue;
+        float ebox[4][2], esside;
+        min_area_rect(expanded, ebox, &esside);
+        mini_box_order(ebox);
+        if (esside < min_sside_out) continue;
+        int64_t q[4][2];
+        for (int i = 0; i < 4; ++i) {
+            const float fx = nearbyintf(ebox[i][0] / (float)W * (float)dest_w), fy = nearbyintf(ebox[i][1] / (float)H * (float)dest_h);
+            q[i][0] = (int64_t)std::min(std::max(fx, 0.f), (float)dest_w);
+            q[i][1] = (int64_t)std::min(std::max(fy, 0.f), (float)dest_h);
+        }
+        int start = 0;
+        if (roll_start) {  // dbnet_utils.py:139-140: start from the corner with the smallest x + y
+            int64_t best = q[0][0] + q[0][1];
+            for (int i = 1; i < 4; ++i)
+                if (q[i][0] + q[i][1] < best) best = q[i][0] + q[i][1], start = i;
+        }
+        for (int i = 0; i < 4; ++i) {
+            boxes_out[(size_t)idx * 8 + 2 * i] = q[(start + i) & 3][0];
+            boxes_out[(size_t)idx * 8 + 2 * i + 1] = q[(start + i) & 3][1];
+        }
+        scores_out[idx] = (float)score;
+    }
+    *n_out = n;
+    return 0;
+}
+
+extern "C" int mit_find_contours_count(const uint8_t *bitmap, int H, int W, int *n_contours, int64_t *n_points) {
+    if (!bitmap || !n_contours || !n_points) return mit_set_error("mit_find_contours_count: null pointer");
+    std::vector<std::vector<Pt>> contours;
+    find_contours(bitmap, H, W, contours);
+    *n_contours = (int)contours.size();
+    int64_t np = 0;
+    for (auto &c : contours) np += (int64_t)c.size();
+    *n_points = np;
+    return 0;
+}

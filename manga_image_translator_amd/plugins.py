@@ -15,8 +15,9 @@ raises), same ``_infer`` signatures, argument meaning and return types, errors a
 reference package is importable the classes derive from its ``OfflineDetector`` / ``OfflineOCR`` /
 ``OfflineInpainter`` and ``register()`` adds them to ``DETECTORS`` / ``OCRS`` / ``INPAINTERS`` (INTEGRATION.md);
 otherwise they derive from a minimal mirror of ``ModelWrapper`` (utils/inference.py:330-350) so the contract can be
-exercised stand-alone.  The OpenCV / pyclipper post-processing of the detector (contours -> boxes, mask refinement)
-is NOT part of the dense path: it is taken from the reference package when present, or injected by the caller.
+exercised stand-alone.  The detectors' box extraction (contours -> min-area boxes -> unclip) runs on the native host routines of the C-ABI library
+(hostglue.py; the reference's OpenCV/pyclipper version can be injected instead); mask refinement and image resizing are
+NOT part of the dense path: they are taken from the reference package when present, or injected by the caller.
 """
 from __future__ import annotations
 
@@ -119,7 +120,7 @@ class HipComicTextDetector(_DetBase):
         mask_u8, lines, _ = self.engine.forward(page)
         mask = mask_u8[0].cpu().numpy()           # postprocess_mask already applied on the GPU (ctd.py:30-44)
         lines_map = lines.cpu().numpy()           # [1,2,h,w], cropped to the un-padded area (:152-153)
-        boxes_fn, refine_fn = self._boxes or _reference_boxes(), self._refine or _reference_refine()
+        boxes_fn, refine_fn = self._boxes or _native_ctd_boxes, self._refine or _reference_refine()
         boxes, scores = boxes_fn(lines_map, im_h, im_w)      # SegDetectorRepresenter(thresh=0.3) (:102,156)
         keep = np.where(scores > 0.6)                        # box_thresh (:157-159)
         boxes, scores = boxes[keep], scores[keep]
@@ -159,7 +160,7 @@ class HipDefaultDetector(_DetBase):
         bilateralFilter + resize_aspect_ratio (:62), SegDetectorRepresenter (:73-77), the x2 mask resize (:89) — comes from
         the reference package or from the injected callables; the network runs on the GPU."""
         pre = self._pre or _reference_default_preprocess()
-        boxes_fn = self._boxes or _reference_default_boxes()
+        boxes_fn = self._boxes or _native_dbnet_boxes
         resize2x = self._resize2x or _reference_resize2x()
         img_resized, target_ratio, pad_w, pad_h = pre(image, detect_size)
         ratio = 1 / target_ratio
@@ -454,6 +455,19 @@ class HipESRGANUpscaler(_UpBase):
 
 
 # ---- pieces taken from the reference package when it is importable ---------------------------------------------
+
+def _native_ctd_boxes(lines_map, im_h, im_w):
+    """SegDetectorRepresenter(thresh=0.3)(None, lines_map, height, width) on the native host routines (hostglue.py)."""
+    from . import hostglue
+
+    return hostglue.ctd_boxes(lines_map, im_h, im_w)
+
+
+def _native_dbnet_boxes(db, h, w, text_threshold, box_threshold, unclip_ratio):
+    from . import hostglue
+
+    return hostglue.dbnet_boxes(db, h, w, text_threshold, box_threshold, unclip_ratio)
+
 
 def _reference_boxes():
     if not HAVE_REFERENCE:

@@ -1,0 +1,101 @@
+"""Detector box extraction on the host (native C++ in libmit_hip.so, no GPU): against closed-form cases and against the
+independent scipy-based oracle.  The OpenCV / pyclipper / shapely routines the reference calls are not installed
+anywhere this can run, so this pins the two restatements to each other and to geometry that can be worked out by hand."""
+import numpy as np
+import pytest
+
+from manga_image_translator_amd import hostglue as HG
+from oracle import hostglue as OH
+
+
+def _blobs(rng, H, W, n):
+    pred = np.zeros((H, W), np.float32)
+    for _ in range(n):
+        h, w = int(rng.integers(3, 24)), int(rng.integers(3, 40))
+        y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+        yy, xx = np.mgrid[0:h, 0:w]
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            m = np.ones((h, w), bool)
+        elif kind == 1:
+            m = ((yy - h / 2) / (h / 2)) ** 2 + ((xx - w / 2) / (w / 2)) ** 2 <= 1.0
+        else:
+            m = (np.abs(yy - h / 2) * w + np.abs(xx - w / 2) * h) <= h * w / 2  # diamond
+        pred[y:y + h, x:x + w][m] = rng.uniform(0.35, 1.0)
+        if h > 8 and w > 8 and rng.random() < 0.5:
+            pred[y + h // 3:y + h // 2 + 1, x + w // 3:x + w // 2 + 1] = rng.uniform(0.0, 0.25)  # a hole
+    return pred + rng.uniform(0, 0.02, size=pred.shape).astype(np.float32)
+
+
+def test_axis_aligned_rectangle_closed_form():
+    pred = np.zeros((100, 120), np.float32)
+    pred[20:40, 30:90] = 0.9            # pixel centres x 30..89, y 20..39 -> 59 x 19 box
+    boxes, scores = HG.ctd_boxes(pred[None, None], 100, 120)
+    assert len(boxes) == 1 and scores[0] == pytest.approx(0.9)
+    d = 59 * 19 * 1.5 / (2 * (59 + 19))  # area * ratio / perimeter
+    x0, y0, x1, y1 = 30 - d, 20 - d, 89 + d, 39 + d
+    exp = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]])
+    assert np.abs(boxes[0] - exp).max() <= 1.0  # integer polygon offset + rounding
+    # destination scaling (boxes are mapped to the page size)
+    b2, _ = HG.boxes_from_bitmap(pred, 0.3, 240, 300, unclip_ratio=1.5, min_sside=2.0)
+    assert np.abs(b2[0] - exp * np.array([2.0, 3.0])).max() <= 3.0
+
+
+def test_counts_holes_and_order():
+    pred = np.zeros((50, 60), np.float32)
+    pred[5:20, 5:30] = 0.8
+    pred[9:15, 10:20] = 0.0   # hole -> its own contour
+    pred[30:45, 35:55] = 0.6
+    pred[2, 50] = 0.9          # isolated pixel: sside 0 -> skipped slot
+    assert HG.contour_count(pred > 0.3)[0] == OH_count(pred > 0.3) == 4
+    boxes, scores = HG.ctd_boxes(pred[None, None], 50, 60)
+    assert len(boxes) == 4
+    assert boxes[0].sum() > 0 and boxes[0][:, 1].min() >= 20          # last found first: the lower rectangle
+    assert not boxes[3].any() and scores[3] == 0                      # the isolated pixel (found first) comes last, skipped
+    assert scores[2] == pytest.approx((15 * 25 - 6 * 10) * 0.8 / (15 * 25), rel=1e-5)  # outer border: hole filled in the mean
+
+
+def OH_count(bitmap):
+    regs = OH._contours_as_regions(bitmap)
+    return len(regs)
+
+
+def test_contour_count_matches_oracle():
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        pred = _blobs(rng, 90, 130, 12)
+        n, pts = HG.contour_count(pred > 0.3)
+        assert n == OH_count(pred > 0.3) and pts >= n
+
+
+@pytest.mark.parametrize("mode", ["ctd", "default"])
+def test_native_matches_oracle_on_random_blobs(mode):
+    rng = np.random.default_rng(7)
+    for trial in range(6):
+        pred = _blobs(rng, 96, 128, 14)
+        kw = dict(unclip_ratio=1.5, min_sside=2.0) if mode == "ctd" else dict(unclip_ratio=2.3, min_sside=3.0, box_thresh=0.5,
+                                                                              min_sside_out=5.0, roll_start=True)
+        nb, ns = HG.boxes_from_bitmap(pred, 0.3, 256, 192, **kw)
+        ob, os_ = OH.boxes_from_bitmap(pred, 0.3, 256, 192, **kw)
+        assert nb.shape == ob.shape and nb.shape[0] >= 8
+        assert np.array_equal(ns == 0, os_ == 0), "different contours skipped"
+        assert np.allclose(ns, os_, atol=1e-5)
+        keep = np.nonzero(ns != 0)[0]
+        same = 0
+        for i in keep:
+            d = np.abs(nb[i] - ob[i]).max()
+            if d <= 2:  # float32 vs float64 calipers + rounding
+                same += 1
+                continue
+            # mirror-symmetric blobs (ellipses, diamonds) have two minimal rectangles of equal area; either is a valid
+            # cv2.minAreaRect answer, so only the rectangle's centre and side lengths must agree
+            side = lambda b: sorted([np.linalg.norm(b[1] - b[0]), np.linalg.norm(b[2] - b[1])])
+            assert np.abs(nb[i].mean(0) - ob[i].mean(0)).max() <= 2 and np.allclose(side(nb[i]), side(ob[i]), atol=3), (i, nb[i], ob[i])
+        assert same >= 0.8 * len(keep)
+
+
+def test_bad_input():
+    with pytest.raises(ValueError):
+        HG.boxes_from_bitmap(np.zeros((2, 3, 4), np.float32), 0.3, 10, 10, unclip_ratio=1.5, min_sside=2)
+    b, s = HG.ctd_boxes(np.zeros((1, 2, 16, 16), np.float32), 16, 16)
+    assert b.shape == (0, 4, 2) and s.shape == (0,)
