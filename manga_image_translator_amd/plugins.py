@@ -207,11 +207,15 @@ class HipModel48pxOCR(_OcrBase):
         self.engine = None
 
     def _directions(self, textlines):
-        """(line, direction) in processing order.  With the reference present: its merge-graph majority vote
-        (ocr/common.py:12-39); stand-alone: each line's own direction."""
+        """(line, direction) in processing order: the merge-graph majority vote of ocr/common.py:12-39 (the reference's own
+        method when the package is present, textline.generate_text_direction otherwise)."""
         if HAVE_REFERENCE:
             return list(self._generate_text_direction(textlines))
-        return [(q, q.direction) for q in textlines]
+        from . import textline as TL
+
+        own = [TL.Quadrilateral(np.asarray(q.pts)) for q in textlines]
+        back = {id(o): q for o, q in zip(own, textlines)}
+        return [(back[id(o)], d) for o, d in TL.generate_text_direction(own)]
 
     @torch.no_grad()
     async def _infer(self, image: np.ndarray, textlines: List, config=None, verbose: bool = False, ignore_bubble: int = 0,

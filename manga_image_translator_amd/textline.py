@@ -103,6 +103,180 @@ class Quadrilateral:
         self.pts[:, 0] = np.clip(np.round(self.pts[:, 0]), 0, width)
         self.pts[:, 1] = np.clip(np.round(self.pts[:, 1]), 0, height)
 
+    @functools.cached_property
+    def xyxy(self):
+        return self.aabb.x, self.aabb.y, self.aabb.x + self.aabb.w, self.aabb.y + self.aabb.h
+
+    def _unit_vecs(self):
+        v1, v2 = self._vecs()
+        return v1 / np.linalg.norm(v1), v2 / np.linalg.norm(v2)
+
+    @functools.cached_property
+    def is_axis_aligned(self) -> bool:  # generic.py:483-494
+        u1, _ = self._unit_vecs()
+        return bool(abs(u1[1]) < 1e-2 or abs(u1[0]) < 1e-2)
+
+    @functools.cached_property
+    def is_approximate_axis_aligned(self) -> bool:  # generic.py:496-507
+        u1, u2 = self._unit_vecs()
+        return bool(abs(u1[1]) < 0.05 or abs(u1[0]) < 0.05 or abs(u2[1]) < 0.05 or abs(u2[0]) < 0.05)
+
+    @functools.cached_property
+    def cosangle(self) -> float:  # generic.py:509-515
+        u1, _ = self._unit_vecs()
+        return float(np.dot(u1, np.array([1, 0])))
+
+    @functools.cached_property
+    def angle(self) -> float:  # generic.py:517-519
+        return float(np.fmod(np.arccos(self.cosangle) + np.pi, np.pi))
+
+    @functools.cached_property
+    def centroid(self) -> np.ndarray:
+        return np.average(self.pts, axis=0)
+
+    def poly_distance(self, other: "Quadrilateral") -> float:
+        """shapely ``self.polygon.distance(other.polygon)`` with polygon = convex hull of the 4 points (generic.py:533-541)."""
+        return polygon_distance(_convex_hull(self.pts), _convex_hull(other.pts))
+
+
+def _convex_hull(pts: np.ndarray) -> np.ndarray:
+    p = sorted(set(map(tuple, np.asarray(pts, dtype=np.float64))))
+    if len(p) < 3:
+        return np.array(p, dtype=np.float64)
+    cross = lambda o, a, b: (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+    lo, up = [], []
+    for q in p:
+        while len(lo) >= 2 and cross(lo[-2], lo[-1], q) <= 0:
+            lo.pop()
+        lo.append(q)
+    for q in reversed(p):
+        while len(up) >= 2 and cross(up[-2], up[-1], q) <= 0:
+            up.pop()
+        up.append(q)
+    return np.array(lo[:-1] + up[:-1], dtype=np.float64)
+
+
+def _seg_point_dist(p, a, b) -> float:
+    ab, ap = b - a, p - a
+    den = float(ab @ ab)
+    t = 0.0 if den == 0 else min(1.0, max(0.0, float(ap @ ab) / den))
+    return float(np.linalg.norm(ap - t * ab))
+
+
+def _segs_intersect(a, b, c, d) -> bool:
+    o = lambda p, q, r: (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0])
+    on = lambda p, q, r: min(p[0], q[0]) <= r[0] <= max(p[0], q[0]) and min(p[1], q[1]) <= r[1] <= max(p[1], q[1])
+    o1, o2, o3, o4 = o(a, b, c), o(a, b, d), o(c, d, a), o(c, d, b)
+    if ((o1 > 0) != (o2 > 0)) and ((o3 > 0) != (o4 > 0)) and o1 * o2 != 0 and o3 * o4 != 0:
+        return True
+    return (o1 == 0 and on(a, b, c)) or (o2 == 0 and on(a, b, d)) or (o3 == 0 and on(c, d, a)) or (o4 == 0 and on(c, d, b))
+
+
+def _point_in_polygon(p, poly) -> bool:
+    inside = False
+    n = len(poly)
+    for i in range(n):
+        a, b = poly[i], poly[(i + 1) % n]
+        if (a[1] > p[1]) != (b[1] > p[1]) and p[0] < (b[0] - a[0]) * (p[1] - a[1]) / (b[1] - a[1]) + a[0]:
+            inside = not inside
+    return inside
+
+
+def polygon_distance(pa: np.ndarray, pb: np.ndarray) -> float:
+    """Minimum distance between two simple polygons given as vertex rings (0 when they touch or overlap) — what
+    shapely's ``Polygon.distance`` returns for the quads of utils/generic.py:660-662."""
+    pa, pb = np.asarray(pa, dtype=np.float64), np.asarray(pb, dtype=np.float64)
+    na, nb = len(pa), len(pb)
+    for i in range(na):
+        for j in range(nb):
+            if _segs_intersect(pa[i], pa[(i + 1) % na], pb[j], pb[(j + 1) % nb]):
+                return 0.0
+    if (na >= 3 and _point_in_polygon(pb[0], pa)) or (nb >= 3 and _point_in_polygon(pa[0], pb)):
+        return 0.0
+    d = 1e300
+    for i in range(na):
+        for j in range(nb):
+            d = min(d, _seg_point_dist(pa[i], pb[j], pb[(j + 1) % nb]), _seg_point_dist(pb[j], pa[i], pa[(i + 1) % na]))
+    return d
+
+
+def quadrilateral_can_merge_region(a: Quadrilateral, b: Quadrilateral, ratio=1.9, discard_connection_gap=2, char_gap_tolerance=0.6,
+                                   char_gap_tolerance2=1.5, font_size_ratio_tol=1.5, aspect_ratio_tol=2) -> bool:
+    """utils/generic.py:653-698, line for line (shapely's polygon distance replaced by ``polygon_distance``)."""
+    b1, b2 = a.aabb, b.aabb
+    char_size = min(a.font_size, b.font_size)
+    x1, y1, w1, h1 = b1.x, b1.y, b1.w, b1.h
+    x2, y2, w2, h2 = b2.x, b2.y, b2.w, b2.h
+    dist = polygon_distance(a.pts, b.pts)  # Polygon(a.pts).distance(Polygon(b.pts))
+    if dist > discard_connection_gap * char_size:
+        return False
+    if max(a.font_size, b.font_size) / char_size > font_size_ratio_tol:
+        return False
+    if a.aspect_ratio > aspect_ratio_tol and b.aspect_ratio < 1. / aspect_ratio_tol:
+        return False
+    if b.aspect_ratio > aspect_ratio_tol and a.aspect_ratio < 1. / aspect_ratio_tol:
+        return False
+    if a.is_approximate_axis_aligned and b.is_approximate_axis_aligned:
+        if dist < char_size * char_gap_tolerance:
+            if abs(x1 + w1 // 2 - (x2 + w2 // 2)) < char_gap_tolerance2:
+                return True
+            if w1 > h1 * ratio and h2 > w2 * ratio:
+                return False
+            if w2 > h2 * ratio and h1 > w1 * ratio:
+                return False
+            if w1 > h1 * ratio or w2 > h2 * ratio:
+                return abs(x1 - x2) < char_size * char_gap_tolerance2 or abs(x1 + w1 - (x2 + w2)) < char_size * char_gap_tolerance2
+            elif h1 > w1 * ratio or h2 > w2 * ratio:
+                return abs(y1 - y2) < char_size * char_gap_tolerance2 or abs(y1 + h1 - (y2 + h2)) < char_size * char_gap_tolerance2
+            return False
+        return False
+    if abs(a.angle - b.angle) < 15 * np.pi / 180:
+        fs_a, fs_b = a.font_size, b.font_size
+        fs = min(fs_a, fs_b)
+        if a.poly_distance(b) > fs * char_gap_tolerance2:
+            return False
+        if abs(fs_a - fs_b) / fs > 0.25:
+            return False
+        return True
+    return False
+
+
+def generate_text_direction(quads: Sequence[Quadrilateral]):
+    """CommonOCR._generate_text_direction (ocr/common.py:12-39): connected components of the merge graph
+    (aspect_ratio_tol = 1), majority direction per component, lines ordered top-to-bottom ('h') or right-to-left ('v').
+    Yields (quad, direction)."""
+    n = len(quads)
+    parent = list(range(n))
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+
+    for u in range(n):
+        for v in range(u + 1, n):
+            if quadrilateral_can_merge_region(quads[u], quads[v], aspect_ratio_tol=1):
+                ru, rv = find(u), find(v)
+                if ru != rv:
+                    parent[max(ru, rv)] = min(ru, rv)
+    comps = {}
+    for i in range(n):  # components in order of their first node, nodes ascending (networkx + CPython set order for small ints)
+        comps.setdefault(find(i), []).append(i)
+    for root in sorted(comps):
+        nodes = comps[root]
+        dirs = [quads[i].direction for i in nodes]
+        counts = {}
+        for d in dirs:  # Counter.most_common(1): highest count, first encountered on ties
+            counts[d] = counts.get(d, 0) + 1
+        majority = max(counts, key=lambda d: (counts[d], -dirs.index(d)))
+        if majority == "h":
+            nodes = sorted(nodes, key=lambda i: quads[i].aabb.y + quads[i].aabb.h // 2)
+        else:
+            nodes = sorted(nodes, key=lambda i: -(quads[i].aabb.x + quads[i].aabb.w))
+        for i in nodes:
+            yield quads[i], majority
+
 
 def homography_4pt(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
     """3x3 H (h33 = 1) with H @ [src,1] ~ [dst,1] for exactly four correspondences.

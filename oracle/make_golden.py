@@ -17,6 +17,7 @@ Fixtures (all small; each .npz also records the reference file whose code produc
   ocr_ctc.npz      OCR.forward + OCR.decode (ocr/model_48px_ctc.py:463-494) on 3 crops padded to max_w+7+128, dict 97
   dbnet.npz        TextDetection.forward + sigmoid (detection/default_utils/DBNet_resnet34.py:98-125, default.py:15-25) on a 256x256 page (fp16 maps + fp32 crops)
   esrgan.npz       RRDBNet.forward + the tensor part of ESRGANUpscalerPytorch._infer (upscaling/esrgan_pytorch.py:67-75,537-546), nb = 2, 40x56 page
+  direction.npz    quadrilateral_can_merge_region + CommonOCR._generate_text_direction (utils/generic.py:653-698, ocr/common.py:12-39)
   textline.npz     sort_pnts / Quadrilateral / get_transformed_region (utils/generic.py:324-481) on 12 quads
 """
 from __future__ import annotations
@@ -226,6 +227,66 @@ def golden_ocr_ctc():
     print("ocr_ctc", logits.shape, T, [len(t) for t in texts], float(logits.std()))
 
 
+def golden_direction():
+    """The reference's own merge test + direction vote (utils/generic.py:653-698, ocr/common.py:12-39) on random line sets,
+    executed with the shapely shim of ref_import (networkx is the real one)."""
+    import itertools
+    from collections import Counter
+
+    import networkx as nx
+
+    G = R.generic()
+    shim = R.shapely_shim()
+    G.Polygon, G.MultiPoint = shim.Polygon, shim.MultiPoint
+    rng = np.random.default_rng(17)
+    sets, merges, orders, dirs = [], [], [], []
+    for trial in range(6):
+        quads = []
+        n_col = int(rng.integers(2, 5))
+        x = 30
+        for c in range(n_col):  # vertical text columns packed closely (they merge), plus a few stray horizontal lines
+            w, h = int(rng.integers(18, 26)), int(rng.integers(120, 260))
+            y = int(rng.integers(20, 60))
+            q = np.array([[x, y], [x + w, y], [x + w, y + h], [x, y + h]])
+            if c % 2 == 1:
+                q = q + rng.integers(-2, 3, size=(4, 2))
+            quads.append(q)
+            x += w + int(rng.integers(2, 14))
+        for _ in range(int(rng.integers(1, 4))):
+            w, h = int(rng.integers(90, 200)), int(rng.integers(16, 24))
+            x0, y0 = int(rng.integers(10, 300)), int(rng.integers(300, 420))
+            quads.append(np.array([[x0, y0], [x0 + w, y0], [x0 + w, y0 + h], [x0, y0 + h]]))
+            if rng.random() < 0.5:  # a second line right below it: the pair merges
+                quads.append(np.array([[x0 + 2, y0 + h + 3], [x0 + w, y0 + h + 3], [x0 + w, y0 + 2 * h + 3], [x0 + 2, y0 + 2 * h + 3]]))
+        objs = [G.Quadrilateral(q.copy(), "", 0) for q in quads]
+        m = np.zeros((len(objs), len(objs)), dtype=np.uint8)
+        gr = nx.Graph()
+        for i in range(len(objs)):
+            gr.add_node(i)
+        for (u, a), (v, b) in itertools.combinations(enumerate(objs), 2):
+            if G.quadrilateral_can_merge_region(a, b, aspect_ratio_tol=1):
+                m[u, v] = m[v, u] = 1
+                gr.add_edge(u, v)
+        order, dd = [], []
+        for node_set in nx.algorithms.components.connected_components(gr):  # ocr/common.py:27-39
+            nodes = list(node_set)
+            majority = Counter([objs[i].direction for i in nodes]).most_common(1)[0][0]
+            if majority == "h":
+                nodes = sorted(nodes, key=lambda i: objs[i].aabb.y + objs[i].aabb.h // 2)
+            else:
+                nodes = sorted(nodes, key=lambda i: -(objs[i].aabb.x + objs[i].aabb.w))
+            order += nodes
+            dd += [majority] * len(nodes)
+        sets.append(np.array(quads))
+        merges.append(m)
+        orders.append(np.array(order))
+        dirs.append(np.array(dd))
+    np.savez_compressed(os.path.join(GOLDEN, "direction.npz"), n_sets=len(sets), source="manga_translator/utils/generic.py + ocr/common.py",
+                        **{f"quads{i}": s for i, s in enumerate(sets)}, **{f"merge{i}": m for i, m in enumerate(merges)},
+                        **{f"order{i}": o for i, o in enumerate(orders)}, **{f"dir{i}": d for i, d in enumerate(dirs)})
+    print("direction", [int(m.sum() // 2) for m in merges], [d.tolist() for d in dirs][:2])
+
+
 def build_ref_dbnet():
     from manga_image_translator_amd import dbnet_schema
 
@@ -284,6 +345,7 @@ def main():
     golden_esrgan()
     golden_ocr_ctc()
     golden_dbnet()
+    golden_direction()
 
 
 if __name__ == "__main__":

@@ -192,3 +192,70 @@ def esrgan():
         m.OfflineUpscaler = type("OfflineUpscaler", (), {})
         sys.modules["manga_translator.upscaling.common"] = m
     return _load("manga_translator.upscaling.esrgan_pytorch", "upscaling/esrgan_pytorch.py")
+
+
+def shapely_shim():
+    """Minimal ``shapely.geometry`` stand-in (Polygon / MultiPoint with area, length, distance, convex_hull) so the reference's
+    own ``quadrilateral_can_merge_region`` / ``Quadrilateral.polygon`` (utils/generic.py) can be executed here.  Geometry by
+    straightforward formulas (shoelace, pairwise segment distances) — an independent restatement from the product's."""
+    import numpy as np
+
+    class Polygon:
+        def __init__(self, pts):
+            self.pts = np.asarray([tuple(p) for p in pts], dtype=np.float64)
+
+        @property
+        def area(self):
+            x, y = self.pts[:, 0], self.pts[:, 1]
+            return float(abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))) / 2)
+
+        @property
+        def length(self):
+            return float(np.linalg.norm(np.roll(self.pts, -1, 0) - self.pts, axis=1).sum())
+
+        def _edges(self):
+            return [(self.pts[i], self.pts[(i + 1) % len(self.pts)]) for i in range(len(self.pts))]
+
+        def _contains(self, p):
+            inside = False
+            for a, b in self._edges():
+                if (a[1] > p[1]) != (b[1] > p[1]) and p[0] < (b[0] - a[0]) * (p[1] - a[1]) / (b[1] - a[1]) + a[0]:
+                    inside = not inside
+            return inside
+
+        def distance(self, other):
+            def seg_seg(a, b, c, d):
+                def pt_seg(p, s, e):
+                    se = e - s
+                    den = float(se @ se)
+                    t = 0.0 if den == 0 else min(1.0, max(0.0, float((p - s) @ se) / den))
+                    return float(np.linalg.norm(p - (s + t * se)))
+                def orient(p, q, r):
+                    return np.sign((q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0]))
+                if orient(a, b, c) != orient(a, b, d) and orient(c, d, a) != orient(c, d, b):
+                    return 0.0
+                return min(pt_seg(a, c, d), pt_seg(b, c, d), pt_seg(c, a, b), pt_seg(d, a, b))
+            if self._contains(other.pts[0]) or other._contains(self.pts[0]):
+                return 0.0
+            return min(seg_seg(a, b, c, d) for a, b in self._edges() for c, d in other._edges())
+
+    class MultiPoint:
+        def __init__(self, pts):
+            self.pts = [tuple(map(float, p)) for p in pts]
+
+        @property
+        def convex_hull(self):
+            p = sorted(set(self.pts))
+            cross = lambda o, a, b: (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+            lo, up = [], []
+            for q in p:
+                while len(lo) >= 2 and cross(lo[-2], lo[-1], q) <= 0:
+                    lo.pop()
+                lo.append(q)
+            for q in reversed(p):
+                while len(up) >= 2 and cross(up[-2], up[-1], q) <= 0:
+                    up.pop()
+                up.append(q)
+            return Polygon(lo[:-1] + up[:-1])
+
+    return types.SimpleNamespace(Polygon=Polygon, MultiPoint=MultiPoint)

@@ -102,3 +102,36 @@ def test_warp_record_layout_matches_c_struct():
     assert TL.WARP_LINE_DTYPE.itemsize == C.sizeof(lib.MitWarpLine)
     for name, *_ in lib.MitWarpLine._fields_:
         assert TL.WARP_LINE_DTYPE.fields[name][1] == getattr(lib.MitWarpLine, name).offset, name
+
+
+def test_merge_graph_and_direction_vote_match_reference_fixture():
+    """quadrilateral_can_merge_region + the OCR-side direction vote vs the reference's own code
+    (utils/generic.py:653-698, ocr/common.py:12-39, run with a shapely stand-in; tests/golden/direction.npz)."""
+    D = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "direction.npz"))
+    edges = 0
+    for s in range(int(D["n_sets"])):
+        quads = [TL.Quadrilateral(q) for q in D[f"quads{s}"]]
+        n = len(quads)
+        m = np.zeros((n, n), dtype=np.uint8)
+        for u in range(n):
+            for v in range(u + 1, n):
+                if TL.quadrilateral_can_merge_region(quads[u], quads[v], aspect_ratio_tol=1):
+                    m[u, v] = m[v, u] = 1
+        assert np.array_equal(m, D[f"merge{s}"]), s
+        edges += int(m.sum() // 2)
+        got = list(TL.generate_text_direction(quads))
+        assert [quads.index(q) for q, _ in got] == D[f"order{s}"].tolist()
+        assert [d for _, d in got] == D[f"dir{s}"].tolist()
+    assert edges >= 10
+
+
+def test_polygon_distance_closed_form():
+    sq = lambda x, y, s: np.array([[x, y], [x + s, y], [x + s, y + s], [x, y + s]], dtype=float)
+    assert TL.polygon_distance(sq(0, 0, 10), sq(13, 0, 10)) == pytest.approx(3.0)
+    assert TL.polygon_distance(sq(0, 0, 10), sq(13, 14, 10)) == pytest.approx(5.0)       # corner to corner (3, 4, 5)
+    assert TL.polygon_distance(sq(0, 0, 10), sq(5, 5, 10)) == 0.0                          # overlap
+    assert TL.polygon_distance(sq(0, 0, 10), sq(2, 2, 3)) == 0.0                           # containment
+    assert TL.polygon_distance(sq(0, 0, 10), sq(10, 0, 4)) == 0.0                          # touching edge
+    a, b = TL.Quadrilateral(sq(0, 0, 10).astype(int)), TL.Quadrilateral(sq(20, 0, 10).astype(int))
+    assert a.poly_distance(b) == pytest.approx(10.0) and a.is_axis_aligned and a.is_approximate_axis_aligned
+    assert a.xyxy == (0, 0, 10, 10) and np.allclose(a.centroid, [5, 5])
