@@ -9,9 +9,10 @@ because none of them is installed where this repo is built or tested.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
+from scipy import ndimage
 
 from . import lib as _lib
 
@@ -52,3 +53,194 @@ def contour_count(bitmap: np.ndarray) -> Tuple[int, int]:
     n, p = C.c_int(0), C.c_int64(0)
     _lib.check(_lib.load().mit_find_contours_count(bitmap.ctypes.data, bitmap.shape[0], bitmap.shape[1], C.byref(n), C.byref(p)))
     return n.value, p.value
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mask refinement of the ctd detector (ctd_utils/textmask.py:16-174) and the image resize around it, on numpy + scipy.
+# The reference runs these through OpenCV; each primitive below states the OpenCV rule it follows (parity unpinned against
+# the real library, pinned against the reference's own Python through tests/golden/refine_mask.npz).
+# ---------------------------------------------------------------------------------------------------------------------
+
+def resize_linear_u8(src: np.ndarray, dsize: Tuple[int, int]) -> np.ndarray:
+    """cv2.resize(src, (w, h), interpolation=cv2.INTER_LINEAR) for uint8 [H,W] or [H,W,C]: an exact 2x shrink is the 2x2 box
+    mean ((a+b+c+d+2)>>2); otherwise separable bilinear with 11-bit fixed-point coefficients, pixel centres aligned,
+    vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2 (OpenCV resize.cpp, 8-bit path)."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    squeeze = src.ndim == 2
+    s = src[..., None] if squeeze else src
+    sh, sw = s.shape[:2]
+    if sh == 2 * dh and sw == 2 * dw:
+        t = s.astype(np.int32)
+        out = ((t[0::2, 0::2] + t[0::2, 1::2] + t[1::2, 0::2] + t[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        return out[..., 0] if squeeze else out
+
+    def taps(n_src, n_dst):
+        d = np.arange(n_dst, dtype=np.float64)
+        f = ((d + 0.5) * (n_src / n_dst) - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        fr = (f - i0.astype(np.float32)).astype(np.float32)
+        lo, hi = i0 < 0, i0 >= n_src - 1
+        i0 = np.where(lo, 0, np.where(hi, n_src - 1, i0))
+        fr = np.where(lo | hi, np.float32(0), fr)
+        c1 = np.rint(fr * np.float32(2048)).astype(np.int64)
+        c0 = np.rint((np.float32(1) - fr) * np.float32(2048)).astype(np.int64)
+        return i0, np.minimum(i0 + 1, n_src - 1), c0, c1
+
+    y0, y1, yc0, yc1 = taps(sh, dh)
+    x0, x1, xc0, xc1 = taps(sw, dw)
+    t = s.astype(np.int64)
+    rows = t[:, x0] * xc0[None, :, None] + t[:, x1] * xc1[None, :, None]
+    out = (((yc0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((yc1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[..., 0] if squeeze else out
+
+
+def enlarge_window(rect, im_w: int, im_h: int, ratio: float = 2.5, aspect_ratio: float = 1.0) -> List[int]:
+    """ctd_utils/utils/imgproc_utils.py:134-150: grow the box so that its area is ``ratio`` x, clipped to the page."""
+    x1, y1, x2, y2 = [int(v) for v in rect]
+    w, h = x2 - x1, y2 - y1
+    roots = np.roots([aspect_ratio, w + h * aspect_ratio, (1 - ratio) * w * h])
+    roots.sort()
+    delta = int(round(float(np.real(roots[-1])) / 2))
+    delta_w = min(x1, im_w - x2, int(delta * aspect_ratio))
+    delta = min(y1, im_h - y2, delta)
+    return [x1 - delta_w, y1 - delta, x2 + delta_w, y2 + delta]
+
+
+def _gray_bgr2gray(img: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) on 8 bits: (c0*1868 + c1*9617 + c2*4899 + 8192) >> 14 (the reference feeds RGB
+    pages to the BGR conversion, textmask.py:57-58; the literal channel weights are kept)."""
+    t = img.astype(np.int64)
+    return ((t[..., 0] * 1868 + t[..., 1] * 9617 + t[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+
+
+def _otsu_threshold(c: np.ndarray) -> int:
+    """OpenCV getThreshVal_Otsu_8u: the grey level maximising the between-class variance (first maximum)."""
+    hist = np.bincount(c.reshape(-1), minlength=256).astype(np.float64)
+    scale = 1.0 / c.size
+    mu = float((np.arange(256) * hist).sum()) * scale
+    q1 = mu1 = 0.0
+    best, best_sigma = 0, 0.0
+    for i in range(256):
+        p_i = hist[i] * scale
+        mu1 *= q1
+        q1 += p_i
+        q2 = 1.0 - q1
+        if min(q1, q2) < 2.220446049250313e-16 or max(q1, q2) > 1.0 - 2.220446049250313e-16:
+            continue
+        mu1 = (mu1 + i * p_i) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
+        if sigma > best_sigma:
+            best_sigma, best = sigma, i
+    return best
+
+
+_RECT3 = np.ones((3, 3), bool)
+_CROSS3 = ndimage.generate_binary_structure(2, 1)  # cv2.getStructuringElement(MORPH_ELLIPSE, (3, 3))
+
+
+def _erode(m: np.ndarray, fp: np.ndarray) -> np.ndarray:  # cv2.erode: outside the image counts as +inf
+    return ndimage.grey_erosion(m, footprint=fp, mode="constant", cval=255)
+
+
+def _dilate(m: np.ndarray, fp: np.ndarray) -> np.ndarray:  # cv2.dilate: outside the image counts as -inf
+    return ndimage.grey_dilation(m, footprint=fp, mode="constant", cval=0)
+
+
+def _xor_sum(a: np.ndarray, b: np.ndarray) -> int:
+    return int(np.bitwise_xor(a, b).sum(dtype=np.uint64))
+
+
+def _minxor_thresh(threshed: np.ndarray, mask: np.ndarray):
+    """textmask.py:29-42 (dilate=False): the candidate or its complement, whichever is closer to the predicted mask."""
+    neg = 255 - threshed
+    a, b = _xor_sum(neg, mask), _xor_sum(threshed, mask)
+    return (neg, a) if a < b else (threshed, b)
+
+
+def _topk_color(color_list, bins, k=3, color_var=10, bin_tol=0.001):
+    """textmask.py:16-27."""
+    idx = np.argsort(bins * -1)
+    color_list, bins = color_list[idx], bins[idx]
+    top = [color_list[0]]
+    tol = np.sum(bins) * bin_tol
+    if len(color_list) > 1:
+        for color, b in zip(color_list[1:], bins[1:]):
+            if np.abs(np.array(top) - color).min() > color_var:
+                top.append(color)
+            if len(top) >= k or b < tol:
+                break
+    return top
+
+
+def _components(mask: np.ndarray, connectivity: int):
+    """cv2.connectedComponentsWithStats(mask, connectivity): (n incl. background, labels, [(x, y, w, h, area)] per label)."""
+    lab, n = ndimage.label(mask > 0, structure=np.ones((3, 3)) if connectivity == 8 else None)
+    zy, zx = np.nonzero(lab == 0)  # label 0 = background: tight box of the zero pixels, like OpenCV
+    stats = [(int(zx.min()), int(zy.min()), int(zx.max() - zx.min() + 1), int(zy.max() - zy.min() + 1), len(zx)) if len(zx) else (0, 0, 0, 0, 0)]
+    for sl, k in zip(ndimage.find_objects(lab), range(1, n + 1)):
+        ys, xs = sl
+        stats.append((xs.start, ys.start, xs.stop - xs.start, ys.stop - ys.start, int((lab[sl] == k).sum())))
+    return n + 1, lab, stats
+
+
+def _merge_mask_list(mask_list, pred_mask: np.ndarray, inpaint_dilate: bool) -> np.ndarray:
+    """textmask.py:74-132 (filter_with_lines False, pred_thresh 30)."""
+    mask_list = sorted(mask_list, key=lambda x: x[1])
+    pred_mask = _erode(pred_mask, _CROSS3)
+    pred_mask = np.where(pred_mask > 60, 255, 0).astype(np.uint8)
+    merged = np.zeros_like(pred_mask)
+
+    def try_merge(lab, k, stat):
+        x, y, w, h, _ = stat
+        sl = (slice(y, y + h), slice(x, x + w))
+        tmp = np.where(lab[sl] == k, 255, 0).astype(np.uint8) | merged[sl]
+        if _xor_sum(tmp, pred_mask[sl]) < _xor_sum(merged[sl], pred_mask[sl]):
+            merged[sl] = tmp
+
+    for cand, _ in mask_list:
+        n, lab, stats = _components(cand, 8)
+        for k in range(1, n):
+            if stats[k][2] * stats[k][3] < 3:
+                continue
+            try_merge(lab, k, stats[k])
+    if inpaint_dilate:
+        merged[...] = _dilate(merged, np.ones((5, 5), bool))
+    # fill holes (:113-131): background components smaller than the second-largest area, when that lowers the XOR
+    n, lab, stats = _components(255 - merged, 8)
+    areas = np.sort(np.array([s[4] for s in stats]))
+    thresh = areas[-2] if len(areas) > 1 else areas[-1]
+    for k in range(n):  # label 0 (the mask itself) is visited too, like the reference; merging it is a no-op
+        if stats[k][4] < thresh:
+            try_merge(lab, k, stats[k])
+    return merged
+
+
+def refine_mask(img: np.ndarray, pred_mask: np.ndarray, quads: Sequence, refine_mode=None) -> np.ndarray:
+    """ctd_utils/textmask.py:158-174: per text line, candidate masks from the 3 dominant grey levels and an Otsu split of
+    the best colour channel, merged component by component where that brings the mask closer to the network's prediction.
+    ``refine_mode`` 0 (REFINEMASK_INPAINT) adds the 5x5 dilation; the ctd detector passes None (ctd.py:177)."""
+    out = np.zeros_like(pred_mask)
+    for q in quads:
+        bx1, by1, bx2, by2 = enlarge_window(q.xyxy, img.shape[1], img.shape[0])
+        im = np.ascontiguousarray(img[by1:by2, bx1:bx2])
+        msk = np.ascontiguousarray(pred_mask[by1:by2, bx1:bx2])
+        if im.size == 0:
+            continue
+        grey = _gray_bgr2gray(im)
+        cand = grey[_erode(msk, _RECT3) > 127]                   # get_topk_masklist :56-71
+        bins, edges = np.histogram(cand, bins=255)
+        masks = []
+        for color in _topk_color(edges, bins, color_var=10, k=3):
+            c_top = min(color + 30, 255)
+            c_bottom = c_top - 60
+            masks.append(list(_minxor_thresh(np.where((grey >= c_bottom) & (grey <= c_top), 255, 0).astype(np.uint8), msk)))
+        otsu = []                                                 # get_otsuthresh_masklist :44-54 (per_channel False)
+        for c in range(3):
+            ch = im[..., c]
+            otsu.append(list(_minxor_thresh(np.where(ch > _otsu_threshold(ch), 255, 0).astype(np.uint8), msk)))
+        otsu.sort(key=lambda x: x[1])
+        masks.append(otsu[0])
+        out[by1:by2, bx1:bx2] |= _merge_mask_list(masks, msk, refine_mode == 0)
+    return out

@@ -120,7 +120,7 @@ class HipComicTextDetector(_DetBase):
         mask_u8, lines, _ = self.engine.forward(page)
         mask = mask_u8[0].cpu().numpy()           # postprocess_mask already applied on the GPU (ctd.py:30-44)
         lines_map = lines.cpu().numpy()           # [1,2,h,w], cropped to the un-padded area (:152-153)
-        boxes_fn, refine_fn = self._boxes or _native_ctd_boxes, self._refine or _reference_refine()
+        boxes_fn, refine_fn = self._boxes or _native_ctd_boxes, self._refine or _native_refine
         boxes, scores = boxes_fn(lines_map, im_h, im_w)      # SegDetectorRepresenter(thresh=0.3) (:102,156)
         keep = np.where(scores > 0.6)                        # box_thresh (:157-159)
         boxes, scores = boxes[keep], scores[keep]
@@ -465,6 +465,13 @@ def _native_ctd_boxes(lines_map, im_h, im_w):
     from . import hostglue
 
     return hostglue.ctd_boxes(lines_map, im_h, im_w)
+
+
+def _native_refine(image, mask, textlines, im_h, im_w):
+    """cv2.resize(mask, (w, h), INTER_LINEAR) + refine_mask(image, mask, textlines, refine_mode=None) (ctd.py:162,177)."""
+    from . import hostglue
+
+    return hostglue.refine_mask(image, hostglue.resize_linear_u8(mask, (im_w, im_h)), textlines, None)
 
 
 def _native_dbnet_boxes(db, h, w, text_threshold, box_threshold, unclip_ratio):

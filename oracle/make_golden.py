@@ -18,6 +18,7 @@ Fixtures (all small; each .npz also records the reference file whose code produc
   dbnet.npz        TextDetection.forward + sigmoid (detection/default_utils/DBNet_resnet34.py:98-125, default.py:15-25) on a 256x256 page (fp16 maps + fp32 crops)
   esrgan.npz       RRDBNet.forward + the tensor part of ESRGANUpscalerPytorch._infer (upscaling/esrgan_pytorch.py:67-75,537-546), nb = 2, 40x56 page
   direction.npz    quadrilateral_can_merge_region + CommonOCR._generate_text_direction (utils/generic.py:653-698, ocr/common.py:12-39)
+  refine_mask.npz  refine_mask / merge_mask_list / enlarge_window (detection/ctd_utils/textmask.py:16-174) on a 384x320 page
   textline.npz     sort_pnts / Quadrilateral / get_transformed_region (utils/generic.py:324-481) on 12 quads
 """
 from __future__ import annotations
@@ -287,6 +288,29 @@ def golden_direction():
     print("direction", [int(m.sum() // 2) for m in merges], [d.tolist() for d in dirs][:2])
 
 
+def golden_refine_mask():
+    """The reference's refine_mask (ctd_utils/textmask.py:158-174) and enlarge_window, executed with the cv2 stand-in, on
+    a synthetic page whose predicted mask is a blurred version of the text boxes."""
+    from scipy import ndimage
+
+    from manga_image_translator_amd import textline as TL
+
+    tm = R.textmask()
+    page, quads, _ = synth.synth_page(21, 384, 320, n_boxes=6)
+    rng = np.random.default_rng(3)
+    page = np.clip(page.astype(np.int32) + rng.integers(-6, 7, size=page.shape), 0, 255).astype(np.uint8)  # three distinct channels
+    pred = np.zeros((384, 320), np.float32)
+    for q in quads:
+        pred[q[0, 1]:q[2, 1], q[0, 0]:q[2, 0]] = 1.0
+    pred = (ndimage.gaussian_filter(pred, 2.0) * 255).astype(np.uint8)
+    lines = [TL.Quadrilateral(q) for q in quads]  # refine_mask only reads .xyxy
+    out_none = tm.refine_mask(page, pred.copy(), lines, refine_mode=None)
+    out_inpaint = tm.refine_mask(page, pred.copy(), lines, refine_mode=tm.REFINEMASK_INPAINT)
+    np.savez_compressed(os.path.join(GOLDEN, "refine_mask.npz"), page=page, pred=pred, quads=np.array(quads), out_none=out_none,
+                        out_inpaint=out_inpaint, source="manga_translator/detection/ctd_utils/textmask.py")
+    print("refine_mask", float((out_none > 0).mean()), float((out_inpaint > 0).mean()), float((pred > 60).mean()))
+
+
 def build_ref_dbnet():
     from manga_image_translator_amd import dbnet_schema
 
@@ -346,6 +370,7 @@ def main():
     golden_ocr_ctc()
     golden_dbnet()
     golden_direction()
+    golden_refine_mask()
 
 
 if __name__ == "__main__":

@@ -161,8 +161,57 @@ def cv2_shim():
         out[top:top + src.shape[0], left:left + src.shape[1]] = src
         return out
 
+    # ---- primitives used by ctd_utils/textmask.py (refine_mask) ----
+    from scipy import ndimage as _nd
+
+    ns.MORPH_RECT, ns.MORPH_ELLIPSE, ns.THRESH_BINARY, ns.THRESH_OTSU, ns.CV_16U, ns.COLOR_BGR2GRAY = 0, 2, 0, 8, 2, 6
+
+    def getStructuringElement(shape, ksize, anchor=None):
+        if shape == ns.MORPH_ELLIPSE and tuple(ksize) == (3, 3):
+            return np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
+        return np.ones((ksize[1], ksize[0]), np.uint8)
+
+    def _morph(src, kernel, iterations, dil):
+        out = src
+        for _ in range(iterations):
+            fn = _nd.grey_dilation if dil else _nd.grey_erosion
+            out = fn(out, footprint=np.asarray(kernel, bool), mode="constant", cval=0 if dil else 255)
+        return out
+
+    def threshold(src, thresh, maxval, typ):
+        if typ & ns.THRESH_OTSU:
+            hist = np.bincount(src.reshape(-1), minlength=256).astype(np.float64) / src.size
+            omega = np.cumsum(hist)
+            mu = np.cumsum(hist * np.arange(256))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                sigma = (mu[-1] * omega - mu) ** 2 / (omega * (1 - omega))
+            sigma[~np.isfinite(sigma)] = 0
+            thresh = int(np.argmax(sigma))
+        return thresh, np.where(src > thresh, maxval, 0).astype(np.uint8)
+
+    def connectedComponentsWithStats(img, connectivity, ltype):
+        lab, n = _nd.label(img > 0, structure=np.ones((3, 3)) if connectivity == 8 else None)
+        stats = np.zeros((n + 1, 5), dtype=np.int32)
+        for k in range(n + 1):
+            ys, xs = np.nonzero(lab == k)
+            if len(ys):
+                stats[k] = [xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1, len(ys)]
+        return n + 1, lab.astype(np.uint16), stats, np.zeros((n + 1, 2))
+
+    def cvtColor(src, code):
+        if code == ns.COLOR_BGR2GRAY:
+            t = src.astype(np.int64)
+            return ((t[..., 0] * 1868 + t[..., 1] * 9617 + t[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+        return src[..., ::-1]
+
+    ns.getStructuringElement = getStructuringElement
+    ns.dilate = lambda src, kernel, iterations=1: _morph(src, kernel, iterations, True)
+    ns.erode = lambda src, kernel, iterations=1: _morph(src, kernel, iterations, False)
+    ns.bitwise_xor, ns.bitwise_or = np.bitwise_xor, np.bitwise_or
+    ns.threshold, ns.connectedComponentsWithStats = threshold, connectedComponentsWithStats
+    ns.inRange = lambda src, lo, hi: np.where((src >= lo) & (src <= hi), 255, 0).astype(np.uint8)
     ns.resize, ns.filter2D, ns.copyMakeBorder = resize, filter2D, copyMakeBorder
-    ns.cvtColor = lambda src, code: src[..., ::-1]
+    ns.cvtColor = cvtColor
     ns.findHomography = lambda s, d, *a, **k: (OT.find_homography_4pt(s, d), None)
     ns.warpPerspective = lambda img, M, dsize, **k: OT.warp_perspective_u8(img, M, dsize)
     ns.rotate = lambda img, code: np.ascontiguousarray(np.rot90(img, 1))
@@ -192,6 +241,16 @@ def esrgan():
         m.OfflineUpscaler = type("OfflineUpscaler", (), {})
         sys.modules["manga_translator.upscaling.common"] = m
     return _load("manga_translator.upscaling.esrgan_pytorch", "upscaling/esrgan_pytorch.py")
+
+
+def textmask():
+    """reference module manga_translator/detection/ctd_utils/textmask.py (refine_mask) with the cv2 stand-in."""
+    _prepare()
+    base = "manga_translator.detection.ctd_utils"
+    ip = _load(base + ".utils.imgproc_utils", "detection/ctd_utils/utils/imgproc_utils.py")
+    tm = _load(base + ".textmask", "detection/ctd_utils/textmask.py")
+    ip.cv2 = tm.cv2 = cv2_shim()
+    return tm
 
 
 def shapely_shim():

@@ -99,3 +99,32 @@ def test_bad_input():
         HG.boxes_from_bitmap(np.zeros((2, 3, 4), np.float32), 0.3, 10, 10, unclip_ratio=1.5, min_sside=2)
     b, s = HG.ctd_boxes(np.zeros((1, 2, 16, 16), np.float32), 16, 16)
     assert b.shape == (0, 4, 2) and s.shape == (0,)
+
+
+def test_refine_mask_matches_reference_fixture():
+    """hostglue.refine_mask / enlarge_window vs the reference's own textmask.py executed with the cv2 stand-in
+    (tests/golden/refine_mask.npz): bit-identical uint8 masks in both refine modes."""
+    import os
+
+    from manga_image_translator_amd import textline as TL
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refine_mask.npz"))
+    quads = [TL.Quadrilateral(q) for q in g["quads"]]
+    for mode, key in ((None, "out_none"), (0, "out_inpaint")):
+        got = HG.refine_mask(g["page"], g["pred"].copy(), quads, mode)
+        assert got.dtype == np.uint8 and np.array_equal(got, g[key]), key
+    assert 0 < (g["out_none"] > 0).sum() < (g["out_inpaint"] > 0).sum() < (g["pred"] > 60).sum()
+    assert HG.enlarge_window([10, 10, 50, 30], 320, 384) == [2, 2, 58, 38]  # d^2 + 60 d - 1200 = 0 -> d = 15.8, delta = round(d / 2) = 8
+    assert HG.enlarge_window([0, 5, 40, 25], 320, 384)[0] == 0  # clipped at the page border
+
+
+def test_resize_linear_u8_matches_oracle_and_box_case():
+    from oracle import ctd as OC
+
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, size=(37, 53), dtype=np.uint8)
+    for dsize in ((106, 74), (80, 20), (53, 37), (19, 91)):
+        assert np.array_equal(HG.resize_linear_u8(src, dsize), OC.resize_linear_u8(src[..., None], dsize)[..., 0]), dsize
+    rgb = rng.integers(0, 256, size=(40, 60, 3), dtype=np.uint8)
+    assert np.array_equal(HG.resize_linear_u8(rgb, (30, 20)), OC.resize_linear_u8(rgb, (30, 20)))  # exact 2x: box mean
+    assert np.array_equal(HG.resize_linear_u8(src, (53, 37)), src)
