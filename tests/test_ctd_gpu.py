@@ -66,3 +66,30 @@ def test_ctd_rejects_bad_input(cuda, ctd_setup):
     eng = ctd_setup[3]
     with pytest.raises(ValueError):
         eng.forward(torch.zeros(1, 64, 64, 4, dtype=torch.uint8, device=cuda))
+
+
+def test_ctd_plugin_standalone(cuda):
+    """HipComicTextDetector with no injected callables: GPU network + native host post-processing (boxes, mask resize,
+    refine_mask) returns exactly what composing the engine outputs with the host routines gives, in the reference's types."""
+    import asyncio
+
+    from manga_image_translator_amd import ctd_schema as S, hostglue as HG, plugins as P, synth, textline as TL
+
+    run = lambda c: asyncio.new_event_loop().run_until_complete(c)
+    g = S.CTD_GAIN
+    weights = {"ctd.yolo": synth.synth_state_dict(S.yolo_schema(), gain=g), "ctd.seg": synth.synth_state_dict(S.unet_head_schema(), gain=g),
+               "ctd.det": synth.synth_state_dict(S.db_head_schema(), gain=g)}
+    page = synth.synth_page(4, 512, 384, n_boxes=6)[0]
+    det = P.HipComicTextDetector(weights=weights)
+    run(det.load("cuda"))
+    tls, mask, extra = run(det.infer(page, 1024, 0.5, 0.7, 2.3))
+    assert extra is None and mask.dtype == np.uint8 and mask.shape == (512, 384)
+    m8, lines, _ = det.engine.forward(torch.from_numpy(page[None]).to(cuda))
+    boxes, scores = HG.ctd_boxes(lines.cpu().numpy(), 512, 384)
+    keep = scores > 0.6
+    assert len(tls) == int(keep.sum())
+    for q, pts, s in zip(tls, boxes[keep], scores[keep]):
+        assert np.array_equal(q.pts, TL.Quadrilateral(pts.astype(int)).pts) and q.prob == pytest.approx(float(s))
+    ref_mask = HG.refine_mask(page, HG.resize_linear_u8(m8[0].cpu().numpy(), (384, 512)), tls, None)
+    assert np.array_equal(mask, ref_mask)
+    run(det.unload())
