@@ -19,6 +19,7 @@ Fixtures (all small; each .npz also records the reference file whose code produc
   esrgan.npz       RRDBNet.forward + the tensor part of ESRGANUpscalerPytorch._infer (upscaling/esrgan_pytorch.py:67-75,537-546), nb = 2, 40x56 page
   direction.npz    quadrilateral_can_merge_region + CommonOCR._generate_text_direction (utils/generic.py:653-698, ocr/common.py:12-39)
   refine_mask.npz  refine_mask / merge_mask_list / enlarge_window (detection/ctd_utils/textmask.py:16-174) on a 384x320 page
+  textline_merge.json  the line sets + expected groupings of the reference's test/test_textline_merge.py and the reference code's own output
   textline.npz     sort_pnts / Quadrilateral / get_transformed_region (utils/generic.py:324-481) on 12 quads
 """
 from __future__ import annotations
@@ -311,6 +312,59 @@ def golden_refine_mask():
     print("refine_mask", float((out_none > 0).mean()), float((out_inpaint > 0).mean()), float((pred > 60).mean()))
 
 
+def golden_textline_merge():
+    """The reference's own golden tests for the text-line merge (test/test_textline_merge.py): the line sets and expected
+    groupings are extracted from the test source, and the reference's merge_bboxes_text_region is run on them (shapely
+    stand-in, real networkx) to record what the code itself returns (groups in yield order, colours)."""
+    import ast
+    import importlib.util
+    import json
+
+    src = open(os.path.join(R.REF_ROOT, "test", "test_textline_merge.py")).read()
+    cases = []
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.AsyncFunctionDef) and node.name.startswith("test_merge"):
+            env = {}
+            for st in node.body:
+                if isinstance(st, ast.Assign):
+                    exec(compile(ast.Module([st], []), "<case>", "exec"), {}, env)
+            cases.append(dict(name=node.name, width=env["width"], height=env["height"], lines=env["lines"],
+                              expected=env["expected_combinations"]))
+    G = R.generic()
+    shim = R.shapely_shim()
+    G.Polygon, G.MultiPoint = shim.Polygon, shim.MultiPoint
+    import sys
+    import types
+
+    utils = types.ModuleType("manga_translator.utils")
+    utils.TextBlock = type("TextBlock", (), {})
+    utils.Quadrilateral, utils.quadrilateral_can_merge_region = G.Quadrilateral, G.quadrilateral_can_merge_region
+    saved = sys.modules.get("manga_translator.utils")
+    sys.modules["manga_translator.utils"] = utils
+    try:
+        spec = importlib.util.spec_from_file_location("manga_translator.textline_merge", os.path.join(R.PKG, "textline_merge", "__init__.py"))
+        TM = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(TM)
+    finally:
+        if saved is not None:
+            sys.modules["manga_translator.utils"] = saved
+    TM.Polygon = shim.Polygon
+    rng = np.random.default_rng(5)
+    for c in cases:
+        cols = rng.integers(0, 256, size=(len(c["lines"]), 6))
+        quads = [G.Quadrilateral(np.array(l), "", 1, *[int(v) for v in col]) for l, col in zip(c["lines"], cols)]
+        groups, colors = [], []
+        for txtlns, fg, bg in TM.merge_bboxes_text_region(quads, c["width"], c["height"]):
+            groups.append([next(i for i, q in enumerate(quads) if q is t) for t in txtlns])
+            colors.append([list(map(int, fg)), list(map(int, bg))])
+        c["colors_in"] = cols.tolist()
+        c["ref_groups"], c["ref_colors"] = groups, colors
+        c["ref_passes_own_test"] = sorted(map(sorted, groups)) == sorted(map(sorted, c["expected"]))
+    json.dump(dict(source="test/test_textline_merge.py + manga_translator/textline_merge/__init__.py", cases=cases),
+              open(os.path.join(GOLDEN, "textline_merge.json"), "w"))
+    print("textline_merge", len(cases), [c["ref_passes_own_test"] for c in cases])
+
+
 def build_ref_dbnet():
     from manga_image_translator_amd import dbnet_schema
 
@@ -371,6 +425,7 @@ def main():
     golden_dbnet()
     golden_direction()
     golden_refine_mask()
+    golden_textline_merge()
 
 
 if __name__ == "__main__":

@@ -34,6 +34,18 @@ def test_fixture_regenerates(tmp_path, monkeypatch, gen, files):
                 assert np.array_equal(a, b), (f, k)
 
 
+def test_textline_merge_fixture_regenerates(tmp_path, monkeypatch):
+    """The reference's test vectors + its own merge output, re-extracted from /root/reference, equal the committed JSON."""
+    import json
+    from oracle import make_golden as MG
+
+    monkeypatch.setattr(MG, "GOLDEN", str(tmp_path))
+    MG.golden_textline_merge()
+    new = json.load(open(tmp_path / "textline_merge.json"))
+    old = json.load(open(os.path.join(GOLDEN, "textline_merge.json")))
+    assert new == old and len(new["cases"]) == 11 and all(c["ref_passes_own_test"] for c in new["cases"])
+
+
 def test_schemas_match_reference_modules():
     """Every synthetic state_dict has exactly the reference modules' parameter names and shapes."""
     from manga_image_translator_amd import ctd_schema, lama_schema, ocr_schema
