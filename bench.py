@@ -45,12 +45,13 @@ def parse():
     ap.add_argument("--pages", type=int, default=64, help="pages per GPU per step (BASELINE config 3: 64)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pages generated per rank (cycled)")
     ap.add_argument("--stages", default="detect,ocr,inpaint")
-    ap.add_argument("--lama-mb", type=int, default=8)
+    ap.add_argument("--lama-mb", type=int, default=16)
     ap.add_argument("--ctd-mb", type=int, default=16)
     ap.add_argument("--group", type=int, default=16)
     ap.add_argument("--overlap", action="store_true", help="two streams: detector + OCR beside LaMa (+8 %% pages/s; per-kernel roofline numbers then include the stretch of concurrent kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prof-dump", default="", help="write one CSV line per conv_gemm launch of the instrumented pass to this path")
     ap.add_argument("--probe-pages", type=int, default=0, help="pages in the instrumented pass (0 = a whole step)")
     return ap.parse_args()
 
@@ -71,7 +72,7 @@ def make_inputs(n_pages, distinct, rank, device):
     return pages_t, quad_objs, masks_t, (pages, quads, masks)
 
 
-def roofline_leg(engine, pages, quads, masks, stages, n_probe):
+def roofline_leg(engine, pages, quads, masks, stages, n_probe, dump=""):
     from manga_image_translator_amd import lib as L
 
     lib = L.load()
@@ -83,6 +84,8 @@ def roofline_leg(engine, pages, quads, masks, stages, n_probe):
     stats = (L.MitProfStat * 32)()
     ncfg = C.c_int(0)
     L.check(lib.mit_prof_read(stats, 32, C.byref(ncfg)), "mit_prof_read")
+    if dump:
+        L.check(lib.mit_prof_dump(dump.encode()), "mit_prof_dump")
     L.check(lib.mit_prof_enable(0), "mit_prof_enable")
     per_cfg = {}
     for i in range(ncfg.value):
@@ -192,7 +195,7 @@ def main():
 
     roof = per_cfg = cpu = None
     if not args.no_roofline and rank == 0:
-        roof, per_cfg = roofline_leg(engine, pages, quads, masks, stages, args.probe_pages)
+        roof, per_cfg = roofline_leg(engine, pages, quads, masks, stages, args.probe_pages, args.prof_dump)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline_leg(weights, host_inputs, stages)
     D.barrier()

@@ -139,6 +139,9 @@ typedef struct MitProfStat {
 int mit_prof_enable(int on); /* clears the records; on != 0 starts recording */
 int mit_prof_tag_next(double alg_flops);
 int mit_prof_read(MitProfStat *stats, int max_cfgs, int *n_cfgs);
+/* One CSV line per recorded launch (tile, M, N, K, taps, Z, act, ms, executed / algorithmic FLOPs): the per-layer view behind
+ * bench.py's per-tile totals (scripts/ocr_layers.py).  Call before mit_prof_enable() clears the records. */
+int mit_prof_dump(const char *path);
 
 /* LaMa inpainting stage: memory-bound pieces ----------------------------------------------
  * Reference: manga_translator/inpainting/inpainting_lama_mpe.py. */

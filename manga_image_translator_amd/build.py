@@ -29,6 +29,10 @@ HIPCC_FLAGS = [
 ]
 
 
+if os.environ.get("MIT_CONV_EXPERIMENTS"):  # rejected scheduling variants + timing ablations of the conv kernel (scripts/bench_conv.py)
+    HIPCC_FLAGS.append("-DMIT_CONV_EXPERIMENTS")
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

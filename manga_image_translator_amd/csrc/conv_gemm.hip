@@ -20,6 +20,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "../../include/mit_hip.h"
@@ -34,26 +36,83 @@ struct RowOff {
     int64_t c, pre, post;
 };
 
-__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
-    switch (act) {
-        case MIT_ACT_RELU: return v > 0.f ? v : 0.f;
-        case MIT_ACT_LEAKY: return v > 0.f ? v : v * alpha;
-        case MIT_ACT_SILU: return v / (1.f + expf(-v));
-        case MIT_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        case MIT_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        default: return v;
-    }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in exact arithmetic, <= 6e-7 in f32 near 0 where GELU multiplies it by x/2):
+// GELU through it is within 2.6e-7 absolute of the erff form over the whole range, at a third of the instructions.
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float x = v * 0.70710678118654752440f;
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.f));
+    float q = 1.061405429f;
+    q = __builtin_fmaf(q, t, -1.453152027f);
+    q = __builtin_fmaf(q, t, 1.421413741f);
+    q = __builtin_fmaf(q, t, -0.284496736f);
+    q = __builtin_fmaf(q, t, 0.254829592f);
+    q *= t;
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
+    const float erf_abs = 1.f - q * e;
+    const float hx = 0.5f * v;
+    return hx + hx * copysignf(erf_abs, x);
+}
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v, float alpha) {
+    if (ACT == MIT_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == MIT_ACT_LEAKY) return v > 0.f ? v : v * alpha;
+    if (ACT == MIT_ACT_SILU) return v / (1.f + expf(-v));
+    if (ACT == MIT_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    if (ACT == MIT_ACT_GELU) return gelu_fast(v);
+    return v;
 }
 
 // ---- epilogue shared by both kernels: row offsets computed once per row, shared through LDS ----
-template <int BM, int TM, int TN>
+// The activation (and whether a residual joins) is a compile-time parameter of the store loop and dispatched once per
+// wave: a per-element switch costs more than the stores on the small-K layers.
+template <int TM, int TN, int ACT, bool HAS_POST, int XE>
+__device__ __forceinline__ void epilogue_store(const MitConvGemm &p, f32x16 (&acc)[TM][TN], const RowOff *rowoff, const int n0,
+                                               const int wm0, const int wn0) {
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const bool has_pre = p.pre.base != nullptr;
+    const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;  // residual joins before the activation (ResNet BasicBlock)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + li;
+        if (n >= p.N) continue;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float bi = p.bias ? p.bias[n] : 0.f;
+        int64_t ncol_c = n, ncol_pre = n, ncol_post = n;
+        if (p.c.nsplit) ncol_c = (int64_t)(n / p.c.nsplit) * p.c.nhi + (n % p.c.nsplit);
+        if (has_pre && p.pre.nsplit) ncol_pre = (int64_t)(n / p.pre.nsplit) * p.pre.nhi + (n % p.pre.nsplit);
+        if (HAS_POST && p.post.nsplit) ncol_post = (int64_t)(n / p.post.nsplit) * p.post.nhi + (n % p.post.nsplit);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const RowOff ro = rowoff[row];
+                if (ro.c < 0) continue;
+                float v = acc[mi][ni][r];
+                if (has_pre) v += p.pre.base[ro.pre + ncol_pre];
+                v = v * sc + bi;
+                if (HAS_POST && post_first) v += p.post.base[ro.post + ncol_post];
+                if (!(XE & 2)) v = apply_act<ACT>(v, p.act_alpha);
+                if (HAS_POST && !post_first) v += p.post.base[ro.post + ncol_post];
+                if (XE & 1) {  // timing ablation: results computed but (practically) never stored
+                    if (v == 12345.678f) p.c.base[ro.c + ncol_c] = v;
+                } else {
+                    p.c.base[ro.c + ncol_c] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int TM, int TN, int XE = 0>
 __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM][TN], float *smem, const int M, const int m0,
                                          const int n0, const int wm0, const int wn0, const int z1, const int z0,
                                          const int HoWo) {
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int li = lane & 31;
-    const int lh = lane >> 5;
     RowOff *rowoff = reinterpret_cast<RowOff *>(smem);  // BM entries (<= A/B staging area)
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
@@ -73,37 +132,19 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
     }
     __syncthreads();
 
-    const bool has_pre = p.pre.base != nullptr;
     const bool has_post = p.post.base != nullptr;
-    const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;  // residual joins before the activation (ResNet BasicBlock)
-    const int act = p.act & 0xff;
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int n = n0 + wn0 + ni * 32 + li;
-        if (n >= p.N) continue;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float bi = p.bias ? p.bias[n] : 0.f;
-        int64_t ncol_c = n, ncol_pre = n, ncol_post = n;
-        if (p.c.nsplit) ncol_c = (int64_t)(n / p.c.nsplit) * p.c.nhi + (n % p.c.nsplit);
-        if (has_pre && p.pre.nsplit) ncol_pre = (int64_t)(n / p.pre.nsplit) * p.pre.nhi + (n % p.pre.nsplit);
-        if (has_post && p.post.nsplit) ncol_post = (int64_t)(n / p.post.nsplit) * p.post.nhi + (n % p.post.nsplit);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const RowOff ro = rowoff[row];
-                if (ro.c < 0) continue;
-                float v = acc[mi][ni][r];
-                if (has_pre) v += p.pre.base[ro.pre + ncol_pre];
-                v = v * sc + bi;
-                if (has_post && post_first) v += p.post.base[ro.post + ncol_post];
-                v = apply_act(v, act, p.act_alpha);
-                if (has_post && !post_first) v += p.post.base[ro.post + ncol_post];
-                p.c.base[ro.c + ncol_c] = v;
-            }
-        }
+#define MIT_EPI(A)                                                                           \
+    if (has_post) epilogue_store<TM, TN, A, true, XE>(p, acc, rowoff, n0, wm0, wn0);           \
+    else epilogue_store<TM, TN, A, false, XE>(p, acc, rowoff, n0, wm0, wn0)
+    switch (p.act & 0xff) {
+        case MIT_ACT_RELU: MIT_EPI(MIT_ACT_RELU); break;
+        case MIT_ACT_LEAKY: MIT_EPI(MIT_ACT_LEAKY); break;
+        case MIT_ACT_SILU: MIT_EPI(MIT_ACT_SILU); break;
+        case MIT_ACT_SIGMOID: MIT_EPI(MIT_ACT_SIGMOID); break;
+        case MIT_ACT_GELU: MIT_EPI(MIT_ACT_GELU); break;
+        default: MIT_EPI(MIT_ACT_NONE); break;
     }
+#undef MIT_EPI
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -303,7 +344,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, con
 // generic kernel, so results are bitwise identical to it.
 constexpr int FAST_MAX_TAPS = 16;
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int ROT = 0>
+// VAR bits (scheduling variants, identical arithmetic): 1 = write-after-barrier rotation, 2 = fragment reads of k-step s+1 pinned
+// ahead of the MFMAs of k-step s (sched_barrier), 4 = gather offsets kept in registers while the tap does not change +
+// incremental weight pointer, 8 = raised wave priority while MFMAs issue.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int VAR = 0>
 __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConvGemm p, const int M, const int MT,
                                                                const int NT, const int KT) {
     constexpr int WM = BM / WAVES_M;
@@ -312,6 +356,14 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     constexpr int TN = WN / 32;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     static_assert(TM >= 1 && TN >= 1, "wave tile");
+    constexpr bool ROT = (VAR & 1) != 0;
+    constexpr bool PIPE = (VAR & 2) != 0;
+    constexpr bool CACHE = (VAR & 4) != 0;
+    constexpr bool PRIO = (VAR & 8) != 0;
+    constexpr bool MID = (VAR & 16) != 0;
+    // timing ablations (WRONG results; scripts/bench_conv.py only): skip the in-loop global loads / LDS stores / barrier / fragment reads
+    constexpr bool X_NOA = (VAR & 512) != 0, X_NOB = (VAR & 1024) != 0, X_HOT = (VAR & 2048) != 0;  // skip A / B loads; A rows folded into 64 KB
+    constexpr bool X_NOLOAD = (VAR & 32) != 0, X_NOSTORE = (VAR & 64) != 0, X_NOBAR = (VAR & 128) != 0, X_NOFRAG = (VAR & 256) != 0;  // next tile's LDS stores issued between the MFMAs of k-steps 4..6, not after the last one
     constexpr int KQ = BK / 4;
     constexpr int A_ITERS = BM * KQ / 256;
     constexpr int A_MSTEP = 256 / KQ;
@@ -390,23 +442,37 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
 
     // (tap, ci0) of the tile being loaded: wave-uniform, advanced incrementally
     int ld_tap = 0, ld_ci0 = 0;
+    int a_off[A_ITERS];
+    const float *__restrict__ w_row = w_thr + (int64_t)bk * p.ldw;  // CACHE: row (kt*BK + bk) of this thread's weight column
+    const int64_t w_kstep = (int64_t)B_KSTEP * p.ldw, w_tstep = (int64_t)BK * p.ldw;
     auto load_tile = [&](int kt) {
         const int *rt = rowtab + ld_tap * BM + am;
         const float *ak = a_thr + ld_ci0;
+        if (!CACHE || ld_ci0 == 0) {  // wave-uniform: the row offsets only change with the tap
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) a_off[i] = rt[i * A_MSTEP];
+        }
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            const int off = rt[i * A_MSTEP];
+            const int off = X_HOT ? (a_off[i] & 0x3ffc) : a_off[i];
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (off >= 0) v = *reinterpret_cast<const f32x4 *>(ak + off);
-            a_reg[i] = v;
+            if (!X_NOA) {
+                if (off >= 0) v = *reinterpret_cast<const f32x4 *>(ak + off);
+                a_reg[i] = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
             const int k = kt * BK + bk + i * B_KSTEP;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_ncol_ok && k < p.Kw) v = *reinterpret_cast<const f32x4 *>(w_thr + (int64_t)k * p.ldw);
-            b_reg[i] = v;
+            if (CACHE) {
+                if (b_ncol_ok && k < p.Kw) v = *reinterpret_cast<const f32x4 *>(w_row + i * w_kstep);
+            } else {
+                if (b_ncol_ok && k < p.Kw) v = *reinterpret_cast<const f32x4 *>(w_thr + (int64_t)k * p.ldw);
+            }
+            if (!X_NOB) b_reg[i] = v;
         }
+        if (CACHE) w_row += w_tstep;
         ld_ci0 += BK;
         if (ld_ci0 >= p.Cin) {
             ld_ci0 = 0;
@@ -414,7 +480,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_a = [&](int buf) {
         float *as = As + buf * A_TILE;
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
@@ -422,12 +488,18 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
 #pragma unroll
             for (int j = 0; j < 4; ++j) as[(aq * 4 + j) * LDA + ml] = a_reg[i][j];
         }
+    };
+    auto store_b = [&](int buf) {
         float *bs = Bs + buf * B_TILE;
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
             const int kl = bk + i * B_KSTEP;
             *reinterpret_cast<f32x4 *>(bs + kl * LDB + bn4 * 4) = b_reg[i];
         }
+    };
+    auto store_tile = [&](int buf) {
+        store_a(buf);
+        store_b(buf);
     };
 
     f32x16 acc[TM][TN];
@@ -448,39 +520,63 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (ROT) {  // tile kt+1 (loaded during the previous iteration) -> LDS right after the barrier, then fetch kt+2
-            if (kt + 1 < KT) store_tile(cur ^ 1);
-            if (kt + 2 < KT) load_tile(kt + 2);
-        } else if (kt + 1 < KT) {
-            load_tile(kt + 1);
-        }
         const float *as = As + cur * A_TILE + lh * LDA + wm0 + li;
         const float *bs = Bs + cur * B_TILE + lh * LDB + wn0 + li;
         float af[2][TM], bf[2][TN];
+        if (MID) {  // first fragments on their way while the global loads are being issued
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) af[0][mi] = as[mi * 32];
+            for (int mi = 0; mi < TM; ++mi) af[0][mi] = as[mi * 32];
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf[0][ni] = bs[ni * 32];
+            for (int ni = 0; ni < TN; ++ni) bf[0][ni] = bs[ni * 32];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ROT) {  // tile kt+1 (loaded during the previous iteration) -> LDS right after the barrier, then fetch kt+2
+            if (kt + 1 < KT) store_tile(cur ^ 1);
+            if (kt + 2 < KT) load_tile(kt + 2);
+        } else if (kt + 1 < KT && !X_NOLOAD) {
+            load_tile(kt + 1);
+        }
+        if (!MID) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) af[0][mi] = as[mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) bf[0][ni] = bs[ni * 32];
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int c = ks & 1;
-            if (ks + 1 < BK / 2) {
+            if (ks + 1 < BK / 2 && !X_NOFRAG) {
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) af[c ^ 1][mi] = as[(2 * ks + 2) * LDA + mi * 32];
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) bf[c ^ 1][ni] = bs[(2 * ks + 2) * LDB + ni * 32];
+            } else if (X_NOFRAG) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) af[c ^ 1][mi] = af[c][mi] + 1.f;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bf[c ^ 1][ni] = bf[c][ni];
             }
+            if (PIPE || MID) __builtin_amdgcn_sched_barrier(0);  // the reads above stay ahead of this step's MFMAs
+            if (PRIO) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][mi], bf[c][ni], acc[mi][ni], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            if (PIPE || MID) __builtin_amdgcn_sched_barrier(0);
+            if (MID && !ROT && kt + 1 < KT) {
+                if (ks == BK / 2 - 4) store_a(cur ^ 1);
+                if (ks == BK / 2 - 3) store_b(cur ^ 1);
+                if (ks == BK / 2 - 4 || ks == BK / 2 - 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (!ROT && kt + 1 < KT) store_tile(cur ^ 1);
-        __syncthreads();
+        if (!ROT && !MID && kt + 1 < KT && !X_NOSTORE) store_tile(cur ^ 1);
+        if (!X_NOBAR) __syncthreads();
     }
+    if (X_NOBAR) __syncthreads();
 
-    epilogue<BM, TM, TN>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+    epilogue<BM, TM, TN, (VAR >> 12) & 3>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
 }
 
 struct CfgEntry {
@@ -512,14 +608,14 @@ void launch_cfg(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int ROT = 0>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int VAR = 0>
 void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
     constexpr int LDA = BM + (BK == 16 ? 2 : 1);
     constexpr int LDB = BN + 4;
     size_t staging = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + (size_t)p.ntaps * BM * sizeof(int);
     size_t rows = (size_t)BM * sizeof(RowOff);
     size_t smem = staging > rows ? staging : rows;
-    auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, ROT>;
+    auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, VAR>;
     static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && smem > 64 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -557,6 +653,29 @@ const CfgEntry kCfgs[] = {
     {"fast128x128x16w4r", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 1>, 1},  // 17: 16 with the write-after-barrier rotation
     {"fast128x64x16r", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 1, 1>, 1},       // 18: 9 with the rotation
     {"fast128x128x16w4rb", 128, 128, 16, launch_fast<128, 128, 16, 2, 2, 4, 1>, 1}, // 19: 14 with the rotation
+    {"fast128x128x16w4c", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4>, 1},     // 20: 16 + gather offsets cached per tap (default wide tile)
+    {"fast128x64x16c", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 1, 4>, 1},           // 21: 9 + cached offsets
+    {"fast192x64x16w4c", 192, 64, 16, launch_fast<192, 64, 16, 2, 2, 4, 4>, 1},         // 22: 128 < M <= 192 per batch entry (W-axis DFTs)
+    {"fast256x128x16w2c", 256, 128, 16, launch_fast<256, 128, 16, 2, 2, 2, 4>, 1},      // 23: wave tile 128 x 64, 2 workgroups per CU
+#ifdef MIT_CONV_EXPERIMENTS  // scheduling variants measured and rejected, and timing ablations (WRONG results) — scripts/bench_conv.py
+    {"fast128x128x16w4p", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 2>, 1},       // 24: pinned fragment prefetch
+    {"fast128x128x16w4pc", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 6>, 1},      // 25
+    {"fast128x128x16w4pcs", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 14>, 1},    // 26: + setprio
+    {"fast128x128x16w4m", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 20>, 1},      // 27: mid-loop LDS stores
+    {"fast128x64x16pc", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 1, 6>, 1},           // 28
+    {"fast128x256x16w2c", 128, 256, 16, launch_fast<128, 256, 16, 1, 4, 2, 4>, 1},       // 29
+    {"xNoA", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 512>, 1},              // 30
+    {"xNoB", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 1024>, 1},             // 31
+    {"xHotA", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 2048>, 1},            // 32
+    {"xNoLoad", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 32>, 1},            // 33
+    {"xNoLoadStore", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 32 + 64>, 1},  // 34
+    {"xNoBar", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 128>, 1},            // 35
+    {"xNoFrag", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 256>, 1},           // 36
+    {"xMfmaOnly", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 32 + 64 + 128 + 256>, 1},  // 37
+    {"xeNoStoreW", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 4096>, 1},       // 38
+    {"xeNoActW", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 8192>, 1},         // 39
+    {"xeNoStoreN", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 1, 4 + 4096>, 1},         // 40
+#endif
 };
 
 // fast kernel preconditions: whole K-tiles inside one tap, table fits, 32-bit element offsets
@@ -575,13 +694,25 @@ bool fast_eligible(const MitConvGemm &p, int BK) {
 }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
+int env_cfg(const char *name, int dflt) {  // tuning knob for scripts/: replaces a default fast tile by another fast tile
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    const int c = atoi(v);
+    return (c >= 0 && c < kNumCfgs && kCfgs[c].fast && kCfgs[c].BK == 16) ? c : dflt;  // dflt may be -1 (rule off)
+}
+
 int pick_cfg(const MitConvGemm &p, int64_t M) {
     // measured on MI355X (scripts/bench_conv.py)
+    static const int wide = env_cfg("MIT_CONV_TILE_WIDE", 20), narrow = env_cfg("MIT_CONV_TILE_NARROW", 9);
+    static const int m192 = env_cfg("MIT_CONV_TILE_M192", 22), bigk = env_cfg("MIT_CONV_TILE_BIGK", -1);
+    static const int narrow_max = getenv("MIT_CONV_NARROW_MAX") ? atoi(getenv("MIT_CONV_NARROW_MAX")) : 64;
     const bool f16 = fast_eligible(p, 16);
     if (p.N <= 32) return 2;
+    if (f16 && m192 >= 0 && M > 128 && M <= 192) return m192;  // 2 x 128 rows would run a 40 % empty second tile
+    if (f16 && bigk >= 0 && p.N % 128 == 0 && p.N <= 128 && p.ntaps * p.Cin >= 4096 && M >= 256 * 1024) return bigk;
     const int rem = p.N % 128;
-    if (p.N <= 64 || (rem != 0 && rem <= 64)) return f16 ? 9 : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
-    return f16 ? 16 : 0;  // 4 waves of 128 x 32, <= 128 registers: 4 workgroups per CU (+3-7 % over the 2 x 2 layout)
+    if (p.N <= 64 || (rem != 0 && rem <= narrow_max)) return f16 ? narrow : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
+    return f16 ? wide : 0;  // 4 waves of 128 x 32, <= 128 registers: 4 workgroups per CU (+3-7 % over the 2 x 2 layout)
 }
 
 // ---- kernel-time probe (mit_prof_*): HIP events around every launch while enabled ----
@@ -589,6 +720,7 @@ struct ProbeRec {
     hipEvent_t start, stop;
     int cfg;
     double exec_flops, alg_flops;
+    int M, N, K, ntaps, Z, act;
 };
 std::mutex g_probe_mu;
 bool g_probe_on = false;
@@ -610,6 +742,25 @@ extern "C" int mit_prof_enable(int on) {
 
 extern "C" int mit_prof_tag_next(double alg_flops) {
     g_next_alg_flops = alg_flops;
+    return 0;
+}
+
+extern "C" int mit_prof_dump(const char *path) {
+    if (!path) return mit_set_error("mit_prof_dump: null path");
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    FILE *f = fopen(path, "w");
+    if (!f) return mit_set_error("mit_prof_dump: cannot open %s", path);
+    fprintf(f, "tile,M,N,K,taps,Z,act,ms,exec_flops,alg_flops\n");
+    for (auto &r : g_probe) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) {
+            fclose(f);
+            return mit_set_error("mit_prof_dump: event query failed");
+        }
+        fprintf(f, "%s,%d,%d,%d,%d,%d,%d,%.6f,%.0f,%.0f\n", kCfgs[r.cfg].name, r.M, r.N, r.K, r.ntaps, r.Z, r.act, ms, r.exec_flops,
+                r.alg_flops);
+    }
+    fclose(f);
     return 0;
 }
 
@@ -688,6 +839,7 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
         r.cfg = cfg;
         r.exec_flops = 2.0 * (double)M * p.N * Ktot * p.Z;
         r.alg_flops = tagged >= 0.0 ? tagged : r.exec_flops;
+        r.M = M, r.N = p.N, r.K = Ktot, r.ntaps = p.ntaps, r.Z = p.Z, r.act = p.act;
         MIT_CHECK_HIP(hipEventRecord(r.start, hs));
         c.launch(p, M, MT, NT, KT, hs);
         MIT_CHECK_HIP(hipEventRecord(r.stop, hs));

@@ -130,6 +130,7 @@ SYMBOLS = {
     "mit_prof_enable": (C.c_int, [C.c_int]),
     "mit_prof_tag_next": (C.c_int, [C.c_double]),
     "mit_prof_read": (C.c_int, [C.POINTER(MitProfStat), C.c_int, C.POINTER(C.c_int)]),
+    "mit_prof_dump": (C.c_int, [C.c_char_p]),
     "mit_ocr_warp_lines": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                      C.c_void_p]),
     "mit_fft_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,

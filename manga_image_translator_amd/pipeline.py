@@ -64,7 +64,7 @@ class PageEngine:
     """Owns the three stage engines of one GPU."""
 
     def __init__(self, weights: Dict[str, Dict[str, torch.Tensor]], device="cuda", lama_blocks: int = 9,
-                 dict_size: int = DICT_SIZE, ctd_mb: int = 16, lama_mb: int = 8, group: int = 16, overlap: bool = False):
+                 dict_size: int = DICT_SIZE, ctd_mb: int = 16, lama_mb: int = 16, group: int = 16, overlap: bool = False):
         self.device = torch.device(device)
         self.ctd = ctd.CtdEngine(weights["ctd.yolo"], weights["ctd.seg"], weights["ctd.det"], device=self.device)
         self.ocr = ocr48.Ocr48Engine(weights["ocr48"], dict_size, device=self.device)

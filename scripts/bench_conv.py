@@ -9,8 +9,8 @@ from manga_image_translator_amd import ops, lib
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", "4"))
-WIDE = [int(c) for c in os.environ.get('WIDE', '7,14,15,16').split(',')]
-NARROW = [int(c) for c in os.environ.get('NARROW', '9,7,14').split(',')]
+WIDE = [int(c) for c in os.environ.get('WIDE', '16,20,23').split(',')]
+NARROW = [int(c) for c in os.environ.get('NARROW', '9,21').split(',')]
 SHAPES = [
     # name, Cin, Cout, H, W, k, s, p, mode, batch, cfgs
     ("lama fused 512->128 3x3", 512, 128, 256, 182, 3, 1, 1, ops.PAD_REFLECT, B, WIDE),
@@ -26,6 +26,8 @@ SHAPES = [
     ("ocr grp pw2 640->160 (300k rows)", 640, 160, 300, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr grp pw1 160->640 (722k rows)", 160, 640, 705, 1024, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
     ("ocr grp pw2 640->160 (722k rows)", 640, 160, 705, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
+    ("ocr grp pw1 320->1280 (360k rows)", 320, 1280, 352, 1024, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
+    ("ocr grp pw2 1280->320 (360k rows)", 1280, 320, 352, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr pw1 320->1280 (16x6x128)", 320, 1280, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
     ("ocr pw2 1280->320 (16x6x128)", 1280, 320, 96, 128, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr pw1 160->640 (16x12x128)", 160, 640, 192, 128, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
@@ -44,6 +46,10 @@ for name, Cin, Cout, H, W, k, s, p, mode, b, cfgs in SHAPES:
     w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
     layer = ops.Conv2d(w, None, stride=s, padding=p, pad_mode=mode, act=ACT, device=dev)
     x = torch.randn(b, H, W, layer.Cin, device=dev)
+    if os.environ.get('ZERO'):
+        x.zero_()
+    if os.environ.get('RELU'):
+        x.relu_()
     Ho, Wo = layer.out_hw(H, W)
     flops = 2.0 * b * Ho * Wo * Cout * Cin * k * k
     ref = None
