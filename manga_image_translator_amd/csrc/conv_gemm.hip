@@ -361,6 +361,10 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     constexpr bool CACHE = (VAR & 4) != 0;
     constexpr bool PRIO = (VAR & 8) != 0;
     constexpr bool MID = (VAR & 16) != 0;
+    // 16384: A fetched in full 128-byte lines — 8 lanes x 16 B per row, i.e. the 16-channel slices of TWO consecutive K-tiles in one
+    // load (8 rows x 128 B per wave instruction instead of 16 rows x 64 B); needs Cin % 32 == 0.  Each half goes to LDS in its own K-tile.
+    constexpr bool A2 = (VAR & 16384) != 0;
+    constexpr int A2_ITERS = BM / 32;
     // timing ablations (WRONG results; scripts/bench_conv.py only): skip the in-loop global loads / LDS stores / barrier / fragment reads
     constexpr bool X_NOA = (VAR & 512) != 0, X_NOB = (VAR & 1024) != 0, X_HOT = (VAR & 2048) != 0;  // skip A / B loads; A rows folded into 64 KB
     constexpr bool X_NOLOAD = (VAR & 32) != 0, X_NOSTORE = (VAR & 64) != 0, X_NOBAR = (VAR & 128) != 0, X_NOFRAG = (VAR & 256) != 0;  // next tile's LDS stores issued between the MFMAs of k-steps 4..6, not after the last one
@@ -443,17 +447,49 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     // (tap, ci0) of the tile being loaded: wave-uniform, advanced incrementally
     int ld_tap = 0, ld_ci0 = 0;
     int a_off[A_ITERS];
+    const int aq8 = tid & 7, am8 = tid >> 3;
+    f32x4 a2_reg[A2 ? A2_ITERS : 1];
+    int a2_off[A2 ? A2_ITERS : 1];
+    auto load_a2 = [&]() {  // K-tiles (2j, 2j + 1): channels ld_ci0 .. ld_ci0 + 31 of tap ld_tap
+        if (ld_ci0 == 0) {
+            const int *rt = rowtab + ld_tap * BM + am8;
+#pragma unroll
+            for (int i = 0; i < A2_ITERS; ++i) a2_off[i] = rt[i * 32];
+        }
+        const float *ak = a_base + ld_ci0 + aq8 * 4;
+#pragma unroll
+        for (int i = 0; i < A2_ITERS; ++i) {
+            const int off = a2_off[i];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (off >= 0) v = *reinterpret_cast<const f32x4 *>(ak + off);
+            a2_reg[i] = v;
+        }
+        ld_ci0 += 2 * BK;
+        if (ld_ci0 >= p.Cin) {
+            ld_ci0 = 0;
+            ++ld_tap;
+        }
+    };
+    auto store_a2 = [&](int buf, int par) {  // the lanes holding K-tile parity `par` of the pair
+        if ((aq8 >> 2) == par) {
+            float *as = As + buf * A_TILE + ((aq8 & 3) * 4) * LDA + am8;
+#pragma unroll
+            for (int i = 0; i < A2_ITERS; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) as[j * LDA + i * 32] = a2_reg[i][j];
+        }
+    };
     const float *__restrict__ w_row = w_thr + (int64_t)bk * p.ldw;  // CACHE: row (kt*BK + bk) of this thread's weight column
     const int64_t w_kstep = (int64_t)B_KSTEP * p.ldw, w_tstep = (int64_t)BK * p.ldw;
     auto load_tile = [&](int kt) {
         const int *rt = rowtab + ld_tap * BM + am;
         const float *ak = a_thr + ld_ci0;
-        if (!CACHE || ld_ci0 == 0) {  // wave-uniform: the row offsets only change with the tap
+        if (!A2 && (!CACHE || ld_ci0 == 0)) {  // wave-uniform: the row offsets only change with the tap
 #pragma unroll
             for (int i = 0; i < A_ITERS; ++i) a_off[i] = rt[i * A_MSTEP];
         }
 #pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) {
+        for (int i = 0; i < (A2 ? 0 : A_ITERS); ++i) {
             const int off = X_HOT ? (a_off[i] & 0x3ffc) : a_off[i];
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (!X_NOA) {
@@ -473,10 +509,12 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
             if (!X_NOB) b_reg[i] = v;
         }
         if (CACHE) w_row += w_tstep;
-        ld_ci0 += BK;
-        if (ld_ci0 >= p.Cin) {
-            ld_ci0 = 0;
-            ++ld_tap;
+        if (!A2) {
+            ld_ci0 += BK;
+            if (ld_ci0 >= p.Cin) {
+                ld_ci0 = 0;
+                ++ld_tap;
+            }
         }
     };
 
@@ -498,7 +536,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
         }
     };
     auto store_tile = [&](int buf) {
-        store_a(buf);
+        if (!A2) store_a(buf);
         store_b(buf);
     };
 
@@ -513,7 +551,9 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     const int wm0 = (wave / WAVES_N) * WM;
     const int wn0 = (wave % WAVES_N) * WN;
 
+    if (A2) load_a2();
     load_tile(0);
+    if (A2) store_a2(0, 0);
     store_tile(0);
     if (ROT && KT > 1) load_tile(1);  // stays in registers across the barrier
     __syncthreads();
@@ -534,6 +574,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
             if (kt + 1 < KT) store_tile(cur ^ 1);
             if (kt + 2 < KT) load_tile(kt + 2);
         } else if (kt + 1 < KT && !X_NOLOAD) {
+            if (A2 && (kt & 1)) load_a2();  // both halves of the previous pair are in LDS by now
             load_tile(kt + 1);
         }
         if (!MID) {
@@ -571,7 +612,10 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
                 if (ks == BK / 2 - 4 || ks == BK / 2 - 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (!ROT && !MID && kt + 1 < KT && !X_NOSTORE) store_tile(cur ^ 1);
+        if (!ROT && !MID && kt + 1 < KT && !X_NOSTORE) {
+            if (A2) store_a2(cur ^ 1, (kt + 1) & 1);
+            store_tile(cur ^ 1);
+        }
         if (!X_NOBAR) __syncthreads();
     }
     if (X_NOBAR) __syncthreads();
@@ -583,7 +627,7 @@ struct CfgEntry {
     const char *name;
     int BM, BN, BK;
     void (*launch)(const MitConvGemm &, int M, int MT, int NT, int KT, hipStream_t);
-    int fast;  // 1: conv_gemm_fast_kernel (needs fast_eligible())
+    int fast;  // 1: conv_gemm_fast_kernel (needs fast_eligible()); 2: and Cin % 32 == 0
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -658,6 +702,8 @@ const CfgEntry kCfgs[] = {
     {"fast192x64x16w4c", 192, 64, 16, launch_fast<192, 64, 16, 2, 2, 4, 4>, 1},         // 22: 128 < M <= 192 per batch entry (W-axis DFTs)
     {"fast256x128x16w2c", 256, 128, 16, launch_fast<256, 128, 16, 2, 2, 2, 4>, 1},      // 23: wave tile 128 x 64, 2 workgroups per CU
 #ifdef MIT_CONV_EXPERIMENTS  // scheduling variants measured and rejected, and timing ablations (WRONG results) — scripts/bench_conv.py
+    {"fast128x128x16w4L", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 16384>, 2},  // 24: 20 with A fetched in full 128-B lines (Cin % 32 == 0)
+    {"fast128x64x16L", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 1, 4 + 16384>, 2},       // 25: 21 likewise
     {"fast128x128x16w4p", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 2>, 1},       // 24: pinned fragment prefetch
     {"fast128x128x16w4pc", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 6>, 1},      // 25
     {"fast128x128x16w4pcs", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 14>, 1},    // 26: + setprio
@@ -705,14 +751,16 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     // measured on MI355X (scripts/bench_conv.py)
     static const int wide = env_cfg("MIT_CONV_TILE_WIDE", 20), narrow = env_cfg("MIT_CONV_TILE_NARROW", 9);
     static const int m192 = env_cfg("MIT_CONV_TILE_M192", 22), bigk = env_cfg("MIT_CONV_TILE_BIGK", -1);
+    static const int wide_l = env_cfg("MIT_CONV_TILE_WIDE_L", -1), narrow_l = env_cfg("MIT_CONV_TILE_NARROW_L", -1);  // experiments: Cin % 32 == 0
     static const int narrow_max = getenv("MIT_CONV_NARROW_MAX") ? atoi(getenv("MIT_CONV_NARROW_MAX")) : 64;
     const bool f16 = fast_eligible(p, 16);
     if (p.N <= 32) return 2;
     if (f16 && m192 >= 0 && M > 128 && M <= 192) return m192;  // 2 x 128 rows would run a 40 % empty second tile
     if (f16 && bigk >= 0 && p.N % 128 == 0 && p.N <= 128 && p.ntaps * p.Cin >= 4096 && M >= 256 * 1024) return bigk;
     const int rem = p.N % 128;
-    if (p.N <= 64 || (rem != 0 && rem <= narrow_max)) return f16 ? narrow : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
-    return f16 ? wide : 0;  // 4 waves of 128 x 32, <= 128 registers: 4 workgroups per CU (+3-7 % over the 2 x 2 layout)
+    const bool lines = f16 && p.Cin % 32 == 0;
+    if (p.N <= 64 || (rem != 0 && rem <= narrow_max)) return f16 ? (lines && narrow_l >= 0 ? narrow_l : narrow) : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
+    return f16 ? (lines && wide_l >= 0 ? wide_l : wide) : 0;  // 4 waves of 128 x 32, <= 128 registers: 4 workgroups per CU (+3-7 % over the 2 x 2 layout)
 }
 
 // ---- kernel-time probe (mit_prof_*): HIP events around every launch while enabled ----
@@ -820,6 +868,7 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     if (cfg < 0) cfg = pick_cfg(p, M64);
     if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
     const CfgEntry &c = kCfgs[cfg];
+    if (c.fast == 2 && (p.Cin % 32)) return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% 32 == 0", c.name);
     if (c.fast && !fast_eligible(p, c.BK))
         return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% %d == 0, <= %d taps and 32-bit element offsets", c.name, c.BK, FAST_MAX_TAPS);
     const int M = (int)M64;

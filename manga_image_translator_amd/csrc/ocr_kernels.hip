@@ -336,14 +336,150 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
         sum += e;
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    __syncthreads();
     const float inv = 1.0f / sum;
+    for (int t = lane; t < Tk; t += 64) ws[t] *= inv;
+    __syncthreads();
     const float *vb = V + (int64_t)kr * v_rs + h * HD;
     float *ob = O + (int64_t)r * o_rs + (int64_t)tq * o_ts + h * HD;
+    constexpr int U = 8;  // values of V in flight per lane; the sum itself stays t-ordered
     for (int d = lane; d < HD; d += 64) {
         float acc = 0.f;
-        for (int t = 0; t < valid; ++t) acc += (ws[t] * inv) * vb[(int64_t)t * v_ts + d];
+        for (int t0 = 0; t0 < valid; t0 += U) {
+            float vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) vv[u] = (t0 + u < valid) ? vb[(int64_t)(t0 + u) * v_ts + d] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (t0 + u < valid) acc += ws[t0 + u] * vv[u];
+        }
         ob[d] = acc;
+    }
+}
+
+// ---- the same attention for ONE query position of G = kv_div consecutive rows that share a K / V block (the beams of a line
+// in cross-attention): one workgroup per (head, K/V block) stages the keys through LDS once instead of once per beam.
+// Per (query, key) dot products, the lane-strided softmax sums and the t-ordered weighted sum are evaluated in exactly the
+// order of attention_kernel, so both give bitwise identical results.
+constexpr int ATT_G_MAX = 8;
+constexpr int ATT_KCHUNK = 64;
+constexpr int ATT_THREADS = 256;
+constexpr int ATT_STAGE = 8;  // float4 loads per thread per chunk: head_dim <= 128
+
+// chunk [nk keys x HD] of one head, global -> registers (coalesced: consecutive threads walk a key row)
+__device__ __forceinline__ void att_chunk_load(float4 (&reg)[ATT_STAGE], const float *base, int64_t ts, int t0, int nk, int HD4, int tid) {
+#pragma unroll
+    for (int j = 0; j < ATT_STAGE; ++j) {
+        const int i = tid + j * ATT_THREADS;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i < nk * HD4) {
+            const int t = i / HD4, d4 = i - t * HD4;
+            v = *reinterpret_cast<const float4 *>(base + (int64_t)(t0 + t) * ts + d4 * 4);
+        }
+        reg[j] = v;
+    }
+}
+
+__device__ __forceinline__ void att_chunk_store(const float4 (&reg)[ATT_STAGE], float *ks, int nk, int HD4, int KP, int tid) {
+#pragma unroll
+    for (int j = 0; j < ATT_STAGE; ++j) {
+        const int i = tid + j * ATT_THREADS;
+        if (i < nk * HD4) {
+            const int t = i / HD4, d4 = i - t * HD4;
+            float *dst = ks + t * KP + d4 * 4;
+            dst[0] = reg[j].x, dst[1] = reg[j].y, dst[2] = reg[j].z, dst[3] = reg[j].w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const float *__restrict__ Q, int64_t q_rs,
+                                                                          const float *__restrict__ K, int64_t k_rs, int64_t k_ts,
+                                                                          const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
+                                                                          float *__restrict__ O, int64_t o_rs,
+                                                                          const int *__restrict__ klen, int Tk, int G, int HD) {
+    extern __shared__ float lds[];
+    const int KP = HD + 1;                    // odd pitch: lane t reads row t conflict-free
+    float *qs = lds;                          // [G][HD]
+    float *ks = qs + G * HD;                  // [ATT_KCHUNK][KP]   keys, then values
+    float *ws = ks + ATT_KCHUNK * KP;         // [G][Tk]
+    const int h = blockIdx.x, kr = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = kr * G;
+    for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = Q[(int64_t)(r0 + i / HD) * q_rs + h * HD + (i % HD)];
+    const int valid = klen ? min(klen[kr], Tk) : Tk;
+    const int HD4 = HD / 4;
+    float4 stage[ATT_STAGE];
+
+    // ---- pass 1: scores.  The next chunk's keys travel to registers while this chunk's dot products run.
+    const float *kb = K + (int64_t)kr * k_rs + h * HD;
+    att_chunk_load(stage, kb, k_ts, 0, min(ATT_KCHUNK, valid), HD4, tid);
+    for (int t0 = 0; t0 < Tk; t0 += ATT_KCHUNK) {
+        const int nk = max(0, min(ATT_KCHUNK, valid - t0));
+        __syncthreads();  // previous chunk consumed (and qs visible)
+        att_chunk_store(stage, ks, nk, HD4, KP, tid);
+        __syncthreads();
+        if (t0 + ATT_KCHUNK < valid) att_chunk_load(stage, kb, k_ts, t0 + ATT_KCHUNK, min(ATT_KCHUNK, valid - t0 - ATT_KCHUNK), HD4, tid);
+        const int t = t0 + lane;
+        if (t < Tk) {
+            const float *kp = ks + lane * KP;
+            for (int g = wave; g < G; g += ATT_THREADS / 64) {
+                float dot = -INFINITY;
+                if (t < valid) {
+                    const float *qp = qs + g * HD;
+                    dot = 0.f;
+                    for (int d = 0; d < HD; ++d) dot += qp[d] * kp[d];
+                }
+                ws[(int64_t)g * Tk + t] = dot;
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = wave; g < G; g += ATT_THREADS / 64) {  // softmax: one wave per query, lanes strided over the keys
+        float *w = ws + (int64_t)g * Tk;
+        float mx = -INFINITY;
+        for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, w[t]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int t = lane; t < Tk; t += 64) {
+            const float e = expf(w[t] - mx);
+            w[t] = e;
+            sum += e;
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float iv = 1.0f / sum;
+        for (int t = lane; t < Tk; t += 64) w[t] *= iv;  // the (weight * 1/sum) factor of the weighted sum, formed once
+    }
+
+    // ---- pass 2: weighted sum of the values, t-ordered per (query, d); thread (d, half) owns the queries g = half, half + 2, ...
+    const float *vb = V + (int64_t)kr * v_rs + h * HD;
+    const int d = tid % HD, half = tid / HD;
+    const bool owner = half < 2;
+    float acc[ATT_G_MAX / 2];
+#pragma unroll
+    for (int j = 0; j < ATT_G_MAX / 2; ++j) acc[j] = 0.f;
+    att_chunk_load(stage, vb, v_ts, 0, min(ATT_KCHUNK, valid), HD4, tid);
+    for (int t0 = 0; t0 < valid; t0 += ATT_KCHUNK) {
+        const int nk = min(ATT_KCHUNK, valid - t0);
+        __syncthreads();  // previous chunk consumed (and the softmax weights visible)
+        att_chunk_store(stage, ks, nk, HD4, KP, tid);
+        __syncthreads();
+        if (t0 + ATT_KCHUNK < valid) att_chunk_load(stage, vb, v_ts, t0 + ATT_KCHUNK, min(ATT_KCHUNK, valid - t0 - ATT_KCHUNK), HD4, tid);
+        if (owner) {
+            for (int t = 0; t < nk; ++t) {
+                const float v = ks[t * KP + d];
+#pragma unroll
+                for (int j = 0; j < ATT_G_MAX / 2; ++j) {
+                    const int g = half + 2 * j;
+                    if (g < G) acc[j] += ws[(int64_t)g * Tk + t0 + t] * v;
+                }
+            }
+        }
+    }
+    if (owner) {
+#pragma unroll
+        for (int j = 0; j < ATT_G_MAX / 2; ++j) {
+            const int g = half + 2 * j;
+            if (g < G) O[(int64_t)(r0 + g) * o_rs + h * HD + d] = acc[j];
+        }
     }
 }
 
@@ -553,6 +689,15 @@ void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out,
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
                     int kv_div, hipStream_t s, int heads, int head_dim) {
+    if (Tq == 1 && kv_div > 1 && kv_div <= ATT_G_MAX && R % kv_div == 0 && R / kv_div <= 65535 && 2 * head_dim <= ATT_THREADS &&
+        ATT_KCHUNK * (head_dim / 4) <= ATT_STAGE * ATT_THREADS) {
+        const size_t sm = ((size_t)kv_div * head_dim + (size_t)ATT_KCHUNK * (head_dim + 1) + (size_t)kv_div * Tk) * sizeof(float);
+        if (sm <= 64 * 1024) {
+            hipLaunchKernelGGL(attention_shared_kv_kernel, dim3(heads, R / kv_div), dim3(ATT_THREADS), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts,
+                               O, o_rs, klen, Tk, kv_div, head_dim);
+            return;
+        }
+    }
     const size_t smem = ((size_t)head_dim + (size_t)Tk) * sizeof(float);
     hipLaunchKernelGGL(attention_kernel, dim3(Tq, heads, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
                        o_ts, klen, Tk, kv_div, head_dim);

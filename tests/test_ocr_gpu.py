@@ -132,3 +132,37 @@ def test_group_encode_equals_per_chunk(cuda, ocr_setup):
         assert torch.equal(gk[:, l0:l0 + n, :L], mk) and torch.equal(gv[:, l0:l0 + n, :L], mv)
         assert not gk[:, l0:l0 + n, L:].any() and not gv[:, l0:l0 + n, L:].any()  # zero padding up to Lmax
         l0 += n
+
+
+@pytest.mark.parametrize("G,Tk,heads,hd", [(5, 70, 4, 80), (5, 200, 4, 80), (3, 64, 8, 40), (8, 129, 2, 16)])
+def test_shared_kv_attention_bitwise_equals_per_row(cuda, G, Tk, heads, hd):
+    """The beams of a line share the K / V block (kv_div = beams): the shared-K/V kernel must give bit for bit what the
+    one-wave-per-row kernel gives on the same K / V repeated per row, and match a float64 softmax(q k^T) v."""
+    import ctypes as C
+
+    from manga_image_translator_amd import lib as L, ops
+
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    NL, E = 7, heads * hd
+    q = torch.randn(NL * G, E, generator=g).to(cuda)
+    k = torch.randn(NL, Tk, E, generator=g).to(cuda)
+    v = torch.randn(NL, Tk, E, generator=g).to(cuda)
+    klen = torch.tensor([Tk, 1, Tk // 2, Tk - 1, 3, Tk, 17][:NL], dtype=torch.int32, device=cuda)
+    out_a, out_b = torch.zeros_like(q), torch.zeros_like(q)
+    st = C.c_void_p(ops.current_stream())
+    L.check(lib.mit_attention_heads(q.data_ptr(), E, E, k.data_ptr(), Tk * E, E, v.data_ptr(), Tk * E, E, out_a.data_ptr(), E, E,
+                                    klen.data_ptr(), NL * G, 1, Tk, G, heads, hd, st), "shared")
+    kr, vr = k.repeat_interleave(G, 0).contiguous(), v.repeat_interleave(G, 0).contiguous()
+    klr = klen.repeat_interleave(G).contiguous()
+    L.check(lib.mit_attention_heads(q.data_ptr(), E, E, kr.data_ptr(), Tk * E, E, vr.data_ptr(), Tk * E, E, out_b.data_ptr(), E, E,
+                                    klr.data_ptr(), NL * G, 1, Tk, 1, heads, hd, st), "per-row")
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    qd = q.double().cpu().view(NL, G, heads, hd)
+    kd, vd = k.double().cpu().view(NL, Tk, heads, hd), v.double().cpu().view(NL, Tk, heads, hd)
+    sc = torch.einsum("nghd,nthd->nght", qd, kd)
+    mask = torch.arange(Tk)[None, :] >= klen.cpu()[:, None]
+    sc = sc.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = torch.einsum("nght,nthd->nghd", sc.softmax(-1), vd).reshape(NL * G, E)
+    assert (out_a.double().cpu() - ref).abs().max() < 2e-5
