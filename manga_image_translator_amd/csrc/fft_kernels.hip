@@ -18,7 +18,48 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int CT = 32;     // columns per workgroup
-constexpr int TG = 8;      // thread groups (rows in flight) per column: 256 threads = 32 x 8
+
+template <int S>
+__device__ __forceinline__ void fft_pass(float *re, float *im, const float2 *tws, const int h, const int s0, const int inverse) {
+    constexpr int P = 1 << S;
+    const int nb = h >> 1;
+    const int ntask = (h >> S) * CT;
+    for (int task = threadIdx.x; task < ntask; task += 256) {
+        const int col = task & (CT - 1), grp = task / CT;
+        const int lo = grp & ((1 << s0) - 1), hi = grp >> s0;
+        const int base = (hi << (s0 + S)) | lo;  // row of member m: base | (m << s0)
+        float xr[P], xi[P];
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            xr[m] = re[(base | (m << s0)) * CT + col];
+            xi[m] = im[(base | (m << s0)) * CT + col];
+        }
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const int s = s0 + t;
+            const int tstep = nb >> s;  // twiddle index stride: k * h / (2 * half), half = 1 << s
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                if (m & (1 << t)) continue;
+                const int m1 = m | (1 << t);
+                const int k = ((m & ((1 << t) - 1)) << s0) | lo;  // row(m) & (half - 1)
+                const float2 w = tws[k * tstep];  // (cos, sin) of 2 pi k tstep / h
+                const float wr = w.x, wi = inverse ? w.y : -w.y;
+                const float tr = xr[m1] * wr - xi[m1] * wi, ti = xr[m1] * wi + xi[m1] * wr;
+                const float ur = xr[m], ui = xi[m];
+                xr[m] = ur + tr;
+                xi[m] = ui + ti;
+                xr[m1] = ur - tr;
+                xi[m1] = ui - ti;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            re[(base | (m << s0)) * CT + col] = xr[m];
+            im[(base | (m << s0)) * CT + col] = xi[m];
+        }
+    }
+}
 
 template <int ROWS>  // rows per thread in the load / store passes = h / 32
 __global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__ in, int64_t in_bs, int64_t in_ts, int64_t in_hs,
@@ -67,26 +108,24 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__
         }
     }
     __syncthreads();
-    // ---- butterflies: thread (col, g); the 32 lanes of a half-wave sit on 32 consecutive banks ----
-    const int col = threadIdx.x & (CT - 1), g = threadIdx.x / CT;
-    const int nb = h >> 1;
-    for (int s = 0; s < logh; ++s) {
-        const int half = 1 << s;
-        const int tstep = nb >> s;  // twiddle index stride: k * h / (2 * half)
-        for (int j = g; j < nb; j += TG) {
-            const int k = j & (half - 1);
-            const int i0 = ((j >> s) << (s + 1)) + k, i1 = i0 + half;
-            const float2 w = tws[k * tstep];  // (cos, sin) of 2 pi k tstep / h
-            const float wr = w.x, wi = inverse ? w.y : -w.y;
-            const float xr = re[i1 * CT + col], xi = im[i1 * CT + col];
-            const float tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-            const float ur = re[i0 * CT + col], ui = im[i0 * CT + col];
-            re[i0 * CT + col] = ur + tr;
-            im[i0 * CT + col] = ui + ti;
-            re[i1 * CT + col] = ur - tr;
-            im[i1 * CT + col] = ui - ti;
+    // ---- butterflies: the radix-2 decimation-in-time graph, S stages at a time in registers.  Stages s0 .. s0+S-1 only mix
+    // the 2^S rows that differ in bits [s0, s0+S) of the row index, so one thread owns such a set for one column and the LDS
+    // round trips drop from logh to ceil(logh / 4).  Every butterfly evaluates the same expression with the same twiddle as
+    // the stage-at-a-time form, so the results are bit-identical to it.
+    {
+        const int npass = (logh + 3) >> 2;
+        int s0 = 0;
+        for (int ps = 0; ps < npass; ++ps) {
+            const int S = (logh - s0 + (npass - ps) - 1) / (npass - ps);  // even split, larger passes first
+            switch (S) {
+                case 1: fft_pass<1>(re, im, tws, h, s0, inverse); break;
+                case 2: fft_pass<2>(re, im, tws, h, s0, inverse); break;
+                case 3: fft_pass<3>(re, im, tws, h, s0, inverse); break;
+                default: fft_pass<4>(re, im, tws, h, s0, inverse); break;
+            }
+            s0 += S;
+            __syncthreads();
         }
-        __syncthreads();
     }
     // ---- store (same mapping as the load) ----
 #pragma unroll

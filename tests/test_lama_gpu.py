@@ -125,3 +125,29 @@ def test_fft_h_matches_dft_gemm_at_page_size(cuda):
     assert (outs[0] - outs[1]).abs().max().item() < 2e-5 * scale
     for o in outs:
         assert (_nchw(o) - ref).abs().max().item() < 5e-5 * scale
+
+
+@pytest.mark.parametrize("h,ncols,inverse", [(32, 36, False), (64, 128, True), (128, 100, False), (256, 92 * 4, False), (256, 92 * 4, True),
+                                             (512, 64, True)])
+def test_fft_cols_against_torch_fft(cuda, h, ncols, inverse):
+    """mit_fft_cols (radix-2 graph, up to 4 stages per LDS round trip) against torch.fft in float64: every power-of-two
+    height the pass splitter can see (5..9 stages = 3+2, 3+3, 4+3, 4+4, 3+3+3), ragged column counts, both directions."""
+    import ctypes as C
+    import math
+
+    from manga_image_translator_amd import lib as L, ops
+
+    g = torch.Generator().manual_seed(h + ncols)
+    B = 3
+    x = torch.randn(B, 2, h, ncols, generator=g)
+    k = torch.arange(h // 2, dtype=torch.float64) * (2 * math.pi / h)
+    tw = torch.stack([torch.cos(k), torch.sin(k)], 1).to(torch.float32).contiguous().to(cuda)
+    xg, out = x.to(cuda), torch.zeros(B, 2, h, ncols, device=cuda)
+    plane = h * ncols
+    L.check(L.load().mit_fft_cols(xg.data_ptr(), 2 * plane, plane, ncols, out.data_ptr(), 2 * plane, plane, ncols, tw.data_ptr(), B, h,
+                                  ncols, int(inverse), 1.0 / math.sqrt(h), C.c_void_p(ops.current_stream())), "mit_fft_cols")
+    torch.cuda.synchronize()
+    z = torch.complex(x[:, 0].double(), x[:, 1].double())
+    ref = (torch.fft.ifft if inverse else torch.fft.fft)(z, dim=1, norm="ortho")
+    got = torch.complex(out[:, 0].double().cpu(), out[:, 1].double().cpu())
+    assert (got - ref).abs().max() < 5e-6 * max(1.0, ref.abs().max().item())
