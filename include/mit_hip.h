@@ -127,6 +127,19 @@ int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *
                         int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k, int pad_mode, int act,
                         float act_alpha, void *stream);
 
+/* ---- Winograd F(4x4, 3x3) for the stride-1 3x3 convolutions of the FFC blocks (inpainting_lama_mpe.py:349-369: convl2l,
+ * convg2l, convl2g under ReflectionPad; the reference calls nn.Conv2d = 9 multiplies per output, this form 2.25):
+ *   mit_wino43_input : x NHWC [B,H,W,C] (strides in floats) -> V [36][T][C], T = B * ceil(H/4) * ceil(W/4), the B^T d B
+ *                      transform of the 6x6 patch (pad 1, MIT_PAD_REFLECT or MIT_PAD_ZERO) of every 4x4 output tile;
+ *   the 36 products M_z = V_z [T x C] @ U_z [C x N] (U = G g G^T, transformed once on the host) run on mit_conv_gemm, Z = 36;
+ *   mit_wino43_output: M [36][T][N] -> y NHWC = act((A^T m A) * scale[n] + bias[n]) + post, outputs past H / W dropped.
+ * fp32 throughout; per-layer error ~1e-5 of the output range against 3e-7 for the direct form (tests/test_winograd_gpu.py). */
+int mit_wino43_input(const float *x_dev, int64_t x_bs, int64_t x_ys, int64_t x_xs, float *v_dev, int B, int H, int W, int C,
+                     int pad_mode, void *stream);
+int mit_wino43_output(const float *m_dev, float *y_dev, int64_t y_bs, int64_t y_ys, int64_t y_xs, const float *post_dev,
+                      int64_t p_bs, int64_t p_ys, int64_t p_xs, const float *scale_dev, const float *bias_dev, int B, int H,
+                      int W, int N, int act, float alpha, void *stream);
+
 /* kernel-time probe (measurement only; bench.py's roofline leg).  While enabled every mit_conv_gemm launch — from the
  * host or from the native decoder loop — is bracketed by HIP events on its own stream; mit_prof_read synchronises those
  * events and returns, per tile configuration, the launch count, the summed kernel time and the summed FLOPs

@@ -132,11 +132,16 @@ def _nearest_map(n_dst: int, n_src: int) -> np.ndarray:
 class _FFC:
     """One FFC_BN_ACT of a res-block (:372-399): packed layers."""
 
-    def __init__(self, sd, p, device):
+    def __init__(self, sd, p, device, winograd=True):
         w_l = torch.cat([sd[p + ".ffc.convl2l.weight"], sd[p + ".ffc.convg2l.weight"]], dim=1)  # [128, 512, 3, 3]
-        self.to_l = ops.Conv2d(w_l, None, padding=1, pad_mode=PAD_REFLECT, bn=_bn(sd, p + ".bn_l"), act=ACT_RELU,
-                               device=device)
-        self.l2g = ops.Conv2d(sd[p + ".ffc.convl2g.weight"], None, padding=1, pad_mode=PAD_REFLECT, device=device)
+        self.winograd = winograd
+        if winograd:  # F(4x4, 3x3): both convs read the same transformed input (convl2g its first 128 channels)
+            self.to_l = ops.WinogradConv3x3(w_l, None, pad_mode=PAD_REFLECT, bn=_bn(sd, p + ".bn_l"), act=ACT_RELU, device=device)
+            self.l2g = ops.WinogradConv3x3(sd[p + ".ffc.convl2g.weight"], None, pad_mode=PAD_REFLECT, device=device)
+        else:
+            self.to_l = ops.Conv2d(w_l, None, padding=1, pad_mode=PAD_REFLECT, bn=_bn(sd, p + ".bn_l"), act=ACT_RELU,
+                                   device=device)
+            self.l2g = ops.Conv2d(sd[p + ".ffc.convl2g.weight"], None, padding=1, pad_mode=PAD_REFLECT, device=device)
         st = p + ".ffc.convg2g"
         self.st_in = ops.Conv2d(sd[st + ".conv1.0.weight"], None, bn=_bn(sd, st + ".conv1.1"), act=ACT_RELU, device=device)
         # spectral 1x1 conv: reference channel index is c*2 + t (:229-231,245-246); ours is planar t*C + c
@@ -155,8 +160,9 @@ class LamaEngine:
     """Batched LaMa generator. ``forward(img_u8[B,H,W,3], mask_u8[B,H,W]) -> u8 [B,H,W,3]`` (device tensors)."""
 
     def __init__(self, gen_sd: Dict[str, torch.Tensor], mpe_sd: Optional[Dict[str, torch.Tensor]] = None,
-                 n_blocks: int = 9, device="cuda", fft_h: bool = True):
+                 n_blocks: int = 9, device="cuda", fft_h: bool = True, winograd: bool = True):
         self.device = torch.device(device)
+        self.winograd = winograd  # False: the FFC blocks' 3x3 convolutions in direct (9-tap) form, for A/B comparison
         self.fft_h = fft_h  # False: keep the H-axis transform on the dense DFT GEMM (for A/B comparison)
         self.n_blocks = n_blocks
         sd, dev = gen_sd, self.device
@@ -169,7 +175,7 @@ class LamaEngine:
         w3 = torch.cat([sd["model.4.ffc.convl2l.weight"], sd["model.4.ffc.convl2g.weight"]], dim=0)  # 256 -> 128+384
         self.down3 = ops.Conv2d(w3, None, stride=2, padding=1, pad_mode=PAD_REFLECT,
                                 bn=_cat_bn(sd, "model.4.bn_l", "model.4.bn_g"), act=ACT_RELU, device=dev)
-        self.blocks = [(_FFC(sd, f"model.{5 + i}.conv1", dev), _FFC(sd, f"model.{5 + i}.conv2", dev))
+        self.blocks = [(_FFC(sd, f"model.{5 + i}.conv1", dev, winograd), _FFC(sd, f"model.{5 + i}.conv2", dev, winograd))
                        for i in range(n_blocks)]
         base = 5 + n_blocks + 1
         self.ups = []
@@ -305,9 +311,16 @@ class LamaEngine:
         x_l, x_g = x[..., :LOCAL_C], x[..., LOCAL_C:]
         res_l = None if residual is None else residual[..., :LOCAL_C]
         res_g = None if residual is None else residual[..., LOCAL_C:]
-        ffc.to_l(x, out=out[..., :LOCAL_C], post=res_l)  # convl2l(x_l) + convg2l(x_g) -> bn_l -> relu (+ id_l)
         P = self._buf("ffc_P", B, h, w, GLOBAL_C)
-        ffc.l2g(x_l, out=P)  # convl2g(x_l), raw
+        if ffc.winograd:
+            T = ops.WinogradConv3x3.tiles(B, h, w)
+            V = self._buf("wino_v", 36, T, LOCAL_C + GLOBAL_C)
+            ffc.to_l.transform_input(x, V)
+            ffc.to_l.gemm_output(V, self._buf("wino_ml", 36, T, LOCAL_C), out[..., :LOCAL_C], post=res_l)
+            ffc.l2g.gemm_output(V, self._buf("wino_mg", 36, T, GLOBAL_C), P)
+        else:
+            ffc.to_l(x, out=out[..., :LOCAL_C], post=res_l)  # convl2l(x_l) + convg2l(x_g) -> bn_l -> relu (+ id_l)
+            ffc.l2g(x_l, out=P)  # convl2g(x_l), raw
         t1 = self._buf("ffc_t1", B, h, w, SPEC_C)
         t2 = self._buf("ffc_t2", B, h, w, SPEC_C)
         ffc.st_in(x_g, out=t1)  # SpectralTransform.conv1 (:272-277)

@@ -131,6 +131,10 @@ SYMBOLS = {
     "mit_prof_tag_next": (C.c_int, [C.c_double]),
     "mit_prof_read": (C.c_int, [C.POINTER(MitProfStat), C.c_int, C.POINTER(C.c_int)]),
     "mit_prof_dump": (C.c_int, [C.c_char_p]),
+    "mit_wino43_input": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]),
+    "mit_wino43_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "mit_ocr_warp_lines": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                      C.c_void_p]),
     "mit_fft_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,

@@ -199,6 +199,91 @@ class Conv2d:
         return out
 
 
+class WinogradConv3x3:
+    """Stride-1, pad-1 3x3 conv (+ folded eval BatchNorm2d + ReLU / LeakyReLU + residual) as Winograd F(4x4, 3x3):
+    ``mit_wino43_input`` (B^T d B per 4x4 output tile) -> 36 independent [T x Cin] @ [Cin x Cout] products on ``mit_conv_gemm``
+    (Z = 36) -> ``mit_wino43_output`` (A^T m A, epilogue).  2.25 multiplies per output instead of 9.
+
+    weight [Cout, Cin, 3, 3] is transformed once (U = G g G^T in float64, rounded to fp32).  The transformed input V
+    [36, T, C] can be shared by several layers that read (a channel prefix of) the same tensor: call ``transform_input``
+    once and ``gemm_output`` per layer (``v_channels`` = row length of V)."""
+
+    G = ((1 / 4, 0, 0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6), (1 / 24, 1 / 12, 1 / 6), (1 / 24, -1 / 12, 1 / 6), (0, 0, 1))
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, pad_mode: int = PAD_ZERO, bn=None,
+                 act: int = ACT_NONE, alpha: float = 0.0, device="cuda"):
+        Cout, Cin, kh, kw = weight.shape
+        if (kh, kw) != (3, 3) or Cin % 4 or Cout % 2:
+            raise ValueError(f"WinogradConv3x3: 3x3 kernels with Cin % 4 == 0 and even Cout only (got {tuple(weight.shape)})")
+        if act not in (ACT_NONE, ACT_RELU, ACT_LEAKY):
+            raise ValueError("WinogradConv3x3: activation must be none / relu / leaky")
+        self.Cin, self.Cout, self.pad_mode, self.act, self.alpha = Cin, Cout, pad_mode, act, alpha
+        G = torch.tensor(self.G, dtype=torch.float64)
+        U = torch.einsum("ia,ocab,jb->ijco", G, weight.detach().to(torch.float64), G).reshape(36, Cin, Cout)
+        self.Kp, self.Np = _round_up(Cin, 16), _round_up(Cout, 4)
+        u = torch.zeros(36, self.Kp, self.Np, dtype=torch.float32)
+        u[:, :Cin, :Cout] = U.to(torch.float32)
+        self.u = u.to(device).contiguous()
+        scale = bias_t = None
+        if bn is not None:
+            scale, bias_t = fold_bn(*bn, conv_bias=bias)
+        elif bias is not None:
+            bias_t = bias.detach().to(torch.float32)
+        self.scale = None if scale is None else scale.to(device).contiguous()
+        self.bias = None if bias_t is None else bias_t.to(device).contiguous()
+
+    @staticmethod
+    def tiles(B: int, H: int, W: int) -> int:
+        return B * ((H + 3) // 4) * ((W + 3) // 4)
+
+    def transform_input(self, x: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """x NHWC [B,H,W,C] (channel-slice views allowed) -> v [36, T, C]."""
+        _check_nhwc(x, "WinogradConv3x3 input")
+        B, H, W, Cx = x.shape
+        T = self.tiles(B, H, W)
+        if tuple(v.shape) != (36, T, Cx) or not v.is_contiguous():
+            raise ValueError(f"WinogradConv3x3: V must be contiguous [36, {T}, {Cx}] (got {tuple(v.shape)})")
+        _lib.check(_lib.load().mit_wino43_input(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), v.data_ptr(), B, H, W, Cx,
+                                                self.pad_mode, C.c_void_p(current_stream())), "mit_wino43_input")
+        return v
+
+    def gemm_desc(self, v: torch.Tensor, m: torch.Tensor) -> MitConvGemm:
+        _, T, Cv = v.shape
+        if Cv < self.Cin or tuple(m.shape) != (36, T, self.Cout) or not m.is_contiguous():
+            raise ValueError(f"WinogradConv3x3: bad V / M shapes {tuple(v.shape)} / {tuple(m.shape)}")
+        cm = MitTensorMap()
+        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = m.data_ptr(), 0, T * self.Cout, 0, 0, self.Cout
+        return conv_gemm_desc(a=v, NB=1, Hi=1, Wi=T, Cin=self.Cin, a_strides=(0, 0, Cv), Ho=1, Wo=T, sy=1, sx=1, taps=[(0, 0, 0)],
+                              pad_mode=PAD_ZERO, w=self.u, ldw=self.Np, Kw=self.Kp, Nw=self.Np, N=self.Cout, c=cm, Z=36,
+                              zdiv=1 << 30, a_zs=(0, T * Cv), w_zs=(0, self.Kp * self.Np))
+
+    def gemm_output(self, v: torch.Tensor, m: torch.Tensor, out: torch.Tensor, post: Optional[torch.Tensor] = None, cfg: int = -1):
+        """36 products from a ready V (its first ``Cin`` channels) and the output transform into ``out`` [B,H,W,Cout]."""
+        _check_nhwc(out, "WinogradConv3x3 output")
+        B, H, W, Co = out.shape
+        if Co != self.Cout or self.tiles(B, H, W) != v.shape[1]:
+            raise ValueError(f"WinogradConv3x3: output {tuple(out.shape)} does not match V {tuple(v.shape)}")
+        if post is not None and tuple(post.shape) != tuple(out.shape):
+            raise ValueError("WinogradConv3x3: residual shape differs from the output")
+        launch_conv_gemm(self.gemm_desc(v, m), cfg)
+        ps = (0, 0, 0) if post is None else (post.stride(0), post.stride(1), post.stride(2))
+        _lib.check(_lib.load().mit_wino43_output(m.data_ptr(), out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), _ptr(post), *ps,
+                                                 _ptr(self.scale), _ptr(self.bias), B, H, W, self.Cout, self.act, self.alpha,
+                                                 C.c_void_p(current_stream())), "mit_wino43_output")
+        return out
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, post: Optional[torch.Tensor] = None,
+                 v: Optional[torch.Tensor] = None, m: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, H, W, Cx = x.shape
+        T = self.tiles(B, H, W)
+        if out is None:
+            out = torch.empty(B, H, W, self.Cout, dtype=torch.float32, device=x.device)
+        v = torch.empty(36, T, Cx, dtype=torch.float32, device=x.device) if v is None else v
+        m = torch.empty(36, T, self.Cout, dtype=torch.float32, device=x.device) if m is None else m
+        self.transform_input(x, v)
+        return self.gemm_output(v, m, out, post)
+
+
 class ConvSmallCout:
     """k x k stride-1 "same" conv with <= 4 output channels (+ bias + activation) on ``mit_conv_small_cout``.
 
