@@ -143,3 +143,65 @@ def test_post_before_activation_epilogue():
     EMU.run(layer.desc(xin, out, post=pin))
     ref = torch.relu(F.batch_norm(F.conv2d(x, w, padding=1), bn[2], bn[3], bn[0], bn[1], False, 0.0, bn[4]) + idt)
     assert torch.allclose(out, _nhwc(ref), atol=2e-5)
+
+
+# ---- Winograd F(4x4, 3x3): the host side (U = G g G^T, the Z = 36 GEMM descriptor, strides of a shared V) -----------------
+_BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+_AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+
+
+def _wino_input(x, reflect):
+    """include/mit_hip.h mit_wino43_input in numpy: x [B,H,W,C] -> V [36, T, C] (float64)."""
+    B, H, W, Cc = x.shape
+    th, tw = (H + 3) // 4, (W + 3) // 4
+
+    def src(i, n):
+        if reflect:
+            i = -i if i < 0 else i
+            i = 2 * n - 2 - i if i >= n else i
+            return max(i, 0)
+        return i if 0 <= i < n else -1
+
+    V = np.zeros((36, B * th * tw, Cc))
+    for b in range(B):
+        for ty in range(th):
+            for tx in range(tw):
+                d = np.zeros((6, 6, Cc))
+                for r in range(6):
+                    for s in range(6):
+                        iy, ix = src(ty * 4 - 1 + r, H), src(tx * 4 - 1 + s, W)
+                        if iy >= 0 and ix >= 0:
+                            d[r, s] = x[b, iy, ix]
+                V[:, (b * th + ty) * tw + tx] = np.einsum("ir,rsc,js->ijc", _BT, d, _BT).reshape(36, Cc)
+    return V
+
+
+def _wino_output(M, B, H, W):
+    th, tw = (H + 3) // 4, (W + 3) // 4
+    N = M.shape[2]
+    y = np.zeros((B, th * 4, tw * 4, N))
+    for t in range(B * th * tw):
+        b, ty, tx = t // (th * tw), (t // tw) % th, t % tw
+        y[b, ty * 4:ty * 4 + 4, tx * 4:tx * 4 + 4] = np.einsum("ar,rsn,es->aen", _AT, M[:, t].reshape(6, 6, N), _AT)
+    return y[:, :H, :W]
+
+
+@pytest.mark.parametrize("reflect", [True, False])
+def test_winograd_host_side_against_conv2d(reflect):
+    """WinogradConv3x3's transformed weights and its 36-way GEMM descriptor (run by the emulator), wrapped in numpy versions of
+    the two transform kernels, reproduce F.conv2d — for the stand-alone layer and for a layer reading a channel prefix of a
+    wider shared V."""
+    g = torch.Generator().manual_seed(21)
+    B, H, W, Cw, Cin, Cout = 2, 7, 10, 32, 16, 6
+    x = torch.randn(B, H, W, Cw, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 12
+    layer = ops.WinogradConv3x3(w, None, pad_mode=ops.PAD_REFLECT if reflect else ops.PAD_ZERO, device="cpu")
+    T = layer.tiles(B, H, W)
+    V = torch.from_numpy(_wino_input(x.numpy().astype(np.float64), reflect)).to(torch.float32).contiguous()  # all Cw channels
+    M = torch.zeros(36, T, Cout)
+    EMU.run(layer.gemm_desc(V, M))  # reads the first Cin channels of every V row
+    got = _wino_output(M.numpy().astype(np.float64), B, H, W)
+    xp = F.pad(x[..., :Cin].permute(0, 3, 1, 2).double(), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    ref = F.conv2d(xp, w.double()).permute(0, 2, 3, 1).numpy()
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
