@@ -14,6 +14,13 @@
 
 namespace {
 
+// consecutive workgroup ids are dealt round-robin to the 8 XCDs (one L2 each): give every XCD one contiguous run of tiles,
+// so that the 6x6 patches of neighbouring tiles (2 shared rows / columns) meet in the same L2 instead of being fetched twice
+__device__ __forceinline__ int64_t xcd_contiguous_block(int64_t bid, int64_t nwg) {
+    const int64_t xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 __device__ __forceinline__ int wino_src_index(int i, int n, int pad_mode) {
     // padded coordinate -> source row/column; -1 = contributes zero.  Coordinates past the far border only feed outputs
     // that are never stored (partial tiles); they are clamped so that the transform sees values of ordinary magnitude.
@@ -45,7 +52,7 @@ __device__ __forceinline__ void bt6(float2 &d0, float2 &d1, float2 &d2, float2 &
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restrict__ x, int64_t x_bs, int64_t x_ys, int64_t x_xs,
                                                            float *__restrict__ v, int B, int H, int W, int C2, int th, int tw,
                                                            int pad_mode, int64_t total, int64_t zstride) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c2 = (int)(idx % C2);
     const int64_t tile = idx / C2;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float *__restr
                                                             int64_t p_ys, int64_t p_xs, const float *__restrict__ scale,
                                                             const float *__restrict__ bias, int B, int H, int W, int N2, int th,
                                                             int tw, int act, float alpha, int64_t total, int64_t zstride) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (idx >= total) return;
     const int n2 = (int)(idx % N2);
     const int64_t tile = idx / N2;
