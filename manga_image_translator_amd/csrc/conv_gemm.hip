@@ -108,7 +108,60 @@ __device__ __forceinline__ void epilogue_store(const MitConvGemm &p, f32x16 (&ac
     }
 }
 
-template <int BM, int TM, int TN, int XE = 0>
+// Vector form of the store loop: each 32x32 accumulator block goes through a per-wave LDS buffer so that a lane ends up with
+// four consecutive columns of one row — 4 dwordx4 stores (and residual loads) per block instead of 16 dword ones.  Same
+// per-element arithmetic in the same order, so results are bit-identical to the scalar loop.  Needs N % 4 == 0, plain (unsplit)
+// column maps and 16-byte aligned bases / strides (MIT_ACT_VEC_OK, set by the launcher).
+constexpr int EPI_PITCH = 36;
+#define MIT_ACT_VEC_OK 0x200
+
+template <int TM, int TN, int ACT, bool HAS_POST, int XE>
+__device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 (&acc)[TM][TN], const RowOff *rowoff, float *tbuf,
+                                                   const int n0, const int wm0, const int wn0) {
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31;
+    const int lh = lane >> 5;
+    const int vr = lane >> 3, vc = (lane & 7) * 4;
+    const bool has_pre = p.pre.base != nullptr;
+    const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = n0 + wn0 + ni * 32 + vc;
+        const bool n_ok = n < p.N;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (n_ok && p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + n);
+        if (n_ok && p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_PITCH + li] = acc[mi][ni][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-synchronous exchange: LDS serves a wave's accesses in order
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rl = vr + 8 * j;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(tbuf + rl * EPI_PITCH + vc);
+                const RowOff ro = rowoff[wm0 + mi * 32 + rl];
+                if (ro.c < 0 || !n_ok) continue;
+                if (has_pre) v += *reinterpret_cast<const f32x4 *>(p.pre.base + ro.pre + n);
+                v = v * sc + bi;
+                f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+                if (HAS_POST) pv = *reinterpret_cast<const f32x4 *>(p.post.base + ro.post + n);
+                if (HAS_POST && post_first) v += pv;
+                if (!(XE & 2)) {
+                    v.x = apply_act<ACT>(v.x, p.act_alpha);
+                    v.y = apply_act<ACT>(v.y, p.act_alpha);
+                    v.z = apply_act<ACT>(v.z, p.act_alpha);
+                    v.w = apply_act<ACT>(v.w, p.act_alpha);
+                }
+                if (HAS_POST && !post_first) v += pv;
+                *reinterpret_cast<f32x4 *>(p.c.base + ro.c + n) = v;
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+template <int BM, int TM, int TN, int XE = 0, int SMEM_FLOATS = 0>
 __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM][TN], float *smem, const int M, const int m0,
                                          const int n0, const int wm0, const int wn0, const int z1, const int z0,
                                          const int HoWo) {
@@ -133,8 +186,15 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
     __syncthreads();
 
     const bool has_post = p.post.base != nullptr;
-#define MIT_EPI(A)                                                                           \
-    if (has_post) epilogue_store<TM, TN, A, true, XE>(p, acc, rowoff, n0, wm0, wn0);           \
+    constexpr int ROWOFF_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4;
+    constexpr bool VEC_FITS = SMEM_FLOATS >= ROWOFF_FLOATS + 4 * 32 * EPI_PITCH && !(XE & 1);
+    float *tbuf = smem + ROWOFF_FLOATS + (tid >> 6) * (32 * EPI_PITCH);
+    const bool vec = VEC_FITS && (p.act & MIT_ACT_VEC_OK);
+#define MIT_EPI(A)                                                                                   \
+    if (VEC_FITS && vec) {                                                                           \
+        if (has_post) epilogue_store_vec<TM, TN, A, true, XE>(p, acc, rowoff, tbuf, n0, wm0, wn0);      \
+        else epilogue_store_vec<TM, TN, A, false, XE>(p, acc, rowoff, tbuf, n0, wm0, wn0);              \
+    } else if (has_post) epilogue_store<TM, TN, A, true, XE>(p, acc, rowoff, n0, wm0, wn0);           \
     else epilogue_store<TM, TN, A, false, XE>(p, acc, rowoff, n0, wm0, wn0)
     switch (p.act & 0xff) {
         case MIT_ACT_RELU: MIT_EPI(MIT_ACT_RELU); break;
@@ -332,7 +392,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, con
         __syncthreads();
     }
 
-    epilogue<BM, TM, TN>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+    epilogue<BM, TM, TN, 0, 2 * A_TILE + 2 * B_TILE>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
 }
 
 // ---- fast path: Cin % BK == 0, so every K-tile lies inside ONE tap ----------------------------
@@ -620,7 +680,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     }
     if (X_NOBAR) __syncthreads();
 
-    epilogue<BM, TM, TN, (VAR >> 12) & 3>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+    epilogue<BM, TM, TN, (VAR >> 12) & 3, 2 * A_TILE + 2 * B_TILE>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
 }
 
 struct CfgEntry {
@@ -840,9 +900,26 @@ extern "C" const char *mit_conv_gemm_config_name(int cfg) {
     return kCfgs[cfg].name;
 }
 
+namespace {
+bool map_vec_ok(const MitTensorMap &m) {
+    return m.nsplit == 0 && !(reinterpret_cast<uintptr_t>(m.base) & 15) && !((m.zs1 | m.zs0 | m.bs | m.ys | m.xs) & 3);
+}
+// dwordx4 epilogue (epilogue_store_vec): whole float4 column groups, contiguous and 16-byte aligned in every tensor it touches
+bool vec_epilogue_ok(const MitConvGemm &p) {
+    static const bool off = getenv("MIT_CONV_SCALAR_EPILOGUE") != nullptr;  // A/B knob for scripts/
+    if (off || (p.N & 3) || !map_vec_ok(p.c)) return false;
+    if (p.pre.base && !map_vec_ok(p.pre)) return false;
+    if (p.post.base && !map_vec_ok(p.post)) return false;
+    return !(reinterpret_cast<uintptr_t>(p.scale) & 15) && !(reinterpret_cast<uintptr_t>(p.bias) & 15);
+}
+}  // namespace
+
 extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     if (!d) return mit_set_error("mit_conv_gemm: null descriptor");
-    const MitConvGemm &p = *d;
+    MitConvGemm pv = *d;
+    if (pv.act & MIT_ACT_VEC_OK) return mit_set_error("mit_conv_gemm: reserved activation bits set");
+    if (vec_epilogue_ok(pv)) pv.act |= MIT_ACT_VEC_OK;
+    const MitConvGemm &p = pv;
     if (!p.a || !p.w || !p.c.base) return mit_set_error("mit_conv_gemm: null operand");
     if (p.Cin <= 0 || (p.Cin & 3)) return mit_set_error("mit_conv_gemm: Cin must be a positive multiple of 4 (got %d)", p.Cin);
     if ((p.ldw & 3) || (p.Nw & 3)) return mit_set_error("mit_conv_gemm: ldw/Nw must be multiples of 4 (ldw=%lld Nw=%d)", (long long)p.ldw, p.Nw);
