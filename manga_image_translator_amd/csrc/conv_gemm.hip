@@ -761,6 +761,8 @@ const CfgEntry kCfgs[] = {
     {"fast128x64x16c", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 1, 4>, 1},           // 21: 9 + cached offsets
     {"fast192x64x16w4c", 192, 64, 16, launch_fast<192, 64, 16, 2, 2, 4, 4>, 1},         // 22: 128 < M <= 192 per batch entry (W-axis DFTs)
     {"fast256x128x16w2c", 256, 128, 16, launch_fast<256, 128, 16, 2, 2, 2, 4>, 1},      // 23: wave tile 128 x 64, 2 workgroups per CU
+    {"fast128x64x16w5c", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 5, 4>, 1},          // 24: 21 held to <= 96 registers (5 workgroups per CU)
+    {"fast128x64x16w6c", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 6, 4>, 1},          // 25: <= 80 registers
 #ifdef MIT_CONV_EXPERIMENTS  // scheduling variants measured and rejected, and timing ablations (WRONG results) — scripts/bench_conv.py
     {"fast128x128x16w4L", 128, 128, 16, launch_fast<128, 128, 16, 1, 4, 4, 4 + 16384>, 2},  // 24: 20 with A fetched in full 128-B lines (Cin % 32 == 0)
     {"fast128x64x16L", 128, 64, 16, launch_fast<128, 64, 16, 2, 2, 1, 4 + 16384>, 2},       // 25: 21 likewise
@@ -809,7 +811,7 @@ int env_cfg(const char *name, int dflt) {  // tuning knob for scripts/: replaces
 
 int pick_cfg(const MitConvGemm &p, int64_t M) {
     // measured on MI355X (scripts/bench_conv.py)
-    static const int wide = env_cfg("MIT_CONV_TILE_WIDE", 20), narrow = env_cfg("MIT_CONV_TILE_NARROW", 9);
+    static const int wide = env_cfg("MIT_CONV_TILE_WIDE", 20), narrow = env_cfg("MIT_CONV_TILE_NARROW", 24);
     static const int m192 = env_cfg("MIT_CONV_TILE_M192", 22), bigk = env_cfg("MIT_CONV_TILE_BIGK", -1);
     static const int wide_l = env_cfg("MIT_CONV_TILE_WIDE_L", -1), narrow_l = env_cfg("MIT_CONV_TILE_NARROW_L", -1);  // experiments: Cin % 32 == 0
     static const int narrow_max = getenv("MIT_CONV_NARROW_MAX") ? atoi(getenv("MIT_CONV_NARROW_MAX")) : 64;
