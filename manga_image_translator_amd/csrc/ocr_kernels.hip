@@ -385,8 +385,7 @@ __device__ __forceinline__ void att_chunk_store(const float4 (&reg)[ATT_STAGE], 
         const int i = tid + j * ATT_THREADS;
         if (i < nk * HD4) {
             const int t = i / HD4, d4 = i - t * HD4;
-            float *dst = ks + t * KP + d4 * 4;
-            dst[0] = reg[j].x, dst[1] = reg[j].y, dst[2] = reg[j].z, dst[3] = reg[j].w;
+            *reinterpret_cast<float4 *>(ks + t * KP + d4 * 4) = reg[j];
         }
     }
 }
@@ -396,8 +395,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
                                                                           const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
                                                                           float *__restrict__ O, int64_t o_rs,
                                                                           const int *__restrict__ klen, int Tk, int G, int HD) {
-    extern __shared__ float lds[];
-    const int KP = HD + 1;                    // odd pitch: lane t reads row t conflict-free
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KP = HD + 4;                    // 16-byte aligned rows; lane t reads row t as float4s (pitch 84: conflict-free per 16 lanes)
     float *qs = lds;                          // [G][HD]
     float *ks = qs + G * HD;                  // [ATT_KCHUNK][KP]   keys, then values
     float *ws = ks + ATT_KCHUNK * KP;         // [G][Tk]
@@ -420,13 +419,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
         if (t0 + ATT_KCHUNK < valid) att_chunk_load(stage, kb, k_ts, t0 + ATT_KCHUNK, min(ATT_KCHUNK, valid - t0 - ATT_KCHUNK), HD4, tid);
         const int t = t0 + lane;
         if (t < Tk) {
-            const float *kp = ks + lane * KP;
+            const float4 *kp = reinterpret_cast<const float4 *>(ks + lane * KP);
             for (int g = wave; g < G; g += ATT_THREADS / 64) {
                 float dot = -INFINITY;
                 if (t < valid) {
-                    const float *qp = qs + g * HD;
+                    const float4 *qp = reinterpret_cast<const float4 *>(qs + g * HD);  // same address in every lane: broadcast
                     dot = 0.f;
-                    for (int d = 0; d < HD; ++d) dot += qp[d] * kp[d];
+                    for (int d4 = 0; d4 < HD4; ++d4) {  // d ascending, one rounding per product and per sum, as in attention_kernel
+                        const float4 kv = kp[d4], qv = qp[d4];
+                        dot += qv.x * kv.x;
+                        dot += qv.y * kv.y;
+                        dot += qv.z * kv.z;
+                        dot += qv.w * kv.w;
+                    }
                 }
                 ws[(int64_t)g * Tk + t] = dot;
             }
@@ -560,32 +565,37 @@ __global__ __launch_bounds__(256) void logsoftmax_top5_kernel(const float *__res
         ci[tid * 5 + j] = ti[j];
     }
     __syncthreads();
-    if (tid == 0) {
-        float bv[5];
-        int bi[5];
-        for (int j = 0; j < 5; ++j) {
-            bv[j] = -INFINITY;
-            bi[j] = 0x7fffffff;
-        }
-        for (int c = 0; c < 256 * 5; ++c) {
-            const float v = cv[c];
-            const int d = ci[c];
-            if (d == 0x7fffffff) continue;
-            if (v > bv[4] || (v == bv[4] && d < bi[4])) {
-                int j = 4;
-                while (j > 0 && (v > bv[j - 1] || (v == bv[j - 1] && d < bi[j - 1]))) {
-                    bv[j] = bv[j - 1];
-                    bi[j] = bi[j - 1];
-                    --j;
-                }
-                bv[j] = v;
-                bi[j] = d;
+    // pairwise merges of the per-thread sorted candidate lists (value descending, lower index first on ties): the order is
+    // total, so the surviving five are the same whatever the merge tree
+    for (int s = 128; s > 0; s >>= 1) {
+        float ov[5];
+        int oi[5];
+        if (tid < s) {
+            const float *av = cv + tid * 5, *bv = cv + (tid + s) * 5;
+            const int *ai = ci + tid * 5, *bi = ci + (tid + s) * 5;
+            int ia = 0, ib = 0;
+            for (int j = 0; j < 5; ++j) {
+                const float va = av[ia], vb = bv[ib];
+                const int da = ai[ia], db = bi[ib];
+                const bool take_a = va > vb || (va == vb && da <= db);
+                ov[j] = take_a ? va : vb;
+                oi[j] = take_a ? da : db;
+                ia += take_a ? 1 : 0;
+                ib += take_a ? 0 : 1;
             }
         }
-        for (int j = 0; j < 5; ++j) {
-            vals[r * 5 + j] = (bv[j] - mx) - lse;  // log_softmax value
-            idx[r * 5 + j] = bi[j];
+        __syncthreads();
+        if (tid < s) {
+            for (int j = 0; j < 5; ++j) {
+                cv[tid * 5 + j] = ov[j];
+                ci[tid * 5 + j] = oi[j];
+            }
         }
+        __syncthreads();
+    }
+    if (tid < 5) {
+        vals[r * 5 + tid] = (cv[tid] - mx) - lse;  // log_softmax value
+        idx[r * 5 + tid] = ci[tid];
     }
 }
 
@@ -691,7 +701,7 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
                     int kv_div, hipStream_t s, int heads, int head_dim) {
     if (Tq == 1 && kv_div > 1 && kv_div <= ATT_G_MAX && R % kv_div == 0 && R / kv_div <= 65535 && 2 * head_dim <= ATT_THREADS &&
         ATT_KCHUNK * (head_dim / 4) <= ATT_STAGE * ATT_THREADS) {
-        const size_t sm = ((size_t)kv_div * head_dim + (size_t)ATT_KCHUNK * (head_dim + 1) + (size_t)kv_div * Tk) * sizeof(float);
+        const size_t sm = ((size_t)kv_div * head_dim + (size_t)ATT_KCHUNK * (head_dim + 4) + (size_t)kv_div * Tk) * sizeof(float);
         if (sm <= 64 * 1024) {
             hipLaunchKernelGGL(attention_shared_kv_kernel, dim3(heads, R / kv_div), dim3(ATT_THREADS), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts,
                                O, o_rs, klen, Tk, kv_div, head_dim);
