@@ -1,0 +1,225 @@
+"""Mask refinement between OCR and inpainting: which connected components of the detector's raw mask belong
+to which text line, per-line clean-up, dilation — the reference's ``mask_refinement.dispatch``
+(/root/reference/manga_translator/mask_refinement/__init__.py:9-50) and ``complete_mask``
+(mask_refinement/text_mask_utils.py:96-195).
+
+Host-side logic, like the reference's.  Native here: the 8-bit linear resizes, component labelling and statistics, the
+component -> text-line assignment (overlap ratio, distance to the line polygon), crop / dilation-size arithmetic, elliptical
+dilation, the final merge.  NOT native: the per-line DenseCRF (``text_mask_utils.refine_mask`` -> pydensecrf) and the
+``cv2.bilateralFilter`` that feeds it; both are injected callables (``refine=`` / ``bilateral=``) which default to the
+reference's own when its package (with pydensecrf / OpenCV) is importable and raise otherwise — there is no silent substitute.
+Pinned against the reference's Python, run with stand-ins for cv2 / shapely and the same two callables stubbed on both sides
+(tests/golden/mask_refinement.npz, oracle/make_golden.py)."""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+from scipy import ndimage as _nd
+
+from . import hostglue as HG
+from .textline import Quadrilateral
+
+RefineFn = Callable[[np.ndarray, np.ndarray], np.ndarray]      # (rgb crop, mask crop) -> mask crop   (refine_mask :71-94)
+BilateralFn = Callable[[np.ndarray], np.ndarray]               # page -> filtered page                (cv2.bilateralFilter(img, 17, 80, 80) :159)
+
+
+def _reference_refine() -> RefineFn:
+    try:
+        from manga_translator.mask_refinement.text_mask_utils import refine_mask  # needs pydensecrf
+    except Exception as ex:  # pragma: no cover - depends on the host
+        raise RuntimeError("mask refinement needs a DenseCRF step: pass refine=..., or install the reference package with pydensecrf") from ex
+    return refine_mask
+
+
+def _reference_bilateral() -> BilateralFn:
+    try:
+        import cv2
+    except Exception as ex:  # pragma: no cover - depends on the host
+        raise RuntimeError("mask refinement needs cv2.bilateralFilter: pass bilateral=..., or install OpenCV") from ex
+    return lambda img: cv2.bilateralFilter(img, 17, 80, 80)
+
+
+def ellipse_kernel(k: int) -> np.ndarray:
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)): row i covers c -+ round(c * sqrt(1 - (dy / r)^2)), r = c = k // 2."""
+    r = c = k // 2
+    out = np.zeros((k, k), dtype=bool)
+    for i in range(k):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(np.rint(c * np.sqrt((r * r - dy * dy) / (r * r)))) if r else 0
+            out[i, max(c - dx, 0):min(c + dx + 1, k)] = True
+    return out
+
+
+def dilate(img: np.ndarray, kernel: np.ndarray) -> np.ndarray:
+    """cv2.dilate with the default anchor / border: maximum over the kernel support, pixels outside the image ignored."""
+    if img.size == 0:
+        return img
+    return _nd.grey_dilation(img, footprint=kernel, mode="constant", cval=0)
+
+
+def _clip_quad_to_rect_area(pts: np.ndarray, x0: float, y0: float, x1: float, y1: float) -> float:
+    """Area of (convex quad) ∩ (axis-aligned rectangle): the quad clipped by the four sides in turn (Sutherland-Hodgman)."""
+    poly = [tuple(map(float, p)) for p in pts]
+    for axis, bound, keep_ge in ((0, x0, True), (0, x1, False), (1, y0, True), (1, y1, False)):
+        if not poly:
+            return 0.0
+        nxt = []
+        for i, p in enumerate(poly):
+            q = poly[(i + 1) % len(poly)]
+            dp, dq = (p[axis] - bound, q[axis] - bound) if keep_ge else (bound - p[axis], bound - q[axis])
+            if dp >= 0:
+                nxt.append(p)
+            if (dp > 0 and dq < 0) or (dp < 0 and dq > 0):
+                t = dp / (dp - dq)
+                nxt.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+        poly = nxt
+    if len(poly) < 3:
+        return 0.0
+    a = np.asarray(poly)
+    x, y = a[:, 0], a[:, 1]
+    return float(abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))) / 2)
+
+
+def _point_in_polygon(pts: np.ndarray, p) -> bool:
+    inside = False
+    n = len(pts)
+    for i in range(n):
+        a, b = pts[i], pts[(i + 1) % n]
+        if (a[1] > p[1]) != (b[1] > p[1]) and p[0] < (b[0] - a[0]) * (p[1] - a[1]) / (b[1] - a[1]) + a[0]:
+            inside = not inside
+    return inside
+
+
+def _polygon_point_distance(pts: np.ndarray, p) -> float:
+    pts = np.asarray(pts, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    if _point_in_polygon(pts, p):
+        return 0.0
+    best = np.inf
+    for i in range(len(pts)):
+        a, b = pts[i], pts[(i + 1) % len(pts)]
+        ab = b - a
+        den = float(ab @ ab)
+        t = 0.0 if den == 0 else min(1.0, max(0.0, float((p - a) @ ab) / den))
+        best = min(best, float(np.linalg.norm(p - (a + t * ab))))
+    return best
+
+
+def _extend_rect(x, y, w, h, max_x, max_y, extend):  # text_mask_utils.py:56-61
+    x1, y1 = max(x - extend, 0), max(y - extend, 0)
+    return x1, y1, min(w + extend * 2, max_x - x1 - 1), min(h + extend * 2, max_y - y1 - 1)
+
+
+def _xywh(q: Quadrilateral):  # BBox.xywh (utils/generic.py:319-321): int32 truncation of the axis-aligned box
+    mn, mx = np.min(q.pts, axis=0), np.max(q.pts, axis=0)
+    return tuple(int(v) for v in np.array([mn[0], mn[1], mx[0] - mn[0], mx[1] - mn[1]], dtype=np.int32))
+
+
+def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadrilateral], keep_threshold: float = 1e-2,
+                  dilation_offset: int = 0, kernel_size: int = 3, refine: Optional[RefineFn] = None,
+                  bilateral: Optional[BilateralFn] = None) -> Optional[np.ndarray]:
+    """text_mask_utils.complete_mask (:96-195).  ``mask`` is modified in place exactly like the reference's (line boxes are
+    outlined with zeros before labelling)."""
+    refine = refine or _reference_refine()
+    bilateral = bilateral or _reference_bilateral()
+    H, W = mask.shape
+    boxes = [_xywh(t) for t in textlines]
+    polys = [np.asarray(t.pts, dtype=np.float64) for t in textlines]
+    areas2 = [HG_area(p) for p in polys]
+    for x, y, w, h in boxes:  # cv2.rectangle(mask, (x, y), (x + w, y + h), 0, 1): one-pixel outline, inclusive corners, clipped
+        xa, xb, ya, yb = max(x, 0), min(x + w, W - 1), max(y, 0), min(y + h, H - 1)
+        if xa > xb or ya > yb:
+            continue
+        for yy in (y, y + h):
+            if 0 <= yy < H:
+                mask[yy, xa:xb + 1] = 0
+        for xx in (x, x + w):
+            if 0 <= xx < W:
+                mask[ya:yb + 1, xx] = 0
+    labels, n = _nd.label(mask > 0, structure=np.ones((3, 3)))  # 8-connectivity (cv2.connectedComponentsWithStats default)
+    objs = _nd.find_objects(labels)
+    counts = np.bincount(labels.reshape(-1), minlength=n + 1)
+    M = len(textlines)
+    ccs = [np.zeros_like(mask) for _ in range(M)]
+    rects: List[Optional[List[int]]] = [None] * M  # [left, top, right, bottom] of the components given to each line
+    valid = False
+    for label in range(1, n + 1):
+        area1 = int(counts[label])
+        if area1 <= 9:
+            continue
+        sy, sx = objs[label - 1]
+        x1, y1, w1, h1 = sx.start, sy.start, sx.stop - sx.start, sy.stop - sy.start
+        ratio = np.zeros(M, dtype=np.float32)
+        dist = np.zeros(M, dtype=np.float32)
+        centre = (x1 + w1 / 2.0, y1 + h1 / 2.0)
+        for i in range(M):
+            ratio[i] = _clip_quad_to_rect_area(polys[i], x1, y1, x1 + w1, y1 + h1) / min(area1, areas2[i])
+            dist[i] = _polygon_point_distance(polys[i], centre)
+        avg = int(np.argmax(ratio))
+        if area1 >= areas2[avg]:
+            continue
+        if ratio[avg] <= keep_threshold:
+            avg = int(np.argmin(dist))
+            unit = max(min([textlines[avg].font_size, w1, h1]), 10)
+            if dist[avg] >= 0.5 * unit:
+                continue
+        region = ccs[avg][y1:y1 + h1, x1:x1 + w1]
+        region[labels[y1:y1 + h1, x1:x1 + w1] == label] = 255
+        r = rects[avg]
+        rects[avg] = [x1, y1, x1 + w1, y1 + h1] if r is None else [min(r[0], x1), min(r[1], y1), max(r[2], x1 + w1), max(r[3], y1 + h1)]
+        valid = True
+    if not valid:
+        return None
+    final = np.zeros_like(mask)
+    img = bilateral(img)
+    for i, cc in enumerate(ccs):
+        if rects[i] is None:  # the reference's sentinel rectangle slices to an empty crop and is skipped (:172-173)
+            continue
+        x1, y1, w1, h1 = rects[i][0], rects[i][1], rects[i][2] - rects[i][0], rects[i][3] - rects[i][1]
+        text_size = min(w1, h1, textlines[i].font_size)
+        x1, y1, w1, h1 = _extend_rect(x1, y1, w1, h1, W, H, int(text_size * 0.1))
+        dilate_size = max((int((text_size + dilation_offset) * 0.3) // 2) * 2 + 1, 3)
+        cc_region = np.ascontiguousarray(cc[y1:y1 + h1, x1:x1 + w1])
+        if cc_region.size == 0:
+            continue
+        cc[y1:y1 + h1, x1:x1 + w1] = refine(np.ascontiguousarray(img[y1:y1 + h1, x1:x1 + w1]), cc_region)
+        x2, y2, w2, h2 = _extend_rect(x1, y1, w1, h1, W, H, -(-dilate_size // 2))
+        cc[y2:y2 + h2, x2:x2 + w2] = dilate(cc[y2:y2 + h2, x2:x2 + w2], ellipse_kernel(dilate_size))
+        final[y2:y2 + h2, x2:x2 + w2] |= cc[y2:y2 + h2, x2:x2 + w2]
+    return dilate(final, ellipse_kernel(kernel_size))
+
+
+def HG_area(pts: np.ndarray) -> float:
+    x, y = pts[:, 0], pts[:, 1]
+    return float(abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))) / 2)
+
+
+def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, method: str = "fit_text", dilation_offset: int = 0,
+                  ignore_bubble: int = 0, verbose: bool = False, kernel_size: int = 3, refine: Optional[RefineFn] = None,
+                  bilateral: Optional[BilateralFn] = None) -> np.ndarray:
+    """mask_refinement.dispatch (:9-33) for ``method='fit_text'`` without the bubble filter (ignore_bubble outside 1..50, the default)."""
+    if method != "fit_text":
+        raise NotImplementedError("mask refinement: only method='fit_text' is native (the reference's 'fill' path references an unset variable)")
+    if 1 <= ignore_bubble <= 50:
+        raise NotImplementedError("mask refinement: the ignore_bubble filter (utils/bubble.py) is not part of the native path")
+    h, w = raw_image.shape[:2]
+    scale = max(min((raw_mask.shape[0] - h / 3) / raw_mask.shape[0], 1), 0.5)
+    size = (int(w * scale), int(h * scale))
+    img_small = HG.resize_linear_u8(raw_image, size)
+    mask_small = HG.resize_linear_u8(raw_mask, size).copy()
+    mask_small[mask_small > 0] = 255
+    lines = [Quadrilateral(np.asarray(l) * scale, "", 0) for region in text_regions for l in region.lines]
+    final = complete_mask(img_small, mask_small, lines, dilation_offset=dilation_offset, kernel_size=kernel_size, refine=refine,
+                          bilateral=bilateral)
+    if final is None:
+        return np.zeros((h, w), dtype=np.uint8)
+    final = HG.resize_linear_u8(final, (w, h)).copy()
+    final[final > 0] = 255
+    return final
+
+
+async def dispatch(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, method: str = "fit_text", dilation_offset: int = 0,
+                   ignore_bubble: int = 0, verbose: bool = False, kernel_size: int = 3, **kw) -> np.ndarray:
+    return dispatch_sync(text_regions, raw_image, raw_mask, method, dilation_offset, ignore_bubble, verbose, kernel_size, **kw)

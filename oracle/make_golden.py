@@ -20,6 +20,7 @@ Fixtures (all small; each .npz also records the reference file whose code produc
   direction.npz    quadrilateral_can_merge_region + CommonOCR._generate_text_direction (utils/generic.py:653-698, ocr/common.py:12-39)
   refine_mask.npz  refine_mask / merge_mask_list / enlarge_window (detection/ctd_utils/textmask.py:16-174) on a 384x320 page
   textline_merge.json  the line sets + expected groupings of the reference's test/test_textline_merge.py and the reference code's own output
+  mask_refinement.npz  the reference's mask_refinement.dispatch / complete_mask on a synthetic page (DenseCRF + bilateralFilter stubbed)
   textline.npz     sort_pnts / Quadrilateral / get_transformed_region (utils/generic.py:324-481) on 12 quads
 """
 from __future__ import annotations
@@ -365,6 +366,61 @@ def golden_textline_merge():
     print("textline_merge", len(cases), [c["ref_passes_own_test"] for c in cases])
 
 
+def mask_refinement_scene(seed=3, H=360, W=300):
+    """Synthetic page for the mask-refinement pin: text lines (two of them rotated), stroke-like blobs inside them, strays just
+    outside (adopted through the distance rule), far strays (dropped), specks (<= 9 px) and one blob larger than its line."""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    mask = np.zeros((H, W), dtype=np.uint8)
+    boxes = [(30, 40, 200, 36), (40, 100, 30, 200), (120, 120, 150, 30), (110, 200, 160, 44), (20, 320, 120, 24)]
+    lines = []
+    for k, (x, y, w, h) in enumerate(boxes):
+        q = np.array([[x, y], [x + w, y], [x + w, y + h], [x, y + h]], dtype=np.float64)
+        if k in (2, 3):  # a few degrees of rotation about the centre
+            a = np.deg2rad(6 if k == 2 else -4)
+            c = q.mean(0)
+            q = (q - c) @ np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]).T + c
+        lines.append(np.rint(q).astype(np.int32))
+        for _ in range(14):  # strokes
+            bw, bh = int(rng.integers(3, 12)), int(rng.integers(3, 12))
+            bx, by = int(rng.integers(x + 2, max(x + 3, x + w - bw - 2))), int(rng.integers(y + 2, max(y + 3, y + h - bh - 2)))
+            mask[by:by + bh, bx:bx + bw] = 255
+    for (bx, by, bw, bh) in [(232, 60, 5, 8), (236, 50, 6, 8), (262, 44, 9, 9), (5, 250, 7, 7), (150, 300, 3, 3), (280, 340, 2, 4), (100, 160, 5, 9)]:
+        mask[by:by + bh, bx:bx + bw] = 255
+    mask[318:350, 18:150] = 255  # larger than line 4: never assigned
+    mask[rng.random((H, W)) < 0.002] = 255
+    return img, mask, np.stack(lines)
+
+
+def mask_refinement_stubs():
+    refine = lambda rgb, m: np.where(rgb[..., 1] > 40, m, 0).astype(np.uint8)  # stands in for the DenseCRF (uses both crops)
+    bilateral = lambda img, *a: (img // 4) * 4                                   # stands in for cv2.bilateralFilter
+    return refine, bilateral
+
+
+def golden_mask_refinement():
+    """mask_refinement.dispatch / complete_mask of the reference (cv2 / shapely stand-ins; DenseCRF and bilateralFilter stubbed — see
+    ref_import.mask_refinement) on the synthetic scene above."""
+    import asyncio
+
+    refine, bilateral = mask_refinement_stubs()
+    mr, tmu, G = R.mask_refinement(refine_stub=refine, bilateral_stub=bilateral)
+    img, mask, lines = mask_refinement_scene()
+    out = {"img": img, "mask": mask, "lines": lines}
+    for tag, off, ks in (("a", 0, 3), ("b", 6, 5)):
+        quads = [G.Quadrilateral(l.astype(np.float64), "", 0) for l in lines]
+        m = mask.copy()
+        out[f"complete_{tag}"] = tmu.complete_mask(img.copy(), m, quads, dilation_offset=off, kernel_size=ks)
+        out[f"complete_{tag}_mask_after"] = m
+        region = type("Region", (), {"lines": lines})()
+        out[f"dispatch_{tag}"] = asyncio.run(mr.dispatch([region], img.copy(), mask.copy(), "fit_text", off, 0, False, ks))
+    empty = type("Region", (), {"lines": lines[:1] + np.array([400, 400])})()
+    out["dispatch_none"] = asyncio.run(mr.dispatch([type("Region", (), {"lines": np.zeros((0, 4, 2), np.int32)})()], img.copy(),
+                                                   np.zeros_like(mask), "fit_text", 0, 0, False, 3))
+    np.savez_compressed(os.path.join(GOLDEN, "mask_refinement.npz"), **out)
+    print("mask_refinement", {k: (v.shape, int(v.sum() // 255) if v.dtype == np.uint8 and v.ndim == 2 else "") for k, v in out.items()})
+
+
 def build_ref_dbnet():
     from manga_image_translator_amd import dbnet_schema
 
@@ -426,6 +482,7 @@ def main():
     golden_direction()
     golden_refine_mask()
     golden_textline_merge()
+    golden_mask_refinement()
 
 
 if __name__ == "__main__":

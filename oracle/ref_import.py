@@ -143,7 +143,7 @@ def cv2_shim():
         if interpolation == ns.INTER_NEAREST:
             return OL.resize_nearest(src, dsize)
         if interpolation == ns.INTER_LINEAR:
-            return OC.resize_linear_u8(src, dsize)
+            return OC.resize_linear_u8(src[..., None], dsize)[..., 0] if src.ndim == 2 else OC.resize_linear_u8(src, dsize)
         raise NotImplementedError(interpolation)
 
     def filter2D(src, ddepth, kernel):
@@ -167,9 +167,18 @@ def cv2_shim():
     ns.MORPH_RECT, ns.MORPH_ELLIPSE, ns.THRESH_BINARY, ns.THRESH_OTSU, ns.CV_16U, ns.COLOR_BGR2GRAY = 0, 2, 0, 8, 2, 6
 
     def getStructuringElement(shape, ksize, anchor=None):
-        if shape == ns.MORPH_ELLIPSE and tuple(ksize) == (3, 3):
-            return np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
-        return np.ones((ksize[1], ksize[0]), np.uint8)
+        w, h = int(ksize[0]), int(ksize[1])
+        if shape == ns.MORPH_ELLIPSE:  # OpenCV morph.cpp: row i spans c -+ round(c * sqrt((r^2 - dy^2) / r^2)), r = h / 2, c = w / 2
+            r, c = h // 2, w // 2
+            inv_r2 = 1.0 / (r * r) if r else 0.0
+            k = np.zeros((h, w), np.uint8)
+            for i in range(h):
+                dy = i - r
+                if abs(dy) <= r:
+                    dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))
+                    k[i, max(c - dx, 0):min(c + dx + 1, w)] = 1
+            return k
+        return np.ones((h, w), np.uint8)
 
     def _morph(src, kernel, iterations, dil):
         out = src
@@ -189,14 +198,41 @@ def cv2_shim():
             thresh = int(np.argmax(sigma))
         return thresh, np.where(src > thresh, maxval, 0).astype(np.uint8)
 
-    def connectedComponentsWithStats(img, connectivity, ltype):
+    ns.CC_STAT_LEFT, ns.CC_STAT_TOP, ns.CC_STAT_WIDTH, ns.CC_STAT_HEIGHT, ns.CC_STAT_AREA, ns.CV_32S = 0, 1, 2, 3, 4, 4
+
+    def connectedComponentsWithStats(img, connectivity=8, ltype=4):
         lab, n = _nd.label(img > 0, structure=np.ones((3, 3)) if connectivity == 8 else None)
         stats = np.zeros((n + 1, 5), dtype=np.int32)
         for k in range(n + 1):
             ys, xs = np.nonzero(lab == k)
             if len(ys):
                 stats[k] = [xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1, len(ys)]
-        return n + 1, lab.astype(np.uint16), stats, np.zeros((n + 1, 2))
+        return n + 1, lab.astype(np.uint16 if ltype == ns.CV_16U else np.int32), stats, np.zeros((n + 1, 2))
+
+    def rectangle(img, pt1, pt2, color, thickness=1):
+        """Axis-aligned rectangle with inclusive corners, clipped to the image; thickness 1 = outline, negative = filled."""
+        (x1, x2), (y1, y2) = sorted((int(pt1[0]), int(pt2[0]))), sorted((int(pt1[1]), int(pt2[1])))
+        c = color[0] if isinstance(color, (tuple, list)) else color
+        H, W = img.shape[:2]
+        xa, xb, ya, yb = max(x1, 0), min(x2, W - 1), max(y1, 0), min(y2, H - 1)
+        if xa > xb or ya > yb:
+            return img
+        if thickness < 0:
+            img[ya:yb + 1, xa:xb + 1] = c
+            return img
+        if thickness != 1:
+            raise NotImplementedError("rectangle: thickness 1 or filled only")
+        for y in (y1, y2):
+            if 0 <= y < H:
+                img[y, xa:xb + 1] = c
+        for x in (x1, x2):
+            if 0 <= x < W:
+                img[ya:yb + 1, x] = c
+        return img
+
+    ns.rectangle = rectangle
+    ns.bitwise_not = lambda a: np.bitwise_not(a)
+    ns.bilateralFilter = lambda img, d, sigma_color, sigma_space: img  # stand-in; replaced by the caller's stub where it matters
 
     def cvtColor(src, code):
         if code == ns.COLOR_BGR2GRAY:
@@ -253,6 +289,47 @@ def textmask():
     return tm
 
 
+def mask_refinement(refine_stub=None, bilateral_stub=None):
+    """reference modules manga_translator/mask_refinement/{text_mask_utils,__init__}.py with the cv2 / shapely stand-ins and the
+    reference's own Quadrilateral.  ``pydensecrf`` exists nowhere this can run: the DenseCRF call (text_mask_utils.refine_mask) and
+    cv2.bilateralFilter are replaced by the caller's deterministic stubs, so what gets pinned is everything AROUND them — component
+    -> text-line assignment, crops, dilation sizes, the resizes of dispatch()."""
+    _prepare()
+    G = generic()
+    shp = shapely_shim()
+    G.Polygon, G.MultiPoint = shp.Polygon, shp.MultiPoint
+    utils = types.ModuleType("manga_translator.utils")
+    utils.Quadrilateral, utils.TextBlock = G.Quadrilateral, type("TextBlock", (), {})
+    utils.image_resize = lambda *a, **k: None
+    bubble = types.ModuleType("manga_translator.utils.bubble")
+    bubble.is_ignore = lambda *a, **k: False
+    saved = {k: sys.modules.get(k) for k in ("manga_translator.utils", "manga_translator.utils.bubble")}
+    sys.modules["manga_translator.utils"], sys.modules["manga_translator.utils.bubble"] = utils, bubble
+    try:
+        _pkg("manga_translator.mask_refinement")
+        for k in ("manga_translator.mask_refinement.text_mask_utils", "manga_translator.mask_refinement"):
+            _loaded.pop(k, None)
+        tmu = _load("manga_translator.mask_refinement.text_mask_utils", "mask_refinement/text_mask_utils.py")
+        spec = importlib.util.spec_from_file_location("manga_translator.mask_refinement._init", os.path.join(PKG, "mask_refinement", "__init__.py"),
+                                                      submodule_search_locations=[])
+        mr = importlib.util.module_from_spec(spec)
+        mr.__package__ = "manga_translator.mask_refinement"
+        spec.loader.exec_module(mr)
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+    cv = cv2_shim()
+    if bilateral_stub is not None:
+        cv.bilateralFilter = bilateral_stub
+    tmu.cv2 = mr.cv2 = cv
+    tmu.Polygon = shp.Polygon
+    tmu.tqdm = lambda it, *a, **k: it
+    if refine_stub is not None:
+        tmu.refine_mask = refine_stub
+    return mr, tmu, G
+
+
 def shapely_shim():
     """Minimal ``shapely.geometry`` stand-in (Polygon / MultiPoint with area, length, distance, convex_hull) so the reference's
     own ``quadrilateral_can_merge_region`` / ``Quadrilateral.polygon`` (utils/generic.py) can be executed here.  Geometry by
@@ -298,6 +375,56 @@ def shapely_shim():
                 return 0.0
             return min(seg_seg(a, b, c, d) for a, b in self._edges() for c, d in other._edges())
 
+    class Point:
+        def __init__(self, x, y):
+            self.x, self.y = float(x), float(y)
+
+    def _poly_centroid(self):
+        x, y = self.pts[:, 0], self.pts[:, 1]
+        xn, yn = np.roll(x, -1), np.roll(y, -1)
+        cr = x * yn - xn * y
+        a = cr.sum() / 2
+        return Point(((x + xn) * cr).sum() / (6 * a), ((y + yn) * cr).sum() / (6 * a))
+
+    def _poly_intersection(self, other):
+        """Convex-convex: ``other`` clipped by the half-plane of every edge of ``self`` (orientation-independent)."""
+        sgn = 1.0 if np.dot(self.pts[:, 0], np.roll(self.pts[:, 1], -1)) - np.dot(self.pts[:, 1], np.roll(self.pts[:, 0], -1)) > 0 else -1.0
+        out = [tuple(p) for p in other.pts]
+        for a, b in self._edges():
+            side = lambda p: sgn * ((b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]))
+            src, out = out, []
+            for i, p in enumerate(src):
+                q = src[(i + 1) % len(src)]
+                sp, sq = side(p), side(q)
+                if sp >= 0:
+                    out.append(p)
+                if (sp > 0 and sq < 0) or (sp < 0 and sq > 0):
+                    t = sp / (sp - sq)
+                    out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+            if len(out) < 3:
+                return Polygon([(0, 0), (0, 0), (0, 0)])
+        return Polygon(out)
+
+    _poly_dist = Polygon.distance
+
+    def _poly_distance(self, other):
+        if isinstance(other, Point):
+            p = np.array([other.x, other.y])
+            if self._contains(p):
+                return 0.0
+            best = np.inf
+            for a, b in self._edges():
+                ab = b - a
+                den = float(ab @ ab)
+                t = 0.0 if den == 0 else min(1.0, max(0.0, float((p - a) @ ab) / den))
+                best = min(best, float(np.linalg.norm(p - (a + t * ab))))
+            return best
+        return _poly_dist(self, other)
+
+    Polygon.centroid = property(_poly_centroid)
+    Polygon.intersection = _poly_intersection
+    Polygon.distance = _poly_distance
+
     class MultiPoint:
         def __init__(self, pts):
             self.pts = [tuple(map(float, p)) for p in pts]
@@ -317,4 +444,4 @@ def shapely_shim():
                 up.append(q)
             return Polygon(lo[:-1] + up[:-1])
 
-    return types.SimpleNamespace(Polygon=Polygon, MultiPoint=MultiPoint)
+    return types.SimpleNamespace(Polygon=Polygon, MultiPoint=MultiPoint, Point=Point)
