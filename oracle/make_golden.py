@@ -414,7 +414,6 @@ def golden_mask_refinement():
         out[f"complete_{tag}_mask_after"] = m
         region = type("Region", (), {"lines": lines})()
         out[f"dispatch_{tag}"] = asyncio.run(mr.dispatch([region], img.copy(), mask.copy(), "fit_text", off, 0, False, ks))
-    empty = type("Region", (), {"lines": lines[:1] + np.array([400, 400])})()
     out["dispatch_none"] = asyncio.run(mr.dispatch([type("Region", (), {"lines": np.zeros((0, 4, 2), np.int32)})()], img.copy(),
                                                    np.zeros_like(mask), "fit_text", 0, 0, False, 3))
     np.savez_compressed(os.path.join(GOLDEN, "mask_refinement.npz"), **out)
