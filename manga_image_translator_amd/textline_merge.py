@@ -205,9 +205,12 @@ class TextBlock:
                 self.text += txt if (first_cjk or second_cjk) else " " + txt
 
 
-def dispatch_sync(textlines: Sequence[Quadrilateral], width: int, height: int) -> List[TextBlock]:
+def dispatch_sync(textlines: Sequence[Quadrilateral], width: int, height: int, block_factory=None) -> List[TextBlock]:
     """textline_merge.dispatch (:186-208).  Keeps the reference's normalisation of the region probability by the area of ALL
-    text lines (:197)."""
+    text lines (:197).  ``block_factory(lines, texts, font_size, angle, prob, fg, bg)`` builds the region object — the mirror
+    ``TextBlock`` by default; inside the reference pass ``lambda l, t, fs, a, p, fg, bg: manga_translator.utils.TextBlock(l, t,
+    font_size=fs, angle=a, prob=p, fg_color=fg, bg_color=bg)`` (its own call, :199-206)."""
+    make = block_factory or TextBlock
     regions: List[TextBlock] = []
     total_area = sum(t.area for t in textlines)
     for lines, fg, bg in merge_bboxes_text_region(textlines, width, height):
@@ -215,10 +218,10 @@ def dispatch_sync(textlines: Sequence[Quadrilateral], width: int, height: int) -
         angle = np.rad2deg(np.mean([t.angle for t in lines])) - 90
         if abs(angle) < 3:
             angle = 0
-        regions.append(TextBlock([t.pts for t in lines], [t.text for t in lines], int(min(t.font_size for t in lines)), float(angle),
-                                 float(np.exp(logp)), fg, bg))
+        regions.append(make([t.pts for t in lines], [t.text for t in lines], int(min(t.font_size for t in lines)), float(angle),
+                            float(np.exp(logp)), fg, bg))
     return regions
 
 
-async def dispatch(textlines: Sequence[Quadrilateral], width: int, height: int, verbose: bool = False) -> List[TextBlock]:
-    return dispatch_sync(textlines, width, height)
+async def dispatch(textlines: Sequence[Quadrilateral], width: int, height: int, verbose: bool = False, block_factory=None) -> List[TextBlock]:
+    return dispatch_sync(textlines, width, height, block_factory)

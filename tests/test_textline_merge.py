@@ -83,3 +83,16 @@ def test_cjk_join():
     assert b.text == "こんにちは"
     b = TM.TextBlock(np.zeros((2, 4, 2)), ["hello", "world"], 10, 0, 1.0, (0, 0, 0), (0, 0, 0))
     assert b.text == "hello world"
+
+
+def test_block_factory_receives_the_reference_constructor_arguments():
+    case = CASES[0]
+    quads = _quads(case)
+    for q in quads:
+        q.text, q.prob = "x", 0.9
+    got = TM.dispatch_sync(quads, case["width"], case["height"], block_factory=lambda *a: a)
+    ref = TM.dispatch_sync(quads, case["width"], case["height"])
+    assert len(got) == len(ref)
+    for (lines, texts, fs, angle, prob, fg, bg), b in zip(got, ref):
+        assert np.array_equal(np.array(lines, dtype=np.int32), b.lines) and texts == b.texts
+        assert (fs, angle, fg, bg) == (b.font_size, b.angle, b.fg_colors, b.bg_colors) and abs(prob - b.prob) < 1e-15
