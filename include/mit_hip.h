@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 1
+#define MIT_ABI_VERSION 2
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -106,6 +106,9 @@ typedef struct MitConvGemm {
 
 const char *mit_last_error(void);
 int mit_abi_version(void);
+/* sha256 over the sources (every .hip / .h under csrc, this header) and compiler flags the library was built from; the Python
+ * binding refuses (or rebuilds) a library whose digest differs from the tree's, so stale kernels are never measured. */
+const char *mit_source_digest(void);
 
 /* device / runtime ------------------------------------------------------------------- */
 int mit_device_count(int *count);
@@ -155,6 +158,16 @@ int mit_prof_read(MitProfStat *stats, int max_cfgs, int *n_cfgs);
 /* One CSV line per recorded launch (tile, M, N, K, taps, Z, act, ms, executed / algorithmic FLOPs): the per-layer view behind
  * bench.py's per-tile totals (scripts/ocr_layers.py).  Call before mit_prof_enable() clears the records. */
 int mit_prof_dump(const char *path);
+/* The same probe for the kernels that are NOT mit_conv_gemm (the HBM-bound transforms / FFTs / element-wise passes, the VALU
+ * output convolution, the OCR attention / softmax kernels): per kernel name, launches, summed time and the summed ALGORITHMIC
+ * bytes (inputs read once + outputs written once at the stored precision) and FLOPs of its launches.
+ * mit_prof_enable() arms and clears it together with the conv probe. */
+typedef struct MitProfKernelStat {
+    char name[48];
+    int64_t launches;
+    double ms, alg_bytes, alg_flops;
+} MitProfKernelStat;
+int mit_prof_kernels_read(MitProfKernelStat *stats, int max_stats, int *n_stats);
 
 /* LaMa inpainting stage: memory-bound pieces ----------------------------------------------
  * Reference: manga_translator/inpainting/inpainting_lama_mpe.py. */

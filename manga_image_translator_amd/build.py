@@ -44,9 +44,24 @@ def _sources() -> list[Path]:
     return sorted(CSRC.glob("*.hip"))
 
 
+def source_digest() -> str:
+    """sha256 over every source the library is built from + the compiler flags (what mit_source_digest() must return)."""
+    return _digest()
+
+
 def _digest() -> str:
     h = hashlib.sha256()
-    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "mit_hip.h"]):
+    for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [PKG_DIR.parent / "include" / "mit_hip.h"]):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def _obj_digest(src: Path) -> str:
+    """Digest of one translation unit: its source, every header it can include, the flags."""
+    h = hashlib.sha256()
+    for p in [src] + sorted(list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc"))) + [PKG_DIR.parent / "include" / "mit_hip.h"]:
         h.update(p.name.encode())
         h.update(p.read_bytes())
     h.update(" ".join(HIPCC_FLAGS).encode())
@@ -54,7 +69,9 @@ def _digest() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every ``csrc/*.hip`` for gfx950 and link ``libmit_hip.so``. Incremental."""
+    """Compile every ``csrc/*.hip`` for gfx950 and link ``libmit_hip.so``.  Incremental per translation unit (an object is
+    reused while its source, the headers and the flags are unchanged); the library as a whole carries the digest of all
+    sources (``mit_source_digest()``), which is what ``lib.load()`` checks."""
     digest = _digest()
     if not force and LIB_PATH.exists() and _STAMP.exists() and _STAMP.read_text().strip() == digest:
         return LIB_PATH
@@ -65,19 +82,27 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objs = []
     for src in _sources():
         obj = objdir / (src.stem + ".o")
+        stamp = objdir / (src.stem + ".digest")
         objs.append(str(obj))
+        od = _obj_digest(src) + (digest if src.name == "capi.hip" else "")
+        if obj.exists() and stamp.exists() and stamp.read_text() == od:
+            continue
         cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        if src.name == "capi.hip":  # mit_source_digest(): lets lib.load() detect a stale binary
+            cmd.insert(1, f'-DMIT_SOURCE_DIGEST="{digest}"')
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        procs.append((src, stamp, od, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
-    for src, proc in procs:
+    for src, stamp, od, proc in procs:
         out, _ = proc.communicate()
         if proc.returncode != 0:
             failed = True
             sys.stderr.write(f"--- hipcc failed for {src.name} ---\n{out}\n")
-        elif verbose and out.strip():
-            sys.stderr.write(out)
+        else:
+            stamp.write_text(od)
+            if verbose and out.strip():
+                sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *objs]

@@ -122,19 +122,15 @@ class CtdEngine:
 
         self.br_binarize = branch("binarize", True)
         self.br_thresh = branch("thresh", False)
-        self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._ws = ops.Workspace(self.device)
         self._prep_tabs: Dict[Tuple, dict] = {}
 
-    def _buf(self, name, *shape, dtype=torch.float32):
-        key = (name, tuple(shape), dtype)
-        t = self._ws.get(key)
-        if t is None:
-            t = torch.empty(*shape, dtype=dtype, device=self.device)
-            self._ws[key] = t
-        return t
+    def _buf(self, name: str, *shape, dtype=torch.float32) -> torch.Tensor:
+        """Named workspace slab, grown to the largest request (ops.Workspace): memory is bounded by the largest page seen."""
+        return self._ws.buf(name, *shape, dtype=dtype)
 
     def release_workspace(self):
-        self._ws.clear()
+        self._ws.release()
 
     # -- letterbox geometry (imgproc_utils.py:69-100) ------------------------------------------
     @staticmethod
@@ -146,6 +142,9 @@ class CtdEngine:
     def _resize_tables(self, H, W, nh, nw):
         key = (H, W, nh, nw)
         if key not in self._prep_tabs:
+            while len(self._prep_tabs) >= 8:  # a few KB per page shape: keep the most recent shapes only
+                self._prep_tabs.pop(next(iter(self._prep_tabs)))
+
             def taps(n_src, n_dst):  # OpenCV resize.cpp linear coefficients, 11-bit fixed point
                 idx = np.zeros(n_dst, dtype=np.int32)
                 co = np.zeros((n_dst, 2), dtype=np.int16)

@@ -70,18 +70,14 @@ class DbnetEngine:
         self.thresh = branch(d + ".thresh", False, ACT_SIGMOID)
         self.mask_convs = [ops.Conv2d(sd[f"conv_mask.{i}.weight"], sd[f"conv_mask.{i}.bias"], padding=1, act=ACT_RELU, device=dev) for i in (0, 2, 4)]
         self.mask_out = ops.Conv2d(sd["conv_mask.6.weight"], sd["conv_mask.6.bias"], act=ACT_SIGMOID, device=dev)
-        self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._ws = ops.Workspace(self.device)
 
-    def _buf(self, name, *shape, dtype=torch.float32):
-        key = (name, tuple(shape), dtype)
-        t = self._ws.get(key)
-        if t is None:
-            t = torch.empty(*shape, dtype=dtype, device=self.device)
-            self._ws[key] = t
-        return t
+    def _buf(self, name: str, *shape, dtype=torch.float32) -> torch.Tensor:
+        """Named workspace slab, grown to the largest request (ops.Workspace): memory is bounded by the largest page seen."""
+        return self._ws.buf(name, *shape, dtype=dtype)
 
     def release_workspace(self):
-        self._ws.clear()
+        self._ws.release()
 
     def _triple(self, tr: _Triple, x, out, tag):
         B, H, W, _ = x.shape

@@ -53,18 +53,14 @@ class EsrganEngine:
         # output is BGR (:545 flips back): emit RGB directly by flipping the output channels
         self.hr1 = ops.ConvSmallCout(sd["model.10.weight"].detach().float().flip(0), sd["model.10.bias"].detach().float().flip(0),
                                      pad_mode=PAD_ZERO, device=dev)
-        self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._ws = ops.Workspace(self.device)
 
-    def _buf(self, name, *shape, dtype=torch.float32):
-        key = (name, tuple(shape), dtype)
-        t = self._ws.get(key)
-        if t is None:
-            t = torch.empty(*shape, dtype=dtype, device=self.device)
-            self._ws[key] = t
-        return t
+    def _buf(self, name: str, *shape, dtype=torch.float32) -> torch.Tensor:
+        """Named workspace slab, grown to the largest request (ops.Workspace): memory is bounded by the largest page seen."""
+        return self._ws.buf(name, *shape, dtype=dtype)
 
     def release_workspace(self):
-        self._ws.clear()
+        self._ws.release()
 
     @torch.no_grad()
     def forward(self, img_u8: torch.Tensor, taps=None) -> torch.Tensor:

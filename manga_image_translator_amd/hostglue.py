@@ -148,6 +148,16 @@ def _dilate(m: np.ndarray, fp: np.ndarray) -> np.ndarray:  # cv2.dilate: outside
     return ndimage.grey_dilation(m, footprint=fp, mode="constant", cval=0)
 
 
+def _in_range_u8(src: np.ndarray, lo: float, hi: float) -> np.ndarray:
+    """cv2.inRange(src_u8, lo, hi) with scalar bounds: OpenCV converts the bounds to int32 with cvRound (half to even) and
+    saturates them to the 8-bit range; an inverted or out-of-range interval selects nothing (core/src/arithm.cpp inRange)."""
+    ilo, ihi = int(np.rint(lo)), int(np.rint(hi))
+    if ilo > ihi or ilo > 255 or ihi < 0:
+        return np.zeros(src.shape, np.uint8)
+    ilo, ihi = max(ilo, 0), min(ihi, 255)
+    return np.where((src >= ilo) & (src <= ihi), 255, 0).astype(np.uint8)
+
+
 def _xor_sum(a: np.ndarray, b: np.ndarray) -> int:
     return int(np.bitwise_xor(a, b).sum(dtype=np.uint64))
 
@@ -235,7 +245,7 @@ def refine_mask(img: np.ndarray, pred_mask: np.ndarray, quads: Sequence, refine_
         for color in _topk_color(edges, bins, color_var=10, k=3):
             c_top = min(color + 30, 255)
             c_bottom = c_top - 60
-            masks.append(list(_minxor_thresh(np.where((grey >= c_bottom) & (grey <= c_top), 255, 0).astype(np.uint8), msk)))
+            masks.append(list(_minxor_thresh(_in_range_u8(grey, c_bottom, c_top), msk)))
         otsu = []                                                 # get_otsuthresh_masklist :44-54 (per_channel False)
         for c in range(3):
             ch = im[..., c]

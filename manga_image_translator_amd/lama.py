@@ -191,28 +191,23 @@ class LamaEngine:
             self.mpe = dict(emb=mpe_sd["rel_pos_emb.weight"].to(torch.float32).to(dev).contiguous(),
                             dirw=mpe_sd["direct_emb.weight"].to(torch.float32).to(dev).contiguous(),
                             alpha5=float(mpe_sd["alpha5"]), alpha6=float(mpe_sd["alpha6"]))
-        self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._ws = ops.Workspace(self.device)
         self._tw: Dict[int, torch.Tensor] = {}
-        self._dft: Dict[Tuple[int, int], Tuple[torch.Tensor, ...]] = {}
-        self._mpe_tabs: Dict[Tuple[int, int], dict] = {}
+        self._dft = ops.ShapeCache(4)       # per-(h, w) DFT matrices: a few page shapes stay resident, older ones are dropped
+        self._mpe_tabs = ops.ShapeCache(4)  # per-(H, W) resize tap tables of the MPE index kernels
 
     # -- workspace -------------------------------------------------------------------------
     def _buf(self, name: str, *shape, dtype=torch.float32) -> torch.Tensor:
-        key = (name, tuple(shape), dtype)
-        t = self._ws.get(key)
-        if t is None:
-            t = torch.empty(*shape, dtype=dtype, device=self.device)
-            self._ws[key] = t
-        return t
+        """Named workspace slab, grown to the largest request (ops.Workspace): memory is bounded by the largest page seen."""
+        return self._ws.buf(name, *shape, dtype=dtype)
 
     def release_workspace(self):
-        self._ws.clear()
+        self._ws.release()
+        self._dft.clear()
+        self._mpe_tabs.clear()
 
     def _dft_mats(self, h, w):
-        k = (h, w)
-        if k not in self._dft:
-            self._dft[k] = tuple(m.to(self.device) for m in dft_matrices(h, w))
-        return self._dft[k]
+        return self._dft.get((h, w), lambda: tuple(m.to(self.device) for m in dft_matrices(h, w)))
 
     def _twiddles(self, h):
         """(cos, sin)(2 pi k / h), k < h/2, rounded once from float64 — the table mit_fft_cols consumes."""
@@ -228,15 +223,15 @@ class LamaEngine:
                                             C.c_void_p(ops.current_stream())), "mit_fft_cols")
 
     def _mpe_tables(self, H, W):
-        k = (H, W)
-        if k not in self._mpe_tabs:
+        def make():
             ys, yc, yw, ymax = _area_taps(H, MPE_S)
             xs, xc, xw, xmax = _area_taps(W, MPE_S)
             dev = self.device
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-            self._mpe_tabs[k] = dict(ys=t(ys), yc=t(yc), yw=t(yw), ymax=ymax, xs=t(xs), xc=t(xc), xw=t(xw), xmax=xmax,
-                                     ymap=t(_nearest_map(H, MPE_S)), xmap=t(_nearest_map(W, MPE_S)))
-        return self._mpe_tabs[k]
+            return dict(ys=t(ys), yc=t(yc), yw=t(yw), ymax=ymax, xs=t(xs), xc=t(xc), xw=t(xw), xmax=xmax,
+                        ymap=t(_nearest_map(H, MPE_S)), xmap=t(_nearest_map(W, MPE_S)))
+
+        return self._mpe_tabs.get((H, W), make)
 
     # -- FourierUnit (:214-257) as DFT GEMMs ---------------------------------------------------
     def _fourier_unit(self, ffc: _FFC, t1: torch.Tensor, t2: torch.Tensor):

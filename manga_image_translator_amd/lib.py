@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 1
+MIT_ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -105,6 +105,11 @@ class MitProfStat(C.Structure):
     _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("exec_flops", C.c_double), ("alg_flops", C.c_double)]
 
 
+class MitProfKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double), ("alg_bytes", C.c_double),
+                ("alg_flops", C.c_double)]
+
+
 class MitWarpLine(C.Structure):
     _fields_ = [("minv", C.c_double * 9), ("page", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32), ("cw", C.c_int32),
                 ("ch", C.c_int32), ("dw", C.c_int32), ("dh", C.c_int32), ("vertical", C.c_int32), ("out_row", C.c_int32),
@@ -120,6 +125,7 @@ class MitRaggedSeg(C.Structure):
 SYMBOLS = {
     "mit_last_error": (C.c_char_p, []),
     "mit_abi_version": (C.c_int, []),
+    "mit_source_digest": (C.c_char_p, []),
     "mit_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mit_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "mit_conv_gemm": (C.c_int, [C.POINTER(MitConvGemm), C.c_void_p]),
@@ -131,6 +137,7 @@ SYMBOLS = {
     "mit_prof_tag_next": (C.c_int, [C.c_double]),
     "mit_prof_read": (C.c_int, [C.POINTER(MitProfStat), C.c_int, C.POINTER(C.c_int)]),
     "mit_prof_dump": (C.c_int, [C.c_char_p]),
+    "mit_prof_kernels_read": (C.c_int, [C.POINTER(MitProfKernelStat), C.c_int, C.POINTER(C.c_int)]),
     "mit_wino43_input": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]),
     "mit_wino43_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
@@ -196,18 +203,31 @@ def lib_path() -> Path:
     return Path(__file__).resolve().parent / "libmit_hip.so"
 
 
+def _stale(path: Path, want: str) -> bool:
+    """True when the binary at ``path`` was built from other sources than the tree's.  The digest is read from the marker
+    string in the file, not through dlopen: a stale library must not stay mapped when its replacement is loaded."""
+    try:
+        return (b"MIT_SOURCE_DIGEST=" + want.encode()) not in path.read_bytes()
+    except OSError:
+        return True
+
+
 def load(build_if_missing: bool = True) -> C.CDLL:
-    """Load ``libmit_hip.so`` (building it with hipcc if absent). Raises on any failure."""
+    """Load ``libmit_hip.so``.  A missing library, or one built from other sources than the tree's (``mit_source_digest()``
+    against ``build.source_digest()``), is rebuilt with hipcc when ``build_if_missing`` — otherwise that is an error: old
+    kernels are never validated or measured silently.  Raises on any failure."""
     global _lib
     if _lib is not None:
         return _lib
-    path = lib_path()
-    if not path.exists():
-        if not build_if_missing:
-            raise RuntimeError(f"{path} is missing: run `python -m manga_image_translator_amd.build`")
-        from . import build as _build
+    from . import build as _build
 
-        _build.build()
+    path = lib_path()
+    want = _build.source_digest()
+    if not path.exists() or _stale(path, want):
+        if not build_if_missing:
+            what = "is missing" if not path.exists() else "was built from different sources than this tree"
+            raise RuntimeError(f"{path} {what}: run `python -m manga_image_translator_amd.build`")
+        _build.build(force=True)
     lib = C.CDLL(str(path))
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
@@ -215,6 +235,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn.argtypes = argtypes
     if lib.mit_abi_version() != MIT_ABI_VERSION:
         raise RuntimeError(f"libmit_hip.so ABI {lib.mit_abi_version()} != binding {MIT_ABI_VERSION}")
+    if lib.mit_source_digest().decode() != want:
+        raise RuntimeError(f"{path} does not match the sources it was just built from (digest mismatch)")
     _lib = lib
     return lib
 

@@ -34,6 +34,57 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+class Workspace:
+    """Named grow-only slabs: ``buf(name, *shape)`` returns a view of the slab ``(name, dtype)``, which is reallocated only
+    when a larger request arrives.  Device memory therefore stays bounded by the LARGEST page seen, not by the number of
+    distinct page shapes (all users of an engine are ordered on one stream, so a slab can be re-viewed at a new shape by the
+    next call; the caching allocator keeps a replaced slab alive until the work queued on it has run)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._slabs = {}
+
+    def buf(self, name: str, *shape, dtype=torch.float32) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        key = (name, dtype)
+        t = self._slabs.get(key)
+        if t is None or t.numel() < max(n, 1):
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._slabs[key] = t
+        return t[:n].view(*shape)
+
+    def release(self) -> None:
+        self._slabs.clear()
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._slabs.values())
+
+
+class ShapeCache:
+    """Tiny LRU for per-(H, W) device tables (DFT matrices, resize taps): at most ``capacity`` page shapes stay resident."""
+
+    def __init__(self, capacity: int = 4):
+        self.capacity, self._d = capacity, {}
+
+    def get(self, key, make):
+        if key in self._d:
+            self._d[key] = self._d.pop(key)  # most recently used last
+            return self._d[key]
+        v = make()
+        self._d[key] = v
+        while len(self._d) > self.capacity:
+            self._d.pop(next(iter(self._d)))
+        return v
+
+    def clear(self):
+        self._d.clear()
+
+    def __len__(self):
+        return len(self._d)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 

@@ -106,6 +106,8 @@ class HipComicTextDetector(_DetBase):
         self.device, self.input_size = device, (input_size, input_size)
 
     async def _unload(self):
+        if self.engine is not None:
+            self.engine.release_workspace()  # device slabs go back to the allocator before the weights do
         self.engine = None
 
     @torch.no_grad()
@@ -151,6 +153,8 @@ class HipDefaultDetector(_DetBase):
         self.device = device
 
     async def _unload(self):
+        if self.engine is not None:
+            self.engine.release_workspace()  # device slabs go back to the allocator before the weights do
         self.engine = None
 
     @torch.no_grad()
@@ -204,6 +208,8 @@ class HipModel48pxOCR(_OcrBase):
         self.device = device
 
     async def _unload(self):
+        if self.engine is not None:
+            self.engine.release_workspace()  # device slabs go back to the allocator before the weights do
         self.engine = None
 
     def _directions(self, textlines):
@@ -379,6 +385,8 @@ class HipLamaMPEInpainter(_InpBase):
         self.device = device
 
     async def _unload(self):
+        if self.engine is not None:
+            self.engine.release_workspace()  # device slabs go back to the allocator before the weights do
         self.engine = None
 
     @torch.no_grad()
@@ -440,6 +448,8 @@ class HipESRGANUpscaler(_UpBase):
         self.device = device
 
     async def _unload(self):
+        if self.engine is not None:
+            self.engine.release_workspace()  # device slabs go back to the allocator before the weights do
         self.engine = None
 
     @torch.no_grad()

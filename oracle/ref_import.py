@@ -245,7 +245,14 @@ def cv2_shim():
     ns.erode = lambda src, kernel, iterations=1: _morph(src, kernel, iterations, False)
     ns.bitwise_xor, ns.bitwise_or = np.bitwise_xor, np.bitwise_or
     ns.threshold, ns.connectedComponentsWithStats = threshold, connectedComponentsWithStats
-    ns.inRange = lambda src, lo, hi: np.where((src >= lo) & (src <= hi), 255, 0).astype(np.uint8)
+    def inRange(src, lo, hi):
+        """scalar bounds on an 8-bit image: cvRound to int32 (half to even), empty when inverted / out of range, saturate"""
+        ilo, ihi = int(np.rint(lo)), int(np.rint(hi))
+        if ilo > ihi or ilo > 255 or ihi < 0:
+            return np.zeros(src.shape, np.uint8)
+        return np.where((src >= max(ilo, 0)) & (src <= min(ihi, 255)), 255, 0).astype(np.uint8)
+
+    ns.inRange = inRange
     ns.resize, ns.filter2D, ns.copyMakeBorder = resize, filter2D, copyMakeBorder
     ns.cvtColor = cvtColor
     ns.findHomography = lambda s, d, *a, **k: (OT.find_homography_4pt(s, d), None)

@@ -69,3 +69,44 @@ def test_ctypes_structs_match_c_layout(tmp_path):
         assert int(out[name]) == C.sizeof(st), name
         for fname, *_ in st._fields_:
             assert int(out[f"{name}.{fname}"]) == getattr(st, fname).offset, f"{name}.{fname}"
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """lib.load() compares the digest embedded in the binary with the digest of the sources in the tree: a library built
+    from other sources is an error when rebuilding is not allowed (never validated or measured silently)."""
+    from manga_image_translator_amd import build, lib
+
+    handle = lib.load(build_if_missing=True)
+    assert handle.mit_source_digest().decode() == build.source_digest()
+    assert not lib._stale(lib.lib_path(), build.source_digest())
+    assert lib._stale(lib.lib_path(), "0" * 64) and lib._stale(tmp_path / "missing.so", build.source_digest())
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(build, "source_digest", lambda: "0" * 64)
+    with pytest.raises(RuntimeError, match="different sources"):
+        lib.load(build_if_missing=False)
+
+
+def test_workspace_is_bounded_by_the_largest_request():
+    """Engine workspaces are grow-only slabs keyed by name: heterogeneous page sizes re-view one slab instead of allocating a
+    buffer set per shape."""
+    import torch
+
+    from manga_image_translator_amd import ops
+
+    ws = ops.Workspace("cpu")
+    a = ws.buf("x", 2, 8, 8, 4)
+    assert a.shape == (2, 8, 8, 4) and a.is_contiguous()
+    big = ws.buf("x", 1, 32, 16, 4)
+    n = ws.nbytes()
+    for shape in [(2, 8, 8, 4), (1, 16, 16, 4), (1, 31, 16, 4), (1, 32, 16, 4)]:
+        t = ws.buf("x", *shape)
+        assert t.data_ptr() == big.data_ptr() and tuple(t.shape) == shape
+    assert ws.nbytes() == n == 1 * 32 * 16 * 4 * 4
+    assert ws.buf("x", 4, dtype=torch.uint8).data_ptr() != big.data_ptr()  # other dtype, other slab
+    ws.release()
+    assert ws.nbytes() == 0
+    sc = ops.ShapeCache(2)
+    made = []
+    for k in [(1, 1), (2, 2), (1, 1), (3, 3), (2, 2)]:
+        sc.get(k, lambda k=k: made.append(k) or k)
+    assert made == [(1, 1), (2, 2), (3, 3), (2, 2)] and len(sc) == 2

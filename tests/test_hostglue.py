@@ -128,3 +128,20 @@ def test_resize_linear_u8_matches_oracle_and_box_case():
     rgb = rng.integers(0, 256, size=(40, 60, 3), dtype=np.uint8)
     assert np.array_equal(HG.resize_linear_u8(rgb, (30, 20)), OC.resize_linear_u8(rgb, (30, 20)))  # exact 2x: box mean
     assert np.array_equal(HG.resize_linear_u8(src, (53, 37)), src)
+
+
+def test_in_range_follows_opencv_scalar_bounds():
+    """cv2.inRange on 8-bit data with float scalar bounds (textmask.py:68 passes np.histogram edges): the bounds become
+    int32 through cvRound (round half to even) and saturate; inverted / out-of-range intervals select nothing."""
+    from oracle import ref_import as R
+
+    g = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    shim = R.cv2_shim().inRange if R.available() else None
+    for lo, hi, first, last in [(99.4, 159.4, 99, 159), (99.6, 159.6, 100, 160), (98.5, 160.5, 98, 160), (99.5, 161.5, 100, 162),
+                                (-31.2, 28.8, 0, 29), (200.0, 255.0, 200, 255), (225.7, 285.7, 226, 255)]:
+        m = HG._in_range_u8(g, lo, hi)
+        sel = np.flatnonzero(m.reshape(-1))
+        assert sel[0] == first and sel[-1] == last and len(sel) == last - first + 1, (lo, hi, sel[0], sel[-1])
+        if shim is not None:
+            assert np.array_equal(shim(g, lo, hi), m)
+    assert not HG._in_range_u8(g, 120.0, 60.0).any() and not HG._in_range_u8(g, 256.2, 300.0).any() and not HG._in_range_u8(g, -50.0, -0.6).any()
