@@ -120,6 +120,9 @@ int mit_conv_gemm(const MitConvGemm *desc, void *stream);
  * reported by mit_conv_gemm_config_name(). */
 int mit_conv_gemm_cfg(const MitConvGemm *desc, int cfg, void *stream);
 const char *mit_conv_gemm_config_name(int cfg);
+/* the kernel's template-id as rocprofv3 prints it (without namespace), e.g. "conv_gemm_fast_kernel<128, 128, 16, 1, 4, 4, 4>":
+ * lets bench.py join its per-tile probe numbers with the profiler's kernel-trace / PMC rows; NULL past the table. */
+const char *mit_conv_gemm_config_kernel(int cfg);
 
 /* k x k (3, 5, 7) stride-1 "same" convolution with 1..4 output channels on the fp32 VALU (an MFMA tile would idle 29 of
  * its 32 columns): out[b,y,x,n] = act(sum in[b,y+dy,x+dx,c] * w4[(ky*k+kx)*Cin + c][n] + bias[n]).  in: NHWC with pixel

@@ -12,7 +12,10 @@ using namespace mitcg;
 namespace {
 
 const CfgEntry kCfgs[] = {
-#define X(g, name, fast, BM, BN, BK, fn, ...) {name, BM, BN, BK, fn<BM, BN, BK, __VA_ARGS__>, fast},
+#define KNAME_launch_cfg "conv_gemm_kernel"
+#define KNAME_launch_fast "conv_gemm_fast_kernel"
+#define X(g, name, fast, BM, BN, BK, fn, ...) \
+    {name, BM, BN, BK, fn<BM, BN, BK, __VA_ARGS__>, fast, KNAME_##fn "<" #BM ", " #BN ", " #BK ", " #__VA_ARGS__ ">"},
 #include "conv_gemm_cfgs.inc"
 #undef X
 };
@@ -132,6 +135,11 @@ extern "C" int mit_prof_read(MitProfStat *stats, int max_cfgs, int *n_cfgs) {
 extern "C" const char *mit_conv_gemm_config_name(int cfg) {
     if (cfg < 0 || cfg >= kNumCfgs) return nullptr;
     return kCfgs[cfg].name;
+}
+
+extern "C" const char *mit_conv_gemm_config_kernel(int cfg) {
+    if (cfg < 0 || cfg >= kNumCfgs) return nullptr;
+    return kCfgs[cfg].kernel;
 }
 
 namespace {

@@ -691,6 +691,7 @@ struct CfgEntry {
     int BM, BN, BK;
     void (*launch)(const MitConvGemm &, int M, int MT, int NT, int KT, hipStream_t);
     int fast;  // 1: conv_gemm_fast_kernel (needs fast_eligible()); 2: and Cin % 32 == 0
+    const char *kernel;  // the kernel's template-id as profilers print it, e.g. "conv_gemm_fast_kernel<128, 128, 16, 1, 4, 4, 4>"
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>

@@ -106,7 +106,7 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w4_dev);
     const int refl = pad_mode == MIT_PAD_REFLECT;
     // VALU-bound: algorithmic FLOPs 2 k^2 Cin Cout per pixel; bytes: input read once + Cout outputs written
-    MitProbeScope probe("conv_small_cout", s, 4.0 * (double)B * H * W * (Cin + Cout), 2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
+    MitProbeScope probe(k == 7 ? "conv_small_cout_kernel<7>" : k == 5 ? "conv_small_cout_kernel<5>" : "conv_small_cout_kernel<3>", s, 4.0 * (double)B * H * W * (Cin + Cout), 2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
     switch (k) {
         case 3: hipLaunchKernelGGL(conv_small_cout_kernel<3>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
         case 5: hipLaunchKernelGGL(conv_small_cout_kernel<5>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;

@@ -168,7 +168,7 @@ extern "C" int mit_fft_cols(const float *in_dev, int64_t in_bs, int64_t in_ts, i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float2 *tw2 = reinterpret_cast<const float2 *>(twiddle_dev);
     // algorithmic bytes: the planar complex spectrum read once and written once; FLOPs: 5 h log2 h per complex column
-    MitProbeScope probe("fft_cols", st, 2.0 * 8.0 * (double)B * h * (double)ncols, 5.0 * (double)h * logh * (double)ncols * B);
+    MitProbeScope probe("fft_cols_kernel", st, 2.0 * 8.0 * (double)B * h * (double)ncols, 5.0 * (double)h * logh * (double)ncols * B);
 #define MIT_FFT_LAUNCH(ROWS)                                                                                                   \
     do {                                                                                                                       \
         auto kern = fft_cols_kernel<ROWS>;                                                                                     \

@@ -192,7 +192,7 @@ extern "C" int mit_lama_prep(const uint8_t *img_dev, const uint8_t *mask_dev, fl
     if (!img_dev || !mask_dev || !out_dev) return mit_set_error("mit_lama_prep: null pointer");
     if (B <= 0 || H <= 0 || W <= 0) return mit_set_error("mit_lama_prep: empty page");
     const int64_t npix = (int64_t)B * H * W;
-    MitProbeScope probe("lama_prep", (hipStream_t)stream, (double)npix * (3 + 1 + 16));
+    MitProbeScope probe("lama_prep_kernel", (hipStream_t)stream, (double)npix * (3 + 1 + 16));
     hipLaunchKernelGGL(lama_prep_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, img_dev, mask_dev,
                        reinterpret_cast<float4 *>(out_dev), npix);
     MIT_CHECK_LAUNCH("mit_lama_prep");
@@ -228,7 +228,7 @@ extern "C" int mit_lama_mpe_add(float *x_dev, const uint8_t *mask_dev, const uin
         return mit_set_error("mit_lama_mpe_add: null pointer");
     const int64_t total = (int64_t)B * H * W * 16;
     // algorithmic bytes: the 64-channel stem output read and written once (+ 1 mask byte per pixel; the 256x256 index maps stay in cache)
-    MitProbeScope probe("mpe_add", (hipStream_t)stream, (double)B * H * W * (2.0 * 64 * 4 + 1));
+    MitProbeScope probe("mpe_add_kernel", (hipStream_t)stream, (double)B * H * W * (2.0 * 64 * 4 + 1));
     hipLaunchKernelGGL(mpe_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x_dev, mask_dev,
                        relpos_dev, direct_dev, ymap_dev, xmap_dev, emb_dev, dirw_dev, alpha5, alpha6, B, H, W);
     MIT_CHECK_LAUNCH("mit_lama_mpe_add");
@@ -239,7 +239,7 @@ extern "C" int mit_lama_post(const float *pred_dev, int64_t pred_pixstride, cons
                              const uint8_t *mask_dev, uint8_t *out_dev, int B, int H, int W, void *stream) {
     if (!pred_dev || !img_dev || !mask_dev || !out_dev) return mit_set_error("mit_lama_post: null pointer");
     const int64_t npix = (int64_t)B * H * W;
-    MitProbeScope probe("lama_post", (hipStream_t)stream, (double)npix * (12 + 3 + 1 + 3));
+    MitProbeScope probe("lama_post_kernel", (hipStream_t)stream, (double)npix * (12 + 3 + 1 + 3));
     hipLaunchKernelGGL(lama_post_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, pred_dev,
                        pred_pixstride, img_dev, mask_dev, out_dev, npix);
     MIT_CHECK_LAUNCH("mit_lama_post");

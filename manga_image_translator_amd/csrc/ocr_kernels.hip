@@ -685,7 +685,7 @@ __global__ void beam_finalize_kernel(const int *__restrict__ hist, int hist_ld, 
 void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
                     int D, float eps, hipStream_t s) {
     const int waves = 4;
-    MitProbeScope probe("layernorm", s, 8.0 * (double)rows * D);
+    MitProbeScope probe("layernorm_kernel", s, 8.0 * (double)rows * D);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + waves - 1) / waves), dim3(64 * waves), 0, s, in, in_rs, w, b, out, out_rs,
                        rows, D, eps);
 }
@@ -693,7 +693,7 @@ void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float 
 void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
                       int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s) {
     const int64_t total = (int64_t)R * T * 160;
-    MitProbeScope probe("xpos_rotate", s, 8.0 * (double)R * T * 320);
+    MitProbeScope probe("xpos_rotate_kernel", s, 8.0 * (double)R * T * 320);
     hipLaunchKernelGGL(xpos_rotate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, in_rs, in_ts, out, out_rs, out_ts, R,
                        T, i0, p0, downscale, tb.cos_t, tb.sin_t, tb.scale_t, tb.iscale_t, tb.pmax);
 }
@@ -706,7 +706,7 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
         const size_t sm = ((size_t)kv_div * head_dim + (size_t)ATT_KCHUNK * (head_dim + 4) + (size_t)kv_div * Tk) * sizeof(float);
         if (sm <= 64 * 1024) {
             // algorithmic bytes: K and V of each line read once for its kv_div beams (+ q in, o out); FLOPs 4 Tk d per query row and head
-            MitProbeScope probe("attention_shared_kv", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * R),
+            MitProbeScope probe("attention_shared_kv_kernel", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * R),
                                 4.0 * (double)R * heads * Tk * head_dim);
             hipLaunchKernelGGL(attention_shared_kv_kernel, dim3(heads, R / kv_div), dim3(ATT_THREADS), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts,
                                O, o_rs, klen, Tk, kv_div, head_dim);
@@ -714,7 +714,7 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
         }
     }
     const size_t smem = ((size_t)head_dim + (size_t)Tk) * sizeof(float);
-    MitProbeScope probe("attention", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * (double)R * Tq),
+    MitProbeScope probe("attention_kernel", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * (double)R * Tq),
                         4.0 * (double)R * Tq * heads * Tk * head_dim);
     hipLaunchKernelGGL(attention_kernel, dim3(Tq, heads, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
                        o_ts, klen, Tk, kv_div, head_dim);
@@ -726,7 +726,7 @@ void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, 
 
 void ocrk_logsoftmax_top5(const float *logits, int64_t ld, int R, int D, int suppress_tok, float *vals, int *idx,
                           float *logp_out, hipStream_t s) {
-    MitProbeScope probe("logsoftmax_top5", s, 4.0 * (double)R * D + (logp_out ? 4.0 * (double)R * D : 0.0));
+    MitProbeScope probe("logsoftmax_top5_kernel", s, 4.0 * (double)R * D + (logp_out ? 4.0 * (double)R * D : 0.0));
     hipLaunchKernelGGL(logsoftmax_top5_kernel, dim3(R), dim3(256), 0, s, logits, ld, D, suppress_tok, vals, idx, logp_out);
 }
 
@@ -782,7 +782,7 @@ extern "C" int mit_dwconv_nhwc_ragged(const float *in_dev, const float *w_dev, c
     // algorithmic bytes: the activation read once and written once (a work item = one row group of up to 4 pixels, so this counts
     // the ragged right edge of each image as full groups: an upper bound within W % 4 of exact); FLOPs 2 k^2 per element
     const double elems = 4.0 * (double)total_groups * C;
-    MitProbeScope probe(k == 7 ? "dwconv_ragged<7>" : k == 5 ? "dwconv_ragged<5>" : "dwconv_ragged<3>", s, 8.0 * elems, 2.0 * k * k * elems);
+    MitProbeScope probe(k == 7 ? "dwconv_ragged_kernel<7>" : k == 5 ? "dwconv_ragged_kernel<5>" : "dwconv_ragged_kernel<3>", s, 8.0 * elems, 2.0 * k * k * elems);
     switch (k) {
         case 3: hipLaunchKernelGGL(dwconv_ragged_kernel<3>, grid, block, 0, s, in_dev, w_dev, scale_dev, bias_dev, out_dev, segs_dev, nsegs, C4, items); break;
         case 5: hipLaunchKernelGGL(dwconv_ragged_kernel<5>, grid, block, 0, s, in_dev, w_dev, scale_dev, bias_dev, out_dev, segs_dev, nsegs, C4, items); break;

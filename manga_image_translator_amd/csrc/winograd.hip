@@ -166,7 +166,7 @@ extern "C" int mit_wino43_input(const float *x_dev, int64_t x_bs, int64_t x_ys, 
     const int64_t nblk = (total + 255) / 256;
     if (nblk > 0x7fffffffLL) return mit_set_error("mit_wino43_input: problem too large");
     // algorithmic bytes: the input read once + the 36/16-times larger transformed tensor written once
-    MitProbeScope probe("wino43_input", (hipStream_t)stream, 4.0 * ((double)B * H * W * C + 36.0 * (double)T * C));
+    MitProbeScope probe("wino43_input_kernel", (hipStream_t)stream, 4.0 * ((double)B * H * W * C + 36.0 * (double)T * C));
     hipLaunchKernelGGL(wino43_input_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x_dev, x_bs, x_ys,
                        x_xs, v_dev, B, H, W, C / 2, th, tw, pad_mode, total, T * C);
     MIT_CHECK_LAUNCH("mit_wino43_input");
@@ -187,7 +187,7 @@ extern "C" int mit_wino43_output(const float *m_dev, float *y_dev, int64_t y_bs,
     const int64_t nblk = (total + 255) / 256;
     if (nblk > 0x7fffffffLL) return mit_set_error("mit_wino43_output: problem too large");
     // algorithmic bytes: the 36 products read once + the output written once (+ the residual read once)
-    MitProbeScope probe("wino43_output", (hipStream_t)stream,
+    MitProbeScope probe("wino43_output_kernel", (hipStream_t)stream,
                         4.0 * (36.0 * (double)T * N + (double)B * H * W * N * (post_dev ? 2.0 : 1.0)));
     hipLaunchKernelGGL(wino43_output_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, m_dev, y_dev, y_bs,
                        y_ys, y_xs, post_dev, p_bs, p_ys, p_xs, scale_dev, bias_dev, B, H, W, N / 2, th, tw, act, alpha, total, T * N);

@@ -131,6 +131,7 @@ SYMBOLS = {
     "mit_conv_gemm": (C.c_int, [C.POINTER(MitConvGemm), C.c_void_p]),
     "mit_conv_gemm_cfg": (C.c_int, [C.POINTER(MitConvGemm), C.c_int, C.c_void_p]),
     "mit_conv_gemm_config_name": (C.c_char_p, [C.c_int]),
+    "mit_conv_gemm_config_kernel": (C.c_char_p, [C.c_int]),
     "mit_conv_small_cout": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "mit_prof_enable": (C.c_int, [C.c_int]),

@@ -59,6 +59,25 @@ class PageBatchResult:
                       self.ocr_prob.view(torch.uint8), self.ocr_colors.reshape(-1).view(torch.uint8)]
         return torch.cat(parts)
 
+    def packed_pages(self, lines_per_page: int) -> torch.Tensor:
+        """One fixed-size uint8 record per page, [B, record_bytes]: detector maps | inpainted page | ``lines_per_page`` OCR slots
+        (tokens, length, prob, colours) placed by the line's index on its page — page i's record does not depend on which
+        other pages shared its batch or on the order the pooled beam search returned the lines, which is what makes the
+        multi-GPU gather order-independent (rank r's rows are the records of its contiguous page block)."""
+        B = self.det_mask.shape[0]
+        parts = [self.det_mask.reshape(B, -1), self.det_shrink.reshape(B, -1), self.inpainted.reshape(B, -1)]
+        if self.ocr_tokens is not None:
+            rows = torch.tensor([p * lines_per_page + l for p, l in self.ocr_order], dtype=torch.long)
+            if rows.numel() and (int(rows.max()) >= B * lines_per_page or len(set(rows.tolist())) != rows.numel()):
+                raise ValueError("packed_pages: a page has more lines than lines_per_page")
+            rows = rows.to(self.ocr_tokens.device)
+            for t in (self.ocr_tokens, self.ocr_length.reshape(-1, 1), self.ocr_prob.reshape(-1, 1), self.ocr_colors):
+                flat = t.reshape(t.shape[0], -1).contiguous().view(torch.uint8)
+                slot = torch.zeros(B * lines_per_page, flat.shape[1], dtype=torch.uint8, device=flat.device)
+                slot.index_copy_(0, rows, flat)
+                parts.append(slot.reshape(B, -1))
+        return torch.cat(parts, dim=1)
+
 
 class PageEngine:
     """Owns the three stage engines of one GPU."""

@@ -1,0 +1,16 @@
+#!/bin/bash
+# One GPU-box call that produces the evidence of a round: GPU tests, the bench line, a rocprofv3 kernel-trace of the same
+# command, and the PMC traffic passes.  usage: scripts/gpu_evidence.sh <tag> [skip-tests]
+set -u
+TAG=${1:-r02a}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+if [ "${2:-}" != "skip-tests" ]; then
+  timeout 1200 python -m pytest tests -m gpu -x -q -s > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
+  tail -5 $OUT/pytest.log
+fi
+timeout 900 python bench.py --prof-dump $OUT/layers.csv > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python bench.py --no-cpu-baseline --no-dropin > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof rc=$?"
+cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
+rm -rf $OUT/prof
+bash scripts/pmc_stage.sh detect,ocr,inpaint 64 $OUT/pmc_traffic.json > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
+head -c 1500 $OUT/bench.json; echo; tail -3 $OUT/bench.err

@@ -35,3 +35,53 @@ def test_bench_cli_parses_without_a_gpu():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_cpu_baseline_and_parity_legs_on_a_small_page(monkeypatch):
+    """bench.py's CPU legs end to end without a GPU: thread sweep + warm-up + timed pages through the oracle, and the parity leg
+    fed with a stand-in for the GPU results built from the oracle outputs themselves (must report ok) and with a corrupted
+    copy (must not)."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from manga_image_translator_amd import pipeline, synth
+
+    monkeypatch.setattr(bench, "H", 256)
+    monkeypatch.setattr(bench, "W", 192)
+    monkeypatch.setattr(bench, "N_BOXES", 4)
+    monkeypatch.setattr(bench, "DECODE_STEPS", 4)
+    weights = pipeline.synthetic_weights(dict_size=64)
+    pages, quads, masks = zip(*[synth.synth_page(i, 256, 192, n_boxes=4) for i in range(2)])
+    cpu, outs = bench.cpu_baseline_leg(weights, (pages, quads, masks), ("detect", "ocr", "inpaint"), 1, [1, 2])
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] in (1, 2) and len(outs) == 2
+    assert set(cpu["seconds_per_stage"]) == {"detect", "ocr", "inpaint"} and set(cpu["thread_sweep_seconds"]["ocr"]) <= {"1", "2"}
+    assert abs(cpu["value"] - 1.0 / sum(cpu["seconds_per_stage"].values())) < 1e-3 * cpu["value"]
+
+    class Res:
+        pass
+
+    T = 4
+    res = Res()
+    res.det_mask = torch.from_numpy(np.stack([o["detect"][0] for o in outs]))
+    res.det_shrink = torch.from_numpy(np.stack([(o["detect"][1][0, 0] > 0.3).astype(np.uint8) for o in outs]))
+    res.inpainted = torch.from_numpy(np.stack([o["inpaint"] for o in outs]))
+    order, toks, lens, probs = [], [], [], []
+    for b, o in enumerate(outs):
+        for indices, r in o["ocr"]:
+            for j, i in enumerate(indices):
+                order.append((b, i))
+                t = r[j][0].numpy()
+                toks.append(np.concatenate([[1], t, np.zeros(T - len(t), np.int64)]))
+                lens.append(1 + len(t))
+                probs.append(r[j][1])
+    res.ocr_order, res.ocr_tokens = order, torch.tensor(np.stack(toks), dtype=torch.int32)
+    res.ocr_length, res.ocr_prob = torch.tensor(lens, dtype=torch.int32), torch.tensor(probs, dtype=torch.float32)
+    par = bench.parity_leg(res, [0, 1], outs, ("detect", "ocr", "inpaint"))
+    assert par["ok"] and par["pages"] == 2 and par["ocr"]["lines"] == 8 and par["inpaint"]["max_abs_u8_diff"] == 0
+    res.inpainted = res.inpainted.clone()
+    res.inpainted[0, :8, :8] = res.inpainted[0, :8, :8] ^ 0x40
+    res.ocr_tokens[0, 1] += 1
+    par = bench.parity_leg(res, [0, 1], outs, ("detect", "ocr", "inpaint"))
+    assert not par["ok"] and par["ocr"]["lines_with_different_tokens"] == 1 and par["inpaint"]["max_abs_u8_diff"] == 64

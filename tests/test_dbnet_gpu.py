@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (2, 256, 512)])
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (2, 256, 512), (1, 1024, 1024)])  # 1024^2: BASELINE config 1's page before its 2x upscale
 def test_dbnet_parity(cuda, B, H, W):
     from manga_image_translator_amd import dbnet, dbnet_schema, synth
     from oracle import dbnet as OD

@@ -10,7 +10,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("nb,B,H,W", [(2, 2, 24, 40), (4, 1, 37, 51)])
+@pytest.mark.parametrize("nb,B,H,W", [(2, 2, 24, 40), (4, 1, 37, 51), (23, 1, 128, 136)],  # nb = 23: the 4xESRGAN checkpoint's depth
+                         ids=["nb2", "nb4", "nb23-128x136"])
 def test_esrgan_parity(cuda, nb, B, H, W):
     from manga_image_translator_amd import esrgan, esrgan_schema, synth
     from oracle import esrgan as OE

@@ -41,7 +41,10 @@ def test_fourier_unit_parity(cuda):
         assert err < 5e-5, (B, h, w, err)
 
 
-@pytest.mark.parametrize("n_blocks,mpe,B,H,W", [(18, False, 2, 64, 88), (9, True, 1, 264, 272), (9, True, 2, 256, 320)])
+@pytest.mark.parametrize("n_blocks,mpe,B,H,W", [(18, False, 2, 64, 88), (9, True, 1, 264, 272), (9, True, 2, 256, 320),
+                                                 (9, True, 1, 2048, 1456),    # the BASELINE page, shipped path (Winograd FFC blocks, LDS FFT)
+                                                 (18, False, 1, 512, 512)],   # lama_large at its nominal 512 px
+                         ids=["large-64x88", "mpe-264x272", "mpe-256x320x2", "mpe-BASELINE-2048x1456", "large-512x512"])
 def test_lama_page_parity(cuda, n_blocks, mpe, B, H, W):
     from manga_image_translator_amd import synth
     from oracle import lama as OL
@@ -93,6 +96,8 @@ def test_lama_page_parity(cuda, n_blocks, mpe, B, H, W):
             frac = np.abs(of - np.round(of))
             assert all(frac[tuple(b)] < 0.05 for b in bad), "uint8 mismatch away from a truncation boundary"
             assert len(bad) < 1e-3 * diff.size
+        print(f"lama {n_blocks} blocks {H}x{W} page {i}: stem {stem_err:.2e}, last block {blk_err:.2e} (range {blk.abs().max().item():.2f}), "
+              f"sigmoid {ferr:.2e}, u8 diffs {len(bad)} of {diff.size}")
 
 
 def test_lama_rejects_bad_input(cuda):

@@ -47,12 +47,9 @@ def test_encoder_memory_parity(cuda, ocr_setup):
         assert klen.cpu().tolist() == [min((w + 3) // 4 + 2, L) for w in widths]
 
 
-@pytest.mark.parametrize("widths,T,suppress", [([50, 77, 120, 121], 12, False), ([200, 33, 90], 10, True)])
-def test_beam_search_parity(cuda, ocr_setup, widths, T, suppress):
+def _check_beam_parity(cuda, sd, D, eng, crops, T, suppress):
     from oracle import ocr48 as OO
 
-    sd, D, eng = ocr_setup
-    crops = _crops(widths, seed=3)
     chunks = list(eng.make_chunks(crops))
     assert len(chunks) == 1
     indices, ws, region = chunks[0]
@@ -65,6 +62,7 @@ def test_beam_search_parity(cuda, ocr_setup, widths, T, suppress):
         ref = OO.infer_beam_batch_tensor(sd, img, ws, max_seq_length=T, trace=trace, suppress_eos=suppress)
     N = len(ws)
     tl = out["trace_logits"].cpu()
+    worst = 0.0
     # step-wise "OCR logits": compare log-softmax of our raw logits with the oracle's log-probs while all samples are alive
     for st in trace:
         s = st["step"]
@@ -85,6 +83,7 @@ def test_beam_search_parity(cuda, ocr_setup, widths, T, suppress):
         else:
             err = (got_lp - ref_lp).abs().max().item()
         assert err < 5e-4, (s, err)
+        worst = max(worst, err)
     toks, lens, probs = out["tokens"].cpu(), out["length"].cpu(), out["prob"].cpu()
     for n, (r_idx, r_prob, fg, bg, fgi, bgi) in enumerate(ref):
         got_tok = toks[n, 1:lens[n]].tolist()
@@ -94,6 +93,35 @@ def test_beam_search_parity(cuda, ocr_setup, widths, T, suppress):
         col = out["colors"][n, :nt].cpu()
         refc = torch.cat([fg[:nt], bg[:nt], fgi[:nt], bgi[:nt]], dim=-1)
         assert (col - refc).abs().max().item() < 2e-4 * max(1.0, refc.abs().max().item())
+    return worst
+
+
+@pytest.mark.parametrize("widths,T,suppress", [([50, 77, 120, 121], 12, False), ([200, 33, 90], 10, True)])
+def test_beam_search_parity(cuda, ocr_setup, widths, T, suppress):
+    sd, D, eng = ocr_setup
+    _check_beam_parity(cuda, sd, D, eng, _crops(widths, seed=3), T, suppress)
+
+
+def test_beam_search_parity_at_bench_config(cuda):
+    """The bench's OCR workload: the 32 text lines of a synthetic 2048x1456 page (two chunks of 16, crop widths 180..600 px),
+    dictionary of 6004 entries, 32 decode steps with EOS suppressed — per-step log-probs within 5e-4 of the oracle, token ids,
+    probabilities and colour heads identical / within tolerance (model_48px.py:678-801)."""
+    from manga_image_translator_amd import ocr48, ocr_schema, pipeline, synth
+    from oracle import textline as OT
+
+    D = pipeline.DICT_SIZE
+    sd = synth.synth_state_dict(ocr_schema.ocr48_schema(D))
+    eng = ocr48.Ocr48Engine(sd, D, device=cuda)
+    page, quads, _ = synth.synth_page(0, 2048, 1456, n_boxes=32)
+    crops = []
+    for pts in quads:
+        sp, vert = OT.sort_pnts(pts)
+        crops.append(OT.get_transformed_region(page, sp, "v" if vert else "h", 48))
+    order = sorted(range(len(crops)), key=lambda i: crops[i].shape[1])
+    assert len(crops) == 32 and crops[order[0]].shape[1] >= 150 and crops[order[-1]].shape[1] <= 640
+    for c in range(0, 32, 16):
+        worst = _check_beam_parity(cuda, sd, D, eng, [crops[i] for i in order[c:c + 16]], 32, True)
+        print(f"bench-config chunk {c // 16}: widths {crops[order[c]].shape[1]}..{crops[order[c + 15]].shape[1]}, worst per-step log-prob error {worst:.2e}")
 
 
 def test_pooled_decode_equals_per_chunk(cuda, ocr_setup):
