@@ -46,16 +46,43 @@ except Exception:  # stand-alone: mirror the ModelWrapper lifecycle
         """Mirror of ModelWrapper's load/unload/infer protocol (utils/inference.py:318-350)."""
         _key = "hip"
 
+        _MODEL_SUB_DIR = ""
+
         def __init__(self, *args, **kwargs):
             self._loaded = False
+            self._downloaded = self._check_downloaded()
 
         def is_loaded(self) -> bool:
             return self._loaded
 
-        async def download(self):  # weights are handed over by the caller / found on disk; nothing to fetch offline
-            return None
+        def is_downloaded(self) -> bool:
+            return self._downloaded
+
+        @property
+        def model_dir(self) -> str:
+            return os.path.join("models", self._MODEL_SUB_DIR)
+
+        def _get_file_path(self, *args) -> str:
+            return os.path.join(self.model_dir, *args)
+
+        def _check_downloaded(self) -> bool:
+            """The files named by ``_MODEL_MAPPING`` exist under model_dir (utils/inference.py:262-293)."""
+            for key, m in self._MODEL_MAPPING.items():
+                names = list(m["archive"]) if "archive" in m else [m["file"] if m.get("file", ".") != "." else m["url"].rsplit("/", 1)[-1]]
+                if not all(os.path.exists(self._get_file_path(n)) for n in names):
+                    return False
+            return True
+
+        async def download(self, force: bool = False):
+            """Stand-alone mode has no downloader (that is the reference's ModelWrapper.download): the checkpoints must already be
+            in place, or the weights handed to the constructor."""
+            if not self.is_downloaded():
+                raise FileNotFoundError(f"{self._key}: checkpoint files {sorted(self._MODEL_MAPPING)} are not under {self.model_dir!r} "
+                                        "and there is no downloader outside the reference package; pass weights= or copy the files")
 
         async def load(self, device: str, *args, **kwargs):
+            if not self.is_downloaded():
+                await self.download()
             if not self.is_loaded():
                 await self._load(*args, **kwargs, device=device)
                 self._loaded = True
@@ -77,6 +104,16 @@ except Exception:  # stand-alone: mirror the ModelWrapper lifecycle
     _DetBase = _InpBase = _OcrBase = _UpBase = _Wrapper
 
 
+_RELEASE = "https://github.com/zyddnys/manga-image-translator/releases/download/beta-0.3/"
+
+
+def _weights_handed_over(plugin, *given) -> None:
+    """State dicts injected through the constructor stand for the checkpoint files: nothing is left to download, so
+    ModelWrapper.load() (utils/inference.py:330-338) must not try to fetch ``_MODEL_MAPPING`` (there is no network offline)."""
+    if all(g is not None for g in given):
+        plugin._downloaded = True
+
+
 def _gpu_device(device: str) -> torch.device:
     """The reference passes 'cpu' | 'cuda' | 'mps' | 'xpu' (ROCm = 'cuda').  This backend has no CPU path."""
     if not str(device).startswith("cuda"):
@@ -88,14 +125,22 @@ def _gpu_device(device: str) -> torch.device:
 
 class HipComicTextDetector(_DetBase):
     """``--detector ctd`` on the HIP engine."""
-    _key = "ctd_hip"
-    _MODEL_MAPPING: Dict = {}
+    _KEY = _key = "ctd_hip"
+    # the torch checkpoint of the reference's own mapping (detection/ctd.py:63-74; its ONNX twin is the reference's CPU path)
+    _MODEL_MAPPING: Dict = {
+        "model-cuda": {
+            "url": _RELEASE + "comictextdetector.pt",
+            "hash": "1f90fa60aeeb1eb82e2ac1167a66bf139a8a61b8780acd351ead55268540cccb",
+            "file": ".",
+        },
+    }
 
     def __init__(self, *args, weights: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
                  boxes_from_maps: Optional[Callable] = None, refine: Optional[Callable] = None, **kwargs):
         super().__init__(*args, **kwargs)
         self._weights, self._boxes, self._refine = weights, boxes_from_maps, refine
         self.engine = None
+        _weights_handed_over(self, weights)
 
     async def _load(self, device: str, input_size=1024, **_):
         from . import ctd
@@ -132,14 +177,21 @@ class HipComicTextDetector(_DetBase):
 
 class HipDefaultDetector(_DetBase):
     """``--detector default`` (DBNet on ResNet-34) on the HIP engine."""
-    _key = "default_hip"
-    _MODEL_MAPPING: Dict = {}
+    _KEY = _key = "default_hip"
+    _MODEL_MAPPING: Dict = {  # detection/default.py:28-34
+        "model": {
+            "url": _RELEASE + "detect-20241225.ckpt",
+            "hash": "67ce1c4ed4793860f038c71189ba9630a7756f7683b1ee5afb69ca0687dc502e",
+            "file": ".",
+        },
+    }
 
     def __init__(self, *args, weights: Optional[Dict[str, torch.Tensor]] = None, preprocess: Optional[Callable] = None,
                  boxes_from_maps: Optional[Callable] = None, resize2x: Optional[Callable] = None, **kwargs):
         super().__init__(*args, **kwargs)
         self._weights, self._pre, self._boxes, self._resize2x = weights, preprocess, boxes_from_maps, resize2x
         self.engine = None
+        _weights_handed_over(self, weights)
 
     async def _load(self, device: str):
         from . import dbnet
@@ -189,14 +241,24 @@ class HipDefaultDetector(_DetBase):
 
 class HipModel48pxOCR(_OcrBase):
     """``--ocr 48px`` on the HIP engine."""
-    _key = "48px_hip"
-    _MODEL_MAPPING: Dict = {}
+    _KEY = _key = "48px_hip"
+    _MODEL_MAPPING: Dict = {  # ocr/model_48px.py:28-37
+        "model": {
+            "url": _RELEASE + "ocr_ar_48px.ckpt",
+            "hash": "29daa46d080818bb4ab239a518a88338cbccff8f901bef8c9db191a7cb97671d",
+        },
+        "dict": {
+            "url": _RELEASE + "alphabet-all-v7.txt",
+            "hash": "f5722368146aa0fbcc9f4726866e4efc3203318ebb66c811d8cbbe915576538a",
+        },
+    }
 
     def __init__(self, *args, weights: Optional[Dict[str, torch.Tensor]] = None, dictionary: Optional[Sequence[str]] = None,
                  **kwargs):
         super().__init__(*args, **kwargs)
         self._weights, self.dictionary = weights, dictionary
         self.engine = None
+        _weights_handed_over(self, weights, dictionary)
 
     async def _load(self, device: str):
         from . import ocr48
@@ -256,7 +318,17 @@ class HipModel48pxOCR(_OcrBase):
 
 class HipModel48pxCTCOCR(HipModel48pxOCR):
     """``--ocr 48px_ctc`` on the HIP engine (ocr/model_48px_ctc.py:62-160)."""
-    _key = "48px_ctc_hip"
+    _KEY = _key = "48px_ctc_hip"
+    _MODEL_MAPPING: Dict = {  # ocr/model_48px_ctc.py:19-28
+        "model": {
+            "url": _RELEASE + "ocr-ctc.zip",
+            "hash": "fc61c52f7a811bc72c54f6be85df814c6b60f63585175db27cb94a08e0c30101",
+            "archive": {
+                "ocr-ctc.ckpt": ".",
+                "alphabet-all-v5.txt": ".",
+            },
+        },
+    }
 
     async def _load(self, device: str):
         from . import ocr_ctc
@@ -365,8 +437,14 @@ def decode_line(token_ids: np.ndarray, colors: np.ndarray, dictionary: Sequence[
 
 class HipLamaMPEInpainter(_InpBase):
     """``--inpainter lama_mpe`` on the HIP engine."""
-    _key = "lama_mpe_hip"
-    _MODEL_MAPPING: Dict = {}
+    _KEY = _key = "lama_mpe_hip"
+    _MODEL_MAPPING: Dict = {  # inpainting/inpainting_lama_mpe.py:32-38
+        "model": {
+            "url": _RELEASE + "inpainting_lama_mpe.ckpt",
+            "hash": "d625aa1b3e0d0408acfd6928aa84f005867aa8dbb9162480346a4e20660786cc",
+            "file": ".",
+        },
+    }
     N_BLOCKS, USE_MPE, CKPT = 9, True, "inpainting_lama_mpe.ckpt"
 
     def __init__(self, *args, weights: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
@@ -374,6 +452,7 @@ class HipLamaMPEInpainter(_InpBase):
         super().__init__(*args, **kwargs)
         self._weights, self._resize = weights, resize
         self.engine = None
+        _weights_handed_over(self, weights)
 
     async def _load(self, device: str):
         from . import lama
@@ -423,20 +502,33 @@ class HipLamaMPEInpainter(_InpBase):
 
 class HipLamaLargeInpainter(HipLamaMPEInpainter):
     """``--inpainter lama_large``: 18 blocks, no MPE (inpainting_lama_mpe.py:121-136)."""
-    _key = "lama_large_hip"
+    _KEY = _key = "lama_large_hip"
+    _MODEL_MAPPING: Dict = {  # inpainting/inpainting_lama_mpe.py:123-129
+        "model": {
+            "url": "https://huggingface.co/dreMaz/AnimeMangaInpainting/resolve/main/lama_large_512px.ckpt",
+            "hash": "11d30fbb3000fb2eceae318b75d9ced9229d99ae990a7f8b3ac35c8d31f2c935",
+            "file": ".",
+        },
+    }
     N_BLOCKS, USE_MPE, CKPT = 18, False, "lama_large_512px.ckpt"
 
 
 class HipESRGANUpscaler(_UpBase):
     """``--upscaler 4xultrasharp`` (RRDBNet 4x) on the HIP engine."""
-    _key = "4xultrasharp_hip"
-    _MODEL_MAPPING: Dict = {}
+    _KEY = _key = "4xultrasharp_hip"
+    _MODEL_MAPPING: Dict = {  # upscaling/esrgan_pytorch.py:513-518
+        "4x-UltraSharp": {
+            "url": _RELEASE + "4xESRGAN.pth",
+            "hash": "545805ce2d861ee90972b5fa50b851f19ee4bb35dedd2eb090be1f7c935b6b00",
+        },
+    }
     _VALID_UPSCALE_RATIOS = [2, 3, 4]
 
     def __init__(self, *args, weights: Optional[Dict[str, torch.Tensor]] = None, **kwargs):
         super().__init__(*args, **kwargs)
         self._weights = weights
         self.engine = None
+        _weights_handed_over(self, weights)
 
     async def _load(self, device: str):
         from . import esrgan
@@ -610,12 +702,20 @@ def register() -> None:
     from manga_translator.inpainting import INPAINTERS  # type: ignore
     from manga_translator.ocr import OCRS  # type: ignore
 
-    DETECTORS["ctd_hip"] = HipComicTextDetector
-    DETECTORS["default_hip"] = HipDefaultDetector
-    OCRS["48px_hip"] = HipModel48pxOCR
-    OCRS["48px_ctc_hip"] = HipModel48pxCTCOCR
-    INPAINTERS["lama_mpe_hip"] = HipLamaMPEInpainter
-    INPAINTERS["lama_large_hip"] = HipLamaLargeInpainter
     from manga_translator.upscaling import UPSCALERS  # type: ignore
+    from manga_translator import config as _cfg  # type: ignore
 
-    UPSCALERS["4xultrasharp_hip"] = HipESRGANUpscaler
+    def key(enum_name: str, value: str):
+        """The enum member when the maintainer has added it to config.py, else the plain string: the
+        registries are ordinary dicts and ``get_detector`` & co only look the key up (detection/__init__.py:22-28)."""
+        enum = getattr(_cfg, enum_name, None)
+        try:
+            return enum(value)
+        except Exception:
+            return value
+
+    for reg, enum_name, cls in ((DETECTORS, "Detector", HipComicTextDetector), (DETECTORS, "Detector", HipDefaultDetector),
+                                (OCRS, "Ocr", HipModel48pxOCR), (OCRS, "Ocr", HipModel48pxCTCOCR),
+                                (INPAINTERS, "Inpainter", HipLamaMPEInpainter), (INPAINTERS, "Inpainter", HipLamaLargeInpainter),
+                                (UPSCALERS, "Upscaler", HipESRGANUpscaler)):
+        reg[key(enum_name, cls._KEY)] = cls

@@ -17,6 +17,8 @@ import sys
 import types
 from unittest import mock
 
+sys.dont_write_bytecode = True  # /root/reference is read-only for this repo: importing from it must not leave __pycache__ there
+
 REF_ROOT = "/root/reference"
 PKG = os.path.join(REF_ROOT, "manga_translator")
 

@@ -19,10 +19,29 @@ def test_lifecycle_and_device_errors(cls):
     assert not p.is_loaded()
     with pytest.raises(Exception, match="without having loaded"):
         run(p.infer(np.zeros((8, 8, 3), np.uint8), 2))
+    if not P.HAVE_REFERENCE:
+        # like ModelWrapper.load (utils/inference.py:330-338) the download step comes first; stand-alone there is no downloader
+        assert not p.is_downloaded() and p._MODEL_MAPPING
+        with pytest.raises(FileNotFoundError, match="pass weights="):
+            run(p.load("cuda"))
+    kw = dict(weights={}, dictionary=[]) if issubclass(cls, P.HipModel48pxOCR) else dict(weights={})
+    p = cls(**kw)                               # state dicts handed over: nothing to download
+    assert p.is_downloaded() and not p.is_loaded()
     with pytest.raises(RuntimeError, match="MI355X only"):
         run(p.load("cpu"))                      # the reference passes 'cpu' without --use-gpu: no CPU fallback here
     assert not p.is_loaded()
     run(p.unload())                             # unloading an unloaded plugin is a no-op, like ModelWrapper.unload
+
+
+def test_model_mappings_are_well_formed():
+    """The checks ModelWrapper._check_for_malformed_model_mapping applies (utils/inference.py:124-134), and the sha256 pins."""
+    import re
+
+    for cls in (P.HipComicTextDetector, P.HipDefaultDetector, P.HipModel48pxOCR, P.HipModel48pxCTCOCR, P.HipLamaMPEInpainter,
+                P.HipLamaLargeInpainter, P.HipESRGANUpscaler):
+        assert cls._MODEL_MAPPING and cls._KEY.endswith("_hip")
+        for key, m in cls._MODEL_MAPPING.items():
+            assert re.search(r"^https?://", m["url"]) and re.fullmatch(r"[0-9a-f]{64}", m["hash"]) and not ("file" in m and "archive" in m)
 
 
 def test_variants():
