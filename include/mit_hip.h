@@ -172,6 +172,20 @@ typedef struct MitProfKernelStat {
 } MitProfKernelStat;
 int mit_prof_kernels_read(MitProfKernelStat *stats, int max_stats, int *n_stats);
 
+/* 8-bit image resizes around the inpainter, on device bytes [B,H,W,C] -> [B,dh,dw,C] (1 <= C <= 4):
+ *   mode 0 = cv2.INTER_LINEAR (8-bit path, 11-bit coefficients)   — the resize to a multiple of 8 and back
+ *            (inpainting_lama_mpe.py:77-79,112-113), detection/common.py:79-84
+ *   mode 1 = exact 2x shrink = 2x2 box mean (what OpenCV substitutes for both linear flavours at scale 1/2)
+ *   mode 2 = cv2.INTER_LINEAR_EXACT (8.8 fixed point)             — resize_keep_aspect (utils/generic.py:251-255, _infer :64-66)
+ * Tap tables (modes 0, 2) come from the host (manga_image_translator_amd/imgproc.py): per destination index the first source
+ * index (int32) and two uint16 weights {w(idx), w(idx+1)}; idx+1 is clamped to the last row / column by the kernel. */
+int mit_resize_u8(const uint8_t *src_dev, int B, int H, int W, int C, uint8_t *dst_dev, int dh, int dw, int mode, const int *yidx_dev,
+                  const uint16_t *ycoef_dev, const int *xidx_dev, const uint16_t *xcoef_dev, void *stream);
+/* out = mask >= thr ? a : b per pixel (C channels): ``img_inpainted * mask_original + img_original * (1 - mask_original)`` with the
+ * original mask thresholded at 127 (inpainting_lama_mpe.py:57-61,116). */
+int mit_select_u8(const uint8_t *mask_dev, int thr, const uint8_t *a_dev, const uint8_t *b_dev, uint8_t *out_dev, int64_t npix, int C,
+                  void *stream);
+
 /* LaMa inpainting stage: memory-bound pieces ----------------------------------------------
  * Reference: manga_translator/inpainting/inpainting_lama_mpe.py. */
 
@@ -206,9 +220,11 @@ int mit_lama_mpe_add(float *x_dev, const uint8_t *mask_dev, const uint8_t *relpo
                      float alpha6, int B, int H, int W, void *stream);
 
 /* predicted fp32 (pixel stride pred_pixstride floats, 3 used) + page + mask -> inpainted u8 [B,H,W,3]:
- * pred*m + (1-m)*img (:726), *255 truncated to u8 (:111), composited with the original through mask >= 127 (:59-60,117). */
+ * pred*m + (1-m)*img (:726), *255 truncated to u8 (:111), composited with the original through mask >= 127 (:59-60,117).
+ * composite == 0 stops after the truncation (``img_inpainted`` of :111, every pixel from the network): what the plugin resizes
+ * back to the page size before compositing there (:112-117) when the page had to be resized. */
 int mit_lama_post(const float *pred_dev, int64_t pred_pixstride, const uint8_t *img_dev, const uint8_t *mask_dev,
-                  uint8_t *out_dev, int B, int H, int W, void *stream);
+                  uint8_t *out_dev, int B, int H, int W, int composite, void *stream);
 
 /* Text-detection stage (ctd): memory-bound pieces and NHWC helpers ---------------------------
  * Reference: manga_translator/detection/ctd.py, ctd_utils/. */

@@ -161,13 +161,13 @@ __global__ void mpe_add_kernel(float *__restrict__ x, const uint8_t *__restrict_
 
 // ---- (3) composite: sigmoid output [B,H,W,3] f32 + page + mask -> inpainted page u8 ----
 __global__ void lama_post_kernel(const float *__restrict__ pred, int64_t pred_pixstride, const uint8_t *__restrict__ img,
-                                 const uint8_t *__restrict__ mask, uint8_t *__restrict__ out, int64_t npix) {
+                                 const uint8_t *__restrict__ mask, uint8_t *__restrict__ out, int64_t npix, int composite) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < npix; i += stride) {
         const uint8_t mk = mask[i];
         const float m = ((float)mk / 255.0f >= 0.5f) ? 1.f : 0.f;
-        const bool keep_inpainted = mk >= 127;  // mask_original :59-60
+        const bool keep_inpainted = !composite || mk >= 127;  // mask_original :59-60 (composite == 0: img_inpainted itself, :111)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const uint8_t px = img[3 * i + c];
@@ -236,12 +236,12 @@ extern "C" int mit_lama_mpe_add(float *x_dev, const uint8_t *mask_dev, const uin
 }
 
 extern "C" int mit_lama_post(const float *pred_dev, int64_t pred_pixstride, const uint8_t *img_dev,
-                             const uint8_t *mask_dev, uint8_t *out_dev, int B, int H, int W, void *stream) {
+                             const uint8_t *mask_dev, uint8_t *out_dev, int B, int H, int W, int composite, void *stream) {
     if (!pred_dev || !img_dev || !mask_dev || !out_dev) return mit_set_error("mit_lama_post: null pointer");
     const int64_t npix = (int64_t)B * H * W;
     MitProbeScope probe("lama_post_kernel", (hipStream_t)stream, (double)npix * (12 + 3 + 1 + 3));
     hipLaunchKernelGGL(lama_post_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, pred_dev,
-                       pred_pixstride, img_dev, mask_dev, out_dev, npix);
+                       pred_pixstride, img_dev, mask_dev, out_dev, npix, composite);
     MIT_CHECK_LAUNCH("mit_lama_post");
     return 0;
 }

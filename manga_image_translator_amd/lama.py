@@ -324,9 +324,11 @@ class LamaEngine:
 
     # -- full generator ------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, img_u8: torch.Tensor, mask_u8: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    def forward(self, img_u8: torch.Tensor, mask_u8: torch.Tensor, taps: Optional[dict] = None, composite: bool = True) -> torch.Tensor:
         """LamaFourier.__call__ (:713-726) + the tensor pre/post of _infer (:82-117) for pages whose
-        H, W are multiples of 8.  img_u8 [B,H,W,3] u8, mask_u8 [B,H,W] u8 (device) -> u8 [B,H,W,3]."""
+        H, W are multiples of 8.  img_u8 [B,H,W,3] u8, mask_u8 [B,H,W] u8 (device) -> u8 [B,H,W,3].
+        ``composite=False`` returns ``img_inpainted`` of :111 (the network's bytes everywhere) instead of the final composite
+        of :117 — the plugin resizes that back to the page size first when the page was resized (:112-117)."""
         if img_u8.dtype != torch.uint8 or mask_u8.dtype != torch.uint8:
             raise TypeError("LamaEngine.forward expects uint8 page and mask tensors")
         if img_u8.dim() != 4 or img_u8.shape[-1] != 3 or tuple(mask_u8.shape) != tuple(img_u8.shape[:3]):
@@ -385,7 +387,7 @@ class LamaEngine:
             taps["pred"] = pred.clone()
         out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=self.device)
         _lib.check(lib.mit_lama_post(pred.data_ptr(), 3, img_u8.data_ptr(), mask_u8.data_ptr(), out.data_ptr(), B, H, W,
-                                     st), "mit_lama_post")
+                                     int(composite), st), "mit_lama_post")
         return out
 
     # algorithmic FLOPs of one page (0.9706 MFLOP per input pixel for 9 blocks)

@@ -164,15 +164,20 @@ class HipComicTextDetector(_DetBase):
             raise ValueError(f"expected uint8 RGB [H,W,3], got {image.dtype} {image.shape}")
         im_h, im_w = image.shape[:2]
         page = torch.from_numpy(np.ascontiguousarray(image)).to(self.engine.device)[None]
-        mask_u8, lines, _ = self.engine.forward(page)
-        mask = mask_u8[0].cpu().numpy()           # postprocess_mask already applied on the GPU (ctd.py:30-44)
+        from . import hostglue, imgproc
+
+        mask_u8, lines, _ = self.engine.forward(page)    # postprocess_mask already applied on the GPU (ctd.py:30-44)
+        if self._refine is None:                         # cv2.resize(mask, (w, h), INTER_LINEAR) (:162) on the GPU as well
+            mask_full = imgproc.resize_u8(mask_u8[:1].contiguous(), (im_w, im_h))[0].cpu().numpy()
         lines_map = lines.cpu().numpy()           # [1,2,h,w], cropped to the un-padded area (:152-153)
-        boxes_fn, refine_fn = self._boxes or _native_ctd_boxes, self._refine or _native_refine
+        boxes_fn = self._boxes or _native_ctd_boxes
         boxes, scores = boxes_fn(lines_map, im_h, im_w)      # SegDetectorRepresenter(thresh=0.3) (:102,156)
         keep = np.where(scores > 0.6)                        # box_thresh (:157-159)
         boxes, scores = boxes[keep], scores[keep]
         textlines = [_RefQuadrilateral(pts.astype(int), "", float(s)) for pts, s in zip(boxes, scores)]
-        return textlines, refine_fn(image, mask, textlines, im_h, im_w), None  # resize + refine_mask (:162,177)
+        if self._refine is not None:                         # injected resize + refine_mask (e.g. the reference's OpenCV one)
+            return textlines, self._refine(image, mask_u8[0].cpu().numpy(), textlines, im_h, im_w), None
+        return textlines, hostglue.refine_mask(image, mask_full, textlines, None), None  # refine_mask(..., refine_mode=None) (:177)
 
 
 class HipDefaultDetector(_DetBase):
@@ -471,33 +476,43 @@ class HipLamaMPEInpainter(_InpBase):
     @torch.no_grad()
     async def _infer(self, image: np.ndarray, mask: np.ndarray, config=None, inpainting_size: int = 1024,
                      verbose: bool = False) -> np.ndarray:
-        """image u8 [H,W,3], mask u8 [H,W] -> inpainted [H,W,3] (inpainting_lama_mpe.py:56-118).  Always fp32: the
-        reference's CPU path never autocasts (:93-95) and that is the parity target."""
+        """image u8 [H,W,3], mask u8 [H,W] -> inpainted [H,W,3] (inpainting_lama_mpe.py:56-118), any page size: the
+        resize_keep_aspect / multiple-of-8 / back-to-page resizes and the final composite run on the GPU (imgproc.py).  Always
+        fp32: the reference's CPU path never autocasts (:93-95) and that is the parity target."""
         if image.ndim != 3 or image.shape[2] != 3 or mask.shape != image.shape[:2]:
             raise ValueError(f"bad shapes: image {image.shape}, mask {mask.shape}")
+        if image.dtype != np.uint8 or mask.dtype != np.uint8:
+            raise ValueError(f"expected uint8 page and mask, got {image.dtype} / {mask.dtype}")
+        from . import imgproc
+
         height, width = image.shape[:2]
-        img, msk = image, mask
-        scale = inpainting_size / max(height, width)
-        h, w = (height, width) if scale >= 1 else (int(round(height * scale)), int(round(width * scale)))
-        new_h, new_w = (h + 7) // 8 * 8, (w + 7) // 8 * 8
-        resized = (new_h, new_w) != (height, width)
-        if resized:  # resize_keep_aspect + cv2.resize to a multiple of 8 (:65-79): OpenCV glue, outside the dense path
-            rs = self._resize or _reference_resize()
-            if (h, w) != (height, width):
-                img, msk = rs(img, (w, h), "keep_aspect"), rs(msk, (w, h), "keep_aspect")
-            if (new_h, new_w) != (h, w):
-                img, msk = rs(img, (new_w, new_h), "linear"), rs(msk, (new_w, new_h), "linear")
         dev = self.engine.device
-        out = self.engine.forward(torch.from_numpy(np.ascontiguousarray(img)).to(dev)[None],
-                                  torch.from_numpy(np.ascontiguousarray(msk)).to(dev)[None])[0].cpu().numpy()
-        if not resized:
-            return out  # composite with the original page already done on the GPU (:117)
-        # the engine composited at the resized scale with the resized mask; the reference composites after resizing
-        # back, with the ORIGINAL mask thresholded at 127 (:59-61,114-117)
-        rs = self._resize or _reference_resize()
-        out = rs(out, (width, height), "linear")
-        m = (mask >= 127)[:, :, None]
-        return np.where(m, out, image)
+        img0 = torch.from_numpy(np.ascontiguousarray(image)).to(dev)[None]     # the page crosses PCIe once, as bytes
+        msk0 = torch.from_numpy(np.ascontiguousarray(mask)).to(dev)[None]
+        img, msk = img0, msk0
+        rs = self._resize  # optional injected callable (img, (w, h), "keep_aspect" | "linear") -> ndarray: e.g. the real OpenCV
+        if max(height, width) > inpainting_size:                                # resize_keep_aspect = INTER_LINEAR_EXACT (:64-66)
+            dsize = imgproc.keep_aspect_size(height, width, inpainting_size)
+            img, msk = self._resized(img, dsize, "keep_aspect", rs), self._resized(msk, dsize, "keep_aspect", rs)
+        h, w = img.shape[1:3]
+        new_h, new_w = (h + 7) // 8 * 8, (w + 7) // 8 * 8                      # pad_size 8, by RESIZING (INTER_LINEAR, :67-79)
+        if (new_h, new_w) != (h, w):
+            img, msk = self._resized(img, (new_w, new_h), "linear", rs), self._resized(msk, (new_w, new_h), "linear", rs)
+        resized = (new_h, new_w) != (height, width)
+        out = self.engine.forward(img, msk, composite=not resized)  # resized: img_inpainted of :111, every pixel from the network
+        if resized:                                                             # back to the page size (:112-113)
+            out = self._resized(out, (width, height), "linear", rs)
+        # img_inpainted * mask_original + img_original * (1 - mask_original), mask_original = mask >= 127 (:57-61,116)
+        return imgproc.select_u8(msk0, 127, out, img0)[0].cpu().numpy()
+
+    @staticmethod
+    def _resized(t: torch.Tensor, dsize, mode: str, injected: Optional[Callable]) -> torch.Tensor:
+        """[1,H,W(,C)] u8 device tensor -> (w, h) = dsize: ``mit_resize_u8`` on the GPU, or the injected host callable."""
+        from . import imgproc
+
+        if injected is None:
+            return imgproc.resize_u8(t, dsize, exact=(mode == "keep_aspect"))
+        return torch.from_numpy(np.ascontiguousarray(injected(t[0].cpu().numpy(), dsize, mode))).to(t.device)[None]
 
 
 class HipLamaLargeInpainter(HipLamaMPEInpainter):

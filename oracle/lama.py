@@ -254,16 +254,30 @@ def lama_call(sd: SD, mpe_sd: Optional[SD], img: torch.Tensor, mask: torch.Tenso
 
 
 def infer(sd: SD, mpe_sd: Optional[SD], image: np.ndarray, mask: np.ndarray, n_blocks: int,
-          taps: Optional[dict] = None) -> np.ndarray:
-    """LamaMPEInpainter._infer :56-118 on the CPU (fp32, no autocast) for pages that need no resize:
-    max(H, W) <= inpainting_size and H, W multiples of 8 (the BASELINE 2048x1456 case)."""
+          taps: Optional[dict] = None, inpainting_size: Optional[int] = None) -> np.ndarray:
+    """LamaMPEInpainter._infer :56-118 on the CPU (fp32, no autocast).  ``inpainting_size=None`` asserts the no-resize case
+    (max(H, W) <= inpainting_size and H, W multiples of 8: the BASELINE 2048x1456 page); with a size, the page is first resized
+    like the reference does — resize_keep_aspect (INTER_LINEAR_EXACT, :64-66), then INTER_LINEAR to a multiple of 8 (:67-79) and
+    back (:112-113) — through the oracle's restatements of those OpenCV resizes (oracle/imgproc.py, oracle/ctd.py)."""
+    from . import ctd as OC, imgproc as OI
+
+    def lin(a, dsize):
+        return OC.resize_linear_u8(a[..., None], dsize)[..., 0] if a.ndim == 2 else OC.resize_linear_u8(a, dsize)
+
     img_original = np.copy(image)
     mask_original = np.copy(mask)
     mask_original[mask_original < 127] = 0  # :59-61
     mask_original[mask_original >= 127] = 1
     mask_original = mask_original[:, :, None]
+    height, width, _ = image.shape
+    if inpainting_size is None:
+        assert height % 8 == 0 and width % 8 == 0, "pass inpainting_size for pages that need the resize path"
+    elif max(height, width) > inpainting_size:  # :64-66
+        image, mask = OI.resize_keep_aspect(image, inpainting_size), OI.resize_keep_aspect(mask, inpainting_size)
     h, w, _ = image.shape
-    assert h % 8 == 0 and w % 8 == 0, "oracle restates the no-resize path only"
+    new_h, new_w = (h + 7) // 8 * 8, (w + 7) // 8 * 8  # :67-76
+    if (new_h, new_w) != (h, w):  # :77-79
+        image, mask = lin(image, (new_w, new_h)), lin(mask, (new_w, new_h))
     img_t = torch.from_numpy(image).permute(2, 0, 1).unsqueeze(0).float() / 255.0  # :82
     mask_t = torch.from_numpy(mask).unsqueeze(0).unsqueeze(0).float() / 255.0  # :85
     mask_t[mask_t < 0.5] = 0
@@ -274,4 +288,6 @@ def infer(sd: SD, mpe_sd: Optional[SD], image: np.ndarray, mask: np.ndarray, n_b
     if taps is not None:
         taps["out_float"] = out
     inpainted = (out.squeeze(0).permute(1, 2, 0).numpy() * 255.0).astype(np.uint8)  # :111
+    if (new_h, new_w) != (height, width):  # :112-113
+        inpainted = lin(inpainted, (width, height))
     return inpainted * mask_original + img_original * (1 - mask_original)  # :117

@@ -12,6 +12,7 @@ primitive: what is pinned is the reference's Python + ATen path, not OpenCV's pi
 Fixtures (all small; each .npz also records the reference file whose code produced it):
   lama_mpe.npz     LamaFourier(use_mpe=True).__call__  (inpainting_lama_mpe.py:713-726, :751-815)   64x72
   lama_large.npz   LamaFourier(large_arch=True).__call__                                             48x40
+  lama_resize.npz  LamaMPEInpainter._infer as a whole (inpainting_lama_mpe.py:56-118), pages 250x333 and 300x200 (inpainting_size 160)
   ctd.npz          preprocess_img + TextDetBase.forward (ctd.py:17-28, ctd_utils/basemodel.py:234-238) 120x90 page
   ocr48.npz        OCR.infer_beam_batch_tensor (ocr/model_48px.py:678-801) on 5 crops, dict 97, T = 9
   ocr_ctc.npz      OCR.forward + OCR.decode (ocr/model_48px_ctc.py:463-494) on 3 crops padded to max_w+7+128, dict 97
@@ -81,6 +82,32 @@ def golden_lama():
         np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), page=page, mask=mask, out_float=out.numpy(),
                             n_blocks=nb, source="manga_translator/inpainting/inpainting_lama_mpe.py", **extra)
         print(name, out.shape, float(out.mean()))
+
+
+def golden_lama_resize():
+    """The reference's own ``LamaMPEInpainter._infer`` (inpainting_lama_mpe.py:56-118) — the whole method, resize legs included —
+    executed on the CPU with the cv2 stand-in: a page that is not a multiple of 8 (resize to 256x336 and back) and a page above
+    ``inpainting_size`` (resize_keep_aspect = INTER_LINEAR_EXACT first)."""
+    import asyncio
+    from unittest import mock
+
+    L = R.lama()
+    shim = R.cv2_shim()
+    G = R.generic()
+    L.cv2 = G.cv2 = shim
+    L.resize_keep_aspect = G.resize_keep_aspect            # the reference's own helper (utils/generic.py:251-255) over the stand-in
+    m, _, _ = build_ref_lama(9, True)
+    plug = L.LamaMPEInpainter.__new__(L.LamaMPEInpainter)
+    plug.model, plug.device, plug.logger = m, "cpu", mock.MagicMock()
+    out = {}
+    for tag, (H, W), size, seed in (("a", (250, 333), 1024, 5), ("b", (300, 200), 160, 6)):
+        page, _, mask = synth.synth_page(seed, H, W, n_boxes=3)
+        mask[4, 9] = 127
+        res = asyncio.new_event_loop().run_until_complete(plug._infer(page, mask, None, size))
+        out.update({f"page_{tag}": page, f"mask_{tag}": mask, f"size_{tag}": size, f"out_{tag}": np.asarray(res).astype(np.uint8)})
+        assert np.asarray(res).min() >= 0 and np.asarray(res).max() <= 255
+        print("lama_resize", tag, res.shape, res.dtype, float(np.asarray(res).mean()))
+    np.savez_compressed(os.path.join(GOLDEN, "lama_resize.npz"), source="manga_translator/inpainting/inpainting_lama_mpe.py:56-118", **out)
 
 
 def build_ref_ctd():
@@ -475,6 +502,7 @@ def main():
     golden_ocr()
     golden_ctd()
     golden_lama()
+    golden_lama_resize()
     golden_esrgan()
     golden_ocr_ctc()
     golden_dbnet()

@@ -135,7 +135,7 @@ def cv2_shim():
     from . import ctd as OC, lama as OL, textline as OT
 
     ns = types.SimpleNamespace()
-    ns.INTER_NEAREST, ns.INTER_LINEAR, ns.INTER_AREA = 0, 1, 3
+    ns.INTER_NEAREST, ns.INTER_LINEAR, ns.INTER_AREA, ns.INTER_LINEAR_EXACT = 0, 1, 3, 5
     ns.BORDER_CONSTANT, ns.RANSAC, ns.ROTATE_90_COUNTERCLOCKWISE = 0, 8, 2
     ns.COLOR_BGR2RGB, ns.COLOR_RGB2BGR = 4, 4
 
@@ -146,6 +146,10 @@ def cv2_shim():
             return OL.resize_nearest(src, dsize)
         if interpolation == ns.INTER_LINEAR:
             return OC.resize_linear_u8(src[..., None], dsize)[..., 0] if src.ndim == 2 else OC.resize_linear_u8(src, dsize)
+        if interpolation == ns.INTER_LINEAR_EXACT:
+            from . import imgproc as OI
+
+            return OI.resize_linear_exact_u8(src, dsize)
         raise NotImplementedError(interpolation)
 
     def filter2D(src, ddepth, kernel):

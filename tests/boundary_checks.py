@@ -187,6 +187,10 @@ class FakeCtdEngine:
 
 @check("CommonDetector.detect (the reference's caller) -> our _infer -> real Quadrilaterals, native host glue")
 def _():
+    from manga_image_translator_amd import imgproc
+
+    # no GPU here: the stand-in engine hands out CPU tensors, so the device resize is replaced by its numpy twin (same tables)
+    imgproc.resize_u8 = lambda t, dsize, exact=False: torch.from_numpy(np.stack([imgproc.resize_u8_host(x, dsize, exact) for x in t.numpy()]))
     det = P.HipComicTextDetector(weights={})
     det.engine, det._loaded = FakeCtdEngine(), True
     page = np.full((1200, 840, 3), 245, np.uint8)

@@ -38,6 +38,24 @@ def test_lama_oracle_matches_reference_fixture(name, mpe):
         assert rel.max() > 0 and direct.any()
 
 
+def test_lama_oracle_resize_path_matches_the_reference_infer():
+    """oracle.lama.infer with the resize legs (resize_keep_aspect, x8 INTER_LINEAR and back, composite with the original mask)
+    against the output of the reference's own LamaMPEInpainter._infer run over the cv2 stand-in (bytes; at most a truncation
+    flip of +-1 where the float sits on an integer)."""
+    from manga_image_translator_amd import lama_schema, synth
+    from oracle import lama as OL
+
+    g = _load("lama_resize.npz")
+    sd = synth.synth_state_dict(lama_schema.lama_generator_schema(9))
+    mpe_sd = synth.synth_state_dict(lama_schema.lama_mpe_schema())
+    for tag in ("a", "b"):
+        got = OL.infer(sd, mpe_sd, g[f"page_{tag}"], g[f"mask_{tag}"], 9, None, int(g[f"size_{tag}"]))
+        d = np.abs(got.astype(np.int32) - g[f"out_{tag}"].astype(np.int32))
+        assert got.shape == g[f"page_{tag}"].shape and d.max() <= 1 and (d != 0).mean() < 1e-3, (tag, d.max(), (d != 0).mean())
+        changed = (got != g[f"page_{tag}"]).any(-1)
+        assert changed.any() and not changed[g[f"mask_{tag}"] < 127].any()  # only pixels under the original mask may change
+
+
 def test_ctd_oracle_matches_reference_fixture():
     from manga_image_translator_amd import ctd_schema as S, synth
     from oracle import ctd as OC
