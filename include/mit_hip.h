@@ -270,6 +270,14 @@ int mit_boxes_from_bitmap(const float *pred, const uint8_t *bitmap, int H, int W
                           int64_t *boxes_out, float *scores_out, int *n_out);
 /* Number of contours / border points cv2.findContours(RETR_LIST) would trace in a 0/1 bitmap (diagnostics, tests). */
 int mit_find_contours_count(const uint8_t *bitmap, int H, int W, int *n_contours, int64_t *n_points);
+/* merge_mask_list of the ctd detector's refine_mask (detection/ctd_utils/textmask.py:74-132; filter_with_lines False), HOST
+ * pointers: n_cands candidate masks [n_cands][h*w] (0 / 255) with their xor scores, the network's mask window pred_mask [h*w];
+ * merged [h*w] receives the result.  Candidates in ascending score, their 8-connected components in raster order of the first
+ * pixel, each joined when that lowers sum(xor(merged, erode(pred) > 60)); inpaint_dilate != 0 adds the 5x5 dilation
+ * (REFINEMASK_INPAINT); then small holes are filled the same way. */
+int mit_merge_mask_list(const uint8_t *cands, const int64_t *scores, int n_cands, const uint8_t *pred_mask, int h, int w,
+                        int inpaint_dilate, uint8_t *merged);
+
 
 /* 48px OCR stage -----------------------------------------------------------------------------
  * Reference: manga_translator/ocr/model_48px.py, ocr/xpos_relative_position.py. */

@@ -265,6 +265,7 @@ class CtdEngine:
         _lib.check(lib.mit_map_to_u8(mask.data_ptr(), mask_u8.data_ptr(), B * S * S, 0, 0.0, st), "mit_map_to_u8")
         if taps is not None:
             taps["mask_f32"] = mask.clone()
+        self.last_mask_f32 = mask[..., 0]  # [B,S,S] view of the workspace, valid until the next forward (the tiled path averages floats)
         return mask_u8[:, :S - dh, :S - dw], lines[:, :, :S - dh, :S - dw], (dw, dh)
 
     def shrink_bitmap(self, lines: torch.Tensor, thr: float = 0.3) -> torch.Tensor:

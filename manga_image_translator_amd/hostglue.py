@@ -196,7 +196,19 @@ def _components(mask: np.ndarray, connectivity: int):
 
 
 def _merge_mask_list(mask_list, pred_mask: np.ndarray, inpaint_dilate: bool) -> np.ndarray:
-    """textmask.py:74-132 (filter_with_lines False, pred_thresh 30)."""
+    """textmask.py:74-132 (filter_with_lines False, pred_thresh 30) on the native routine (csrc/hostmask.hip)."""
+    cands = np.ascontiguousarray(np.stack([np.where(m[0] > 0, 255, 0).astype(np.uint8) for m in mask_list]))
+    scores = np.ascontiguousarray(np.array([int(m[1]) for m in mask_list], dtype=np.int64))
+    pred = np.ascontiguousarray(pred_mask, dtype=np.uint8)
+    h, w = pred.shape
+    merged = np.empty((h, w), np.uint8)
+    _lib.check(_lib.load().mit_merge_mask_list(cands.ctypes.data, scores.ctypes.data, len(mask_list), pred.ctypes.data, h, w,
+                                               int(bool(inpaint_dilate)), merged.ctypes.data), "mit_merge_mask_list")
+    return merged
+
+
+def _merge_mask_list_numpy(mask_list, pred_mask: np.ndarray, inpaint_dilate: bool) -> np.ndarray:
+    """The same in numpy / scipy (the statement the native routine is tested against; ~100x slower on a real text line)."""
     mask_list = sorted(mask_list, key=lambda x: x[1])
     pred_mask = _erode(pred_mask, _CROSS3)
     pred_mask = np.where(pred_mask > 60, 255, 0).astype(np.uint8)

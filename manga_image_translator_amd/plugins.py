@@ -140,6 +140,7 @@ class HipComicTextDetector(_DetBase):
         super().__init__(*args, **kwargs)
         self._weights, self._boxes, self._refine = weights, boxes_from_maps, refine
         self.engine = None
+        self.input_size = (1024, 1024)  # ctd.py:84: fixed, whatever detect_size the caller passes
         _weights_handed_over(self, weights)
 
     async def _load(self, device: str, input_size=1024, **_):
@@ -164,12 +165,17 @@ class HipComicTextDetector(_DetBase):
             raise ValueError(f"expected uint8 RGB [H,W,3], got {image.dtype} {image.shape}")
         im_h, im_w = image.shape[:2]
         page = torch.from_numpy(np.ascontiguousarray(image)).to(self.engine.device)[None]
-        from . import hostglue, imgproc
+        from . import hostglue, imgproc, rearrange
 
-        mask_u8, lines, _ = self.engine.forward(page)    # postprocess_mask already applied on the GPU (ctd.py:30-44)
+        S = self.input_size[0]
+        if rearrange.plan(im_h, im_w, S) is not None:    # webtoon strip: det_rearrange_forward (ctd.py:137, generic.py:876-997)
+            lines_map, mask_f = rearrange.forward(image, self._tiles_forward, S)
+            mask_u8 = torch.from_numpy((mask_f.squeeze() * 255).astype(np.uint8)).to(self.engine.device)[None]  # postprocess_mask (:155)
+        else:
+            mask_u8, lines, _ = self.engine.forward(page)    # postprocess_mask already applied on the GPU (ctd.py:30-44)
+            lines_map = lines.cpu().numpy()           # [1,2,h,w], cropped to the un-padded area (:152-153)
         if self._refine is None:                         # cv2.resize(mask, (w, h), INTER_LINEAR) (:162) on the GPU as well
             mask_full = imgproc.resize_u8(mask_u8[:1].contiguous(), (im_w, im_h))[0].cpu().numpy()
-        lines_map = lines.cpu().numpy()           # [1,2,h,w], cropped to the un-padded area (:152-153)
         boxes_fn = self._boxes or _native_ctd_boxes
         boxes, scores = boxes_fn(lines_map, im_h, im_w)      # SegDetectorRepresenter(thresh=0.3) (:102,156)
         keep = np.where(scores > 0.6)                        # box_thresh (:157-159)
@@ -178,6 +184,20 @@ class HipComicTextDetector(_DetBase):
         if self._refine is not None:                         # injected resize + refine_mask (e.g. the reference's OpenCV one)
             return textlines, self._refine(image, mask_u8[0].cpu().numpy(), textlines, im_h, im_w), None
         return textlines, hostglue.refine_mask(image, mask_full, textlines, None), None  # refine_mask(..., refine_mode=None) (:177)
+
+
+    def _tiles_forward(self, squares: np.ndarray):
+        """det_batch_forward_ctd (ctd.py:106-127) for <= 4 rearranged squares: u8 [n,s,s,3] -> (lines [n,2,S,S], mask [n,1,S,S])
+        float32.  Squares larger than the input size are shrunk on the GPU (square_pad_resize's INTER_LINEAR, generic.py:870-872);
+        at exactly S x S the engine's letterbox is the identity, i.e. the reference's plain ``/ 255``."""
+        from . import imgproc
+
+        S = self.input_size[0]
+        t = torch.from_numpy(np.ascontiguousarray(squares)).to(self.engine.device)
+        if t.shape[1] != S:
+            t = imgproc.resize_u8(t, (S, S))
+        _, lines, _ = self.engine.forward(t)
+        return lines.cpu().numpy(), self.engine.last_mask_f32.cpu().numpy()[:, None]
 
 
 class HipDefaultDetector(_DetBase):
@@ -220,14 +240,29 @@ class HipDefaultDetector(_DetBase):
         """-> (textlines, raw_mask u8 [H,W], None) (default.py:56-103, the non-rearranged branch).  The OpenCV glue —
         bilateralFilter + resize_aspect_ratio (:62), SegDetectorRepresenter (:73-77), the x2 mask resize (:89) — comes from
         the reference package or from the injected callables; the network runs on the GPU."""
-        pre = self._pre or _reference_default_preprocess()
+        from . import imgproc, rearrange
+
         boxes_fn = self._boxes or _native_dbnet_boxes
-        resize2x = self._resize2x or _reference_resize2x()
-        img_resized, target_ratio, pad_w, pad_h = pre(image, detect_size)
-        ratio = 1 / target_ratio
-        h, w = img_resized.shape[:2]
-        db, mask = self.engine.forward(torch.from_numpy(np.ascontiguousarray(img_resized)).to(self.engine.device)[None])
-        db, mask = db.cpu().numpy(), mask[0].cpu().numpy()
+        resize2x = self._resize2x or (lambda m: _resize2x_f32(m))
+        if rearrange.plan(image.shape[0], image.shape[1], detect_size) is not None:  # webtoon strip (default.py:60, generic.py:876-997)
+            def tiles(squares):  # det_batch_forward_default (:15-25): x / 127.5 - 1 happens inside the engine
+                t = torch.from_numpy(np.ascontiguousarray(squares)).to(self.engine.device)
+                if t.shape[1] != detect_size:
+                    t = imgproc.resize_u8(t, (detect_size, detect_size))
+                d, m = self.engine.forward(t)
+                return d.cpu().numpy(), m.cpu().numpy()[:, None]
+
+            db, mask4 = rearrange.forward(image, tiles, detect_size)
+            mask = mask4[0, 0]
+            h, w = image.shape[:2]
+            ratio, pad_w, pad_h = 1.0, 0, 0
+        else:
+            pre = self._pre or _reference_default_preprocess()
+            img_resized, target_ratio, pad_w, pad_h = pre(image, detect_size)
+            ratio = 1 / target_ratio
+            h, w = img_resized.shape[:2]
+            db, mask = self.engine.forward(torch.from_numpy(np.ascontiguousarray(img_resized)).to(self.engine.device)[None])
+            db, mask = db.cpu().numpy(), mask[0].cpu().numpy()
         boxes, scores = boxes_fn(db, h, w, text_threshold, box_threshold, unclip_ratio)
         if boxes.size == 0:
             polys, scores = [], []
@@ -649,6 +684,27 @@ def _reference_default_boxes():
         return boxes[0], scores[0]
 
     return fn
+
+
+def _resize2x_f32(m: np.ndarray) -> np.ndarray:
+    """cv2.resize(mask, (2w, 2h), INTER_LINEAR) on a float32 map (default.py:89): plain bilinear at pixel centres with edge
+    replication — float data takes OpenCV's unquantised path (coefficients 1 - f, f in float32)."""
+    h, w = m.shape
+
+    def taps(n):
+        f = ((np.arange(2 * n, dtype=np.float64) + 0.5) * 0.5 - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        fr = (f - i0.astype(np.float32)).astype(np.float32)
+        lo, hi = i0 < 0, i0 >= n - 1
+        i0 = np.where(lo, 0, np.where(hi, n - 1, i0))
+        fr = np.where(lo | hi, np.float32(0), fr).astype(np.float32)
+        return i0, np.minimum(i0 + 1, n - 1), (np.float32(1) - fr).astype(np.float32), fr
+
+    y0, y1, wy0, wy1 = taps(h)
+    x0, x1, wx0, wx1 = taps(w)
+    m = m.astype(np.float32)
+    rows = m[:, x0] * wx0[None, :] + m[:, x1] * wx1[None, :]
+    return (rows[y0] * wy0[:, None] + rows[y1] * wy1[:, None]).astype(np.float32)
 
 
 def _reference_resize2x():

@@ -207,6 +207,12 @@ def quadrilateral_can_merge_region(a: Quadrilateral, b: Quadrilateral, ratio=1.9
     char_size = min(a.font_size, b.font_size)
     x1, y1, w1, h1 = b1.x, b1.y, b1.w, b1.h
     x2, y2, w2, h2 = b2.x, b2.y, b2.w, b2.h
+    # the gap between the axis-aligned boxes is a lower bound of the polygon distance: far-apart pairs (most of the O(K^2)
+    # pairs of a page) fail the first test of the reference without the exact distance being needed — same decisions, always
+    gx = max(0, max(x1, x2) - min(x1 + w1, x2 + w2))
+    gy = max(0, max(y1, y2) - min(y1 + h1, y2 + h2))
+    if gx * gx + gy * gy > (discard_connection_gap * char_size) ** 2:
+        return False
     dist = polygon_distance(a.pts, b.pts)  # Polygon(a.pts).distance(Polygon(b.pts))
     if dist > discard_connection_gap * char_size:
         return False

@@ -18,6 +18,7 @@ Fixtures (all small; each .npz also records the reference file whose code produc
   ocr_ctc.npz      OCR.forward + OCR.decode (ocr/model_48px_ctc.py:463-494) on 3 crops padded to max_w+7+128, dict 97
   dbnet.npz        TextDetection.forward + sigmoid (detection/default_utils/DBNet_resnet34.py:98-125, default.py:15-25) on a 256x256 page (fp16 maps + fp32 crops)
   esrgan.npz       RRDBNet.forward + the tensor part of ESRGANUpscalerPytorch._infer (upscaling/esrgan_pytorch.py:67-75,537-546), nb = 2, 40x56 page
+  rearrange.npz    det_rearrange_forward + square_pad_resize (utils/generic.py:848-997) on tall / wide strips, stand-in network
   direction.npz    quadrilateral_can_merge_region + CommonOCR._generate_text_direction (utils/generic.py:653-698, ocr/common.py:12-39)
   refine_mask.npz  refine_mask / merge_mask_list / enlarge_window (detection/ctd_utils/textmask.py:16-174) on a 384x320 page
   textline_merge.json  the line sets + expected groupings of the reference's test/test_textline_merge.py and the reference code's own output
@@ -255,6 +256,44 @@ def golden_ocr_ctc():
     np.savez_compressed(os.path.join(GOLDEN, "ocr_ctc.npz"), region=region, widths=np.array(widths), logits=logits.numpy(),
                         colors=colors.numpy(), ids=ids, vals=vals, dict_size=OCR_DICT, source="manga_translator/ocr/model_48px_ctc.py")
     print("ocr_ctc", logits.shape, T, [len(t) for t in texts], float(logits.std()))
+
+
+def fake_detector(batch: np.ndarray, device=None):
+    """Deterministic stand-in for the detector network inside det_rearrange_forward: per-pixel functions of the input squares
+    (db at input resolution, mask at half resolution like the default detector's), so the golden pins the tiling / stitching
+    and not a network."""
+    b = np.asarray(batch).astype(np.float32) / 255.0
+    n, s = b.shape[0], b.shape[1]
+    ramp = (np.arange(s, dtype=np.float32) / s)[None, :, None]
+    db = np.stack([b[..., 0], b[..., 1] * 0.5 + 0.25 * ramp + 0.0 * b[..., 1]], axis=1)
+    m = b[..., 2]
+    mask = ((m[:, 0::2, 0::2] + m[:, 0::2, 1::2] + m[:, 1::2, 0::2] + m[:, 1::2, 1::2]) * np.float32(0.25))[:, None]
+    return db.astype(np.float32), mask.astype(np.float32)
+
+
+def golden_rearrange():
+    """The reference's own det_rearrange_forward (utils/generic.py:876-997, with square_pad_resize :848-874 over the cv2 stand-in)
+    on a tall strip, a wide strip (transposed path), a strip whose squares need shrinking and a page that is not rearranged."""
+    G = R.generic()
+    G.cv2 = R.cv2_shim()
+    import hashlib
+
+    out = {}
+    for tag, (H, W), tgt, seed in (("tall", (1400, 150), 320, 21), ("wide", (130, 1000), 192, 22), ("shrink", (2000, 350), 256, 23),
+                                   ("none", (900, 600), 512, 24)):
+        page = synth.synth_page(seed, H, W, n_boxes=6)[0]
+        db, mask = G.det_rearrange_forward(page, fake_detector, tgt, 4, "cpu", False)
+        out[f"shape_{tag}"], out[f"tgt_{tag}"], out[f"seed_{tag}"] = np.array([H, W]), tgt, seed  # the page is synth_page(seed, H, W, n_boxes=6)
+        if db is None:
+            assert tag == "none" and mask is None
+            continue
+        db, mask = np.ascontiguousarray(db, dtype=np.float32), np.ascontiguousarray(mask, dtype=np.float32)
+        # full maps as sha256 of their float32 bytes (bit-exactness is the bar), plus shapes and a strided sample for diagnostics
+        out[f"db_shape_{tag}"], out[f"mask_shape_{tag}"] = np.array(db.shape), np.array(mask.shape)
+        out[f"db_sha_{tag}"], out[f"mask_sha_{tag}"] = hashlib.sha256(db.tobytes()).hexdigest(), hashlib.sha256(mask.tobytes()).hexdigest()
+        out[f"db_sample_{tag}"], out[f"mask_sample_{tag}"] = db[..., ::7, ::5].copy(), mask[..., ::7, ::5].copy()
+        print("rearrange", tag, db.shape, mask.shape, float(db.mean()), float(mask.mean()))
+    np.savez_compressed(os.path.join(GOLDEN, "rearrange.npz"), source="manga_translator/utils/generic.py:848-997", **out)
 
 
 def golden_direction():
@@ -507,6 +546,7 @@ def main():
     golden_ocr_ctc()
     golden_dbnet()
     golden_direction()
+    golden_rearrange()
     golden_refine_mask()
     golden_textline_merge()
     golden_mask_refinement()

@@ -93,3 +93,39 @@ def test_ctd_plugin_standalone(cuda):
     ref_mask = HG.refine_mask(page, HG.resize_linear_u8(m8[0].cpu().numpy(), (384, 512)), tls, None)
     assert np.array_equal(mask, ref_mask)
     run(det.unload())
+
+
+@pytest.mark.parametrize("H,W", [(3072, 512), (560, 2900)], ids=["tall-1:6", "wide"])
+def test_ctd_plugin_webtoon_strip(cuda, H, W):
+    """Pages with long/1024 > 2.5 and aspect > 3 take the reference's det_rearrange_forward branch (ctd.py:137,
+    utils/generic.py:876-997): bands -> squares (shrunk on the GPU) -> engine -> stitched maps.  The tiling itself is pinned to the
+    reference function on the CPU (tests/test_rearrange.py); here the engine-fed maps are compared with the same tiling fed by the
+    oracle network, and the plugin is run end to end with no injected callables."""
+    import asyncio
+
+    from manga_image_translator_amd import ctd_schema as S, plugins as P, rearrange as RA, synth
+    from oracle import ctd as OC
+
+    run = lambda c: asyncio.new_event_loop().run_until_complete(c)
+    g = S.CTD_GAIN
+    weights = {"ctd.yolo": synth.synth_state_dict(S.yolo_schema(), gain=g), "ctd.seg": synth.synth_state_dict(S.unet_head_schema(), gain=g),
+               "ctd.det": synth.synth_state_dict(S.db_head_schema(), gain=g)}
+    page = synth.synth_page(12, H, W, n_boxes=8)[0]
+    assert RA.plan(H, W, 1024) is not None
+    det = P.HipComicTextDetector(weights=weights)
+    run(det.load("cuda"))
+    lines_gpu, mask_gpu = RA.forward(page, det._tiles_forward, 1024)
+
+    def oracle_net(sq):
+        x = torch.from_numpy(sq.astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous()   # det_batch_forward_ctd :108-112
+        with torch.no_grad():
+            mask, lines = OC.textdet_forward(weights["ctd.yolo"], weights["ctd.seg"], weights["ctd.det"], x)
+        return lines.numpy(), mask.numpy()
+
+    lines_ref, mask_ref = RA.forward(page, oracle_net, 1024, resize=lambda a, ds: OC.resize_linear_u8(a, ds))
+    assert lines_gpu.shape == lines_ref.shape and mask_gpu.shape == mask_ref.shape
+    assert np.abs(lines_gpu - lines_ref).max() < 1e-4 and np.abs(mask_gpu - mask_ref).max() < 1e-4
+    tls, mask, extra = run(det.infer(page, 1024, 0.5, 0.7, 2.3))
+    assert extra is None and mask.dtype == np.uint8 and mask.shape == (H, W)
+    assert all(0 <= q.pts[:, 0].min() and q.pts[:, 0].max() <= W and q.pts[:, 1].max() <= H for q in tls)
+    run(det.unload())
