@@ -193,10 +193,27 @@ int mit_select_u8(const uint8_t *mask_dev, int thr, const uint8_t *a_dev, const 
  * stride 1), B batches: element (b, t, r, c) at base + b*bs + t*ts + r*hs + c with t = 0 (re) / 1 (im).
  * out[k] = scale * sum_r in[r] * exp(-/+ 2 pi i k r / h) (inverse != 0: +).  twiddle_dev: h/2 (cos, sin) pairs of 2 pi k / h.
  * In-place (in == out with equal strides) is allowed.  The H-axis half of torch.fft.rfftn / irfftn(norm='ortho') in
- * FourierUnit.forward (inpainting_lama_mpe.py:228,252); the W axis stays a dense DFT on mit_conv_gemm. */
+ * FourierUnit.forward (inpainting_lama_mpe.py:228,252); the W axis is mit_rfft_rows / mit_irfft_rows (or a dense DFT on
+ * mit_conv_gemm for widths those do not cover). */
 int mit_fft_cols(const float *in_dev, int64_t in_bs, int64_t in_ts, int64_t in_hs, float *out_dev, int64_t out_bs,
                  int64_t out_ts, int64_t out_hs, const float *twiddle_dev, int B, int h, int64_t ncols, int inverse, float scale,
                  void *stream);
+
+/* Real FFT of length w along the W axis of NHWC rows: x[b, h, :, c] (element at in + b*in_bs + h*in_hs + x*in_ws + c) -> the
+ * w/2+1 Hermitian bins, planar: element (b, t, h, k, c) at out + b*out_bs + t*out_ts + h*out_hs + k*out_ks + c, t = 0 (re) / 1 (im),
+ * multiplied by `scale` (1/sqrt(w) for norm='ortho').  w must be even, <= 512, with w/2 a product of {2,3,5,7,11,13}
+ * (mit_rfft_rows_supported); C % 4 == 0.  tables_dev: w/2 (cos, sin) pairs of 2 pi j / (w/2) followed by w/2+1 pairs of
+ * 2 pi k / w (fp32, rounded from float64 on the host).  Mixed-radix Stockham butterflies in LDS on the packed sequence
+ * z[n] = x[2n] + i x[2n+1].  The W-axis half of torch.fft.rfftn(norm='ortho') in FourierUnit.forward (inpainting_lama_mpe.py:228). */
+int mit_rfft_rows_supported(int w);
+int mit_rfft_rows(const float *in_dev, int64_t in_bs, int64_t in_hs, int64_t in_ws, float *out_dev, int64_t out_bs, int64_t out_ts,
+                  int64_t out_hs, int64_t out_ks, const float *tables_dev, int B, int h, int w, int C, float scale, void *stream);
+/* Inverse of mit_rfft_rows: out[b, h, x, c] = scale * irfft_w(in[b, :, h, :, c]) (+ res[b, h, x, c] when res_dev != NULL), the
+ * imaginary parts of the DC and Nyquist bins ignored like pocketfft's c2r.  The W-axis half of torch.fft.irfftn(norm='ortho') and
+ * the ``x + fu(x)`` of SpectralTransform.forward (inpainting_lama_mpe.py:252,305). */
+int mit_irfft_rows(const float *in_dev, int64_t in_bs, int64_t in_ts, int64_t in_hs, int64_t in_ks, float *out_dev, int64_t out_bs,
+                   int64_t out_hs, int64_t out_ws, const float *res_dev, int64_t res_bs, int64_t res_hs, int64_t res_ws,
+                   const float *tables_dev, int B, int h, int w, int C, float scale, void *stream);
 
 /* u8 page [B,H,W,3] + u8 mask [B,H,W] -> fp32 NHWC [B,H,W,4] = (rgb/255*(1-m), m), m = (mask/255 >= 0.5).
  * Replaces the host-side tensor prep of LamaMPEInpainter._infer :82-92 and the torch.cat of

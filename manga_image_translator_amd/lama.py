@@ -8,9 +8,11 @@ MI355X:
   are the local branch and last 384 the global branch, so ``convl2l(x_l) + convg2l(x_g)`` (:365) is a
   single 3x3 conv over 512 input channels and torch.cat / ConcatTupleLayer (:535-542) cost nothing;
 * every BatchNorm is folded into the producing conv's epilogue, ReLU / sigmoid / residual adds too;
-* FourierUnit's rfftn / irfftn (:228,252) run as four dense DFT GEMMs on the same MFMA kernel
-  (W-axis real DFT, H-axis complex DFT and their inverses), with the re/im planes kept planar so the
-  384->384 spectral 1x1 conv reads them as two "taps" and no permute/stack/complex copy exists;
+* FourierUnit's rfftn / irfftn (:228,252) run as LDS butterflies: a mixed-radix real FFT along W
+  (mit_rfft_rows / mit_irfft_rows, 182 = 2*7*13 for the BASELINE page) and a radix-2 complex FFT along H
+  (mit_fft_cols); sizes those kernels do not cover fall back to dense DFT GEMMs on the MFMA kernel.  The
+  re/im planes stay planar so the 384->384 spectral 1x1 conv reads them as two "taps" and no
+  permute/stack/complex copy exists;
 * uint8 pages in, uint8 pages out: only bytes cross PCIe.
 """
 from __future__ import annotations
@@ -92,6 +94,14 @@ def dft_matrices(h: int, w: int):
     return f32(F1), f32(G2), f32(G2i), f32(Fi)
 
 
+def rfft_row_tables(w: int) -> torch.Tensor:
+    """Twiddle tables mit_rfft_rows / mit_irfft_rows consume for an even row length w: (cos, sin)(2 pi j / (w/2)), j < w/2,
+    then (cos, sin)(2 pi k / w), k <= w/2 — float64 on the host, rounded once to fp32."""
+    n = w // 2
+    a = np.concatenate([2.0 * np.pi * np.arange(n) / n, 2.0 * np.pi * np.arange(n + 1) / w])
+    return torch.from_numpy(np.stack([np.cos(a), np.sin(a)], 1).astype(np.float32)).contiguous()
+
+
 # ------------------------------------------------------------------------------------------
 # host tables for the MPE index kernels (same formulas as OpenCV's resize)
 # ------------------------------------------------------------------------------------------
@@ -160,10 +170,11 @@ class LamaEngine:
     """Batched LaMa generator. ``forward(img_u8[B,H,W,3], mask_u8[B,H,W]) -> u8 [B,H,W,3]`` (device tensors)."""
 
     def __init__(self, gen_sd: Dict[str, torch.Tensor], mpe_sd: Optional[Dict[str, torch.Tensor]] = None,
-                 n_blocks: int = 9, device="cuda", fft_h: bool = True, winograd: bool = True):
+                 n_blocks: int = 9, device="cuda", fft_h: bool = True, winograd: bool = True, fft_w: bool = True):
         self.device = torch.device(device)
         self.winograd = winograd  # False: the FFC blocks' 3x3 convolutions in direct (9-tap) form, for A/B comparison
         self.fft_h = fft_h  # False: keep the H-axis transform on the dense DFT GEMM (for A/B comparison)
+        self.fft_w = fft_w  # False: keep the W-axis transform on the dense DFT GEMM (for A/B comparison)
         self.n_blocks = n_blocks
         sd, dev = gen_sd, self.device
         self.stem = ops.Conv2d(sd["model.1.ffc.convl2l.weight"], None, padding=3, pad_mode=PAD_REFLECT,
@@ -193,6 +204,7 @@ class LamaEngine:
                             alpha5=float(mpe_sd["alpha5"]), alpha6=float(mpe_sd["alpha6"]))
         self._ws = ops.Workspace(self.device)
         self._tw: Dict[int, torch.Tensor] = {}
+        self._tw_rows: Dict[int, torch.Tensor] = {}
         self._dft = ops.ShapeCache(4)       # per-(h, w) DFT matrices: a few page shapes stay resident, older ones are dropped
         self._mpe_tabs = ops.ShapeCache(4)  # per-(H, W) resize tap tables of the MPE index kernels
 
@@ -216,6 +228,11 @@ class LamaEngine:
             self._tw[h] = torch.from_numpy(np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)).to(self.device).contiguous()
         return self._tw[h]
 
+    def _row_tables(self, w):
+        if w not in self._tw_rows:
+            self._tw_rows[w] = rfft_row_tables(w).to(self.device)
+        return self._tw_rows[w]
+
     def _fft_h(self, src, dst, dst_strides, B, h, ncols, plane, inverse):
         """H-axis complex FFT on planar re/im [B,2,h,ncols] (src) -> dst with (batch, plane, row) strides ``dst_strides``."""
         _lib.check(_lib.load().mit_fft_cols(src.data_ptr(), 2 * plane, plane, ncols, dst.data_ptr(), *dst_strides,
@@ -233,12 +250,11 @@ class LamaEngine:
 
         return self._mpe_tabs.get((H, W), make)
 
-    # -- FourierUnit (:214-257) as DFT GEMMs ---------------------------------------------------
+    # -- FourierUnit (:214-257): LDS-butterfly FFTs (dense DFT GEMMs for the sizes they do not cover) ---------------------------------------------------
     def _fourier_unit(self, ffc: _FFC, t1: torch.Tensor, t2: torch.Tensor):
         """t2 = t1 + irfft2(relu(bn(conv1x1(rfft2(t1)))))   (x + fu(x), :305)."""
         B, h, w, Cc = t1.shape
         wk = w // 2 + 1
-        F1, G2, G2i, Fi = self._dft_mats(h, w)
         plane = h * wk * Cc
         Y = self._buf("fu_Y", B, 2, h, wk, Cc)
         Zf = self._buf("fu_Z", B, 2, h, wk, Cc)
@@ -249,17 +265,27 @@ class LamaEngine:
         # each of its two GEMM launches is credited half of it in the roofline probe instead of its dense-DFT FLOPs
         fft_half = 0.5 * 2.5 * h * w * math.log2(h * w) * Cc * B
         tag = lambda: _lib.load().mit_prof_tag_next(fft_half)
-        # S1: real DFT along W.  rows (t,kw) = F1 @ t1[b,h] ([w] x [C]);  z = (b, h)
-        cm = ops.MitTensorMap()
-        cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Y.data_ptr(), 2 * plane, wk * Cc, 0, plane, Cc
-        tag()
-        launch_conv_gemm(conv_gemm_desc(
-            a=F1, NB=1, Hi=2, Wi=wk, Cin=F1.shape[1], a_strides=(0, wk * F1.shape[1], F1.shape[1]), Ho=2, Wo=wk, sy=1,
-            sx=1, taps=one, pad_mode=PAD_ZERO, w=t1, ldw=Cc, Kw=w, Nw=Cc, N=Cc, c=cm, Z=B * h, zdiv=h,
-            w_zs=(h * w * Cc, w * Cc)))
+        # S1: real DFT along W: mixed-radix LDS butterflies when w is an even product of small primes (W/8 = 182 = 2*7*13 for
+        # the BASELINE page), else the dense DFT GEMM  rows (t,kw) = F1 @ t1[b,h] ([w] x [C]);  z = (b, h)
+        lib = _lib.load()
+        use_fft_w = self.fft_w and Cc % 4 == 0 and bool(lib.mit_rfft_rows_supported(w))
+        use_fft = h >= 2 and (h & (h - 1)) == 0 and h <= 512 and self.fft_h
+        if not (use_fft_w and use_fft):
+            F1, G2, G2i, Fi = self._dft_mats(h, w)
+        st = C.c_void_p(ops.current_stream())
+        if use_fft_w:
+            _lib.check(lib.mit_rfft_rows(t1.data_ptr(), h * w * Cc, w * Cc, Cc, Y.data_ptr(), 2 * plane, plane, wk * Cc, Cc,
+                                         self._row_tables(w).data_ptr(), B, h, w, Cc, 1.0 / math.sqrt(w), st), "mit_rfft_rows")
+        else:
+            cm = ops.MitTensorMap()
+            cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Y.data_ptr(), 2 * plane, wk * Cc, 0, plane, Cc
+            tag()
+            launch_conv_gemm(conv_gemm_desc(
+                a=F1, NB=1, Hi=2, Wi=wk, Cin=F1.shape[1], a_strides=(0, wk * F1.shape[1], F1.shape[1]), Ho=2, Wo=wk, sy=1,
+                sx=1, taps=one, pad_mode=PAD_ZERO, w=t1, ldw=Cc, Kw=w, Nw=Cc, N=Cc, c=cm, Z=B * h, zdiv=h,
+                w_zs=(h * w * Cc, w * Cc)))
         # S2: complex DFT along H on planar re/im: LDS-butterfly FFT when h is a power of two (H/8 = 256 for the BASELINE
         # page), else the dense [2h x 2h] DFT GEMM  Z[b] = G2 @ Y[b]
-        use_fft = h >= 2 and (h & (h - 1)) == 0 and h <= 512 and self.fft_h
         if use_fft:
             self._fft_h(Y, Zf, (2 * plane, plane, wk * Cc), B, h, wk * Cc, plane, False)
         else:
@@ -290,6 +316,11 @@ class LamaEngine:
                 pad_mode=PAD_ZERO, w=Z2, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
                 w_zs=(0, 2 * plane)))
         # S4: complex->real inverse DFT along W, + t1.  t2[b,h] = Fi @ U[b,h] ([2wk] x [C]) + t1[b,h]
+        if use_fft_w:
+            _lib.check(lib.mit_irfft_rows(U.data_ptr(), 2 * plane, wk * Cc, 2 * wk * Cc, Cc, t2.data_ptr(), h * w * Cc, w * Cc,
+                                          Cc, t1.data_ptr(), h * w * Cc, w * Cc, Cc, self._row_tables(w).data_ptr(), B, h, w, Cc,
+                                          1.0 / math.sqrt(w), st), "mit_irfft_rows")
+            return
         cm = ops.MitTensorMap()
         cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = t2.data_ptr(), 0, w * Cc, 0, 0, Cc
         pm = ops.MitTensorMap()

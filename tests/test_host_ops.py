@@ -205,3 +205,60 @@ def test_winograd_host_side_against_conv2d(reflect):
     xp = F.pad(x[..., :Cin].permute(0, 3, 1, 2).double(), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
     ref = F.conv2d(xp, w.double()).permute(0, 2, 3, 1).numpy()
     assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_rfft_row_plan_and_tables():
+    """Host side of the mixed-radix W-axis FFT: the widths the kernel accepts (C-ABI predicate, no GPU needed) and the
+    twiddle tables, checked by running the kernel's algorithm (packed real FFT: Stockham stages + untangle) in numpy on
+    those very tables against numpy.fft.rfft / irfft."""
+    import numpy as np
+
+    from manga_image_translator_amd import lama, lib
+
+    L = lib.load()
+    assert all(L.mit_rfft_rows_supported(w) for w in (182, 8, 42, 64, 210, 26, 364, 512, 4))
+    assert not any(L.mit_rfft_rows_supported(w) for w in (181, 362, 34, 514, 2, 0))
+
+    def plan(n):  # same greedy order as make_plan in csrc/fft_rows.hip
+        out = []
+        for r in (4, 2, 3, 5, 7, 11, 13):
+            while n % r == 0:
+                out.append(r)
+                n //= r
+        assert n == 1
+        return out
+
+    def stockham(z, tw, inverse):
+        N = len(z)
+        x, n, s = z.copy(), N, 1
+        for P in plan(N):
+            m, y = n // P, np.empty_like(z)
+            for bf in range(N // P):
+                q, p = bf % s, bf // s
+                xi = np.array([x[q + s * (p + m * i)] for i in range(P)])
+                for k in range(P):
+                    wp = np.exp((2j if inverse else -2j) * np.pi * np.arange(P) * k / P)
+                    t = tw[(p * k * (N // n)) % N]
+                    y[q + s * (P * p + k)] = (xi * wp).sum() * (t if inverse else np.conj(t))
+            x, n, s = y, m, s * P
+        return x
+
+    rng = np.random.default_rng(5)
+    for w in (182, 42, 64):
+        N = w // 2
+        tabs = lama.rfft_row_tables(w).numpy().astype(np.float64)
+        assert tabs.shape == (2 * N + 1, 2)
+        tw, tw2 = tabs[:N, 0] + 1j * tabs[:N, 1], tabs[N:, 0] + 1j * tabs[N:, 1]
+        x = rng.standard_normal(w)
+        Z = stockham(x[0::2] + 1j * x[1::2], tw, False)
+        k = np.arange(N + 1)
+        zk, zn = Z[k % N], np.conj(Z[(N - k) % N])
+        X = ((zk + zn) - 1j * np.conj(tw2) * (zk - zn)) * 0.5 / np.sqrt(w)
+        assert np.abs(X - np.fft.rfft(x, norm="ortho")).max() < 1e-6
+        A, Bc = X[:N].copy(), np.conj(X[N - np.arange(N)])
+        A[0] = A[0].real
+        Bc[0] = Bc[0].real
+        zz = stockham((A + Bc) + 1j * tw2[:N] * (A - Bc), tw, True) / np.sqrt(w)
+        back = np.empty(w)
+        back[0::2], back[1::2] = zz.real, zz.imag
+        assert np.abs(back - x).max() < 1e-6

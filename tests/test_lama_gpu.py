@@ -109,8 +109,9 @@ def test_lama_rejects_bad_input(cuda):
 
 
 def test_fft_h_matches_dft_gemm_at_page_size(cuda):
-    """FourierUnit at the BASELINE page's spectral size (256 x 182, 192 ch): the LDS-butterfly H-axis FFT and the dense
-    DFT-GEMM path agree to fp32 round-off, and both match torch.fft (the reference's rfftn/irfftn) through the oracle."""
+    """FourierUnit at the BASELINE page's spectral size (256 x 182, 192 ch): the LDS-butterfly FFTs (mixed-radix along W,
+    radix-2 along H) and the dense DFT-GEMM paths agree to fp32 round-off in every combination, and all match torch.fft
+    (the reference's rfftn/irfftn) through the oracle."""
     from manga_image_translator_amd import lama, lama_schema, synth
     from oracle import lama as OL
 
@@ -118,8 +119,8 @@ def test_fft_h_matches_dft_gemm_at_page_size(cuda):
     g = torch.Generator().manual_seed(11)
     t1 = torch.randn(1, 256, 182, 192, generator=g)
     outs = []
-    for fft_h in (True, False):
-        eng = lama.LamaEngine(sd, None, n_blocks=1, device=cuda, fft_h=fft_h)
+    for fft_h, fft_w in ((True, True), (False, False), (True, False), (False, True)):  # shipped path first
+        eng = lama.LamaEngine(sd, None, n_blocks=1, device=cuda, fft_h=fft_h, fft_w=fft_w)
         t2 = torch.empty(1, 256, 182, 192, device=cuda)
         eng._fourier_unit(eng.blocks[0][0], t1.to(cuda), t2)
         torch.cuda.synchronize()
@@ -127,7 +128,8 @@ def test_fft_h_matches_dft_gemm_at_page_size(cuda):
     x = _nchw(t1)
     ref = _nchw((x + OL.fourier_unit(x, sd, "model.5.conv1.ffc.convg2g.fu")).permute(0, 2, 3, 1))
     scale = ref.abs().max().item()
-    assert (outs[0] - outs[1]).abs().max().item() < 2e-5 * scale
+    for o in outs[1:]:
+        assert (outs[0] - o).abs().max().item() < 2e-5 * scale
     for o in outs:
         assert (_nchw(o) - ref).abs().max().item() < 5e-5 * scale
 
@@ -156,3 +158,55 @@ def test_fft_cols_against_torch_fft(cuda, h, ncols, inverse):
     ref = (torch.fft.ifft if inverse else torch.fft.fft)(z, dim=1, norm="ortho")
     got = torch.complex(out[:, 0].double().cpu(), out[:, 1].double().cpu())
     assert (got - ref).abs().max() < 5e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("w,C_,h", [(182, 192, 5), (8, 4, 3), (42, 36, 2), (64, 32, 4), (210, 68, 2), (26, 192, 3), (364, 64, 2),
+                                    (512, 40, 2), (4, 8, 1), (198, 32, 2)])
+def test_rfft_rows_against_torch_fft(cuda, w, C_, h):
+    """mit_rfft_rows / mit_irfft_rows (packed real FFT, Stockham stages over the radices {2,3,4,5,7,11,13}) against
+    torch.fft.rfft / irfft(norm='ortho') in float64: the BASELINE width 182 = 2*7*13, every radix, ragged channel counts,
+    the residual add, and Im(DC) / Im(Nyquist) ignored by the inverse like pocketfft's c2r."""
+    import ctypes as C
+    import math
+
+    from manga_image_translator_amd import lama, lib as L, ops
+
+    Lh = L.load()
+    assert Lh.mit_rfft_rows_supported(w)
+    g = torch.Generator().manual_seed(w * 7 + C_)
+    B, wk = 2, w // 2 + 1
+    x = torch.randn(B, h, w, C_, generator=g)
+    tabs = lama.rfft_row_tables(w).to(cuda)
+    st = C.c_void_p(ops.current_stream())
+    xg = x.to(cuda)
+    Y = torch.full((B, 2, h, wk, C_), float("nan"), device=cuda)
+    plane = h * wk * C_
+    L.check(Lh.mit_rfft_rows(xg.data_ptr(), h * w * C_, w * C_, C_, Y.data_ptr(), 2 * plane, plane, wk * C_, C_, tabs.data_ptr(), B, h, w,
+                             C_, 1.0 / math.sqrt(w), st), "mit_rfft_rows")
+    torch.cuda.synchronize()
+    ref = torch.fft.rfft(x.double(), dim=2, norm="ortho")  # [B, h, wk, C]
+    got = torch.complex(Y[:, 0].double().cpu(), Y[:, 1].double().cpu())
+    tol = 5e-6 * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max() < tol
+    # inverse on a spectrum with junk in Im(DC) / Im(Nyquist), laid out [B, h, 2, wk, C] like the engine's U buffer
+    spec = torch.randn(B, h, 2, wk, C_, generator=g)
+    res = torch.randn(B, h, w, C_, generator=g)
+    out = torch.full((B, h, w, C_), float("nan"), device=cuda)
+    sg, rg = spec.to(cuda), res.to(cuda)
+    for use_res in (True, False):
+        L.check(Lh.mit_irfft_rows(sg.data_ptr(), h * 2 * wk * C_, wk * C_, 2 * wk * C_, C_, out.data_ptr(), h * w * C_, w * C_, C_,
+                                  rg.data_ptr() if use_res else None, h * w * C_, w * C_, C_, tabs.data_ptr(), B, h, w, C_,
+                                  1.0 / math.sqrt(w), st), "mit_irfft_rows")
+        torch.cuda.synchronize()
+        z = torch.complex(spec[:, :, 0].double(), spec[:, :, 1].double())
+        ref = torch.fft.irfft(z, n=w, dim=2, norm="ortho") + (res.double() if use_res else 0.0)
+        assert (out.double().cpu() - ref).abs().max() < 5e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_rfft_rows_rejects_unsupported_widths(cuda):
+    from manga_image_translator_amd import lib as L
+
+    Lh = L.load()
+    for w in (181, 362, 2 * 17, 514, 2, 0, -4):  # odd, 2 * prime > 13, too long, too short
+        assert not Lh.mit_rfft_rows_supported(w)
+    assert Lh.mit_rfft_rows(None, 0, 0, 0, None, 0, 0, 0, 0, None, 1, 1, 182, 192, 1.0, None) != 0
