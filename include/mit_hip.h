@@ -181,10 +181,38 @@ int mit_prof_kernels_read(MitProfKernelStat *stats, int max_stats, int *n_stats)
  * index (int32) and two uint16 weights {w(idx), w(idx+1)}; idx+1 is clamped to the last row / column by the kernel. */
 int mit_resize_u8(const uint8_t *src_dev, int B, int H, int W, int C, uint8_t *dst_dev, int dh, int dw, int mode, const int *yidx_dev,
                   const uint16_t *ycoef_dev, const int *xidx_dev, const uint16_t *xcoef_dev, void *stream);
+/* cv2.bilateralFilter on 8-bit RGB pages [B,H,W,3] (mask_refinement/text_mask_utils.py:159 and detection/default.py:64 call it
+ * with d = 17, sigmaColor = sigmaSpace = 80): BORDER_REFLECT_101, `ntaps` taps of the circular support in row-major order, tap k at
+ * (dy, dx) = (tap_ofs[k] >> 16, (int16)(tap_ofs[k] & 0xffff)) with spatial weight tap_w[k]; colour weight
+ * color_w[|dr| + |dg| + |db|] (768 floats); fp32 sums in tap order, result = round-half-even(sum / wsum).  The tables are OpenCV's
+ * ((float)exp(double)), built by the host (imgproc.bilateral_tables).  radius <= 16.  src and dst must not alias. */
+int mit_bilateral_u8c3(const uint8_t *src_dev, uint8_t *dst_dev, int B, int H, int W, int radius, int ntaps, const int *tap_ofs_dev,
+                       const float *tap_w_dev, const float *color_w_dev, void *stream);
 /* out = mask >= thr ? a : b per pixel (C channels): ``img_inpainted * mask_original + img_original * (1 - mask_original)`` with the
  * original mask thresholded at 127 (inpainting_lama_mpe.py:57-61,116). */
 int mit_select_u8(const uint8_t *mask_dev, int thr, const uint8_t *a_dev, const uint8_t *b_dev, uint8_t *out_dev, int64_t npix, int C,
                   void *stream);
+
+/* Mask refinement between OCR and inpainting -----------------------------------------------------
+ * Reference: manga_translator/mask_refinement/text_mask_utils.py:68-94 (refine_mask -> pydensecrf). */
+
+typedef struct MitCrfCrop {
+    int x, y, w, h; /* crop rectangle inside the page, pixels */
+} MitCrfCrop;
+
+/* Bytes of device workspace mit_densecrf_refine needs for these crops (-1: bad crops / batch too large). */
+int64_t mit_densecrf_workspace_bytes(const MitCrfCrop *crops, int n_crops);
+/* DenseCRF2D mean-field refinement of every text line's mask crop of one page, batched:
+ *   unary = -log(clip([1 - m, m], 1e-5, 1)) through unary_lut_dev (256 x 2 floats, built by the host),
+ *   pairwise Gaussian (x, y) / sxy_gauss with Potts weight w_gauss + bilateral (x, y) / sxy_bilateral, rgb / srgb_bilateral with
+ *   w_bilateral, both through a permutohedral-lattice filter (DIAG_KERNEL, NO_NORMALIZATION), `iterations` mean-field steps,
+ *   out = 255 * argmax(Q).   The reference's call is (1, 3, 23, 7, 20, 5).
+ * page_dev: u8 [H,W,3] on the device (the bilateral-filtered page); crops: HOST array; mask_dev / out_dev: the crops' masks back to
+ * back (crop c at offset sum_{c'<c} w*h, row-major); q_dev (optional): float [sum w*h][2] final marginals.  Synchronises the stream. */
+int mit_densecrf_refine(const uint8_t *page_dev, int H, int W, const MitCrfCrop *crops, int n_crops, const uint8_t *mask_dev,
+                        uint8_t *out_dev, float *q_dev, float sxy_gauss, float w_gauss, float sxy_bilateral, float srgb_bilateral,
+                        float w_bilateral, int iterations, const float *unary_lut_dev, void *workspace_dev, int64_t workspace_bytes,
+                        void *stream);
 
 /* LaMa inpainting stage: memory-bound pieces ----------------------------------------------
  * Reference: manga_translator/inpainting/inpainting_lama_mpe.py. */

@@ -150,3 +150,53 @@ def select_u8(mask: torch.Tensor, thr: int, a: torch.Tensor, b: torch.Tensor) ->
     _lib.check(_lib.load().mit_select_u8(mask.data_ptr(), int(thr), a.data_ptr(), b.data_ptr(), out.data_ptr(), mask.numel(), a.shape[3],
                                          C.c_void_p(ops.current_stream())), "mit_select_u8")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# cv2.bilateralFilter (8-bit, 3 channels) — mask_refinement/text_mask_utils.py:159, detection/default.py:64
+# ------------------------------------------------------------------------------------------------------------------------
+
+@lru_cache(maxsize=8)
+def bilateral_tables(d: int, sigma_color: float, sigma_space: float):
+    """The tables of OpenCV's bilateralFilter_8u: (radius, tap offsets (dy << 16 | dx & 0xffff) int32, spatial weights float32,
+    colour weights float32[256 * 3]).  radius = d / 2 (or round(1.5 sigma_space) for d <= 0), circular support in row-major
+    order, weights (float)exp(double)."""
+    sigma_color = sigma_color if sigma_color > 0 else 1.0
+    sigma_space = sigma_space if sigma_space > 0 else 1.0
+    gc, gs = -0.5 / (sigma_color * sigma_color), -0.5 / (sigma_space * sigma_space)
+    radius = max(int(np.rint(sigma_space * 1.5)) if d <= 0 else d // 2, 1)
+    color_w = np.exp((np.arange(256 * 3, dtype=np.float64) ** 2) * gc).astype(np.float32)
+    ofs, wts = [], []
+    for i in range(-radius, radius + 1):
+        for j in range(-radius, radius + 1):
+            r = np.sqrt(float(i) * i + float(j) * j)
+            if r > radius:
+                continue
+            ofs.append(np.int32(np.uint32((i & 0xffff) << 16 | (j & 0xffff)).astype(np.int32)))
+            wts.append(np.float32(np.exp(r * r * gs)))
+    return radius, np.asarray(ofs, dtype=np.int32), np.asarray(wts, dtype=np.float32), color_w
+
+
+_BILATERAL_DEV = {}
+
+
+def bilateral_filter_u8(img: torch.Tensor, d: int = 17, sigma_color: float = 80.0, sigma_space: float = 80.0) -> torch.Tensor:
+    """cv2.bilateralFilter(img, d, sigma_color, sigma_space) for uint8 RGB pages [B,H,W,3] (or [H,W,3]) on the device
+    (``mit_bilateral_u8c3``)."""
+    from . import lib as _lib
+    from . import ops
+
+    if img.dtype != torch.uint8 or img.shape[-1] != 3 or img.dim() not in (3, 4) or not img.is_cuda:
+        raise ValueError(f"bilateral_filter_u8 expects a uint8 device tensor [B,H,W,3] or [H,W,3], got {img.dtype} {tuple(img.shape)}")
+    squeeze = img.dim() == 3
+    s = (img[None] if squeeze else img).contiguous()
+    key = (int(d), float(sigma_color), float(sigma_space), s.device)
+    if key not in _BILATERAL_DEV:
+        radius, ofs, wts, cw = bilateral_tables(int(d), float(sigma_color), float(sigma_space))
+        _BILATERAL_DEV[key] = (radius, torch.from_numpy(ofs).to(s.device), torch.from_numpy(wts).to(s.device), torch.from_numpy(cw).to(s.device))
+    radius, ofs, wts, cw = _BILATERAL_DEV[key]
+    out = torch.empty_like(s)
+    B, H, W, _ = s.shape
+    _lib.check(_lib.load().mit_bilateral_u8c3(s.data_ptr(), out.data_ptr(), B, H, W, radius, ofs.numel(), ofs.data_ptr(), wts.data_ptr(),
+                                              cw.data_ptr(), C.c_void_p(ops.current_stream())), "mit_bilateral_u8c3")
+    return out[0] if squeeze else out

@@ -116,6 +116,10 @@ class MitWarpLine(C.Structure):
                 ("_pad", C.c_int32)]
 
 
+class MitCrfCrop(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
 class MitRaggedSeg(C.Structure):
     _fields_ = [("pixel_start", C.c_int64), ("group_start", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("_pad", C.c_int32)]
@@ -153,6 +157,11 @@ SYMBOLS = {
     "mit_irfft_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                  C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p]),
+    "mit_bilateral_u8c3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "mit_densecrf_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int]),
+    "mit_densecrf_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mit_lama_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_lama_mpe_index": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,

@@ -3,13 +3,16 @@ to which text line, per-line clean-up, dilation — the reference's ``mask_refin
 (/root/reference/manga_translator/mask_refinement/__init__.py:9-50) and ``complete_mask``
 (mask_refinement/text_mask_utils.py:96-195).
 
-Host-side logic, like the reference's.  Native here: the 8-bit linear resizes, component labelling and statistics, the
-component -> text-line assignment (overlap ratio, distance to the line polygon), crop / dilation-size arithmetic, elliptical
-dilation, the final merge.  NOT native: the per-line DenseCRF (``text_mask_utils.refine_mask`` -> pydensecrf) and the
-``cv2.bilateralFilter`` that feeds it; both are injected callables (``refine=`` / ``bilateral=``) which default to the
-reference's own when its package (with pydensecrf / OpenCV) is importable and raise otherwise — there is no silent substitute.
+Host-side control flow like the reference's, with the two heavy steps on the GPU.  Native on the host: the 8-bit linear resizes,
+component labelling and statistics, the component -> text-line assignment (overlap ratio, distance to the line polygon), crop /
+dilation-size arithmetic, elliptical dilation, the final merge.  On the GPU (default backend ``GpuMaskBackend``): the
+``cv2.bilateralFilter(img, 17, 80, 80)`` of the page (``mit_bilateral_u8c3``) and the per-line DenseCRF
+(``text_mask_utils.refine_mask`` -> pydensecrf), all lines of the page in ONE batched call (``mit_densecrf_refine``) on the
+filtered page that never leaves the device.  There is no CPU substitute: without the HIP library / a GPU the default backend
+raises.  ``refine=`` / ``bilateral=`` still inject per-crop / per-page callables (the reference's own, or the stubs the pin uses).
 Pinned against the reference's Python, run with stand-ins for cv2 / shapely and the same two callables stubbed on both sides
-(tests/golden/mask_refinement.npz, oracle/make_golden.py)."""
+(tests/golden/mask_refinement.npz, oracle/make_golden.py); the GPU steps are checked against oracle/densecrf.py and
+oracle/imgproc.bilateral_filter_u8 (parity with pydensecrf / OpenCV themselves is unpinned: neither is installed anywhere this runs)."""
 from __future__ import annotations
 
 from typing import Callable, List, Optional, Sequence
@@ -24,20 +27,69 @@ RefineFn = Callable[[np.ndarray, np.ndarray], np.ndarray]      # (rgb crop, mask
 BilateralFn = Callable[[np.ndarray], np.ndarray]               # page -> filtered page                (cv2.bilateralFilter(img, 17, 80, 80) :159)
 
 
-def _reference_refine() -> RefineFn:
-    try:
-        from manga_translator.mask_refinement.text_mask_utils import refine_mask  # needs pydensecrf
-    except Exception as ex:  # pragma: no cover - depends on the host
-        raise RuntimeError("mask refinement needs a DenseCRF step: pass refine=..., or install the reference package with pydensecrf") from ex
-    return refine_mask
+class CallableMaskBackend:
+    """The two heavy steps as host callables: ``bilateral(page) -> page`` and ``refine(rgb crop, mask crop) -> mask crop``
+    (e.g. the reference's own ``cv2.bilateralFilter`` / ``refine_mask``, or the stubs of the golden pin)."""
+
+    def __init__(self, refine: RefineFn, bilateral: BilateralFn):
+        self._refine, self._bilateral = refine, bilateral
+
+    def filter_page(self, img: np.ndarray):
+        return self._bilateral(img)
+
+    def refine(self, page, rects, masks):
+        return [self._refine(np.ascontiguousarray(page[y:y + h, x:x + w]), m) for (x, y, w, h), m in zip(rects, masks)]
 
 
-def _reference_bilateral() -> BilateralFn:
-    try:
-        import cv2
-    except Exception as ex:  # pragma: no cover - depends on the host
-        raise RuntimeError("mask refinement needs cv2.bilateralFilter: pass bilateral=..., or install OpenCV") from ex
-    return lambda img: cv2.bilateralFilter(img, 17, 80, 80)
+class GpuMaskBackend:
+    """Default backend: bilateral filter + batched DenseCRF on the device (imgproc.bilateral_filter_u8, densecrf.DenseCrfRefiner)."""
+
+    def __init__(self, device=None):
+        import torch
+
+        from . import densecrf, lib
+
+        lib.load()  # fails loudly without the HIP library
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("mask refinement: the bilateral filter and the DenseCRF run on the GPU and no GPU is available "
+                                   "(pass refine= / bilateral= callables to run them elsewhere)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self._crf = densecrf.DenseCrfRefiner(self.device)
+
+    def filter_page(self, img: np.ndarray):
+        import torch
+
+        from . import imgproc
+
+        return imgproc.bilateral_filter_u8(torch.from_numpy(np.ascontiguousarray(img)).to(self.device), 17, 80.0, 80.0)
+
+    def refine(self, page, rects, masks):
+        return self._crf.refine(page, rects, masks)
+
+    def release_workspace(self):
+        self._crf.release_workspace()
+
+
+_DEFAULT_BACKEND = None
+
+
+def default_backend():
+    global _DEFAULT_BACKEND
+    if _DEFAULT_BACKEND is None:
+        _DEFAULT_BACKEND = GpuMaskBackend()
+    return _DEFAULT_BACKEND
+
+
+def _backend_for(refine: Optional[RefineFn], bilateral: Optional[BilateralFn], backend):
+    if backend is not None:
+        return backend
+    if refine is None and bilateral is None:
+        return default_backend()
+    if refine is None or bilateral is None:
+        raise ValueError("mask refinement: inject both refine= and bilateral= (or neither, for the GPU backend)")
+    return CallableMaskBackend(refine, bilateral)
 
 
 def ellipse_kernel(k: int) -> np.ndarray:
@@ -119,11 +171,11 @@ def _xywh(q: Quadrilateral):  # BBox.xywh (utils/generic.py:319-321): int32 trun
 
 def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadrilateral], keep_threshold: float = 1e-2,
                   dilation_offset: int = 0, kernel_size: int = 3, refine: Optional[RefineFn] = None,
-                  bilateral: Optional[BilateralFn] = None) -> Optional[np.ndarray]:
+                  bilateral: Optional[BilateralFn] = None, backend=None) -> Optional[np.ndarray]:
     """text_mask_utils.complete_mask (:96-195).  ``mask`` is modified in place exactly like the reference's (line boxes are
-    outlined with zeros before labelling)."""
-    refine = refine or _reference_refine()
-    bilateral = bilateral or _reference_bilateral()
+    outlined with zeros before labelling).  The per-line DenseCRF calls of :172-176 are independent of each other (each line owns
+    its component image, all read the same filtered page), so they are collected and refined as one batch."""
+    be = _backend_for(refine, bilateral, backend)
     H, W = mask.shape
     boxes = [_xywh(t) for t in textlines]
     polys = [np.asarray(t.pts, dtype=np.float64) for t in textlines]
@@ -173,7 +225,8 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
     if not valid:
         return None
     final = np.zeros_like(mask)
-    img = bilateral(img)
+    page = be.filter_page(img)
+    jobs = []  # (line index, crop rectangle, dilation size)
     for i, cc in enumerate(ccs):
         if rects[i] is None:  # the reference's sentinel rectangle slices to an empty crop and is skipped (:172-173)
             continue
@@ -181,10 +234,13 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
         text_size = min(w1, h1, textlines[i].font_size)
         x1, y1, w1, h1 = _extend_rect(x1, y1, w1, h1, W, H, int(text_size * 0.1))
         dilate_size = max((int((text_size + dilation_offset) * 0.3) // 2) * 2 + 1, 3)
-        cc_region = np.ascontiguousarray(cc[y1:y1 + h1, x1:x1 + w1])
-        if cc_region.size == 0:
+        if cc[y1:y1 + h1, x1:x1 + w1].size == 0:
             continue
-        cc[y1:y1 + h1, x1:x1 + w1] = refine(np.ascontiguousarray(img[y1:y1 + h1, x1:x1 + w1]), cc_region)
+        jobs.append((i, (x1, y1, w1, h1), dilate_size))
+    refined = be.refine(page, [r for _, r, _ in jobs], [np.ascontiguousarray(ccs[i][y:y + h, x:x + w]) for i, (x, y, w, h), _ in jobs])
+    for (i, (x1, y1, w1, h1), dilate_size), region in zip(jobs, refined):
+        cc = ccs[i]
+        cc[y1:y1 + h1, x1:x1 + w1] = region
         x2, y2, w2, h2 = _extend_rect(x1, y1, w1, h1, W, H, -(-dilate_size // 2))
         cc[y2:y2 + h2, x2:x2 + w2] = dilate(cc[y2:y2 + h2, x2:x2 + w2], ellipse_kernel(dilate_size))
         final[y2:y2 + h2, x2:x2 + w2] |= cc[y2:y2 + h2, x2:x2 + w2]
@@ -198,7 +254,7 @@ def HG_area(pts: np.ndarray) -> float:
 
 def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, method: str = "fit_text", dilation_offset: int = 0,
                   ignore_bubble: int = 0, verbose: bool = False, kernel_size: int = 3, refine: Optional[RefineFn] = None,
-                  bilateral: Optional[BilateralFn] = None) -> np.ndarray:
+                  bilateral: Optional[BilateralFn] = None, backend=None) -> np.ndarray:
     """mask_refinement.dispatch (:9-33) for ``method='fit_text'`` without the bubble filter (ignore_bubble outside 1..50, the default)."""
     if method != "fit_text":
         raise NotImplementedError("mask refinement: only method='fit_text' is native (the reference's 'fill' path references an unset variable)")
@@ -212,7 +268,7 @@ def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, met
     mask_small[mask_small > 0] = 255
     lines = [Quadrilateral(np.asarray(l) * scale, "", 0) for region in text_regions for l in region.lines]
     final = complete_mask(img_small, mask_small, lines, dilation_offset=dilation_offset, kernel_size=kernel_size, refine=refine,
-                          bilateral=bilateral)
+                          bilateral=bilateral, backend=backend)
     if final is None:
         return np.zeros((h, w), dtype=np.uint8)
     final = HG.resize_linear_u8(final, (w, h)).copy()

@@ -73,3 +73,48 @@ def resize_keep_aspect(img: np.ndarray, size: int) -> np.ndarray:
     """utils/generic.py:251-255 with the restated INTER_LINEAR_EXACT."""
     ratio = float(size) / max(img.shape[0], img.shape[1])
     return resize_linear_exact_u8(img, (round(img.shape[1] * ratio), round(img.shape[0] * ratio)))
+
+
+def bilateral_filter_u8(img: np.ndarray, d: int = 17, sigma_color: float = 80.0, sigma_space: float = 80.0) -> np.ndarray:
+    """cv2.bilateralFilter(img, d, sigmaColor, sigmaSpace) for 8-bit 3-channel images, restated from OpenCV's
+    imgproc/src/bilateral_filter.dispatch.cpp (bilateralFilter_8u / bilateralFilterInvoker_8u); parity with the real library is
+    unpinned.  Reference call sites: mask_refinement/text_mask_utils.py:159, detection/default.py:64.
+
+      radius = d / 2 (d > 0); copyMakeBorder(BORDER_REFLECT_101); colour table (float)exp(i^2 * -0.5 / sigmaColor^2), i < 768;
+      taps (i, j) with sqrt(i^2 + j^2) <= radius, rows outer, weight (float)exp(r^2 * -0.5 / sigmaSpace^2);
+      per pixel, fp32, in tap order:  w = space[k] * colour[|b - b0| + |g - g0| + |r - r0|];  sum_c += c * w;  wsum += w;
+      result = cvRound(sum_c * (1 / wsum)).
+    Written as whole-image numpy passes per tap (one fp32 multiply and one fp32 add per accumulation, like the scalar loop);
+    shares no code with manga_image_translator_amd/imgproc.py."""
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+    sc = sigma_color if sigma_color > 0 else 1.0
+    ss = sigma_space if sigma_space > 0 else 1.0
+    radius = max(int(_round_half_even(ss * 1.5)) if d <= 0 else d // 2, 1)
+    colour = np.array([np.float32(math.exp(i * i * (-0.5 / (sc * sc)))) for i in range(768)], dtype=np.float32)
+    H, W, _ = img.shape
+
+    def refl(p, n):
+        if n == 1:
+            return 0
+        while p < 0 or p >= n:
+            p = -p if p < 0 else 2 * n - 2 - p
+        return p
+
+    ys = np.array([refl(y, H) for y in range(-radius, H + radius)])
+    xs = np.array([refl(x, W) for x in range(-radius, W + radius)])
+    pad = img[ys][:, xs].astype(np.int32)
+    c0 = img.astype(np.int32)
+    sums = np.zeros((H, W, 3), dtype=np.float32)
+    wsum = np.zeros((H, W), dtype=np.float32)
+    for i in range(-radius, radius + 1):
+        for j in range(-radius, radius + 1):
+            r = math.sqrt(float(i) * i + float(j) * j)
+            if r > radius:
+                continue
+            sw = np.float32(math.exp(r * r * (-0.5 / (ss * ss))))
+            nb = pad[radius + i:radius + i + H, radius + j:radius + j + W]
+            w = sw * colour[np.abs(nb - c0).sum(2)]
+            sums += nb.astype(np.float32) * w[..., None]
+            wsum += w
+    inv = np.float32(1.0) / wsum
+    return np.rint(sums * inv[..., None]).astype(np.uint8)
