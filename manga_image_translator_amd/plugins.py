@@ -237,9 +237,9 @@ class HipDefaultDetector(_DetBase):
     @torch.no_grad()
     async def _infer(self, image: np.ndarray, detect_size: int, text_threshold: float, box_threshold: float,
                      unclip_ratio: float, verbose: bool = False):
-        """-> (textlines, raw_mask u8 [H,W], None) (default.py:56-103, the non-rearranged branch).  The OpenCV glue —
-        bilateralFilter + resize_aspect_ratio (:62), SegDetectorRepresenter (:73-77), the x2 mask resize (:89) — comes from
-        the reference package or from the injected callables; the network runs on the GPU."""
+        """-> (textlines, raw_mask u8 [H,W], None) (default.py:56-103).  bilateralFilter + resize_aspect_ratio (:62) and the
+        network run on the GPU; SegDetectorRepresenter (:73-77) is the native host extraction (csrc/hostglue.hip), the x2 mask
+        resize (:89) a numpy bilinear; every step can still be injected (preprocess= / boxes_from_maps= / resize2x=)."""
         from . import imgproc, rearrange
 
         boxes_fn = self._boxes or _native_dbnet_boxes
@@ -257,11 +257,15 @@ class HipDefaultDetector(_DetBase):
             h, w = image.shape[:2]
             ratio, pad_w, pad_h = 1.0, 0, 0
         else:
-            pre = self._pre or _reference_default_preprocess()
-            img_resized, target_ratio, pad_w, pad_h = pre(image, detect_size)
+            if self._pre is not None:
+                img_resized, target_ratio, pad_w, pad_h = self._pre(image, detect_size)
+                page = torch.from_numpy(np.ascontiguousarray(img_resized)).to(self.engine.device)[None]
+            else:  # cv2.bilateralFilter + resize_aspect_ratio (:62) on the device: the page crosses PCIe once, as bytes
+                page, target_ratio, pad_w, pad_h = default_preprocess_gpu(
+                    torch.from_numpy(np.ascontiguousarray(image)).to(self.engine.device), detect_size)
             ratio = 1 / target_ratio
-            h, w = img_resized.shape[:2]
-            db, mask = self.engine.forward(torch.from_numpy(np.ascontiguousarray(img_resized)).to(self.engine.device)[None])
+            h, w = int(page.shape[1]), int(page.shape[2])
+            db, mask = self.engine.forward(page)
             db, mask = db.cpu().numpy(), mask[0].cpu().numpy()
         boxes, scores = boxes_fn(db, h, w, text_threshold, box_threshold, unclip_ratio)
         if boxes.size == 0:
@@ -657,6 +661,26 @@ def _reference_refine():
         return refine_mask(image, mask, textlines, refine_mode=None)
 
     return fn
+
+
+def default_preprocess_gpu(image: torch.Tensor, detect_size: int):
+    """``imgproc.resize_aspect_ratio(cv2.bilateralFilter(image, 17, 80, 80), detect_size, cv2.INTER_LINEAR, mag_ratio=1)``
+    (detection/default.py:62, default_utils/imgproc.py:37-70) on the device: bilateral filter (mit_bilateral_u8c3), 8-bit
+    INTER_LINEAR resize of the long side to ``detect_size`` (mit_resize_u8), zero canvas padded right / bottom to a multiple of 256.
+    image u8 [H,W,3] (device) -> (page u8 [1,H',W',3], ratio, pad_w, pad_h)."""
+    from . import imgproc
+
+    height, width = int(image.shape[0]), int(image.shape[1])
+    ratio = detect_size / max(height, width)
+    target_h, target_w = int(round(height * ratio)), int(round(width * ratio))
+    proc = imgproc.resize_u8(imgproc.bilateral_filter_u8(image, 17, 80.0, 80.0)[None], (target_w, target_h))
+    pad_h = (256 - target_h % 256) % 256
+    pad_w = (256 - target_w % 256) % 256
+    if pad_h or pad_w:
+        canvas = torch.zeros(1, target_h + pad_h, target_w + pad_w, 3, dtype=torch.uint8, device=image.device)
+        canvas[:, :target_h, :target_w] = proc
+        proc = canvas
+    return proc, ratio, pad_w, pad_h
 
 
 def _reference_default_preprocess():

@@ -67,3 +67,29 @@ def test_default_detector_plugin(cuda):
     ref_mask = np.clip(np.repeat(np.repeat(rmask[0, 0], 2, 0), 2, 1)[:, :-56] * 255, 0, 255).astype(np.uint8)
     assert np.abs(raw_mask.astype(int) - ref_mask.astype(int)).max() <= 1
     run(det.unload())
+
+
+@pytest.mark.gpu
+def test_default_detector_native_preprocess(cuda):
+    """HipDefaultDetector without an injected preprocess: cv2.bilateralFilter(image, 17, 80, 80) + resize_aspect_ratio
+    (default.py:62, default_utils/imgproc.py:37-70) run on the device and equal the CPU restatement byte for byte
+    (oracle bilateral filter, the oracle's INTER_LINEAR resize, zero canvas to a multiple of 256); the plugin then runs end to end
+    with only native pieces (GPU preprocess + network, native host box extraction)."""
+    import asyncio
+
+    from manga_image_translator_amd import dbnet_schema, plugins as P, synth
+    from oracle import ctd as OC, imgproc as OI
+
+    page = synth.synth_page(9, 300, 210, n_boxes=3)[0]
+    got, ratio, pad_w, pad_h = P.default_preprocess_gpu(torch.from_numpy(page).to(cuda), 512)
+    assert ratio == 512 / 300 and (pad_w, pad_h) == (154, 0) and tuple(got.shape) == (1, 512, 512, 3)
+    ref = np.zeros((512, 512, 3), np.uint8)
+    ref[:, :358] = OC.resize_linear_u8(OI.bilateral_filter_u8(page, 17, 80.0, 80.0), (358, 512))
+    assert np.array_equal(got[0].cpu().numpy(), ref)
+    run = lambda c: asyncio.new_event_loop().run_until_complete(c)
+    sd = synth.synth_state_dict(dbnet_schema.text_detection_schema(), gain=1.2)
+    det = P.HipDefaultDetector(weights=sd)
+    run(det.load("cuda"))
+    tls, raw_mask, extra = run(det.infer(page, 512, 0.5, 0.7, 2.3))
+    assert extra is None and raw_mask.dtype == np.uint8 and raw_mask.shape == (512, 358)
+    run(det.unload())
