@@ -193,6 +193,31 @@ int mit_bilateral_u8c3(const uint8_t *src_dev, uint8_t *dst_dev, int B, int H, i
 int mit_select_u8(const uint8_t *mask_dev, int thr, const uint8_t *a_dev, const uint8_t *b_dev, uint8_t *out_dev, int64_t npix, int C,
                   void *stream);
 
+/* ctd detector: refine_mask on the GPU ------------------------------------------------------------
+ * Reference: manga_translator/detection/ctd_utils/textmask.py:158-174 (refine_mask; :29-132 its helpers), called from
+ * detection/ctd.py:177 with refine_mode=None.  Three phases over all text-line windows of a page; the host does numpy's histogram /
+ * top-k colour / Otsu arithmetic between them (hostglue.refine_mask_gpu).  Bit-identical to hostglue.refine_mask. */
+typedef struct MitRefineWindow {
+    int x1, y1, x2, y2; /* crop [y1:y2, x1:x2] of the page (enlarge_window of the line's box) */
+} MitRefineWindow;
+typedef struct MitRefineCand {
+    int kind;   /* 0 = none, 1 = inRange(grey, lo, hi), 2 + c = channel c > lo */
+    int lo, hi; /* bounds (already rounded / saturated like cv2.inRange) or the Otsu threshold in lo */
+    int invert; /* 1: take the complement (minxor_thresh picked cv2.bitwise_not) */
+} MitRefineCand;
+int64_t mit_ctd_refine_workspace_bytes(const MitRefineWindow *windows, int n);
+/* phase A: hist_host[n][4][256] = grey levels under erode3x3(mask crop) > 127, then the three channel histograms of the crop.
+ * page_dev u8 [H,W,3], pred_dev u8 [H,W] (the network's mask at page size), windows: HOST array.  Synchronises the stream. */
+int mit_ctd_refine_hist(const uint8_t *page_dev, const uint8_t *pred_dev, int H, int W, const MitRefineWindow *windows, int n, int *hist_host,
+                        void *workspace_dev, int64_t workspace_bytes, void *stream);
+/* phase B: sums_host[n][6] = sum over the crop of (candidate ^ mask) as bytes for 6 raw candidates per line (cands_host[n][6]). */
+int mit_ctd_refine_scores(const uint8_t *page_dev, const uint8_t *pred_dev, int H, int W, const MitRefineWindow *windows, int n,
+                          const MitRefineCand *cands_host, uint64_t *sums_host, void *workspace_dev, int64_t workspace_bytes, void *stream);
+/* phase C: merge_mask_list per line over its (up to 4) candidates in the given order (order_host[n][4]), hole filling, and
+ * out_dev[H,W] |= merged inside each window (out_dev must be zeroed by the caller).  Asynchronous on the stream. */
+int mit_ctd_refine_merge(const uint8_t *page_dev, const uint8_t *pred_dev, int H, int W, const MitRefineWindow *windows, int n,
+                         const MitRefineCand *order_host, uint8_t *out_dev, void *workspace_dev, int64_t workspace_bytes, void *stream);
+
 /* Mask refinement between OCR and inpainting -----------------------------------------------------
  * Reference: manga_translator/mask_refinement/text_mask_utils.py:68-94 (refine_mask -> pydensecrf). */
 

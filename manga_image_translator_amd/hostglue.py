@@ -266,3 +266,138 @@ def refine_mask(img: np.ndarray, pred_mask: np.ndarray, quads: Sequence, refine_
         masks.append(otsu[0])
         out[by1:by2, bx1:bx2] |= _merge_mask_list(masks, msk, refine_mode == 0)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# refine_mask on the GPU (csrc/ctd_refine.hip): the pixel work of every text line of a page in a few batched launches; the
+# per-line scalar decisions (numpy's own histogram binning, top-k colours, Otsu, candidate order) stay here, on 256-bin
+# histograms and six xor sums per line.  Bit-identical to refine_mask above (tests/test_ctd_refine_gpu.py).
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _otsu_from_hist(hist: np.ndarray, size: int) -> int:
+    """_otsu_threshold on a 256-bin histogram (same float64 arithmetic, same order)."""
+    h = hist.astype(np.float64)
+    scale = 1.0 / size
+    mu = float((np.arange(256) * h).sum()) * scale
+    q1 = mu1 = 0.0
+    best, best_sigma = 0, 0.0
+    for i in range(256):
+        p_i = h[i] * scale
+        mu1 *= q1
+        q1 += p_i
+        q2 = 1.0 - q1
+        if min(q1, q2) < 2.220446049250313e-16 or max(q1, q2) > 1.0 - 2.220446049250313e-16:
+            continue
+        mu1 = (mu1 + i * p_i) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
+        if sigma > best_sigma:
+            best_sigma, best = sigma, i
+    return best
+
+
+def _in_range_bounds(lo: float, hi: float):
+    """The integer interval cv2.inRange(src_u8, lo, hi) selects (see _in_range_u8), or None when it selects nothing."""
+    ilo, ihi = int(np.rint(lo)), int(np.rint(hi))
+    if ilo > ihi or ilo > 255 or ihi < 0:
+        return None
+    return max(ilo, 0), min(ihi, 255)
+
+
+class _RefineWorkspace:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device):
+        import torch
+
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_REFINE_WS = _RefineWorkspace()
+
+
+def refine_mask_gpu(page_dev, pred_dev, quads: Sequence, refine_mode=None):
+    """refine_mask (ctd_utils/textmask.py:158-174) with the page (u8 [H,W,3]) and the network's mask at page size (u8 [H,W]) on
+    the device; returns the refined mask as a device tensor u8 [H,W].  ``refine_mode`` must be None (the ctd detector's call,
+    ctd.py:177): the REFINEMASK_INPAINT dilation variant is only in the host routine."""
+    import ctypes as C
+
+    import torch
+
+    from . import ops
+
+    if refine_mode is not None:
+        raise NotImplementedError("refine_mask_gpu: only refine_mode=None (the detector's call) runs on the GPU")
+    if page_dev.dtype != torch.uint8 or pred_dev.dtype != torch.uint8 or not page_dev.is_cuda or not pred_dev.is_cuda:
+        raise ValueError("refine_mask_gpu expects uint8 device tensors")
+    H, W = int(page_dev.shape[0]), int(page_dev.shape[1])
+    if tuple(page_dev.shape) != (H, W, 3) or tuple(pred_dev.shape) != (H, W):
+        raise ValueError(f"refine_mask_gpu: page {tuple(page_dev.shape)} / mask {tuple(pred_dev.shape)}")
+    page_dev, pred_dev = page_dev.contiguous(), pred_dev.contiguous()
+    out = torch.zeros(H, W, dtype=torch.uint8, device=page_dev.device)
+    wins = []
+    for q in quads:
+        bx1, by1, bx2, by2 = enlarge_window(q.xyxy, W, H)
+        bx1, by1, bx2, by2 = max(bx1, 0), max(by1, 0), min(bx2, W), min(by2, H)   # what the numpy slices of refine_mask keep
+        if bx2 > bx1 and by2 > by1:
+            wins.append((bx1, by1, bx2, by2))
+    n = len(wins)
+    if n == 0:
+        return out
+    L = _lib.load()
+    warr = (_lib.MitRefineWindow * n)()
+    for i, (a, b, c, d) in enumerate(wins):
+        warr[i].x1, warr[i].y1, warr[i].x2, warr[i].y2 = a, b, c, d
+    need = L.mit_ctd_refine_workspace_bytes(C.byref(warr), n)
+    if need < 0:
+        raise RuntimeError("refine_mask_gpu: bad windows or too many window pixels")
+    ws = _REFINE_WS.get(need, page_dev.device)
+    st = C.c_void_p(ops.current_stream())
+    args = (page_dev.data_ptr(), pred_dev.data_ptr(), H, W, C.byref(warr), n)
+    hist = np.zeros((n, 4, 256), dtype=np.int32)
+    _lib.check(L.mit_ctd_refine_hist(*args, hist.ctypes.data, ws.data_ptr(), ws.numel(), st), "mit_ctd_refine_hist")
+    # get_topk_masklist (:56-71) + get_otsuthresh_masklist (:44-54) on the histograms
+    cands = (_lib.MitRefineCand * (6 * n))()
+    levels = np.arange(256, dtype=np.uint8)
+    for i, (a, b, c, d) in enumerate(wins):
+        size = (c - a) * (d - b)
+        g = hist[i, 0]
+        present = g > 0
+        bins_w, edges = np.histogram(levels[present], bins=255, weights=g[present].astype(np.float64))
+        bins = np.rint(bins_w).astype(np.int64)   # the integer counts np.histogram(cand, bins=255) returns
+        for k, color in enumerate(_topk_color(edges, bins, color_var=10, k=3)):
+            c_top = min(color + 30, 255)
+            bounds = _in_range_bounds(c_top - 60, c_top)
+            e = cands[i * 6 + k]
+            e.kind, e.lo, e.hi, e.invert = (1, bounds[0], bounds[1], 0) if bounds else (1, 1, 0, 0)  # lo > hi: selects nothing
+        for ch in range(3):
+            e = cands[i * 6 + 3 + ch]
+            e.kind, e.lo, e.hi, e.invert = 2 + ch, _otsu_from_hist(hist[i, 1 + ch], size), 0, 0
+    sums = np.zeros((n, 6), dtype=np.uint64)
+    _lib.check(L.mit_ctd_refine_scores(*args, C.byref(cands), sums.ctypes.data, ws.data_ptr(), ws.numel(), st), "mit_ctd_refine_scores")
+    # minxor_thresh (:29-42) per candidate, the best Otsu channel, merge order by score (stable, like sorted())
+    order = (_lib.MitRefineCand * (4 * n))()
+    for i, (a, b, c, d) in enumerate(wins):
+        total = 255 * (c - a) * (d - b)
+        picked = []
+        for k in range(6):
+            e = cands[i * 6 + k]
+            if e.kind == 0:
+                picked.append(None)
+                continue
+            s_pos = int(sums[i, k])
+            s_neg = total - s_pos
+            picked.append((1, s_neg) if s_neg < s_pos else (0, s_pos))
+        mask_list = [(k, picked[k]) for k in range(3) if picked[k] is not None]
+        otsu = sorted([(k, picked[k]) for k in range(3, 6)], key=lambda t: t[1][1])
+        mask_list.append(otsu[0])
+        mask_list.sort(key=lambda t: t[1][1])
+        for slot, (k, (inv, _)) in enumerate(mask_list):
+            src, dst = cands[i * 6 + k], order[i * 4 + slot]
+            dst.kind, dst.lo, dst.hi, dst.invert = src.kind, src.lo, src.hi, inv
+    _lib.check(L.mit_ctd_refine_merge(*args, C.byref(order), out.data_ptr(), ws.data_ptr(), ws.numel(), st), "mit_ctd_refine_merge")
+    return out

@@ -120,6 +120,14 @@ class MitCrfCrop(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
 
 
+class MitRefineWindow(C.Structure):
+    _fields_ = [("x1", C.c_int32), ("y1", C.c_int32), ("x2", C.c_int32), ("y2", C.c_int32)]
+
+
+class MitRefineCand(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lo", C.c_int32), ("hi", C.c_int32), ("invert", C.c_int32)]
+
+
 class MitRaggedSeg(C.Structure):
     _fields_ = [("pixel_start", C.c_int64), ("group_start", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("_pad", C.c_int32)]
@@ -162,6 +170,13 @@ SYMBOLS = {
     "mit_densecrf_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int]),
     "mit_densecrf_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mit_ctd_refine_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int]),
+    "mit_ctd_refine_hist": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p]),
+    "mit_ctd_refine_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_void_p]),
+    "mit_ctd_refine_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_void_p]),
     "mit_lama_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_lama_mpe_index": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,

@@ -175,7 +175,7 @@ class HipComicTextDetector(_DetBase):
             mask_u8, lines, _ = self.engine.forward(page)    # postprocess_mask already applied on the GPU (ctd.py:30-44)
             lines_map = lines.cpu().numpy()           # [1,2,h,w], cropped to the un-padded area (:152-153)
         if self._refine is None:                         # cv2.resize(mask, (w, h), INTER_LINEAR) (:162) on the GPU as well
-            mask_full = imgproc.resize_u8(mask_u8[:1].contiguous(), (im_w, im_h))[0].cpu().numpy()
+            mask_full = imgproc.resize_u8(mask_u8[:1].contiguous(), (im_w, im_h))[0]
         boxes_fn = self._boxes or _native_ctd_boxes
         boxes, scores = boxes_fn(lines_map, im_h, im_w)      # SegDetectorRepresenter(thresh=0.3) (:102,156)
         keep = np.where(scores > 0.6)                        # box_thresh (:157-159)
@@ -183,7 +183,8 @@ class HipComicTextDetector(_DetBase):
         textlines = [_RefQuadrilateral(pts.astype(int), "", float(s)) for pts, s in zip(boxes, scores)]
         if self._refine is not None:                         # injected resize + refine_mask (e.g. the reference's OpenCV one)
             return textlines, self._refine(image, mask_u8[0].cpu().numpy(), textlines, im_h, im_w), None
-        return textlines, hostglue.refine_mask(image, mask_full, textlines, None), None  # refine_mask(..., refine_mode=None) (:177)
+        # refine_mask(image, mask, textlines, refine_mode=None) (:177): page and mask are already on the device (csrc/ctd_refine.hip)
+        return textlines, hostglue.refine_mask_gpu(page[0], mask_full, textlines, None).cpu().numpy(), None
 
 
     def _tiles_forward(self, squares: np.ndarray):

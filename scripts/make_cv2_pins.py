@@ -1,0 +1,195 @@
+"""Generate REAL-library pins for the glue this repo restates (VERDICT r1 "missing" #6).
+
+OpenCV, pyclipper, shapely, torchvision and pydensecrf are installed nowhere this repo was built or tested, so the
+restatements of their primitives (oracle/ref_import.cv2_shim, oracle/imgproc.py, oracle/hostglue.py, oracle/densecrf.py,
+oracle/dbnet.py's ResNet-34) are "parity unpinned".  Run THIS script on any machine that has them:
+
+    pip install opencv-python pyclipper shapely torchvision         # + pydensecrf from git, optional
+    python scripts/make_cv2_pins.py            # writes tests/golden/cv2_pins.npz (a few MB)
+    python -m pytest tests/test_cv2_pins.py -q # compares every restatement / native routine with the real library's output
+
+Each section is independent: a library that is missing only drops its own keys (the test skips what is absent).  Inputs are
+seeded; nothing here needs a GPU or the reference checkout.  Commit the .npz to retire the "unpinned" flag for the rows it covers
+(a2 letterbox resize, a4 box extraction, a5 refine_mask primitives, a7 ResNet-34, a9 homography warp, a17 MPE resizes,
+f1 bilateral / DenseCRF)."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden", "cv2_pins.npz")
+
+
+def _images(rng):
+    a = rng.integers(0, 256, (97, 131, 3)).astype(np.uint8)
+    b = np.zeros((240, 180, 3), np.uint8)
+    yy, xx = np.mgrid[0:240, 0:180]
+    b[..., 0] = (xx * 255 // 179).astype(np.uint8)
+    b[..., 1] = (yy * 255 // 239).astype(np.uint8)
+    b[..., 2] = ((xx + yy) % 256).astype(np.uint8)
+    b[60:180, 40:140] = rng.integers(0, 60, (120, 100, 3)).astype(np.uint8)
+    return a, b
+
+
+def cv2_section(out):
+    import cv2
+
+    out["cv2_version"] = np.array(cv2.__version__)
+    rng = np.random.default_rng(1234)
+    a, b = _images(rng)
+    out["img_a"], out["img_b"] = a, b
+    # ---- resizes (a2 letterbox, a14 page resize, a17 MPE) ----
+    for name, img in (("a", a), ("b", b)):
+        h, w = img.shape[:2]
+        for tag, (dw, dh) in {"half": (w // 2, h // 2), "up": (w * 2 + 3, h + 17), "odd": (77, 53), "x8": ((w + 7) // 8 * 8, (h + 7) // 8 * 8)}.items():
+            out[f"resize_linear_{name}_{tag}"] = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LINEAR)
+            out[f"resize_exact_{name}_{tag}"] = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LINEAR_EXACT)
+            out[f"resize_area_{name}_{tag}"] = cv2.resize(img[..., 0], (dw, dh), interpolation=cv2.INTER_AREA)
+            out[f"resize_nearest_{name}_{tag}"] = cv2.resize(img[..., 0], (dw, dh), interpolation=cv2.INTER_NEAREST)
+    mask = (rng.random((200, 150)) < 0.3).astype(np.uint8) * 255
+    out["mask_in"] = mask
+    out["resize_area_mask_256"] = cv2.resize(mask, (256, 256), interpolation=cv2.INTER_AREA)
+    m32 = rng.random((40, 60)).astype(np.float32)
+    out["f32_in"] = m32
+    out["resize_linear_f32_2x"] = cv2.resize(m32, (120, 80), interpolation=cv2.INTER_LINEAR)
+    # ---- colour / morphology / thresholds / components (a5 refine_mask, f1) ----
+    out["gray_bgr2gray_a"] = cv2.cvtColor(a, cv2.COLOR_BGR2GRAY)
+    blob = (cv2.GaussianBlur(rng.random((120, 160)).astype(np.float32), (0, 0), 3) > 0.5).astype(np.uint8) * 255
+    out["blob"] = blob
+    out["erode_rect3"] = cv2.erode(blob, np.ones((3, 3), np.uint8))
+    out["erode_cross3"] = cv2.erode(blob, cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (3, 3)))
+    out["dilate_rect5"] = cv2.dilate(blob, np.ones((5, 5), np.uint8))
+    for k in (1, 3, 5, 7, 9, 15):
+        out[f"ellipse_{k}"] = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k))
+        out[f"dilate_ellipse_{k}"] = cv2.dilate(blob, cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)))
+    g = cv2.cvtColor(b, cv2.COLOR_BGR2GRAY)
+    out["inrange_lo_hi"] = np.array([[37.4, 97.4], [37.5, 97.5], [38.5, 98.5], [-20.0, 40.2], [200.7, 300.0], [90.0, 80.0]])
+    for i, (lo, hi) in enumerate(out["inrange_lo_hi"]):
+        out[f"inrange_{i}"] = cv2.inRange(g, float(lo), float(hi))
+    for c in range(3):
+        t, th = cv2.threshold(b[..., c], 1, 255, cv2.THRESH_OTSU + cv2.THRESH_BINARY)
+        out[f"otsu_thr_{c}"], out[f"otsu_img_{c}"] = np.array(t), th
+    n, lab, stats, cent = cv2.connectedComponentsWithStats(blob, 8, cv2.CV_16U)
+    out["cc_n"], out["cc_labels"], out["cc_stats"] = np.array(n), lab, stats
+    out["filter2d_3x3"] = cv2.filter2D(blob, -1, np.ones((3, 3), np.float32))
+    out["rot90ccw"] = cv2.rotate(a, cv2.ROTATE_90_COUNTERCLOCKWISE)
+    rect = np.zeros((60, 80), np.uint8)
+    out["rectangle_outline"] = cv2.rectangle(rect.copy() + 255, (10, 5), (50, 40), 0, 1)
+    # ---- bilateral filter (f1, a7) ----
+    out["bilateral_a_17_80_80"] = cv2.bilateralFilter(a, 17, 80, 80)
+    out["bilateral_b_17_80_80"] = cv2.bilateralFilter(b, 17, 80, 80)
+    out["bilateral_b_9_25_3"] = cv2.bilateralFilter(b, 9, 25, 3)
+    # ---- perspective warp (a9 get_transformed_region) ----
+    src = np.array([[20.3, 30.1], [150.2, 22.8], [160.9, 70.5], [25.4, 80.2]], np.float32)
+    dst = np.array([[0, 0], [199, 0], [199, 47], [0, 47]], np.float32)
+    M, _ = cv2.findHomography(src, dst, cv2.RANSAC, 5.0)
+    out["homography_src"], out["homography_dst"], out["homography_M"] = src, dst, M
+    out["warp_b_200x48"] = cv2.warpPerspective(b, M, (200, 48))
+    # ---- contours -> rotated boxes (a4 SegDetectorRepresenter pieces) ----
+    bitmap = np.zeros((128, 160), np.uint8)
+    cv2.fillPoly(bitmap, [np.array([[20, 20], [100, 30], [95, 60], [15, 50]], np.int32)], 1)
+    cv2.fillPoly(bitmap, [np.array([[110, 80], [150, 70], [155, 110], [120, 118]], np.int32)], 1)
+    bitmap[5:8, 5:9] = 1
+    out["bitmap"] = bitmap
+    contours, _ = cv2.findContours((bitmap * 255).astype(np.uint8), cv2.RETR_LIST, cv2.CHAIN_APPROX_SIMPLE)
+    out["contours_n"] = np.array(len(contours))
+    for i, c in enumerate(contours):
+        out[f"contour_{i}"] = c
+        out[f"minarearect_points_{i}"] = cv2.boxPoints(cv2.minAreaRect(c))
+    pred = cv2.GaussianBlur(bitmap.astype(np.float32), (0, 0), 1.5)
+    out["pred_map"] = pred
+    box = np.array([[20, 20], [100, 30], [95, 60], [15, 50]], np.float32)
+    mk = np.zeros((128, 160), np.uint8)
+    cv2.fillPoly(mk, [box.astype(np.int32)], 1)
+    out["box_score_fast"] = np.array(cv2.mean(pred, mk)[0])
+
+
+def clipper_section(out):
+    import pyclipper
+    from shapely.geometry import Polygon
+
+    box = np.array([[20, 20], [100, 30], [95, 60], [15, 50]], np.float64)
+    poly = Polygon(box)
+    for i, ratio in enumerate((1.5, 2.3, 0.6)):
+        dist = poly.area * ratio / poly.length
+        off = pyclipper.PyclipperOffset()
+        off.AddPath([tuple(p) for p in box], pyclipper.JT_ROUND, pyclipper.ET_CLOSEDPOLYGON)
+        out[f"unclip_{i}"] = np.array(off.Execute(dist)[0])
+        out[f"unclip_dist_{i}"] = np.array(dist)
+    out["unclip_box"] = box
+    # complete_mask's geometry (text_mask_utils.py:127-131): text-line quad vs the axis-aligned box of a component
+    a = Polygon([(0, 0), (10, 0), (12, 8), (1, 9)])
+    rects = np.array([[5, -3, 15, 6], [-4, 2, 3, 20], [20, 20, 30, 30], [2, 2, 6, 5]], np.float64)  # x0, y0, x1, y1
+    out["shapely_quad"] = np.array(a.exterior.coords)[:4]
+    out["shapely_rects"] = rects
+    out["shapely_quad_area"] = np.array(a.area)
+    res = []
+    for x0, y0, x1, y1 in rects:
+        r = Polygon([(x0, y0), (x1, y0), (x1, y1), (x0, y1)])
+        res.append([a.intersection(r).area, a.distance(r.centroid)])
+    out["shapely_intersection_and_centroid_distance"] = np.array(res)
+
+
+def torchvision_section(out):
+    import torch
+    import torchvision
+
+    torch.manual_seed(0)
+    net = torchvision.models.resnet34(weights=None).eval()
+    x = torch.randn(1, 3, 64, 96)
+    with torch.no_grad():
+        f = net.maxpool(net.relu(net.bn1(net.conv1(x))))
+        feats = []
+        for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+            f = layer(f)
+            feats.append(f.numpy())
+    out["resnet34_x"] = x.numpy()
+    for i, f in enumerate(feats):
+        out[f"resnet34_layer{i + 1}"] = f
+    for k, v in net.state_dict().items():
+        if not k.startswith("fc."):
+            out["resnet34_sd/" + k] = v.numpy()
+
+
+def densecrf_section(out):
+    import pydensecrf.densecrf as dcrf
+    from pydensecrf.utils import unary_from_softmax
+
+    rng = np.random.default_rng(7)
+    h, w = 40, 120
+    img = rng.integers(90, 170, (h, w, 3)).astype(np.uint8)
+    mask = ((rng.random((h, w)) < 0.5) * 255).astype(np.uint8)
+    sm = np.stack([255 - mask, mask]).astype(np.float32) / 255.0
+    unary = np.ascontiguousarray(unary_from_softmax(sm.reshape(2, -1)))
+    out["crf_img"], out["crf_mask"], out["crf_unary"] = img, mask, unary
+    for it in (1, 2, 5):
+        d = dcrf.DenseCRF2D(w, h, 2)
+        d.setUnaryEnergy(unary)
+        d.addPairwiseGaussian(sxy=1, compat=3, kernel=dcrf.DIAG_KERNEL, normalization=dcrf.NO_NORMALIZATION)
+        d.addPairwiseBilateral(sxy=23, srgb=7, rgbim=np.ascontiguousarray(img), compat=20, kernel=dcrf.DIAG_KERNEL,
+                               normalization=dcrf.NO_NORMALIZATION)
+        out[f"crf_Q_{it}"] = np.array(d.inference(it))
+
+
+def main():
+    out = {}
+    for name, fn in (("cv2", cv2_section), ("pyclipper+shapely", clipper_section), ("torchvision", torchvision_section),
+                     ("pydensecrf", densecrf_section)):
+        try:
+            fn(out)
+            print(f"[pins] {name}: ok")
+        except ImportError as ex:
+            print(f"[pins] {name}: skipped ({ex})")
+    if not out:
+        print("[pins] none of the libraries is importable here; nothing written")
+        return 1
+    np.savez_compressed(OUT, **out)
+    print(f"[pins] wrote {OUT}: {len(out)} arrays")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
