@@ -14,6 +14,7 @@ namespace {
 const CfgEntry kCfgs[] = {
 #define KNAME_launch_cfg "conv_gemm_kernel"
 #define KNAME_launch_fast "conv_gemm_fast_kernel"
+#define KNAME_launch_gemv "conv_gemv_kernel"
 #define X(g, name, fast, BM, BN, BK, fn, ...) \
     {name, BM, BN, BK, fn<BM, BN, BK, __VA_ARGS__>, fast, KNAME_##fn "<" #BM ", " #BN ", " #BK ", " #__VA_ARGS__ ">"},
 #include "conv_gemm_cfgs.inc"
@@ -35,12 +36,20 @@ bool fast_eligible(const MitConvGemm &p, int BK) {
     return maxoff + tmax < 0x7fffffffLL;
 }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kCfgGemv16 = 26, kCfgGemv4 = 27;
+
+// conv_gemv_kernel preconditions: <= 4 output columns, plain (unbatched, unsplit) maps, the whole weight panel in LDS
+bool gemv_eligible(const MitConvGemm &p, int lpr) {
+    if (p.N > 4 || p.Z != 1 || p.Cin % (4 * lpr) || (int64_t)p.ntaps * p.Cin > 8192) return false;
+    if (p.c.nsplit || p.pre.nsplit || p.post.nsplit) return false;
+    return true;
+}
 
 int env_cfg(const char *name, int dflt) {  // tuning knob for scripts/: replaces a default fast tile by another fast tile
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
     const int c = atoi(v);
-    return (c >= 0 && c < kNumCfgs && kCfgs[c].fast && kCfgs[c].BK == 16) ? c : dflt;  // dflt may be -1 (rule off)
+    return (c >= 0 && c < kNumCfgs && (kCfgs[c].fast == 1 || kCfgs[c].fast == 2) && kCfgs[c].BK == 16) ? c : dflt;  // dflt may be -1 (rule off)
 }
 
 int pick_cfg(const MitConvGemm &p, int64_t M) {
@@ -50,6 +59,9 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     static const int wide_l = env_cfg("MIT_CONV_TILE_WIDE_L", -1), narrow_l = env_cfg("MIT_CONV_TILE_NARROW_L", -1);  // experiments: Cin % 32 == 0
     static const int narrow_max = getenv("MIT_CONV_NARROW_MAX") ? atoi(getenv("MIT_CONV_NARROW_MAX")) : 64;
     const bool f16 = fast_eligible(p, 16);
+    static const bool gemv_off = getenv("MIT_CONV_NO_GEMV") != nullptr;  // A/B knob for scripts/
+    if (!gemv_off && gemv_eligible(p, 16)) return kCfgGemv16;
+    if (!gemv_off && gemv_eligible(p, 4)) return kCfgGemv4;
     if (p.N <= 32) return 2;
     if (f16 && m192 >= 0 && M > 128 && M <= 192) return m192;  // 2 x 128 rows would run a 40 % empty second tile
     if (f16 && bigk >= 0 && p.N % 128 == 0 && p.N <= 128 && p.ntaps * p.Cin >= 4096 && M >= 256 * 1024) return bigk;
@@ -184,11 +196,39 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     const int64_t M64 = (int64_t)p.NB * p.Ho * p.Wo;
     if (M64 > 0x7fffffffLL) return mit_set_error("mit_conv_gemm: M too large");
     if (p.Z > 65535) return mit_set_error("mit_conv_gemm: Z too large");
+    if (cfg < 0 && p.Z == 1 && p.NB > 1 && p.Cin % 16 == 0 && p.ntaps <= FAST_MAX_TAPS && p.a_bs > 0 && !fast_eligible(p, 16)) {
+        // The fast kernels index A with 32-bit element offsets.  A batch whose activations exceed 2^31 elements (16 pages of
+        // 2048 x 1456 x 64: LaMa's first stride-2 conv) is cut into runs of whole images that fit, instead of falling to the generic kernel.
+        MitConvGemm one = p;
+        one.NB = 1;
+        if (fast_eligible(one, 16)) {
+            int nbc = p.NB;
+            while (nbc > 1) {
+                one.NB = nbc;
+                if (fast_eligible(one, 16)) break;
+                nbc = (nbc + 1) / 2;
+            }
+            for (int b0 = 0; b0 < p.NB; b0 += nbc) {
+                MitConvGemm sub = *d;
+                sub.NB = p.NB - b0 < nbc ? p.NB - b0 : nbc;
+                sub.a = d->a + (int64_t)b0 * d->a_bs;
+                sub.c.base = d->c.base + (int64_t)b0 * d->c.bs;
+                if (d->pre.base) sub.pre.base = d->pre.base + (int64_t)b0 * d->pre.bs;
+                if (d->post.base) sub.post.base = d->post.base + (int64_t)b0 * d->post.bs;
+                if (g_next_alg_flops >= 0.0) g_next_alg_flops = -1.0;  // a tagged cost does not survive the split
+                const int rc = mit_conv_gemm_cfg(&sub, -1, stream);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
     if (cfg < 0) cfg = pick_cfg(p, M64);
     if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
     const CfgEntry &c = kCfgs[cfg];
     if (c.fast == 2 && (p.Cin % 32)) return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% 32 == 0", c.name);
-    if (c.fast && !fast_eligible(p, c.BK))
+    if (c.fast == 3 && !gemv_eligible(p, cfg == kCfgGemv16 ? 16 : 4))
+        return mit_set_error("mit_conv_gemm: cfg %s needs N <= 4, Z == 1, unsplit maps and Cin %% %d == 0", c.name, cfg == kCfgGemv16 ? 64 : 16);
+    if ((c.fast == 1 || c.fast == 2) && !fast_eligible(p, c.BK))
         return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% %d == 0, <= %d taps and 32-bit element offsets", c.name, c.BK, FAST_MAX_TAPS);
     const int M = (int)M64;
     const int MT = (M + c.BM - 1) / c.BM;

@@ -686,11 +686,99 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
 
     epilogue<BM, TM, TN, (VAR >> 12) & 3, 2 * A_TILE + 2 * B_TILE>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
 }
+// ---- N <= 4: one output column group per row — a dot product, not a tile ------------------------------------------------
+// An MFMA tile would idle >= 28 of its 32 columns (the ctd heads' last ConvTranspose2d 64 -> 1 and 16 -> 1 ran at 2 TFLOP/s on
+// the 128 x 32 tile).  Here LPR lanes share one output row: each tap's Cin contiguous floats are read as float4 by those lanes
+// together (64 / LPR rows x Cin * 4 bytes per wave instruction, fully coalesced), weights come transposed from LDS, partial sums
+// meet in a shuffle tree.  L1/L2-bound on the A gather.  The summation order is lane-major (not the k-sequential chain of the
+// MFMA tiles), so results differ from them by fp32 rounding (<= 1e-6 relative on these layers).
+template <int RPI, int NMAX, int KV, int LPR>
+__global__ __launch_bounds__(256) void conv_gemv_kernel(const MitConvGemm p, const int M, const int MT, const int NT, const int KT) {
+    static_assert(NMAX == 4 && KV == 4 && (LPR == 4 || LPR == 16), "gemv shape");
+    constexpr int RPW = 64 / LPR;  // rows per wave per iteration
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Ktot = p.ntaps * p.Cin;
+    float *wt = smem;  // [NMAX][Ktot]
+    for (int i = threadIdx.x; i < Ktot * NMAX; i += 256) {
+        const int n = i / Ktot, k = i - n * Ktot;
+        wt[i] = (n < p.Nw) ? p.w[(int64_t)k * p.ldw + n] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rslot = lane / LPR;
+    const int HoWo = p.Ho * p.Wo;
+    const int cq = p.Cin >> 2;  // float4 chunks per tap
+#pragma unroll 1
+    for (int it = 0; it < RPI; ++it) {
+        const int m = ((blockIdx.x * 4 + wave) * RPI + it) * RPW + rslot;
+        const bool mok = m < M;
+        int nb = 0, oy = 0, ox = 0;
+        if (mok) {
+            nb = m / HoWo;
+            const int rem = m - nb * HoWo;
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
+        }
+        const float *arow = p.a + (int64_t)nb * p.a_bs;
+        float acc[NMAX] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < p.ntaps; ++t) {
+            int iy = oy * p.sy + p.tap_dy[t], ix = ox * p.sx + p.tap_dx[t];
+            bool ok = mok;
+            if (p.pad_mode == MIT_PAD_REFLECT) {
+                iy = iy < 0 ? -iy : (iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy);
+                ix = ix < 0 ? -ix : (ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix);
+            } else {
+                ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            }
+            const float *ptr = arow + (int64_t)iy * p.a_ys + (int64_t)ix * p.a_xs + p.tap_off[t];
+            for (int q = sub; q < cq; q += LPR) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4 *>(ptr + q * 4);
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wt + n * Ktot + t * p.Cin + q * 4);
+                    acc[n] = __builtin_fmaf(v.x, w4.x, acc[n]);
+                    acc[n] = __builtin_fmaf(v.y, w4.y, acc[n]);
+                    acc[n] = __builtin_fmaf(v.z, w4.z, acc[n]);
+                    acc[n] = __builtin_fmaf(v.w, w4.w, acc[n]);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o);
+        if (mok && sub == 0) {
+            const int64_t oc = (int64_t)nb * p.c.bs + (int64_t)oy * p.c.ys + (int64_t)ox * p.c.xs;
+            const int64_t opre = (int64_t)nb * p.pre.bs + (int64_t)oy * p.pre.ys + (int64_t)ox * p.pre.xs;
+            const int64_t opost = (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys + (int64_t)ox * p.post.xs;
+            const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;
+            for (int n = 0; n < p.N; ++n) {
+                float v = acc[n];
+                if (p.pre.base) v += p.pre.base[opre + n];
+                v = v * (p.scale ? p.scale[n] : 1.f) + (p.bias ? p.bias[n] : 0.f);
+                const float pv = p.post.base ? p.post.base[opost + n] : 0.f;
+                if (post_first) v += pv;
+                switch (p.act & 0xff) {
+                    case MIT_ACT_RELU: v = apply_act<MIT_ACT_RELU>(v, p.act_alpha); break;
+                    case MIT_ACT_LEAKY: v = apply_act<MIT_ACT_LEAKY>(v, p.act_alpha); break;
+                    case MIT_ACT_SILU: v = apply_act<MIT_ACT_SILU>(v, p.act_alpha); break;
+                    case MIT_ACT_SIGMOID: v = apply_act<MIT_ACT_SIGMOID>(v, p.act_alpha); break;
+                    case MIT_ACT_GELU: v = apply_act<MIT_ACT_GELU>(v, p.act_alpha); break;
+                    default: break;
+                }
+                if (!post_first) v += pv;
+                p.c.base[oc + n] = v;
+            }
+        }
+    }
+}
+
 struct CfgEntry {
     const char *name;
     int BM, BN, BK;
     void (*launch)(const MitConvGemm &, int M, int MT, int NT, int KT, hipStream_t);
-    int fast;  // 1: conv_gemm_fast_kernel (needs fast_eligible()); 2: and Cin % 32 == 0
+    int fast;  // 1: conv_gemm_fast_kernel (needs fast_eligible()); 2: and Cin % 32 == 0; 3: conv_gemv_kernel (needs gemv_eligible())
     const char *kernel;  // the kernel's template-id as profilers print it, e.g. "conv_gemm_fast_kernel<128, 128, 16, 1, 4, 4, 4>"
 };
 
@@ -731,5 +819,12 @@ void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
     }
     dim3 grid(MT * NT, p.Z, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
+}
+template <int RPI, int NMAX, int KV, int LPR>
+void launch_gemv(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
+    constexpr int ROWS_PER_BLOCK = 4 * RPI * (64 / LPR);
+    const size_t smem = (size_t)p.ntaps * p.Cin * NMAX * sizeof(float);
+    dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 1, 1);
+    hipLaunchKernelGGL((conv_gemv_kernel<RPI, NMAX, KV, LPR>), grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 }  // namespace mitcg

@@ -49,6 +49,10 @@ CASES = [
     (1, 80, 320, 12, 40, 1, 1, 0, "zero", 5, False, 5),
     (1, 32, 64, 8, 8, 3, 1, 1, "zero", 0, False, 6),
     (1, 160, 160, 6, 33, (2, 1), (2, 1), 0, "zero", 1, True, -1),
+    (2, 64, 1, 20, 24, 3, 1, 1, "zero", 4, True, -1),      # N = 1: conv_gemv_kernel, 16 lanes per row
+    (1, 16, 1, 19, 21, 1, 1, 0, "zero", 4, False, -1),     # N = 1, Cin = 16: 4 lanes per row
+    (1, 16, 2, 15, 18, 3, 1, 1, "reflect", 1, True, 27),   # N = 2 forced onto gemv4
+    (1, 128, 4, 9, 40, 3, 2, 1, "zero", 2, False, 26),     # N = 4, stride 2, forced onto gemv16
 ]
 
 
@@ -198,3 +202,22 @@ def test_conv_small_cout(cuda, cout, cin, k, mode, act):
     assert (wide[..., cout:] == 7.0).all()
     with pytest.raises(ValueError):
         ops.ConvSmallCout(torch.zeros(5, 16, 3, 3), device=cuda)
+
+
+def test_large_batch_is_split_for_the_fast_kernel(cuda):
+    """A batch whose activations exceed 2^31 elements (LaMa's first stride-2 conv at 16 pages: 3.05 G floats) is cut into runs of
+    whole images for the 32-bit-offset fast kernel instead of dropping to the generic one; the k-sequential accumulation makes
+    the two bit-identical."""
+    from manga_image_translator_amd import ops
+
+    B, H, W, Cin, Cout = 12, 2048, 1456, 64, 128
+    assert B * H * W * Cin > 2 ** 31
+    g = torch.Generator(device=cuda).manual_seed(5)
+    x = torch.randn(B, H, W, Cin, device=cuda, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    layer = ops.Conv2d(w, None, stride=2, padding=1, pad_mode=ops.PAD_REFLECT, act=ops.ACT_RELU, device=cuda)
+    fast = layer(x)                 # auto: split + fast tile
+    generic = layer(x, cfg=0)       # the generic 128x128 kernel on the whole batch
+    torch.cuda.synchronize()
+    assert torch.equal(fast, generic)
+    assert fast[-1].abs().sum().item() > 0   # the last run of images was written
