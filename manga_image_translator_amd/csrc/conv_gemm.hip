@@ -36,11 +36,11 @@ bool fast_eligible(const MitConvGemm &p, int BK) {
     return maxoff + tmax < 0x7fffffffLL;
 }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-constexpr int kCfgGemv16 = 26, kCfgGemv4 = 27;
+constexpr int kCfgGemv16 = 26, kCfgGemv4 = 27, kCfgGemv16N1 = 28, kCfgGemv4N1 = 29;
 
 // conv_gemv_kernel preconditions: <= 4 output columns, plain (unbatched, unsplit) maps, the whole weight panel in LDS
 bool gemv_eligible(const MitConvGemm &p, int lpr) {
-    if (p.N > 4 || p.Z != 1 || p.Cin % (4 * lpr) || (int64_t)p.ntaps * p.Cin > 8192) return false;
+    if (p.N > 4 || p.Z != 1 || p.Cin % (4 * lpr) || (int64_t)p.ntaps * p.Cin > 8192 || (int64_t)p.NB * p.Ho > 65535) return false;  // one output row per blockIdx.y
     if (p.c.nsplit || p.pre.nsplit || p.post.nsplit) return false;
     return true;
 }
@@ -60,8 +60,8 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     static const int narrow_max = getenv("MIT_CONV_NARROW_MAX") ? atoi(getenv("MIT_CONV_NARROW_MAX")) : 64;
     const bool f16 = fast_eligible(p, 16);
     static const bool gemv_off = getenv("MIT_CONV_NO_GEMV") != nullptr;  // A/B knob for scripts/
-    if (!gemv_off && gemv_eligible(p, 16)) return kCfgGemv16;
-    if (!gemv_off && gemv_eligible(p, 4)) return kCfgGemv4;
+    if (!gemv_off && gemv_eligible(p, 16)) return p.N == 1 ? kCfgGemv16N1 : kCfgGemv16;
+    if (!gemv_off && gemv_eligible(p, 4)) return p.N == 1 ? kCfgGemv4N1 : kCfgGemv4;
     if (p.N <= 32) return 2;
     if (f16 && m192 >= 0 && M > 128 && M <= 192) return m192;  // 2 x 128 rows would run a 40 % empty second tile
     if (f16 && bigk >= 0 && p.N % 128 == 0 && p.N <= 128 && p.ntaps * p.Cin >= 4096 && M >= 256 * 1024) return bigk;
@@ -226,8 +226,11 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
     const CfgEntry &c = kCfgs[cfg];
     if (c.fast == 2 && (p.Cin % 32)) return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% 32 == 0", c.name);
-    if (c.fast == 3 && !gemv_eligible(p, cfg == kCfgGemv16 ? 16 : 4))
-        return mit_set_error("mit_conv_gemm: cfg %s needs N <= 4, Z == 1, unsplit maps and Cin %% %d == 0", c.name, cfg == kCfgGemv16 ? 64 : 16);
+    if (c.fast == 3) {
+        const int lpr = (cfg == kCfgGemv16 || cfg == kCfgGemv16N1) ? 16 : 4;
+        if (!gemv_eligible(p, lpr) || p.N > c.BN)
+            return mit_set_error("mit_conv_gemm: cfg %s needs N <= %d, Z == 1, unsplit maps and Cin %% %d == 0", c.name, c.BN, 4 * lpr);
+    }
     if ((c.fast == 1 || c.fast == 2) && !fast_eligible(p, c.BK))
         return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% %d == 0, <= %d taps and 32-bit element offsets", c.name, c.BK, FAST_MAX_TAPS);
     const int M = (int)M64;

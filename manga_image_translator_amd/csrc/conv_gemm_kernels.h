@@ -694,8 +694,8 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
 // MFMA tiles), so results differ from them by fp32 rounding (<= 1e-6 relative on these layers).
 template <int RPI, int NMAX, int KV, int LPR>
 __global__ __launch_bounds__(256) void conv_gemv_kernel(const MitConvGemm p, const int M, const int MT, const int NT, const int KT) {
-    static_assert(NMAX == 4 && KV == 4 && (LPR == 4 || LPR == 16), "gemv shape");
-    constexpr int RPW = 64 / LPR;  // rows per wave per iteration
+    static_assert((NMAX == 1 || NMAX == 4) && KV == 4 && (LPR == 4 || LPR == 16), "gemv shape");
+    constexpr int RPW = 64 / LPR;  // output pixels per wave per iteration
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Ktot = p.ntaps * p.Cin;
     float *wt = smem;  // [NMAX][Ktot]
@@ -706,37 +706,39 @@ __global__ __launch_bounds__(256) void conv_gemv_kernel(const MitConvGemm p, con
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR, rslot = lane / LPR;
-    const int HoWo = p.Ho * p.Wo;
+    // one output row (nb, oy) per blockIdx.y: the row decode and every tap's input row are wave-uniform
+    const int nb = blockIdx.y / p.Ho, oy = blockIdx.y - nb * p.Ho;
+    const float *arow = p.a + (int64_t)nb * p.a_bs;
     const int cq = p.Cin >> 2;  // float4 chunks per tap
+    const int64_t oc0 = (int64_t)nb * p.c.bs + (int64_t)oy * p.c.ys;
+    const int64_t opre0 = (int64_t)nb * p.pre.bs + (int64_t)oy * p.pre.ys;
+    const int64_t opost0 = (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys;
+    const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;
+    const bool reflect = p.pad_mode == MIT_PAD_REFLECT;
 #pragma unroll 1
     for (int it = 0; it < RPI; ++it) {
-        const int m = ((blockIdx.x * 4 + wave) * RPI + it) * RPW + rslot;
-        const bool mok = m < M;
-        int nb = 0, oy = 0, ox = 0;
-        if (mok) {
-            nb = m / HoWo;
-            const int rem = m - nb * HoWo;
-            oy = rem / p.Wo;
-            ox = rem - oy * p.Wo;
-        }
-        const float *arow = p.a + (int64_t)nb * p.a_bs;
-        float acc[NMAX] = {0.f, 0.f, 0.f, 0.f};
+        const int ox = ((blockIdx.x * 4 + wave) * RPI + it) * RPW + rslot;
+        const bool mok = ox < p.Wo;
+        float acc[NMAX];
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
         for (int t = 0; t < p.ntaps; ++t) {
             int iy = oy * p.sy + p.tap_dy[t], ix = ox * p.sx + p.tap_dx[t];
             bool ok = mok;
-            if (p.pad_mode == MIT_PAD_REFLECT) {
+            if (reflect) {
                 iy = iy < 0 ? -iy : (iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy);
                 ix = ix < 0 ? -ix : (ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix);
             } else {
                 ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
             }
             const float *ptr = arow + (int64_t)iy * p.a_ys + (int64_t)ix * p.a_xs + p.tap_off[t];
+            const float *wrow = wt + t * p.Cin;
             for (int q = sub; q < cq; q += LPR) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (ok) v = *reinterpret_cast<const f32x4 *>(ptr + q * 4);
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wt + n * Ktot + t * p.Cin + q * 4);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wrow + n * Ktot + q * 4);
                     acc[n] = __builtin_fmaf(v.x, w4.x, acc[n]);
                     acc[n] = __builtin_fmaf(v.y, w4.y, acc[n]);
                     acc[n] = __builtin_fmaf(v.z, w4.z, acc[n]);
@@ -749,11 +751,10 @@ __global__ __launch_bounds__(256) void conv_gemv_kernel(const MitConvGemm p, con
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o);
         if (mok && sub == 0) {
-            const int64_t oc = (int64_t)nb * p.c.bs + (int64_t)oy * p.c.ys + (int64_t)ox * p.c.xs;
-            const int64_t opre = (int64_t)nb * p.pre.bs + (int64_t)oy * p.pre.ys + (int64_t)ox * p.pre.xs;
-            const int64_t opost = (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys + (int64_t)ox * p.post.xs;
-            const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;
-            for (int n = 0; n < p.N; ++n) {
+            const int64_t oc = oc0 + (int64_t)ox * p.c.xs, opre = opre0 + (int64_t)ox * p.pre.xs, opost = opost0 + (int64_t)ox * p.post.xs;
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                if (n >= p.N) break;
                 float v = acc[n];
                 if (p.pre.base) v += p.pre.base[opre + n];
                 v = v * (p.scale ? p.scale[n] : 1.f) + (p.bias ? p.bias[n] : 0.f);
@@ -822,9 +823,9 @@ void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
 }
 template <int RPI, int NMAX, int KV, int LPR>
 void launch_gemv(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
-    constexpr int ROWS_PER_BLOCK = 4 * RPI * (64 / LPR);
+    constexpr int X_PER_BLOCK = 4 * RPI * (64 / LPR);
     const size_t smem = (size_t)p.ntaps * p.Cin * NMAX * sizeof(float);
-    dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, 1, 1);
+    dim3 grid((p.Wo + X_PER_BLOCK - 1) / X_PER_BLOCK, p.NB * p.Ho, 1);
     hipLaunchKernelGGL((conv_gemv_kernel<RPI, NMAX, KV, LPR>), grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 }  // namespace mitcg

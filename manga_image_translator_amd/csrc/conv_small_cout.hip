@@ -7,11 +7,20 @@
 // are wave-uniform, i.e. scalar loads feeding v_fma_f32 from SGPRs.  Accumulation order: channel slice, tap (ky, kx),
 // channel — a single fmaf chain per output, like the MFMA kernel's (k order differs: slice-major instead of tap-major).
 //
+// Cout <= 3 (the LaMa layer) takes conv_small_cout3_kernel: packed fp32 math (v_pk_fma_f32, two FMAs per lane per issue — the
+// plain kernel sat at 85 % of the unpacked VALU peak) on 2 x 2 output pixels per thread.  The two rows (y, y + 8) of a thread are
+// the two halves of every packed operand: the LDS tile stores, per pixel and channel pair, (row y c0, row y+8 c0, row y c1,
+// row y+8 c1), so one ds_read_b128 yields two ready-made packed operands; the two columns (x, x + 1) share a sliding window of
+// K + 1 such reads per kernel row.  Even / odd pixels of a tile row sit in separate halves of the LDS row so that the 64 lanes of
+// a wave (stride 2 pixels) read consecutive 16-byte slots.  No 4th accumulator.  Accumulation order: 4-channel slice, channel
+// pair, tap (ky, kx), channel.
+//
 // Reference op: FFCResNetGenerator.model[-2:] = ReflectionPad2d(3) + Conv2d(64, 3, 7) + sigmoid
 // (manga_translator/inpainting/inpainting_lama_mpe.py:597-600).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/mit_hip.h"
 #include "common.h"
 
@@ -89,6 +98,87 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__res
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TW3 = 64, TH3 = 16;
+
+template <int K>
+__global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__restrict__ in, int64_t in_pix, const f32x4 *__restrict__ w4,
+                                                                const float *__restrict__ bias, float *__restrict__ out,
+                                                                int64_t out_pix, int H, int W, int Cin, int Cout, int reflect,
+                                                                int act, float alpha) {
+    constexpr int R = K / 2;
+    constexpr int PR = TH3 / 2 + 2 * R;  // row pairs (y, y + 8) held per tile
+    constexpr int HW_ = TW3 + 2 * R;     // even for odd K
+    constexpr int HALF = HW_ / 2;
+    __shared__ f32x4 tile[2][PR][HW_];   // [channel pair][pair row][even pixels | odd pixels] = (A c0, B c0, A c1, B c1)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * TW3, y0 = blockIdx.y * TH3, b = blockIdx.z;
+    const float *ib = in + (int64_t)b * H * W * in_pix;
+    f32x2 acc[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[j][n] = f32x2{0.f, 0.f};
+    for (int c0 = 0; c0 < Cin; c0 += 4) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < PR * HW_; i += 256) {
+            const int ly = i / HW_, lx = i - ly * HW_;
+            int ya = y0 + ly - R, yb = ya + TH3 / 2, xx = x0 + lx - R;
+            if (reflect) {
+                ya = ya < 0 ? -ya : (ya >= H ? 2 * H - 2 - ya : ya);
+                yb = yb < 0 ? -yb : (yb >= H ? 2 * H - 2 - yb : yb);
+                xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+            }
+            const bool xok = xx >= 0 && xx < W;  // still outside after one reflection: tile overhang, never used
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, bq = {0.f, 0.f, 0.f, 0.f};
+            if (xok && ya >= 0 && ya < H) a = *reinterpret_cast<const f32x4 *>(ib + ((int64_t)ya * W + xx) * in_pix + c0);
+            if (xok && yb >= 0 && yb < H) bq = *reinterpret_cast<const f32x4 *>(ib + ((int64_t)yb * W + xx) * in_pix + c0);
+            const int slot = (lx >> 1) + (lx & 1) * HALF;
+            tile[0][ly][slot] = f32x4{a.x, bq.x, a.y, bq.y};
+            tile[1][ly][slot] = f32x4{a.z, bq.z, a.w, bq.w};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                f32x4 win[K + 1];
+#pragma unroll
+                for (int i = 0; i <= K; ++i) win[i] = tile[cp][ty + ky][tx + (i >> 1) + (i & 1) * HALF];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const f32x4 *wt = w4 + (int64_t)(ky * K + kx) * Cin + c0 + cp * 2;  // wave-uniform -> scalar loads
+                    const f32x4 wa = wt[0], wb = wt[1];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 v = win[kx + j];
+                        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+                        acc[j][0] = __builtin_elementwise_fma(lo, f32x2{wa.x, wa.x}, acc[j][0]);
+                        acc[j][1] = __builtin_elementwise_fma(lo, f32x2{wa.y, wa.y}, acc[j][1]);
+                        acc[j][2] = __builtin_elementwise_fma(lo, f32x2{wa.z, wa.z}, acc[j][2]);
+                        acc[j][0] = __builtin_elementwise_fma(hi, f32x2{wb.x, wb.x}, acc[j][0]);
+                        acc[j][1] = __builtin_elementwise_fma(hi, f32x2{wb.y, wb.y}, acc[j][1]);
+                        acc[j][2] = __builtin_elementwise_fma(hi, f32x2{wb.z, wb.z}, acc[j][2]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = x0 + 2 * tx + j;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0 + ty + r * (TH3 / 2);
+            if (x < W && y < H) {
+                float *o = out + (((int64_t)b * H + y) * W + x) * out_pix;
+                for (int n = 0; n < Cout; ++n) o[n] = act_fn(acc[j][n][r] + (bias ? bias[n] : 0.f), act, alpha);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *w4_dev, const float *bias_dev,
@@ -107,6 +197,18 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     const int refl = pad_mode == MIT_PAD_REFLECT;
     // VALU-bound: algorithmic FLOPs 2 k^2 Cin Cout per pixel; bytes: input read once + Cout outputs written
     MitProbeScope probe(k == 7 ? "conv_small_cout_kernel<7>" : k == 5 ? "conv_small_cout_kernel<5>" : "conv_small_cout_kernel<3>", s, 4.0 * (double)B * H * W * (Cin + Cout), 2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
+    static const bool no_pk = getenv("MIT_SMALL_COUT_NO_PK") != nullptr;  // A/B knob for scripts/
+    if (Cout <= 3 && !no_pk) {
+        dim3 grid3(mit_div_up(W, TW3), mit_div_up(H, TH3), B);
+        switch (k) {
+            case 3: hipLaunchKernelGGL(conv_small_cout3_kernel<3>, grid3, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            case 5: hipLaunchKernelGGL(conv_small_cout3_kernel<5>, grid3, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            case 7: hipLaunchKernelGGL(conv_small_cout3_kernel<7>, grid3, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
+        }
+        MIT_CHECK_LAUNCH("mit_conv_small_cout");
+        return 0;
+    }
     switch (k) {
         case 3: hipLaunchKernelGGL(conv_small_cout_kernel<3>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
         case 5: hipLaunchKernelGGL(conv_small_cout_kernel<5>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
