@@ -39,7 +39,7 @@ __device__ __forceinline__ float act_fn(float v, int act, float alpha) {
     }
 }
 
-template <int K>
+template <int K, int NACC = 4>
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__restrict__ in, int64_t in_pix, const f32x4 *__restrict__ w4,
                                                                const float *__restrict__ bias, float *__restrict__ out,
                                                                int64_t out_pix, int H, int W, int Cin, int Cout, int reflect,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__res
                         acc.x = fmaf(v[e], ww.x, acc.x);
                         acc.y = fmaf(v[e], ww.y, acc.y);
                         acc.z = fmaf(v[e], ww.z, acc.z);
-                        acc.w = fmaf(v[e], ww.w, acc.w);
+                        if (NACC == 4) acc.w = fmaf(v[e], ww.w, acc.w);  // Cout <= 3: the 4th chain is dead weight (25 % of the FMAs)
                     }
                 }
             }
@@ -196,9 +196,15 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w4_dev);
     const int refl = pad_mode == MIT_PAD_REFLECT;
     // VALU-bound: algorithmic FLOPs 2 k^2 Cin Cout per pixel; bytes: input read once + Cout outputs written
-    MitProbeScope probe(k == 7 ? "conv_small_cout_kernel<7>" : k == 5 ? "conv_small_cout_kernel<5>" : "conv_small_cout_kernel<3>", s, 4.0 * (double)B * H * W * (Cin + Cout), 2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
-    static const bool no_pk = getenv("MIT_SMALL_COUT_NO_PK") != nullptr;  // A/B knob for scripts/
-    if (Cout <= 3 && !no_pk) {
+    static const char *kNames[3][2] = {{"conv_small_cout_kernel<3, 3>", "conv_small_cout_kernel<3, 4>"},
+                                       {"conv_small_cout_kernel<5, 3>", "conv_small_cout_kernel<5, 4>"},
+                                       {"conv_small_cout_kernel<7, 3>", "conv_small_cout_kernel<7, 4>"}};  // as profilers print them
+    MitProbeScope probe(kNames[k == 7 ? 2 : k == 5 ? 1 : 0][Cout <= 3 ? 0 : 1], s, 4.0 * (double)B * H * W * (Cin + Cout),
+                        2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
+    // measured and NOT the default: the packed-FMA kernel issues 2.7x fewer VALU instructions but its 4-channel slices fetch every
+    // 128-byte line of the NHWC input 8 times (25 ms per 16 pages against 17.7 for the plain kernel, HBM-bound); see DESIGN.md
+    static const bool use_pk = getenv("MIT_SMALL_COUT_PK") != nullptr;
+    if (Cout <= 3 && use_pk) {
         dim3 grid3(mit_div_up(W, TW3), mit_div_up(H, TH3), B);
         switch (k) {
             case 3: hipLaunchKernelGGL(conv_small_cout3_kernel<3>, grid3, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
@@ -209,12 +215,14 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
         MIT_CHECK_LAUNCH("mit_conv_small_cout");
         return 0;
     }
+#define MIT_CSC(KK, NA) hipLaunchKernelGGL((conv_small_cout_kernel<KK, NA>), grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha)
     switch (k) {
-        case 3: hipLaunchKernelGGL(conv_small_cout_kernel<3>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
-        case 5: hipLaunchKernelGGL(conv_small_cout_kernel<5>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
-        case 7: hipLaunchKernelGGL(conv_small_cout_kernel<7>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+        case 3: if (Cout <= 3) MIT_CSC(3, 3); else MIT_CSC(3, 4); break;
+        case 5: if (Cout <= 3) MIT_CSC(5, 3); else MIT_CSC(5, 4); break;
+        case 7: if (Cout <= 3) MIT_CSC(7, 3); else MIT_CSC(7, 4); break;
         default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
     }
+#undef MIT_CSC
     MIT_CHECK_LAUNCH("mit_conv_small_cout");
     return 0;
 }

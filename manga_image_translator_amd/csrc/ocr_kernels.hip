@@ -89,7 +89,15 @@ __global__ __launch_bounds__(256) void dwconv_ragged_kernel(const float *__restr
     constexpr int R = K / 2;
     const int C = C4 * 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total_items; it += stride) {
+    // XCD-aware block -> item mapping: workgroup b runs on XCD b % 8, each XCD has its own L2, and an input row is read by K
+    // output rows.  With the plain order those K rows land on all 8 XCDs and every row is fetched from HBM up to 8 times (PMC:
+    // 3.3 GB fetched per launch for 0.58 GB of input); giving each XCD a contiguous run of items keeps a row's readers on one L2.
+    int vb = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+        vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    }
+    for (int64_t it = (int64_t)vb * blockDim.x + threadIdx.x; it < total_items; it += stride) {
         const int c4 = (int)(it % C4);
         const int64_t g = it / C4;  // (segment, image row, x group)
         int lo = 0, hi = nsegs - 1;
