@@ -432,6 +432,11 @@ typedef struct MitRaggedSeg {
 int mit_dwconv_nhwc_ragged(const float *in_dev, const float *w_dev, const float *scale_dev, const float *bias_dev,
                            float *out_dev, const MitRaggedSeg *segs_dev, int nsegs, int64_t total_groups, int C, int k,
                            void *stream);
+/* The same when every segment has height common_H: rows are processed YT = 4 (or 2) at a time per thread with the weights in LDS
+ * (bit-identical results, about a third of the L1 loads).  common_H <= 0, odd heights or K*K*C*4 > 64 KB fall back to the call above. */
+int mit_dwconv_nhwc_ragged_rows(const float *in_dev, const float *w_dev, const float *scale_dev, const float *bias_dev,
+                                float *out_dev, const MitRaggedSeg *segs_dev, int nsegs, int64_t total_groups, int C, int k,
+                                int common_H, void *stream);
 /* nn.LayerNorm over the last dim (transformer norm1/2/3). */
 int mit_layernorm(const float *in_dev, int64_t in_rowstride, const float *w_dev, const float *b_dev, float *out_dev,
                   int64_t out_rowstride, int rows, int D, float eps, void *stream);

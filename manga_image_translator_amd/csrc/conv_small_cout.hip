@@ -199,7 +199,7 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     static const char *kNames[3][2] = {{"conv_small_cout_kernel<3, 3>", "conv_small_cout_kernel<3, 4>"},
                                        {"conv_small_cout_kernel<5, 3>", "conv_small_cout_kernel<5, 4>"},
                                        {"conv_small_cout_kernel<7, 3>", "conv_small_cout_kernel<7, 4>"}};  // as profilers print them
-    MitProbeScope probe(kNames[k == 7 ? 2 : k == 5 ? 1 : 0][Cout <= 3 ? 0 : 1], s, 4.0 * (double)B * H * W * (Cin + Cout),
+    MitProbeScope probe(kNames[k == 7 ? 2 : k == 5 ? 1 : 0][(Cout <= 3 && !getenv("MIT_SMALL_COUT_4ACC")) ? 0 : 1], s, 4.0 * (double)B * H * W * (Cin + Cout),
                         2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
     // measured and NOT the default: the packed-FMA kernel issues 2.7x fewer VALU instructions but its 4-channel slices fetch every
     // 128-byte line of the NHWC input 8 times (25 ms per 16 pages against 17.7 for the plain kernel, HBM-bound); see DESIGN.md
@@ -215,11 +215,13 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
         MIT_CHECK_LAUNCH("mit_conv_small_cout");
         return 0;
     }
+    static const bool four = getenv("MIT_SMALL_COUT_4ACC") != nullptr;  // A/B knob for scripts/: the 4-accumulator form for every Cout
+    const bool three = Cout <= 3 && !four;
 #define MIT_CSC(KK, NA) hipLaunchKernelGGL((conv_small_cout_kernel<KK, NA>), grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha)
     switch (k) {
-        case 3: if (Cout <= 3) MIT_CSC(3, 3); else MIT_CSC(3, 4); break;
-        case 5: if (Cout <= 3) MIT_CSC(5, 3); else MIT_CSC(5, 4); break;
-        case 7: if (Cout <= 3) MIT_CSC(7, 3); else MIT_CSC(7, 4); break;
+        case 3: if (three) MIT_CSC(3, 3); else MIT_CSC(3, 4); break;
+        case 5: if (three) MIT_CSC(5, 3); else MIT_CSC(5, 4); break;
+        case 7: if (three) MIT_CSC(7, 3); else MIT_CSC(7, 4); break;
         default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
     }
 #undef MIT_CSC

@@ -204,6 +204,8 @@ SYMBOLS = {
                                   C.c_int, C.c_int, C.c_void_p]),
     "mit_dwconv_nhwc_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mit_dwconv_nhwc_ragged_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                 C.c_float, C.c_void_p]),
     "mit_xpos_rotate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,

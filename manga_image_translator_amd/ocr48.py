@@ -280,11 +280,13 @@ class Ocr48Engine:
             t_flat = self._buf(f"g.dw{si}", rows, Cc)
             h_flat = self._buf(f"g.h{si}", rows, 4 * Cc)
             x4, t4, h4 = x_flat.view(1, 1, rows, Cc), t_flat.view(1, 1, rows, Cc), h_flat.view(1, 1, rows, 4 * Cc)
+            heights = {h for _, h, _ in sh}
+            common_h = heights.pop() if len(heights) == 1 else 0  # every chunk of a 48 px recogniser has the same height per stage
             for blk in blocks:
-                _lib.check(lib.mit_dwconv_nhwc_ragged(x_flat.data_ptr(), blk.dw_w.data_ptr(), blk.dw_scale.data_ptr(),
-                                                      blk.dw_bias.data_ptr(), t_flat.data_ptr(),
-                                                      tab_dev.data_ptr() + int(tab_off[si]), nc, tabs[si][1], Cc, blk.ks, st),
-                           "mit_dwconv_nhwc_ragged")
+                _lib.check(lib.mit_dwconv_nhwc_ragged_rows(x_flat.data_ptr(), blk.dw_w.data_ptr(), blk.dw_scale.data_ptr(),
+                                                           blk.dw_bias.data_ptr(), t_flat.data_ptr(),
+                                                           tab_dev.data_ptr() + int(tab_off[si]), nc, tabs[si][1], Cc, blk.ks,
+                                                           common_h, st), "mit_dwconv_nhwc_ragged_rows")
                 blk.pw1(t4, out=h4)
                 blk.pw2(h4, out=x4, post=x4)
             nsh = [(n, *down.out_hw(h, w)) for n, h, w in sh]

@@ -194,3 +194,42 @@ def test_shared_kv_attention_bitwise_equals_per_row(cuda, G, Tk, heads, hd):
     sc = sc.masked_fill(mask[:, None, None, :], float("-inf"))
     ref = torch.einsum("nght,nthd->nghd", sc.softmax(-1), vd).reshape(NL * G, E)
     assert (out_a.double().cpu() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("k,C_,H,shapes", [(7, 80, 24, [(2, 37), (1, 64), (3, 9)]), (7, 160, 12, [(1, 150), (2, 5)]), (5, 320, 6, [(2, 33), (1, 70)]),
+                                           (3, 320, 3, [(2, 40)]), (5, 16, 8, [(1, 3), (1, 4)])])
+def test_dwconv_ragged_rows_equals_per_row_kernel(cuda, k, C_, H, shapes):
+    """mit_dwconv_nhwc_ragged_rows (YT output rows per thread, weights in LDS) == mit_dwconv_nhwc_ragged bit for bit: same fmaf
+    chain per output.  Covers YT = 4 (H = 24, 12, 8), YT = 2 (H = 6), the fallback (H = 3), ragged right edges and W < 4."""
+    import ctypes as C
+
+    from manga_image_translator_amd import lib as L, ops
+    from manga_image_translator_amd.lib import MitRaggedSeg
+
+    g = torch.Generator().manual_seed(k * 100 + H)
+    segs = (MitRaggedSeg * len(shapes))()
+    pix = grp = 0
+    for i, (n, w) in enumerate(shapes):
+        segs[i].pixel_start, segs[i].group_start, segs[i].B, segs[i].H, segs[i].W = pix, grp, n, H, w
+        pix += n * H * w
+        grp += n * H * ((w + 3) // 4)
+    x = torch.randn(pix, C_, generator=g).to(cuda)
+    wt = torch.randn(k * k, C_, generator=g).to(cuda)
+    sc, bi = (torch.rand(C_, generator=g) + 0.5).to(cuda), torch.randn(C_, generator=g).to(cuda)
+    tab = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.uint8).to(cuda)
+    a, b = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    st = C.c_void_p(ops.current_stream())
+    Lh = L.load()
+    L.check(Lh.mit_dwconv_nhwc_ragged(x.data_ptr(), wt.data_ptr(), sc.data_ptr(), bi.data_ptr(), a.data_ptr(), tab.data_ptr(), len(shapes), grp,
+                                      C_, k, st), "mit_dwconv_nhwc_ragged")
+    L.check(Lh.mit_dwconv_nhwc_ragged_rows(x.data_ptr(), wt.data_ptr(), sc.data_ptr(), bi.data_ptr(), b.data_ptr(), tab.data_ptr(), len(shapes),
+                                           grp, C_, k, H, st), "mit_dwconv_nhwc_ragged_rows")
+    torch.cuda.synchronize()
+    assert not torch.isnan(a).any() and torch.equal(a, b)
+    # and against torch's depthwise conv on the first segment
+    n0, w0 = shapes[0]
+    ref = torch.nn.functional.conv2d(x[:n0 * H * w0].view(n0, H, w0, C_).permute(0, 3, 1, 2).cpu().double(),
+                                     wt.cpu().double().t().reshape(C_, 1, k, k), padding=k // 2, groups=C_)
+    ref = ref * sc.cpu().double().view(1, -1, 1, 1) + bi.cpu().double().view(1, -1, 1, 1)
+    got = b[:n0 * H * w0].view(n0, H, w0, C_).permute(0, 3, 1, 2).cpu().double()
+    assert (got - ref).abs().max() < 1e-4
