@@ -39,7 +39,7 @@ __device__ __forceinline__ float act_fn(float v, int act, float alpha) {
     }
 }
 
-template <int K, int NACC = 4>
+template <int K, bool LW = false>
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__restrict__ in, int64_t in_pix, const f32x4 *__restrict__ w4,
                                                                const float *__restrict__ bias, float *__restrict__ out,
                                                                int64_t out_pix, int H, int W, int Cin, int Cout, int reflect,
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__res
     constexpr int R = K / 2;
     constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
     __shared__ f32x4 tile[CCH / 4][HH_][HW_];
+    __shared__ f32x4 wsl[LW ? K * K * CCH : 1];  // LW: this slice's weights [tap][channel] (the 50 KB weight set overflows the 16 KB scalar cache)
     const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
     const float *ib = in + (int64_t)b * H * W * in_pix;
@@ -70,12 +71,14 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__res
             if (ok) v = *reinterpret_cast<const f32x4 *>(ib + ((int64_t)yy * W + xx) * in_pix + c0 + q * 4);
             tile[q][py][px] = v;
         }
+        if (LW)
+            for (int i = threadIdx.x; i < K * K * CCH; i += 256) wsl[i] = w4[(int64_t)(i / CCH) * Cin + c0 + (i % CCH)];
         __syncthreads();
 #pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const f32x4 *wt = w4 + (int64_t)(ky * K + kx) * Cin + c0;  // wave-uniform -> scalar loads
+                const f32x4 *wt = LW ? wsl + (ky * K + kx) * CCH : w4 + (int64_t)(ky * K + kx) * Cin + c0;  // wave-uniform: scalar loads, or LDS broadcasts
 #pragma unroll
                 for (int q = 0; q < CCH / 4; ++q) {
                     const f32x4 v = tile[q][ty + ky][tx + kx];
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__res
                         acc.x = fmaf(v[e], ww.x, acc.x);
                         acc.y = fmaf(v[e], ww.y, acc.y);
                         acc.z = fmaf(v[e], ww.z, acc.z);
-                        if (NACC == 4) acc.w = fmaf(v[e], ww.w, acc.w);  // Cout <= 3: the 4th chain is dead weight (25 % of the FMAs)
+                        acc.w = fmaf(v[e], ww.w, acc.w);  // kept for Cout = 3 as well: dropping the chain measured 1.5 % SLOWER (A/B in one call)
                     }
                 }
             }
@@ -196,11 +199,7 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w4_dev);
     const int refl = pad_mode == MIT_PAD_REFLECT;
     // VALU-bound: algorithmic FLOPs 2 k^2 Cin Cout per pixel; bytes: input read once + Cout outputs written
-    static const char *kNames[3][2] = {{"conv_small_cout_kernel<3, 3>", "conv_small_cout_kernel<3, 4>"},
-                                       {"conv_small_cout_kernel<5, 3>", "conv_small_cout_kernel<5, 4>"},
-                                       {"conv_small_cout_kernel<7, 3>", "conv_small_cout_kernel<7, 4>"}};  // as profilers print them
-    MitProbeScope probe(kNames[k == 7 ? 2 : k == 5 ? 1 : 0][(Cout <= 3 && !getenv("MIT_SMALL_COUT_4ACC")) ? 0 : 1], s, 4.0 * (double)B * H * W * (Cin + Cout),
-                        2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
+    MitProbeScope probe(k == 7 ? "conv_small_cout_kernel<7>" : k == 5 ? "conv_small_cout_kernel<5>" : "conv_small_cout_kernel<3>", s, 4.0 * (double)B * H * W * (Cin + Cout), 2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
     // measured and NOT the default: the packed-FMA kernel issues 2.7x fewer VALU instructions but its 4-channel slices fetch every
     // 128-byte line of the NHWC input 8 times (25 ms per 16 pages against 17.7 for the plain kernel, HBM-bound); see DESIGN.md
     static const bool use_pk = getenv("MIT_SMALL_COUT_PK") != nullptr;
@@ -215,13 +214,12 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
         MIT_CHECK_LAUNCH("mit_conv_small_cout");
         return 0;
     }
-    static const bool four = getenv("MIT_SMALL_COUT_4ACC") != nullptr;  // A/B knob for scripts/: the 4-accumulator form for every Cout
-    const bool three = Cout <= 3 && !four;
-#define MIT_CSC(KK, NA) hipLaunchKernelGGL((conv_small_cout_kernel<KK, NA>), grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha)
+    static const bool ldsw = getenv("MIT_SMALL_COUT_LDSW") != nullptr;  // A/B knob for scripts/: weights through LDS instead of scalar loads
+#define MIT_CSC(KK, LL) hipLaunchKernelGGL((conv_small_cout_kernel<KK, LL>), grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha)
     switch (k) {
-        case 3: if (three) MIT_CSC(3, 3); else MIT_CSC(3, 4); break;
-        case 5: if (three) MIT_CSC(5, 3); else MIT_CSC(5, 4); break;
-        case 7: if (three) MIT_CSC(7, 3); else MIT_CSC(7, 4); break;
+        case 3: if (ldsw) MIT_CSC(3, true); else MIT_CSC(3, false); break;
+        case 5: if (ldsw) MIT_CSC(5, true); else MIT_CSC(5, false); break;
+        case 7: if (ldsw) MIT_CSC(7, true); else MIT_CSC(7, false); break;
         default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
     }
 #undef MIT_CSC

@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/mit_hip.h"
 #include "common.h"
 
@@ -24,7 +25,7 @@ __device__ __forceinline__ void fft_pass(float *re, float *im, const float2 *tws
     constexpr int P = 1 << S;
     const int nb = h >> 1;
     const int ntask = (h >> S) * CT;
-    for (int task = threadIdx.x; task < ntask; task += 256) {
+    for (int task = threadIdx.x; task < ntask; task += blockDim.x) {
         const int col = task & (CT - 1), grp = task / CT;
         const int lo = grp & ((1 << s0) - 1), hi = grp >> s0;
         const int base = (hi << (s0 + S)) | lo;  // row of member m: base | (m << s0)
@@ -61,8 +62,8 @@ __device__ __forceinline__ void fft_pass(float *re, float *im, const float2 *tws
     }
 }
 
-template <int ROWS>  // rows per thread in the load / store passes = h / 32
-__global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__ in, int64_t in_bs, int64_t in_ts, int64_t in_hs,
+template <int ROWS, int NT = 256>  // rows per thread in the load / store passes = h / (NT / 8)
+__global__ __launch_bounds__(NT) void fft_cols_kernel(const float *__restrict__ in, int64_t in_bs, int64_t in_ts, int64_t in_hs,
                                                         float *__restrict__ out, int64_t out_bs, int64_t out_ts, int64_t out_hs,
                                                         const float2 *__restrict__ tw, int h, int logh, int64_t ncols,
                                                         int inverse, float scale) {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__
     f32x4 va[ROWS], vb[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-        const int r = rg + 32 * i;
+        const int r = rg + (NT / 8) * i;
         va[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         vb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (r < h) {
@@ -97,10 +98,10 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__
             }
         }
     }
-    for (int k = threadIdx.x; k < (h >> 1); k += 256) tws[k] = tw[k];
+    for (int k = threadIdx.x; k < (h >> 1); k += NT) tws[k] = tw[k];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-        const int r = rg + 32 * i;
+        const int r = rg + (NT / 8) * i;
         if (r < h) {
             const int rr = __brev((unsigned)r) >> (32 - logh);
             *reinterpret_cast<f32x4 *>(re + rr * CT + cq * 4) = va[i];
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(const float *__restrict__
     // ---- store (same mapping as the load) ----
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-        const int r = rg + 32 * i;
+        const int r = rg + (NT / 8) * i;
         if (r >= h) continue;
         f32x4 a = *reinterpret_cast<const f32x4 *>(re + r * CT + cq * 4);
         f32x4 b = *reinterpret_cast<const f32x4 *>(im + r * CT + cq * 4);
@@ -164,27 +165,30 @@ extern "C" int mit_fft_cols(const float *in_dev, int64_t in_bs, int64_t in_ts, i
         (reinterpret_cast<uintptr_t>(in_dev) & 15) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
         return mit_set_error("mit_fft_cols: column count, strides and bases must be multiples of 4 floats");
     const size_t smem = (size_t)2 * h * CT * sizeof(float) + (size_t)(h / 2) * sizeof(float2);
-    dim3 grid(mit_div_up(ncols, CT), B), block(256);
+    dim3 grid(mit_div_up(ncols, CT), B);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float2 *tw2 = reinterpret_cast<const float2 *>(twiddle_dev);
     // algorithmic bytes: the planar complex spectrum read once and written once; FLOPs: 5 h log2 h per complex column
     MitProbeScope probe("fft_cols_kernel", st, 2.0 * 8.0 * (double)B * h * (double)ncols, 5.0 * (double)h * logh * (double)ncols * B);
-#define MIT_FFT_LAUNCH(ROWS)                                                                                                   \
+#define MIT_FFT_LAUNCH(ROWS, NT)                                                                                               \
     do {                                                                                                                       \
-        auto kern = fft_cols_kernel<ROWS>;                                                                                     \
+        auto kern = fft_cols_kernel<ROWS, NT>;                                                                                 \
         static bool attr_set = false;                                                                                          \
         if (!attr_set && smem > 64 * 1024) {                                                                                   \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                   \
         }                                                                                                                      \
-        hipLaunchKernelGGL(kern, grid, block, smem, st, in_dev, in_bs, in_ts, in_hs, out_dev, out_bs, out_ts, out_hs, tw2, h, logh, \
+        hipLaunchKernelGGL(kern, grid, dim3(NT), smem, st, in_dev, in_bs, in_ts, in_hs, out_dev, out_bs, out_ts, out_hs, tw2, h, logh, \
                            ncols, inverse, scale);                                                                            \
     } while (0)
-    if (h <= 32) MIT_FFT_LAUNCH(1);
-    else if (h <= 64) MIT_FFT_LAUNCH(2);
-    else if (h <= 128) MIT_FFT_LAUNCH(4);
-    else if (h <= 256) MIT_FFT_LAUNCH(8);
-    else MIT_FFT_LAUNCH(16);
+    // 64 KB of LDS per workgroup at h = 256 allows two workgroups per CU; 512 threads each (instead of 256) double the waves that
+    // keep loads and stores in flight while the other workgroup is in its butterfly passes
+    static const bool nt256 = getenv("MIT_FFT_256") != nullptr;  // A/B knob for scripts/
+    if (h <= 32) MIT_FFT_LAUNCH(1, 256);
+    else if (h <= 64) MIT_FFT_LAUNCH(2, 256);
+    else if (h <= 128) MIT_FFT_LAUNCH(4, 256);
+    else if (h <= 256) { if (nt256) MIT_FFT_LAUNCH(8, 256); else MIT_FFT_LAUNCH(4, 512); }
+    else { if (nt256) MIT_FFT_LAUNCH(16, 256); else MIT_FFT_LAUNCH(8, 512); }
 #undef MIT_FFT_LAUNCH
     MIT_CHECK_LAUNCH("mit_fft_cols");
     return 0;
