@@ -39,7 +39,7 @@ __device__ __forceinline__ float act_fn(float v, int act, float alpha) {
     }
 }
 
-template <int K, bool LW = false>
+template <int K>
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__restrict__ in, int64_t in_pix, const f32x4 *__restrict__ w4,
                                                                const float *__restrict__ bias, float *__restrict__ out,
                                                                int64_t out_pix, int H, int W, int Cin, int Cout, int reflect,
@@ -47,7 +47,6 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__res
     constexpr int R = K / 2;
     constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
     __shared__ f32x4 tile[CCH / 4][HH_][HW_];
-    __shared__ f32x4 wsl[LW ? K * K * CCH : 1];  // LW: this slice's weights [tap][channel] (the 50 KB weight set overflows the 16 KB scalar cache)
     const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
     const float *ib = in + (int64_t)b * H * W * in_pix;
@@ -71,14 +70,12 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float *__res
             if (ok) v = *reinterpret_cast<const f32x4 *>(ib + ((int64_t)yy * W + xx) * in_pix + c0 + q * 4);
             tile[q][py][px] = v;
         }
-        if (LW)
-            for (int i = threadIdx.x; i < K * K * CCH; i += 256) wsl[i] = w4[(int64_t)(i / CCH) * Cin + c0 + (i % CCH)];
         __syncthreads();
 #pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const f32x4 *wt = LW ? wsl + (ky * K + kx) * CCH : w4 + (int64_t)(ky * K + kx) * Cin + c0;  // wave-uniform: scalar loads, or LDS broadcasts
+                const f32x4 *wt = w4 + (int64_t)(ky * K + kx) * Cin + c0;  // wave-uniform -> scalar loads (staging them in LDS measured 3 % slower)
 #pragma unroll
                 for (int q = 0; q < CCH / 4; ++q) {
                     const f32x4 v = tile[q][ty + ky][tx + kx];
@@ -214,15 +211,12 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
         MIT_CHECK_LAUNCH("mit_conv_small_cout");
         return 0;
     }
-    static const bool ldsw = getenv("MIT_SMALL_COUT_LDSW") != nullptr;  // A/B knob for scripts/: weights through LDS instead of scalar loads
-#define MIT_CSC(KK, LL) hipLaunchKernelGGL((conv_small_cout_kernel<KK, LL>), grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha)
     switch (k) {
-        case 3: if (ldsw) MIT_CSC(3, true); else MIT_CSC(3, false); break;
-        case 5: if (ldsw) MIT_CSC(5, true); else MIT_CSC(5, false); break;
-        case 7: if (ldsw) MIT_CSC(7, true); else MIT_CSC(7, false); break;
+        case 3: hipLaunchKernelGGL(conv_small_cout_kernel<3>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+        case 5: hipLaunchKernelGGL(conv_small_cout_kernel<5>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+        case 7: hipLaunchKernelGGL(conv_small_cout_kernel<7>, grid, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
         default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
     }
-#undef MIT_CSC
     MIT_CHECK_LAUNCH("mit_conv_small_cout");
     return 0;
 }
