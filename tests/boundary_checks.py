@@ -191,6 +191,9 @@ def _():
 
     # no GPU here: the stand-in engine hands out CPU tensors, so the device resize is replaced by its numpy twin (same tables)
     imgproc.resize_u8 = lambda t, dsize, exact=False: torch.from_numpy(np.stack([imgproc.resize_u8_host(x, dsize, exact) for x in t.numpy()]))
+    # likewise the device refine_mask is replaced by the host routine it is bit-identical to (tests/test_ctd_refine_gpu.py)
+    from manga_image_translator_amd import hostglue
+    hostglue.refine_mask_gpu = lambda pg, pm, quads, mode=None: torch.from_numpy(hostglue.refine_mask(pg.numpy(), pm.numpy(), quads, mode))
     det = P.HipComicTextDetector(weights={})
     det.engine, det._loaded = FakeCtdEngine(), True
     page = np.full((1200, 840, 3), 245, np.uint8)
