@@ -1,0 +1,117 @@
+"""Multi-GPU path on one GPU box: what can be checked without a second GPU.
+
+* two ranks (gloo rendezvous, both on cuda:0) run the real PageEngine on their contiguous page blocks and rank 0 gathers the
+  per-page records: byte-identical to one process running all pages — a page's result does not depend on the world size, the
+  shard it landed in, or its neighbours in a batch (the reference processes pages independently, manga_translator.py:1491-1519);
+* a world-size-1 RCCL group (backend "nccl") runs the collectives dist.py uses — uint8 arena broadcast, gather to rank 0,
+  MAX all-reduce, barrier — on device tensors."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+H, W, LINES, T, D = 256, 192, 3, 4, 96
+N_PAGES = 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _records(weights, lo, hi):
+    from manga_image_translator_amd import pipeline, synth
+
+    dev = torch.device("cuda:0")
+    eng = pipeline.PageEngine(weights, device=dev, dict_size=D)
+    pages, quads, masks = zip(*[synth.synth_page(i, H, W, n_boxes=LINES) for i in range(lo, hi)])
+    res = eng.run(torch.from_numpy(np.stack(pages)).to(dev), [pipeline.quads_from_array(q) for q in quads],
+                  torch.from_numpy(np.stack(masks)).to(dev), max_seq_length=T, suppress_eos=True)
+    torch.cuda.synchronize()
+    return res.packed_pages(LINES)
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      MIT_DIST_BACKEND="gloo")
+    try:
+        from manga_image_translator_amd import dist as Dm, pipeline
+
+        Dm.init()
+        weights = Dm.broadcast_weights(pipeline.synthetic_weights(dict_size=D) if rank == 0 else None)
+        lo, hi = Dm.shard_range(N_PAGES, rank, world)
+        out = Dm.gather_pages(_records(weights, lo, hi))
+        if rank == 0:
+            q.put(("records", out.reshape(N_PAGES, -1).cpu().numpy()))
+        Dm.barrier()
+        torch.distributed.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:
+        q.put((rank, repr(e)))
+        raise
+
+
+def test_page_records_do_not_depend_on_world_size(cuda):
+    from manga_image_translator_amd import pipeline
+
+    single = _records(pipeline.synthetic_weights(dict_size=D), 0, N_PAGES).cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, oks = None, []
+    for _ in range(3):
+        item = q.get(timeout=600)
+        if item[0] == "records":
+            got = item[1]
+        else:
+            oks.append(item)
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(oks) == [(0, "ok"), (1, "ok")], oks
+    assert got.shape == single.shape and got.dtype == np.uint8
+    assert np.array_equal(got, single), f"{(got != single).sum()} bytes differ between world 1 and world 2"
+
+
+def _rccl_worker(port, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        dev = torch.device("cuda:0")
+        arena = torch.arange(1 << 20, dtype=torch.int64, device=dev).to(torch.uint8)
+        ref = arena.clone()
+        dist.broadcast(arena, src=0)                                     # the weight arena (dist.broadcast_weights)
+        packed = torch.arange(4096, dtype=torch.int32, device=dev).view(torch.uint8)
+        out = torch.empty((1,) + tuple(packed.shape), dtype=torch.uint8, device=dev)
+        dist.gather(packed, list(out.unbind(0)), dst=0)                  # the per-page records (dist.gather_pages)
+        t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                          # max-over-ranks timing (dist.max_over_ranks)
+        dist.barrier(device_ids=[0])
+        torch.cuda.synchronize()
+        ok = torch.equal(arena, ref) and torch.equal(out[0], packed) and float(t.item()) == 3.5
+        dist.destroy_process_group()
+        q.put("ok" if ok else "wrong results")
+    except Exception as e:
+        q.put(repr(e))
+        raise
+
+
+def test_rccl_world_size_one_smoke(cuda):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res == "ok", res
