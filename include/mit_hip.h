@@ -347,6 +347,9 @@ int mit_find_contours_count(const uint8_t *bitmap, int H, int W, int *n_contours
  * (REFINEMASK_INPAINT); then small holes are filled the same way. */
 int mit_merge_mask_list(const uint8_t *cands, const int64_t *scores, int n_cands, const uint8_t *pred_mask, int h, int w,
                         int inpaint_dilate, uint8_t *merged);
+/* cv2.threshold(..., THRESH_OTSU)'s threshold (getThreshVal_Otsu_8u) for n 256-bin histograms (host arrays): the per-channel
+ * Otsu splits of get_otsuthresh_masklist (ctd_utils/textmask.py:44-54) on the histograms mit_ctd_refine_hist returns. */
+int mit_otsu_from_hist(const int32_t *hist, int n, int32_t *thresholds);
 
 
 /* 48px OCR stage -----------------------------------------------------------------------------

@@ -178,3 +178,41 @@ extern "C" int mit_merge_mask_list(const uint8_t *cands, const int64_t *scores, 
         if (comps[l].area < thresh) try_merge(pixels.data() + comps[l].first, comps[l].area, pred.data(), merged);
     return 0;
 }
+
+// OpenCV's getThreshVal_Otsu_8u on 256-bin histograms (cv2.threshold(..., THRESH_OTSU) of get_otsuthresh_masklist,
+// ctd_utils/textmask.py:44-54): the grey level maximising the between-class variance, first maximum, same double-precision
+// recurrence as hostglue._otsu_threshold — evaluated here for the (3 channels x lines) histograms the GPU refine_mask hands back,
+// where the Python loop cost more than the GPU phases.
+extern "C" int mit_otsu_from_hist(const int32_t *hist, int n, int32_t *thresholds) {
+    if (!hist || !thresholds || n < 0) return mit_set_error("mit_otsu_from_hist: bad arguments");
+    for (int h = 0; h < n; ++h) {
+        const int32_t *hp = hist + (size_t)h * 256;
+        int64_t size = 0;
+        for (int i = 0; i < 256; ++i) size += hp[i];
+        int best = 0;
+        if (size > 0) {
+            const double scale = 1.0 / (double)size;
+            double mu = 0.0;
+            for (int i = 0; i < 256; ++i) mu += (double)i * (double)hp[i];
+            mu *= scale;
+            double q1 = 0.0, mu1 = 0.0, best_sigma = 0.0;
+            for (int i = 0; i < 256; ++i) {
+                const double p_i = (double)hp[i] * scale;
+                mu1 *= q1;
+                q1 += p_i;
+                const double q2 = 1.0 - q1;
+                const double mn = q1 < q2 ? q1 : q2, mx = q1 < q2 ? q2 : q1;
+                if (mn < 2.220446049250313e-16 || mx > 1.0 - 2.220446049250313e-16) continue;
+                mu1 = (mu1 + (double)i * p_i) / q1;
+                const double mu2 = (mu - q1 * mu1) / q2;
+                const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                if (sigma > best_sigma) {
+                    best_sigma = sigma;
+                    best = i;
+                }
+            }
+        }
+        thresholds[h] = best;
+    }
+    return 0;
+}

@@ -363,6 +363,9 @@ def refine_mask_gpu(page_dev, pred_dev, quads: Sequence, refine_mode=None):
     # get_topk_masklist (:56-71) + get_otsuthresh_masklist (:44-54) on the histograms
     cands = (_lib.MitRefineCand * (6 * n))()
     levels = np.arange(256, dtype=np.uint8)
+    ch_hist = np.ascontiguousarray(hist[:, 1:4])                      # Otsu thresholds of the three channels of every line, natively
+    otsu = np.zeros((n, 3), dtype=np.int32)
+    _lib.check(L.mit_otsu_from_hist(ch_hist.ctypes.data, 3 * n, otsu.ctypes.data), "mit_otsu_from_hist")
     for i, (a, b, c, d) in enumerate(wins):
         size = (c - a) * (d - b)
         g = hist[i, 0]
@@ -376,7 +379,7 @@ def refine_mask_gpu(page_dev, pred_dev, quads: Sequence, refine_mode=None):
             e.kind, e.lo, e.hi, e.invert = (1, bounds[0], bounds[1], 0) if bounds else (1, 1, 0, 0)  # lo > hi: selects nothing
         for ch in range(3):
             e = cands[i * 6 + 3 + ch]
-            e.kind, e.lo, e.hi, e.invert = 2 + ch, _otsu_from_hist(hist[i, 1 + ch], size), 0, 0
+            e.kind, e.lo, e.hi, e.invert = 2 + ch, int(otsu[i, ch]), 0, 0
     sums = np.zeros((n, 6), dtype=np.uint64)
     _lib.check(L.mit_ctd_refine_scores(*args, C.byref(cands), sums.ctypes.data, ws.data_ptr(), ws.numel(), st), "mit_ctd_refine_scores")
     # minxor_thresh (:29-42) per candidate, the best Otsu channel, merge order by score (stable, like sorted())

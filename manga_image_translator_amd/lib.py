@@ -198,6 +198,7 @@ SYMBOLS = {
     "mit_boxes_from_bitmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mit_merge_mask_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mit_otsu_from_hist": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mit_find_contours_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "mit_ocr_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_dwconv_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

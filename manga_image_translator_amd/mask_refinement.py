@@ -34,6 +34,13 @@ class CallableMaskBackend:
     def __init__(self, refine: RefineFn, bilateral: BilateralFn):
         self._refine, self._bilateral = refine, bilateral
 
+    def resize_image(self, img: np.ndarray, size):
+        """cv2.resize(img, (w, h), INTER_LINEAR) of the page (mask_refinement/__init__.py:17); may return a backend handle."""
+        return HG.resize_linear_u8(img, size)
+
+    def resize_mask(self, mask: np.ndarray, size) -> np.ndarray:
+        return HG.resize_linear_u8(mask, size)
+
     def filter_page(self, img: np.ndarray):
         return self._bilateral(img)
 
@@ -58,12 +65,27 @@ class GpuMaskBackend:
         self.device = torch.device(device)
         self._crf = densecrf.DenseCrfRefiner(self.device)
 
-    def filter_page(self, img: np.ndarray):
+    def _dev(self, a):
         import torch
 
+        return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def resize_image(self, img, size):
+        """The scaled page stays on the device: it only feeds the bilateral filter and the CRF crops (same tables as the host
+        resize, bit-identical bytes)."""
         from . import imgproc
 
-        return imgproc.bilateral_filter_u8(torch.from_numpy(np.ascontiguousarray(img)).to(self.device), 17, 80.0, 80.0)
+        return imgproc.resize_u8(self._dev(img)[None], size)[0]
+
+    def resize_mask(self, mask: np.ndarray, size) -> np.ndarray:
+        from . import imgproc
+
+        return imgproc.resize_u8(self._dev(mask)[None], size)[0].cpu().numpy()
+
+    def filter_page(self, img):
+        from . import imgproc
+
+        return imgproc.bilateral_filter_u8(self._dev(img), 17, 80.0, 80.0)
 
     def refine(self, page, rects, masks):
         return self._crf.refine(page, rects, masks)
@@ -180,6 +202,8 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
     boxes = [_xywh(t) for t in textlines]
     polys = [np.asarray(t.pts, dtype=np.float64) for t in textlines]
     areas2 = [HG_area(p) for p in polys]
+    pmin = np.array([p.min(0) for p in polys]).reshape(-1, 2)
+    pmax = np.array([p.max(0) for p in polys]).reshape(-1, 2)
     for x, y, w, h in boxes:  # cv2.rectangle(mask, (x, y), (x + w, y + h), 0, 1): one-pixel outline, inclusive corners, clipped
         xa, xb, ya, yb = max(x, 0), min(x + w, W - 1), max(y, 0), min(y + h, H - 1)
         if xa > xb or ya > yb:
@@ -204,15 +228,17 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
         sy, sx = objs[label - 1]
         x1, y1, w1, h1 = sx.start, sy.start, sx.stop - sx.start, sy.stop - sy.start
         ratio = np.zeros(M, dtype=np.float32)
-        dist = np.zeros(M, dtype=np.float32)
-        centre = (x1 + w1 / 2.0, y1 + h1 / 2.0)
-        for i in range(M):
+        # a line whose bounding box misses the component's has overlap exactly 0: only the others are clipped (:129-130)
+        near = np.nonzero((pmin[:, 0] <= x1 + w1) & (pmax[:, 0] >= x1) & (pmin[:, 1] <= y1 + h1) & (pmax[:, 1] >= y1))[0]
+        for i in near:
             ratio[i] = _clip_quad_to_rect_area(polys[i], x1, y1, x1 + w1, y1 + h1) / min(area1, areas2[i])
-            dist[i] = _polygon_point_distance(polys[i], centre)
         avg = int(np.argmax(ratio))
         if area1 >= areas2[avg]:
             continue
         if ratio[avg] <= keep_threshold:
+            # the distance matrix of :131 is only read on this branch, so it is only evaluated here
+            centre = (x1 + w1 / 2.0, y1 + h1 / 2.0)
+            dist = np.array([_polygon_point_distance(polys[i], centre) for i in range(M)], dtype=np.float32)
             avg = int(np.argmin(dist))
             unit = max(min([textlines[avg].font_size, w1, h1]), 10)
             if dist[avg] >= 0.5 * unit:
@@ -263,15 +289,15 @@ def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, met
     h, w = raw_image.shape[:2]
     scale = max(min((raw_mask.shape[0] - h / 3) / raw_mask.shape[0], 1), 0.5)
     size = (int(w * scale), int(h * scale))
-    img_small = HG.resize_linear_u8(raw_image, size)
-    mask_small = HG.resize_linear_u8(raw_mask, size).copy()
+    be = _backend_for(refine, bilateral, backend)
+    img_small = be.resize_image(raw_image, size)  # a device tensor with the GPU backend: it never comes back to the host
+    mask_small = be.resize_mask(raw_mask, size).copy()
     mask_small[mask_small > 0] = 255
     lines = [Quadrilateral(np.asarray(l) * scale, "", 0) for region in text_regions for l in region.lines]
-    final = complete_mask(img_small, mask_small, lines, dilation_offset=dilation_offset, kernel_size=kernel_size, refine=refine,
-                          bilateral=bilateral, backend=backend)
+    final = complete_mask(img_small, mask_small, lines, dilation_offset=dilation_offset, kernel_size=kernel_size, backend=be)
     if final is None:
         return np.zeros((h, w), dtype=np.uint8)
-    final = HG.resize_linear_u8(final, (w, h)).copy()
+    final = be.resize_mask(final, (w, h)).copy()
     final[final > 0] = 255
     return final
 

@@ -145,3 +145,19 @@ def test_in_range_follows_opencv_scalar_bounds():
         if shim is not None:
             assert np.array_equal(shim(g, lo, hi), m)
     assert not HG._in_range_u8(g, 120.0, 60.0).any() and not HG._in_range_u8(g, 256.2, 300.0).any() and not HG._in_range_u8(g, -50.0, -0.6).any()
+
+
+def test_native_otsu_from_histograms_matches_the_python_recurrence():
+    """mit_otsu_from_hist (the GPU refine_mask's host half) == hostglue._otsu_threshold on the image the histogram came from,
+    including constant and two-level images."""
+    from manga_image_translator_amd import hostglue as HG, lib
+
+    L = lib.load()
+    rng = np.random.default_rng(0)
+    imgs = [np.full((9, 9), 77, np.uint8), np.where(rng.random((20, 30)) < 0.3, 10, 240).astype(np.uint8)]
+    imgs += [rng.normal(rng.integers(40, 200), rng.integers(5, 60), (50, 70)).clip(0, 255).astype(np.uint8) for _ in range(12)]
+    hist = np.stack([np.bincount(i.reshape(-1), minlength=256) for i in imgs]).astype(np.int32)
+    out = np.zeros(len(imgs), np.int32)
+    lib.check(L.mit_otsu_from_hist(hist.ctypes.data, len(imgs), out.ctypes.data), "mit_otsu_from_hist")
+    assert out.tolist() == [HG._otsu_threshold(i) for i in imgs]
+    assert L.mit_otsu_from_hist(None, 1, None) != 0
