@@ -1,4 +1,4 @@
-"""ESRGAN 4x upscaler (``--upscaler esrgan``, ``4x-UltraSharp`` weights) on the gfx950 engine.
+"""ESRGAN 4x upscaler (``--upscaler 4xultrasharp``: RRDBNet with the ``4x-UltraSharp`` weights) on the gfx950 engine.
 
 Same network as ``RRDBNet(3, 3, nf=64, nb=23, upscale=4)`` of the reference
 (/root/reference/manga_translator/upscaling/esrgan_pytorch.py:28-167) and the tensor part of

@@ -1,8 +1,12 @@
 """Text-line geometry on the host: the ``Quadrilateral`` type that crosses every stage boundary and the
 plan for rectifying a line into a 48-px-high crop.
 
-Mirror of the reference's ``sort_pnts`` / ``Quadrilateral`` (/root/reference/manga_translator/utils/generic.py:324-443)
-and of the geometry half of ``Quadrilateral.get_transformed_region`` (:445-481).  The pixel half of that function
+Follows the reference's ``sort_pnts`` / ``Quadrilateral`` (/root/reference/manga_translator/utils/generic.py:324-443)
+and the geometry half of ``Quadrilateral.get_transformed_region`` (:445-481).  This is the interface type of the plugin
+boundary and its decision logic is integer-exact: ``sort_pnts`` (:334-353) and the predicate chain of
+``quadrilateral_can_merge_region`` (:656-695) are restated step for step — same comparisons, same thresholds, in the same order —
+because any other formulation changes which lines merge; results are pinned to the reference's own functions
+(tests/golden/textline.npz, direction.npz).  The pixel half of that function
 (cv2.warpPerspective + cv2.rotate) runs on the GPU: ``warp_plan`` only produces the crop rectangle, the destination
 size and the inverse homography that ``mit_ocr_warp_lines`` (csrc/ocr_warp.hip) consumes.
 """
