@@ -273,6 +273,11 @@ int mit_irfft_rows(const float *in_dev, int64_t in_bs, int64_t in_ts, int64_t in
  * FFCResNetGenerator.forward :604. */
 int mit_lama_prep(const uint8_t *img_dev, const uint8_t *mask_dev, float *out_dev, int B, int H, int W, void *stream);
 
+/* The same network input, written as the reflect-padded image [B, H + 2*pad, Wp, 4] (Wp >= W + 2*pad, the surplus columns zero) that
+ * the row-packed stem convolution reads: ReflectionPad2d(3) of FFCResNetGenerator.model[0] (inpainting_lama_mpe.py:560) materialised
+ * once, so that each kernel row of the 7x7 4->64 stem is ONE contiguous 32-float read (7 pixels x 4 channels + 4 zero-weight floats). */
+int mit_lama_prep_padded(const uint8_t *img_dev, const uint8_t *mask_dev, float *out_dev, int B, int H, int W, int pad, int Wp, void *stream);
+
 /* Masked positional-encoding index maps on the 256x256 structure grid:
  * hole = (INTER_AREA resize of the binary mask) > 0; relpos = clipped ring distance; direct = 4 direction bits.
  * Replaces LamaFourier.load_masked_position_encoding :751-807 (cv2.resize + the cv2.filter2D loop on the CPU).

@@ -32,6 +32,37 @@ __global__ void lama_prep_kernel(const uint8_t *__restrict__ img, const uint8_t 
     }
 }
 
+// ---- (1b) the same, written as the reflect-padded image the row-packed stem convolution reads: [B, H + 2 pad, Wp, 4] with
+// ReflectionPad2d(pad) materialised (inpainting_lama_mpe.py:560) and the columns beyond W + 2 pad zeroed (they meet zero weights,
+// but must be finite) ----
+__global__ void lama_prep_padded_kernel(const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask, float4 *__restrict__ out, int B,
+                                        int H, int W, int pad, int Wp) {
+    const int Hp = H + 2 * pad;
+    const int64_t total = (int64_t)B * Hp * Wp;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int x = (int)(i % Wp);
+        const int64_t r = i / Wp;
+        const int y = (int)(r % Hp);
+        const int64_t b = r / Hp;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (x < W + 2 * pad) {
+            int yy = y - pad, xx = x - pad;
+            yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+            xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+            const int64_t s = (b * H + yy) * W + xx;
+            const float m = ((float)mask[s] / 255.0f >= 0.5f) ? 1.f : 0.f;
+            const float k = 1.f - m;
+            v.x = ((float)img[3 * s + 0] / 255.0f) * k;
+            v.y = ((float)img[3 * s + 1] / 255.0f) * k;
+            v.z = ((float)img[3 * s + 2] / 255.0f) * k;
+            v.w = m;
+        }
+        out[i] = v;
+    }
+}
+
 // ---- (2a) area-resize of the binary mask to 256x256, "> 0" after rounding (:764-765) ----
 // Separable weights come from the host (same formula as the oracle restatement of cv2 INTER_AREA):
 // for destination index d, taps [start[d], start[d]+cnt[d]) with weights w[d*maxtaps + j].
@@ -196,6 +227,19 @@ extern "C" int mit_lama_prep(const uint8_t *img_dev, const uint8_t *mask_dev, fl
     hipLaunchKernelGGL(lama_prep_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, img_dev, mask_dev,
                        reinterpret_cast<float4 *>(out_dev), npix);
     MIT_CHECK_LAUNCH("mit_lama_prep");
+    return 0;
+}
+
+extern "C" int mit_lama_prep_padded(const uint8_t *img_dev, const uint8_t *mask_dev, float *out_dev, int B, int H, int W, int pad, int Wp,
+                                    void *stream) {
+    if (!img_dev || !mask_dev || !out_dev) return mit_set_error("mit_lama_prep_padded: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0) return mit_set_error("mit_lama_prep_padded: empty page");
+    if (pad < 0 || pad >= H || pad >= W || Wp < W + 2 * pad) return mit_set_error("mit_lama_prep_padded: bad padding (pad %d, Wp %d for %d x %d)", pad, Wp, H, W);
+    const int64_t npix = (int64_t)B * (H + 2 * pad) * Wp;
+    MitProbeScope probe("lama_prep_kernel", (hipStream_t)stream, (double)B * H * W * 4 + (double)npix * 16);
+    hipLaunchKernelGGL(lama_prep_padded_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, img_dev, mask_dev,
+                       reinterpret_cast<float4 *>(out_dev), B, H, W, pad, Wp);
+    MIT_CHECK_LAUNCH("mit_lama_prep_padded");
     return 0;
 }
 

@@ -139,6 +139,38 @@ def _nearest_map(n_dst: int, n_src: int) -> np.ndarray:
     return np.minimum(np.floor(np.arange(n_dst) * (n_src / n_dst)).astype(np.int64), n_src - 1).astype(np.int32)
 
 
+class _RowPackedStem:
+    """The 7x7 4->64 stem (ReflectionPad2d(3) + Conv2d + BN + ReLU, :560-563) on the 32-bit-offset fast GEMM kernel.
+
+    With Cin = 4 the implicit GEMM's K-tiles straddle taps, which sends the layer to the generic kernel (84 TFLOP/s).  On a
+    reflect-padded input [B, H+6, W+8, 4] a kernel ROW is one contiguous read of 8 pixels x 4 channels = 32 floats, so the layer
+    becomes 7 taps of "Cin = 32" with pixel stride 4: K = 224 instead of 196 (the 8th pixel meets zero weights), whole 16-float
+    K-tiles, no padding logic in the gather.  The accumulation order (ky, kx, c) is the generic kernel's, and the extra terms are
+    exact zeros, so the result is bit-identical to ``ops.Conv2d`` with reflect padding."""
+
+    K, PAD, WIN = 7, 3, 8
+
+    def __init__(self, conv: "ops.Conv2d", weight: torch.Tensor, device):
+        Cout, Cin, kh, kw = weight.shape
+        if (kh, kw) != (self.K, self.K) or Cin > 4:
+            raise ValueError("row-packed stem: 7x7 kernels with <= 4 input channels only")
+        w = torch.zeros(self.K, self.WIN, 4, Cout, dtype=torch.float32)   # [ky][pixel][c][n]
+        w[:, :self.K, :Cin] = weight.detach().to(torch.float32).permute(2, 3, 1, 0)
+        self.w, self.Kp, self.Np = ops.pack_weight_kn(w.reshape(self.K * self.WIN * 4, Cout), device)
+        self.Cout, self.scale, self.bias, self.act = Cout, conv.scale, conv.bias, conv.act
+
+    def padded_shape(self, B, H, W):
+        return (B, H + 2 * self.PAD, W + self.WIN, 4)
+
+    def __call__(self, xp: torch.Tensor, out: torch.Tensor):
+        B, Hp, Wp, _ = xp.shape
+        H, W = Hp - 2 * self.PAD, Wp - self.WIN
+        launch_conv_gemm(conv_gemm_desc(
+            a=xp, NB=B, Hi=Hp, Wi=W, Cin=self.WIN * 4, a_strides=(Hp * Wp * 4, Wp * 4, 4), Ho=H, Wo=W, sy=1, sx=1,
+            taps=[(ky, 0, 0) for ky in range(self.K)], pad_mode=PAD_ZERO, w=self.w, ldw=self.Np, Kw=self.Kp, Nw=self.Np,
+            N=self.Cout, c=tensor_map(out), scale=self.scale, bias=self.bias, act=self.act))
+
+
 class _FFC:
     """One FFC_BN_ACT of a res-block (:372-399): packed layers."""
 
@@ -170,7 +202,8 @@ class LamaEngine:
     """Batched LaMa generator. ``forward(img_u8[B,H,W,3], mask_u8[B,H,W]) -> u8 [B,H,W,3]`` (device tensors)."""
 
     def __init__(self, gen_sd: Dict[str, torch.Tensor], mpe_sd: Optional[Dict[str, torch.Tensor]] = None,
-                 n_blocks: int = 9, device="cuda", fft_h: bool = True, winograd: bool = True, fft_w: bool = True):
+                 n_blocks: int = 9, device="cuda", fft_h: bool = True, winograd: bool = True, fft_w: bool = True,
+                 row_packed_stem: bool = True):
         self.device = torch.device(device)
         self.winograd = winograd  # False: the FFC blocks' 3x3 convolutions in direct (9-tap) form, for A/B comparison
         self.fft_h = fft_h  # False: keep the H-axis transform on the dense DFT GEMM (for A/B comparison)
@@ -179,6 +212,7 @@ class LamaEngine:
         sd, dev = gen_sd, self.device
         self.stem = ops.Conv2d(sd["model.1.ffc.convl2l.weight"], None, padding=3, pad_mode=PAD_REFLECT,
                                bn=_bn(sd, "model.1.bn_l"), act=ACT_RELU, device=dev)
+        self.stem_packed = _RowPackedStem(self.stem, sd["model.1.ffc.convl2l.weight"], dev) if row_packed_stem else None
         self.down1 = ops.Conv2d(sd["model.2.ffc.convl2l.weight"], None, stride=2, padding=1, pad_mode=PAD_REFLECT,
                                 bn=_bn(sd, "model.2.bn_l"), act=ACT_RELU, device=dev)
         self.down2 = ops.Conv2d(sd["model.3.ffc.convl2l.weight"], None, stride=2, padding=1, pad_mode=PAD_REFLECT,
@@ -370,10 +404,16 @@ class LamaEngine:
         img_u8, mask_u8 = img_u8.contiguous(), mask_u8.contiguous()
         lib = _lib.load()
         st = C.c_void_p(ops.current_stream())
-        x4 = self._buf("in4", B, H, W, 4)
-        _lib.check(lib.mit_lama_prep(img_u8.data_ptr(), mask_u8.data_ptr(), x4.data_ptr(), B, H, W, st), "mit_lama_prep")
         s64 = self._buf("full64", B, H, W, 64)
-        self.stem(x4, out=s64)
+        if self.stem_packed is not None and H > 3 and W > 3:
+            xp = self._buf("in4p", *self.stem_packed.padded_shape(B, H, W))
+            _lib.check(lib.mit_lama_prep_padded(img_u8.data_ptr(), mask_u8.data_ptr(), xp.data_ptr(), B, H, W, 3, xp.shape[2], st),
+                       "mit_lama_prep_padded")
+            self.stem_packed(xp, s64)
+        else:  # row_packed_stem=False: the plain reflect-padded Conv2d on the generic kernel (A/B comparison)
+            x4 = self._buf("in4", B, H, W, 4)
+            _lib.check(lib.mit_lama_prep(img_u8.data_ptr(), mask_u8.data_ptr(), x4.data_ptr(), B, H, W, st), "mit_lama_prep")
+            self.stem(x4, out=s64)
         if self.mpe is not None:
             tb = self._mpe_tables(H, W)
             hole = self._buf("mpe_hole", B, MPE_S, MPE_S, dtype=torch.uint8)

@@ -8,7 +8,7 @@ B = int(os.environ.get("B", "4")); H, W = 2048, 1456
 nb = int(os.environ.get("NB", "9"))
 sd = synth.synth_state_dict(lama_schema.lama_generator_schema(nb))
 mpe_sd = synth.synth_state_dict(lama_schema.lama_mpe_schema()) if nb == 9 else None
-eng = lama.LamaEngine(sd, mpe_sd, n_blocks=nb, device=dev)
+eng = lama.LamaEngine(sd, mpe_sd, n_blocks=nb, device=dev, row_packed_stem=not os.environ.get("PLAIN_STEM"))
 pages, masks = zip(*[(p, m) for p, _, m in (synth.synth_page(i) for i in range(B))])
 img = torch.from_numpy(np.stack(pages)).to(dev); msk = torch.from_numpy(np.stack(masks)).to(dev)
 for _ in range(2):

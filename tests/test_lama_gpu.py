@@ -210,3 +210,24 @@ def test_rfft_rows_rejects_unsupported_widths(cuda):
     for w in (181, 362, 2 * 17, 514, 2, 0, -4):  # odd, 2 * prime > 13, too long, too short
         assert not Lh.mit_rfft_rows_supported(w)
     assert Lh.mit_rfft_rows(None, 0, 0, 0, None, 0, 0, 0, 0, None, 1, 1, 182, 192, 1.0, None) != 0
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 72, 2), (256, 184, 1), (8, 8, 1)])
+def test_row_packed_stem_is_bit_identical(cuda, H, W, B):
+    """The 7x7 4->64 stem as 7 taps of one contiguous 32-float read on the reflect-padded input (fast kernel) == the plain
+    reflect-padded Conv2d on the generic kernel: same (ky, kx, c) accumulation order, the surplus terms are exact zeros."""
+    from manga_image_translator_amd import lama, lama_schema, synth
+
+    sd = synth.synth_state_dict(lama_schema.lama_generator_schema(1))
+    rng = np.random.default_rng(H + W)
+    img = torch.from_numpy(rng.integers(0, 256, (B, H, W, 3)).astype(np.uint8)).to(cuda)
+    msk = torch.from_numpy((rng.random((B, H, W)) < 0.3).astype(np.uint8) * 255).to(cuda)
+    taps = []
+    for packed in (True, False):
+        eng = lama.LamaEngine(sd, None, n_blocks=1, device=cuda, row_packed_stem=packed)
+        t = {}
+        eng.forward(img, msk, taps=t)
+        torch.cuda.synchronize()
+        taps.append(t)
+    assert torch.equal(taps[0]["stem"], taps[1]["stem"])
+    assert torch.equal(taps[0]["pred"], taps[1]["pred"])
