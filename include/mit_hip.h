@@ -320,12 +320,6 @@ int mit_maxpool2d_nhwc(const float *in_dev, float *out_dev, int B, int H, int W,
 /* NHWC 2x2/2 average pool — nn.AvgPool2d(2, 2) of double_conv_c3 (ctd_utils/basemodel.py:28-39). */
 int mit_avgpool2_nhwc(const float *in_dev, int64_t in_pixstride, float *out_dev, int64_t out_pixstride, int B, int Ho,
                       int Wo, int C, void *stream);
-/* ConvTranspose2d with 1..4 output channels as ONE GEMM + col2im: p_dev = X . W_all, [B,H,W, kh*kw*Cout] (column (ky*kw + kx)*Cout + n),
- * is gathered into out[B,Ho,Wo] (pixel stride out_pixstride floats): out = act(scale * sum of the taps that land on the pixel + bias).
- * Replaces the stride^2 sub-pixel launches of the ctd heads' last ConvTranspose2d(64, 1, 4, 2, 1) (ctd_utils/basemodel.py:52,93-96),
- * each of which re-read the input for a 1-column contraction. */
-int mit_col2im_small(const float *p_dev, float *out_dev, int64_t out_pixstride, int B, int H, int W, int kh, int kw, int stride, int padding,
-                     int output_padding, int Cout, const float *scale_dev, const float *bias_dev, int act, float act_alpha, void *stream);
 /* channel-slice copy between NHWC buffers (torch.cat inputs that need a second home, basemodel.py:62-68,102-103). */
 int mit_copy_channels(const float *in_dev, int64_t in_pixstride, float *out_dev, int64_t out_pixstride, int64_t npix,
                       int C, void *stream);

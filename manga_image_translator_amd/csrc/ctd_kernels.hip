@@ -181,51 +181,6 @@ __global__ void axpy_kernel(float4 *__restrict__ out, float a, const float4 *__r
     }
 }
 
-// ---- col2im for transposed convolutions with <= 4 output channels: out[b, Y, X, n] = act(scale * sum over the kernel taps
-// (ky, kx) with (Y + p - ky) % s == 0, (X + p - kx) % s == 0 of P[b, (Y + p - ky) / s, (X + p - kx) / s, (ky * kw + kx) * Cout + n]
-// + bias), P = X . W_all being ONE GEMM with N = kh * kw * Cout columns.  The sub-pixel form would run stride^2 launches of an
-// N = Cout <= 4 contraction each re-reading the input; this reads it once. ----
-__global__ void col2im_small_kernel(const float *__restrict__ P, float *__restrict__ out, int64_t out_pix, int B, int H, int W, int Ho, int Wo,
-                                    int kh, int kw, int s, int p, int Cout, const float *__restrict__ scale,
-                                    const float *__restrict__ bias, int act, float alpha) {
-    const int64_t total = (int64_t)B * Ho * Wo;
-    const int NP = kh * kw * Cout;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int X = (int)(i % Wo);
-        const int64_t r = i / Wo;
-        const int Y = (int)(r % Ho);
-        const int64_t b = r / Ho;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int ky = 0; ky < kh; ++ky) {
-            const int ty = Y + p - ky;
-            if (ty < 0 || ty % s) continue;
-            const int y = ty / s;
-            if (y >= H) continue;
-            for (int kx = 0; kx < kw; ++kx) {
-                const int tx = X + p - kx;
-                if (tx < 0 || tx % s) continue;
-                const int x = tx / s;
-                if (x >= W) continue;
-                const float *pp = P + ((b * H + y) * W + x) * NP + (ky * kw + kx) * Cout;
-                for (int n = 0; n < Cout; ++n) acc[n] += pp[n];
-            }
-        }
-        float *o = out + i * out_pix;
-        for (int n = 0; n < Cout; ++n) {
-            float v = acc[n] * (scale ? scale[n] : 1.f) + (bias ? bias[n] : 0.f);
-            switch (act) {
-                case MIT_ACT_RELU: v = v > 0.f ? v : 0.f; break;
-                case MIT_ACT_LEAKY: v = v > 0.f ? v : v * alpha; break;
-                case MIT_ACT_SILU: v = v / (1.f + expf(-v)); break;
-                case MIT_ACT_SIGMOID: v = 1.f / (1.f + expf(-v)); break;
-                default: break;
-            }
-            o[n] = v;
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" int mit_maxpool2d_nhwc(const float *in_dev, float *out_dev, int B, int H, int W, int C, int k, int s, int p, void *stream) {
@@ -286,22 +241,6 @@ extern "C" int mit_avgpool2_nhwc(const float *in_dev, int64_t in_pixstride, floa
     hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in_dev, in_pixstride,
                        out_dev, out_pixstride, B, Ho, Wo, C / 4);
     MIT_CHECK_LAUNCH("mit_avgpool2_nhwc");
-    return 0;
-}
-
-extern "C" int mit_col2im_small(const float *p_dev, float *out_dev, int64_t out_pixstride, int B, int H, int W, int kh, int kw, int stride,
-                                int padding, int output_padding, int Cout, const float *scale_dev, const float *bias_dev, int act,
-                                float act_alpha, void *stream) {
-    if (!p_dev || !out_dev) return mit_set_error("mit_col2im_small: null pointer");
-    if (B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || padding < 0 || Cout < 1 || Cout > 4 || out_pixstride < Cout)
-        return mit_set_error("mit_col2im_small: bad arguments (1 <= Cout <= 4)");
-    const int Ho = (H - 1) * stride - 2 * padding + kh + output_padding, Wo = (W - 1) * stride - 2 * padding + kw + output_padding;
-    if (Ho <= 0 || Wo <= 0) return mit_set_error("mit_col2im_small: empty output");
-    const int64_t total = (int64_t)B * Ho * Wo;
-    MitProbeScope probe("col2im_small_kernel", (hipStream_t)stream, 4.0 * ((double)B * H * W * kh * kw * Cout + (double)total * Cout));
-    hipLaunchKernelGGL(col2im_small_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, p_dev, out_dev, out_pixstride, B, H, W,
-                       Ho, Wo, kh, kw, stride, padding, Cout, scale_dev, bias_dev, act, act_alpha);
-    MIT_CHECK_LAUNCH("mit_col2im_small");
     return 0;
 }
 

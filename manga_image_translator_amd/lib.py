@@ -193,8 +193,6 @@ SYMBOLS = {
                                      C.c_void_p]),
     "mit_avgpool2_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p]),
-    "mit_col2im_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                   C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "mit_copy_channels": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "mit_map_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "mit_axpy": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -10,7 +10,6 @@ which is how concat and the sub-pixel form of ConvTranspose2d are expressed with
 from __future__ import annotations
 
 import ctypes as C
-import os
 import math
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
@@ -415,9 +414,6 @@ class UpsampleConv2d:
     def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, cfg: int = -1) -> torch.Tensor:
         if out is None:
             out = torch.empty(x.shape[0], 2 * x.shape[1], 2 * x.shape[2], self.Cout, dtype=torch.float32, device=x.device)
-        if self.scatter is not None and cfg < 0:
-            self._scatter_call(x, out)
-            return out
         for d in self.descs(x, out):
             launch_conv_gemm(d, cfg)
         return out
@@ -463,30 +459,9 @@ class ConvTranspose2d:
             bias_t = bias.detach().to(torch.float32)
         self.scale = None if scale is None else scale.to(device).contiguous()
         self.bias = None if bias_t is None else bias_t.to(device).contiguous()
-        # Cout <= 4 with a kernel larger than the stride: one GEMM X . W_all [Cin, kh*kw*Cout] + col2im (mit_col2im_small) instead of
-        # stride^2 sub-pixel launches that each re-read the input for a <= 4-column contraction
-        self.scatter = None
-        if Cout <= 4 and kh * kw > stride * stride and Cin % 16 == 0 and not os.environ.get("MIT_CONVT_NO_SCATTER"):
-            w_all = w.permute(0, 2, 3, 1).reshape(Cin, kh * kw * Cout)  # column (ky*kw + kx)*Cout + n
-            self.scatter = _Packed(*pack_weight_kn(w_all, device), [(0, 0, 0)])
 
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         return ((H - 1) * self.s - 2 * self.p + self.k[0] + self.op, (W - 1) * self.s - 2 * self.p + self.k[1] + self.op)
-
-    def _scatter_call(self, x: torch.Tensor, out: torch.Tensor) -> None:
-        B, H, W, _ = x.shape
-        pk = self.scatter
-        ncol = self.k[0] * self.k[1] * self.Cout
-        P = torch.empty(B, H, W, ncol, dtype=torch.float32, device=x.device)
-        launch_conv_gemm(conv_gemm_desc(
-            a=x, NB=B, Hi=H, Wi=W, Cin=self.Cin, a_strides=(x.stride(0), x.stride(1), x.stride(2)), Ho=H, Wo=W, sy=1, sx=1,
-            taps=pk.taps, pad_mode=PAD_ZERO, w=pk.w, ldw=pk.Np, Kw=pk.Kp, Nw=pk.Np, N=ncol, c=tensor_map(P)))
-        if not out.is_contiguous() and (out.stride(3) != 1 or out.stride(2) < self.Cout or out.stride(1) != out.shape[2] * out.stride(2)
-                                        or out.stride(0) != out.shape[1] * out.stride(1)):
-            raise ValueError("ConvTranspose2d: the col2im form needs a pixel-strided output (channel slice of a contiguous NHWC tensor)")
-        _lib.check(_lib.load().mit_col2im_small(P.data_ptr(), out.data_ptr(), out.stride(2), B, H, W, self.k[0], self.k[1], self.s, self.p,
-                                                self.op, self.Cout, _ptr(self.scale), _ptr(self.bias), self.act, self.alpha,
-                                                C.c_void_p(current_stream())), "mit_col2im_small")
 
     def descs(self, x: torch.Tensor, out: torch.Tensor) -> List[MitConvGemm]:
         _check_nhwc(x, "ConvTranspose2d input")
