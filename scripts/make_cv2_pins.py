@@ -47,8 +47,8 @@ def cv2_section(out):
         for tag, (dw, dh) in {"half": (w // 2, h // 2), "up": (w * 2 + 3, h + 17), "odd": (77, 53), "x8": ((w + 7) // 8 * 8, (h + 7) // 8 * 8)}.items():
             out[f"resize_linear_{name}_{tag}"] = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LINEAR)
             out[f"resize_exact_{name}_{tag}"] = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LINEAR_EXACT)
-            out[f"resize_area_{name}_{tag}"] = cv2.resize(img[..., 0], (dw, dh), interpolation=cv2.INTER_AREA)
-            out[f"resize_nearest_{name}_{tag}"] = cv2.resize(img[..., 0], (dw, dh), interpolation=cv2.INTER_NEAREST)
+            out[f"resize_area_{name}_{tag}"] = cv2.resize(np.ascontiguousarray(img[..., 0]), (dw, dh), interpolation=cv2.INTER_AREA)
+            out[f"resize_nearest_{name}_{tag}"] = cv2.resize(np.ascontiguousarray(img[..., 0]), (dw, dh), interpolation=cv2.INTER_NEAREST)
     mask = (rng.random((200, 150)) < 0.3).astype(np.uint8) * 255
     out["mask_in"] = mask
     out["resize_area_mask_256"] = cv2.resize(mask, (256, 256), interpolation=cv2.INTER_AREA)
@@ -70,9 +70,9 @@ def cv2_section(out):
     for i, (lo, hi) in enumerate(out["inrange_lo_hi"]):
         out[f"inrange_{i}"] = cv2.inRange(g, float(lo), float(hi))
     for c in range(3):
-        t, th = cv2.threshold(b[..., c], 1, 255, cv2.THRESH_OTSU + cv2.THRESH_BINARY)
+        t, th = cv2.threshold(np.ascontiguousarray(b[..., c]), 1, 255, cv2.THRESH_OTSU + cv2.THRESH_BINARY)
         out[f"otsu_thr_{c}"], out[f"otsu_img_{c}"] = np.array(t), th
-    n, lab, stats, cent = cv2.connectedComponentsWithStats(blob, 8, cv2.CV_16U)
+    n, lab, stats, cent = cv2.connectedComponentsWithStats(blob, connectivity=8, ltype=cv2.CV_32S)
     out["cc_n"], out["cc_labels"], out["cc_stats"] = np.array(n), lab, stats
     out["filter2d_3x3"] = cv2.filter2D(blob, -1, np.ones((3, 3), np.float32))
     out["rot90ccw"] = cv2.rotate(a, cv2.ROTATE_90_COUNTERCLOCKWISE)
