@@ -36,7 +36,7 @@ bool fast_eligible(const MitConvGemm &p, int BK) {
     return maxoff + tmax < 0x7fffffffLL;
 }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-constexpr int kCfgGemv16 = 26, kCfgGemv4 = 27, kCfgGemv16N1 = 28, kCfgGemv4N1 = 29;
+constexpr int kCfgSmall = 26, kCfgGemv16 = 27, kCfgGemv4 = 28, kCfgGemv16N1 = 29, kCfgGemv4N1 = 30;
 
 // conv_gemv_kernel preconditions: <= 4 output columns, plain (unbatched, unsplit) maps, the whole weight panel in LDS
 bool gemv_eligible(const MitConvGemm &p, int lpr) {
@@ -65,6 +65,10 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     if (p.N <= 32) return 2;
     if (f16 && m192 >= 0 && M > 128 && M <= 192) return m192;  // 2 x 128 rows would run a 40 % empty second tile
     if (f16 && bigk >= 0 && p.N % 128 == 0 && p.N <= 128 && p.ntaps * p.Cin >= 4096 && M >= 256 * 1024) return bigk;
+    // under-filled launches (the decoder's GEMMs: M = lines x beams = 10240): a 128-row tiling leaves most CUs with one workgroup or
+    // none, 64 x 64 tiles double the count
+    static const int small = getenv("MIT_CONV_NO_SMALL_TILE") ? -1 : kCfgSmall;
+    if (f16 && small >= 0 && p.Z == 1 && p.N > 32 && ((M + 127) / 128) * ((p.N + 63) / 64) < 640) return small;
     const int rem = p.N % 128;
     const bool lines = f16 && p.Cin % 32 == 0;
     if (p.N <= 64 || (rem != 0 && rem <= narrow_max)) return f16 ? (lines && narrow_l >= 0 ? narrow_l : narrow) : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile

@@ -51,8 +51,10 @@ CASES = [
     (1, 160, 160, 6, 33, (2, 1), (2, 1), 0, "zero", 1, True, -1),
     (2, 64, 1, 20, 24, 3, 1, 1, "zero", 4, True, -1),      # N = 1: conv_gemv_kernel, 16 lanes per row
     (1, 16, 1, 19, 21, 1, 1, 0, "zero", 4, False, -1),     # N = 1, Cin = 16: 4 lanes per row
-    (1, 16, 2, 15, 18, 3, 1, 1, "reflect", 1, True, 27),   # N = 2 forced onto gemv4
-    (1, 128, 4, 9, 40, 3, 2, 1, "zero", 2, False, 26),     # N = 4, stride 2, forced onto gemv16
+    (1, 16, 2, 15, 18, 3, 1, 1, "reflect", 1, True, 28),   # N = 2 forced onto gemv4
+    (1, 128, 4, 9, 40, 3, 2, 1, "zero", 2, False, 27),     # N = 4, stride 2, forced onto gemv16
+    (2, 320, 320, 7, 33, 1, 1, 0, "zero", 5, False, 26),   # the 64 x 64 fast tile (decoder-sized GEMM), GELU
+    (1, 64, 96, 12, 10, 3, 1, 1, "reflect", 1, True, 26),  # 64 x 64 fast tile, 3x3 reflect, ragged N
 ]
 
 
