@@ -68,7 +68,8 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     // under-filled launches (the decoder's GEMMs: M = lines x beams = 10240): a 128-row tiling leaves most CUs with one workgroup or
     // none, 64 x 64 tiles double the count
     static const int small = getenv("MIT_CONV_NO_SMALL_TILE") ? -1 : kCfgSmall;
-    if (f16 && small >= 0 && p.Z == 1 && p.N > 32 && ((M + 127) / 128) * ((p.N + 63) / 64) < 640) return small;
+    static const int64_t small_max = getenv("MIT_CONV_SMALL_MAX") ? atoll(getenv("MIT_CONV_SMALL_MAX")) : 640;
+    if (f16 && small >= 0 && p.Z == 1 && p.N > 32 && ((M + 127) / 128) * ((p.N + 63) / 64) < small_max) return small;
     const int rem = p.N % 128;
     const bool lines = f16 && p.Cin % 32 == 0;
     if (p.N <= 64 || (rem != 0 && rem <= narrow_max)) return f16 ? (lines && narrow_l >= 0 ? narrow_l : narrow) : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile

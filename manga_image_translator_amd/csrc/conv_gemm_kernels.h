@@ -684,7 +684,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     }
     if (X_NOBAR) __syncthreads();
 
-    epilogue<BM, TM, TN, (VAR >> 12) & 3, 2 * A_TILE + 2 * B_TILE>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+    // the launcher sizes the dynamic LDS for the larger of the staging area and the epilogue's row table + per-wave transpose
+    // buffers, so small tiles (64 x 64) get the dwordx4 store path too
+    constexpr int EPI_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4 + 4 * 32 * EPI_PITCH;
+    constexpr int SMEM_F = (2 * A_TILE + 2 * B_TILE) > EPI_FLOATS ? (2 * A_TILE + 2 * B_TILE) : EPI_FLOATS;
+    epilogue<BM, TM, TN, (VAR >> 12) & 3, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
 }
 // ---- N <= 4: one output column group per row — a dot product, not a tile ------------------------------------------------
 // An MFMA tile would idle >= 28 of its 32 columns (the ctd heads' last ConvTranspose2d 64 -> 1 and 16 -> 1 ran at 2 TFLOP/s on
@@ -810,7 +814,7 @@ void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
     constexpr int LDA = BM + (BK == 16 ? 2 : 1);
     constexpr int LDB = BN + 4;
     size_t staging = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + (size_t)p.ntaps * BM * sizeof(int);
-    size_t rows = (size_t)BM * sizeof(RowOff);
+    size_t rows = ((size_t)BM * sizeof(RowOff) + 15) / 16 * 16 + (size_t)4 * 32 * EPI_PITCH * sizeof(float);  // row table + transpose buffers
     size_t smem = staging > rows ? staging : rows;
     auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, VAR>;
     static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
