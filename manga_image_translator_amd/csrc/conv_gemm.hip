@@ -68,7 +68,7 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     // under-filled launches (the decoder's GEMMs: M = lines x beams = 10240): a 128-row tiling leaves most CUs with one workgroup or
     // none, 64 x 64 tiles double the count
     static const int small = getenv("MIT_CONV_NO_SMALL_TILE") ? -1 : kCfgSmall;
-    static const int64_t small_max = getenv("MIT_CONV_SMALL_MAX") ? atoll(getenv("MIT_CONV_SMALL_MAX")) : 640;
+    static const int64_t small_max = getenv("MIT_CONV_SMALL_MAX") ? atoll(getenv("MIT_CONV_SMALL_MAX")) : 1280;  // swept 640 .. 5120 on the OCR and detector stages (same-box A/B): 1280 = one full wave of workgroups
     if (f16 && small >= 0 && p.Z == 1 && p.N > 32 && ((M + 127) / 128) * ((p.N + 63) / 64) < small_max) return small;
     const int rem = p.N % 128;
     const bool lines = f16 && p.Cin % 32 == 0;
