@@ -12,8 +12,9 @@
 // the two halves of every packed operand: the LDS tile stores, per pixel and channel pair, (row y c0, row y+8 c0, row y c1,
 // row y+8 c1), so one ds_read_b128 yields two ready-made packed operands; the two columns (x, x + 1) share a sliding window of
 // K + 1 such reads per kernel row.  Even / odd pixels of a tile row sit in separate halves of the LDS row so that the 64 lanes of
-// a wave (stride 2 pixels) read consecutive 16-byte slots.  No 4th accumulator.  Accumulation order: 4-channel slice, channel
-// pair, tap (ky, kx), channel.
+// a wave (stride 2 pixels) read consecutive 16-byte slots.  No 4th accumulator.  Each thread stages a 16-channel group (whole
+// 64-byte pieces of its tile cells) in registers and feeds four 4-channel LDS slices from it, so a 128-byte input line is touched
+// by 4 groups, not by 16 slices.  Accumulation order: 4-channel slice, channel pair, tap (ky, kx), channel.
 //
 // Reference op: FFCResNetGenerator.model[-2:] = ReflectionPad2d(3) + Conv2d(64, 3, 7) + sigmoid
 // (manga_translator/inpainting/inpainting_lama_mpe.py:597-600).
@@ -120,9 +121,14 @@ __global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__re
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int n = 0; n < 3; ++n) acc[j][n] = f32x2{0.f, 0.f};
-    for (int c0 = 0; c0 < Cin; c0 += 4) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < PR * HW_; i += 256) {
+    constexpr int ITEMS = (PR * HW_ + 255) / 256;  // (pair row, pixel) cells of the tile per thread
+    for (int g0 = 0; g0 < Cin; g0 += 16) {
+        // stage a 16-channel group of every cell in registers: whole 64-byte pieces per pixel (two rows), so each 128-byte line of
+        // the NHWC input is touched by 4 such groups instead of by 16 four-channel slices
+        f32x4 ra[ITEMS][4], rb[ITEMS][4];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int i = threadIdx.x + it * 256;
             const int ly = i / HW_, lx = i - ly * HW_;
             int ya = y0 + ly - R, yb = ya + TH3 / 2, xx = x0 + lx - R;
             if (reflect) {
@@ -130,36 +136,55 @@ __global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__re
                 yb = yb < 0 ? -yb : (yb >= H ? 2 * H - 2 - yb : yb);
                 xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
             }
-            const bool xok = xx >= 0 && xx < W;  // still outside after one reflection: tile overhang, never used
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, bq = {0.f, 0.f, 0.f, 0.f};
-            if (xok && ya >= 0 && ya < H) a = *reinterpret_cast<const f32x4 *>(ib + ((int64_t)ya * W + xx) * in_pix + c0);
-            if (xok && yb >= 0 && yb < H) bq = *reinterpret_cast<const f32x4 *>(ib + ((int64_t)yb * W + xx) * in_pix + c0);
-            const int slot = (lx >> 1) + (lx & 1) * HALF;
-            tile[0][ly][slot] = f32x4{a.x, bq.x, a.y, bq.y};
-            tile[1][ly][slot] = f32x4{a.z, bq.z, a.w, bq.w};
+            const bool cell = i < PR * HW_ && xx >= 0 && xx < W;  // still outside after one reflection: tile overhang, never used
+            const bool oka = cell && ya >= 0 && ya < H, okb = cell && yb >= 0 && yb < H;
+            const float *pa = ib + ((int64_t)ya * W + xx) * in_pix + g0, *pb = ib + ((int64_t)yb * W + xx) * in_pix + g0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ra[it][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                rb[it][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (oka) ra[it][q] = *reinterpret_cast<const f32x4 *>(pa + q * 4);
+                if (okb) rb[it][q] = *reinterpret_cast<const f32x4 *>(pb + q * 4);
+            }
         }
-        __syncthreads();
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = g0 + q * 4;
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < PR * HW_) {
+                    const int ly = i / HW_, lx = i - ly * HW_;
+                    const int slot = (lx >> 1) + (lx & 1) * HALF;
+                    const f32x4 a = ra[it][q], bq = rb[it][q];
+                    tile[0][ly][slot] = f32x4{a.x, bq.x, a.y, bq.y};
+                    tile[1][ly][slot] = f32x4{a.z, bq.z, a.w, bq.w};
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
 #pragma unroll 1
-            for (int ky = 0; ky < K; ++ky) {
-                f32x4 win[K + 1];
+                for (int ky = 0; ky < K; ++ky) {
+                    f32x4 win[K + 1];
 #pragma unroll
-                for (int i = 0; i <= K; ++i) win[i] = tile[cp][ty + ky][tx + (i >> 1) + (i & 1) * HALF];
+                    for (int i = 0; i <= K; ++i) win[i] = tile[cp][ty + ky][tx + (i >> 1) + (i & 1) * HALF];
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-                    const f32x4 *wt = w4 + (int64_t)(ky * K + kx) * Cin + c0 + cp * 2;  // wave-uniform -> scalar loads
-                    const f32x4 wa = wt[0], wb = wt[1];
+                    for (int kx = 0; kx < K; ++kx) {
+                        const f32x4 *wt = w4 + (int64_t)(ky * K + kx) * Cin + c0 + cp * 2;  // wave-uniform -> scalar loads
+                        const f32x4 wa = wt[0], wb = wt[1];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const f32x4 v = win[kx + j];
-                        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-                        acc[j][0] = __builtin_elementwise_fma(lo, f32x2{wa.x, wa.x}, acc[j][0]);
-                        acc[j][1] = __builtin_elementwise_fma(lo, f32x2{wa.y, wa.y}, acc[j][1]);
-                        acc[j][2] = __builtin_elementwise_fma(lo, f32x2{wa.z, wa.z}, acc[j][2]);
-                        acc[j][0] = __builtin_elementwise_fma(hi, f32x2{wb.x, wb.x}, acc[j][0]);
-                        acc[j][1] = __builtin_elementwise_fma(hi, f32x2{wb.y, wb.y}, acc[j][1]);
-                        acc[j][2] = __builtin_elementwise_fma(hi, f32x2{wb.z, wb.z}, acc[j][2]);
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x4 v = win[kx + j];
+                            const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+                            acc[j][0] = __builtin_elementwise_fma(lo, f32x2{wa.x, wa.x}, acc[j][0]);
+                            acc[j][1] = __builtin_elementwise_fma(lo, f32x2{wa.y, wa.y}, acc[j][1]);
+                            acc[j][2] = __builtin_elementwise_fma(lo, f32x2{wa.z, wa.z}, acc[j][2]);
+                            acc[j][0] = __builtin_elementwise_fma(hi, f32x2{wb.x, wb.x}, acc[j][0]);
+                            acc[j][1] = __builtin_elementwise_fma(hi, f32x2{wb.y, wb.y}, acc[j][1]);
+                            acc[j][2] = __builtin_elementwise_fma(hi, f32x2{wb.z, wb.z}, acc[j][2]);
+                        }
                     }
                 }
             }
