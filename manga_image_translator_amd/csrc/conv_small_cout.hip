@@ -221,10 +221,12 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w4_dev);
     const int refl = pad_mode == MIT_PAD_REFLECT;
     // VALU-bound: algorithmic FLOPs 2 k^2 Cin Cout per pixel; bytes: input read once + Cout outputs written
-    MitProbeScope probe(k == 7 ? "conv_small_cout_kernel<7>" : k == 5 ? "conv_small_cout_kernel<5>" : "conv_small_cout_kernel<3>", s, 4.0 * (double)B * H * W * (Cin + Cout), 2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
-    // measured and NOT the default: the packed-FMA kernel issues 2.7x fewer VALU instructions but its 4-channel slices fetch every
-    // 128-byte line of the NHWC input 8 times (25 ms per 16 pages against 17.7 for the plain kernel, HBM-bound); see DESIGN.md
-    static const bool use_pk = getenv("MIT_SMALL_COUT_PK") != nullptr;
+    MitProbeScope probe(Cout <= 3 && !getenv("MIT_SMALL_COUT_PLAIN") ? (k == 7 ? "conv_small_cout3_kernel<7>" : k == 5 ? "conv_small_cout3_kernel<5>" : "conv_small_cout3_kernel<3>")
+                                                                    : (k == 7 ? "conv_small_cout_kernel<7>" : k == 5 ? "conv_small_cout_kernel<5>" : "conv_small_cout_kernel<3>"), s, 4.0 * (double)B * H * W * (Cin + Cout), 2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
+    // Cout <= 3: the packed-FMA kernel (2.7x fewer VALU instructions).  With 4-channel slices loaded straight from HBM it fetched
+    // every 128-byte input line 8 times and was slower than the plain kernel (25 vs 17.7 ms per 16 pages); staging 16-channel groups
+    // in registers brought it to 15.9 ms (same-box A/B).  MIT_SMALL_COUT_PLAIN=1 selects the plain kernel for comparison.
+    static const bool use_pk = getenv("MIT_SMALL_COUT_PLAIN") == nullptr;
     if (Cout <= 3 && use_pk) {
         dim3 grid3(mit_div_up(W, TW3), mit_div_up(H, TH3), B);
         switch (k) {
