@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01[a-z]_bench.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9][a-z]_bench.json")))
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -28,6 +28,14 @@ def test_committed_bench_lines_follow_the_contract(path):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    if os.path.basename(path) >= "r02a":  # round 2 lines: per-stage roofline, HBM kernel table, parity and drop-in legs
+        assert set(r["stages"]) == {"ctd", "ocr48", "lama_mpe"} and all(0 < v["frac_of_fp32_mfma_peak"] < 1 for v in r["stages"].values())
+        assert 0 < r["whole_step"]["frac_of_fp32_mfma_peak"] <= r["frac"]
+        big = [v for v in r["hbm_kernels"].values() if v.get("alg_GB_per_launch", 0) > 0.5]
+        assert big and all(0 < v["frac_of_hbm_peak"] < 1 for v in big)
+        assert d["parity_checked"]["ok"] is True and d["parity_checked"]["ocr"]["lines_with_different_tokens"] == 0
+        assert d["dropin"]["batch"] == 1 and d["dropin"]["unit"] == "pages/s" and d["dropin"]["value"] < d["value"]
+        assert "thread" in c["sample"] and c["cores"] in (8, 16, 32, 64, 128)
 
 
 def test_bench_cli_parses_without_a_gpu():
