@@ -4,7 +4,8 @@
   per-page records: byte-identical to one process running all pages — a page's result does not depend on the world size, the
   shard it landed in, or its neighbours in a batch (the reference processes pages independently, manga_translator.py:1491-1519);
 * a world-size-1 RCCL group (backend "nccl") runs the collectives dist.py uses — uint8 arena broadcast, gather to rank 0,
-  MAX all-reduce, barrier — on device tensors."""
+  MAX all-reduce, barrier — on device tensors (inside rank 0's process of the same spawn: a fresh interpreter costs minutes of
+  imports on a cold box)."""
 import os
 import socket
 
@@ -51,13 +52,15 @@ def _shard_worker(rank, world, port, q):
             q.put(("records", out.reshape(N_PAGES, -1).cpu().numpy()))
         Dm.barrier()
         torch.distributed.destroy_process_group()
+        if rank == 0:  # same process, second group: the RCCL smoke (a spawned interpreter costs minutes of imports on a cold box)
+            q.put(("rccl", _rccl_smoke(_free_port())))
         q.put((rank, "ok"))
     except Exception as e:
         q.put((rank, repr(e)))
         raise
 
 
-def test_page_records_do_not_depend_on_world_size(cuda):
+def test_page_records_do_not_depend_on_world_size_and_rccl_smoke(cuda):
     from manga_image_translator_amd import pipeline
 
     single = _records(pipeline.synthetic_weights(dict_size=D), 0, N_PAGES).cpu().numpy()
@@ -67,11 +70,13 @@ def test_page_records_do_not_depend_on_world_size(cuda):
     procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, oks = None, []
-    for _ in range(3):
-        item = q.get(timeout=600)
+    got, rccl, oks = None, None, []
+    for _ in range(4):
+        item = q.get(timeout=900)
         if item[0] == "records":
             got = item[1]
+        elif item[0] == "rccl":
+            rccl = item[1]
         else:
             oks.append(item)
     for p in procs:
@@ -79,15 +84,17 @@ def test_page_records_do_not_depend_on_world_size(cuda):
     assert sorted(oks) == [(0, "ok"), (1, "ok")], oks
     assert got.shape == single.shape and got.dtype == np.uint8
     assert np.array_equal(got, single), f"{(got != single).sum()} bytes differ between world 1 and world 2"
+    assert rccl == "ok", rccl  # world-size-1 RCCL group: uint8 broadcast, gather to rank 0, MAX all-reduce, barrier
 
 
-def _rccl_worker(port, q):
+def _rccl_smoke(port):
+    """A world-size-1 RCCL group (backend "nccl") running the collectives dist.py uses, on device tensors."""
+    import torch.distributed as dist
+
     os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
     try:
-        import torch.distributed as dist
-
-        torch.cuda.set_device(0)
-        dist.init_process_group(backend="nccl", rank=0, world_size=1)
         dev = torch.device("cuda:0")
         arena = torch.arange(1 << 20, dtype=torch.int64, device=dev).to(torch.uint8)
         ref = arena.clone()
@@ -99,19 +106,6 @@ def _rccl_worker(port, q):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                          # max-over-ranks timing (dist.max_over_ranks)
         dist.barrier(device_ids=[0])
         torch.cuda.synchronize()
-        ok = torch.equal(arena, ref) and torch.equal(out[0], packed) and float(t.item()) == 3.5
+        return "ok" if torch.equal(arena, ref) and torch.equal(out[0], packed) and float(t.item()) == 3.5 else "wrong results"
+    finally:
         dist.destroy_process_group()
-        q.put("ok" if ok else "wrong results")
-    except Exception as e:
-        q.put(repr(e))
-        raise
-
-
-def test_rccl_world_size_one_smoke(cuda):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
-    p.start()
-    res = q.get(timeout=300)
-    p.join(timeout=60)
-    assert res == "ok", res
