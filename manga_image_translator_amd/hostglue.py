@@ -274,34 +274,60 @@ def refine_mask(img: np.ndarray, pred_mask: np.ndarray, quads: Sequence, refine_
 # histograms and six xor sums per line.  Bit-identical to refine_mask above (tests/test_ctd_refine_gpu.py).
 # ---------------------------------------------------------------------------------------------------------------------
 
-def _otsu_from_hist(hist: np.ndarray, size: int) -> int:
-    """_otsu_threshold on a 256-bin histogram (same float64 arithmetic, same order)."""
-    h = hist.astype(np.float64)
-    scale = 1.0 / size
-    mu = float((np.arange(256) * h).sum()) * scale
-    q1 = mu1 = 0.0
-    best, best_sigma = 0, 0.0
-    for i in range(256):
-        p_i = h[i] * scale
-        mu1 *= q1
-        q1 += p_i
-        q2 = 1.0 - q1
-        if min(q1, q2) < 2.220446049250313e-16 or max(q1, q2) > 1.0 - 2.220446049250313e-16:
-            continue
-        mu1 = (mu1 + i * p_i) / q1
-        mu2 = (mu - q1 * mu1) / q2
-        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
-        if sigma > best_sigma:
-            best_sigma, best = sigma, i
-    return best
-
-
 def _in_range_bounds(lo: float, hi: float):
     """The integer interval cv2.inRange(src_u8, lo, hi) selects (see _in_range_u8), or None when it selects nothing."""
     ilo, ihi = int(np.rint(lo)), int(np.rint(hi))
     if ilo > ihi or ilo > 255 or ihi < 0:
         return None
     return max(ilo, 0), min(ihi, 255)
+
+
+def refine_candidates(hist: np.ndarray):
+    """Host half 1 of refine_mask_gpu: from the per-line histograms (n x 4 x 256: grey under the eroded mask, then the three
+    channels) to the six raw candidates of every line as (kind, lo, hi, invert) — get_topk_masklist (textmask.py:56-71: numpy's own
+    255-bin histogram of the grey levels, the top-k colours, +-30 in cv2.inRange's rounding) and the per-channel Otsu thresholds of
+    get_otsuthresh_masklist (:44-54).  kind 0 = absent, 1 = inRange(grey, lo, hi), 2 + c = channel c > lo."""
+    n = hist.shape[0]
+    levels = np.arange(256, dtype=np.uint8)
+    ch_hist = np.ascontiguousarray(hist[:, 1:4], dtype=np.int32)
+    otsu = np.zeros((n, 3), dtype=np.int32)
+    _lib.check(_lib.load().mit_otsu_from_hist(ch_hist.ctypes.data, 3 * n, otsu.ctypes.data), "mit_otsu_from_hist")
+    out = []
+    for i in range(n):
+        g = hist[i, 0]
+        present = g > 0
+        bins_w, edges = np.histogram(levels[present], bins=255, weights=g[present].astype(np.float64))
+        bins = np.rint(bins_w).astype(np.int64)   # the integer counts np.histogram(cand, bins=255) returns
+        line = [(0, 0, 0, 0)] * 3
+        for k, color in enumerate(_topk_color(edges, bins, color_var=10, k=3)):
+            c_top = min(color + 30, 255)
+            bounds = _in_range_bounds(c_top - 60, c_top)
+            line[k] = (1, bounds[0], bounds[1], 0) if bounds else (1, 1, 0, 0)  # lo > hi: selects nothing
+        out.append(line + [(2 + ch, int(otsu[i, ch]), 0, 0) for ch in range(3)])
+    return out
+
+
+def refine_merge_order(raw, sums: np.ndarray, sizes: Sequence[int]):
+    """Host half 2: minxor_thresh (textmask.py:29-42) per candidate — the candidate or its complement, whichever byte-xor sum
+    against the mask crop is smaller (``sums[i, k]`` = the candidate's, 255 * size - that = the complement's) — then the best Otsu
+    channel and the merge order of the <= 4 survivors by score (stable, like sorted())."""
+    out = []
+    for i, line in enumerate(raw):
+        total = 255 * int(sizes[i])
+        picked = []
+        for k, (kind, lo, hi, _) in enumerate(line):
+            if kind == 0:
+                picked.append(None)
+                continue
+            s_pos = int(sums[i, k])
+            s_neg = total - s_pos
+            picked.append((1, s_neg) if s_neg < s_pos else (0, s_pos))
+        mask_list = [(k, picked[k]) for k in range(3) if picked[k] is not None]
+        best_otsu = sorted([(k, picked[k]) for k in range(3, 6)], key=lambda t: t[1][1])[0]
+        mask_list.append(best_otsu)
+        mask_list.sort(key=lambda t: t[1][1])
+        out.append([(line[k][0], line[k][1], line[k][2], inv) for k, (inv, _) in mask_list])
+    return out
 
 
 class _RefineWorkspace:
@@ -360,47 +386,19 @@ def refine_mask_gpu(page_dev, pred_dev, quads: Sequence, refine_mode=None):
     args = (page_dev.data_ptr(), pred_dev.data_ptr(), H, W, C.byref(warr), n)
     hist = np.zeros((n, 4, 256), dtype=np.int32)
     _lib.check(L.mit_ctd_refine_hist(*args, hist.ctypes.data, ws.data_ptr(), ws.numel(), st), "mit_ctd_refine_hist")
-    # get_topk_masklist (:56-71) + get_otsuthresh_masklist (:44-54) on the histograms
+    raw = refine_candidates(hist)
     cands = (_lib.MitRefineCand * (6 * n))()
-    levels = np.arange(256, dtype=np.uint8)
-    ch_hist = np.ascontiguousarray(hist[:, 1:4])                      # Otsu thresholds of the three channels of every line, natively
-    otsu = np.zeros((n, 3), dtype=np.int32)
-    _lib.check(L.mit_otsu_from_hist(ch_hist.ctypes.data, 3 * n, otsu.ctypes.data), "mit_otsu_from_hist")
-    for i, (a, b, c, d) in enumerate(wins):
-        size = (c - a) * (d - b)
-        g = hist[i, 0]
-        present = g > 0
-        bins_w, edges = np.histogram(levels[present], bins=255, weights=g[present].astype(np.float64))
-        bins = np.rint(bins_w).astype(np.int64)   # the integer counts np.histogram(cand, bins=255) returns
-        for k, color in enumerate(_topk_color(edges, bins, color_var=10, k=3)):
-            c_top = min(color + 30, 255)
-            bounds = _in_range_bounds(c_top - 60, c_top)
-            e = cands[i * 6 + k]
-            e.kind, e.lo, e.hi, e.invert = (1, bounds[0], bounds[1], 0) if bounds else (1, 1, 0, 0)  # lo > hi: selects nothing
-        for ch in range(3):
-            e = cands[i * 6 + 3 + ch]
-            e.kind, e.lo, e.hi, e.invert = 2 + ch, int(otsu[i, ch]), 0, 0
-    sums = np.zeros((n, 6), dtype=np.uint64)
-    _lib.check(L.mit_ctd_refine_scores(*args, C.byref(cands), sums.ctypes.data, ws.data_ptr(), ws.numel(), st), "mit_ctd_refine_scores")
-    # minxor_thresh (:29-42) per candidate, the best Otsu channel, merge order by score (stable, like sorted())
-    order = (_lib.MitRefineCand * (4 * n))()
-    for i, (a, b, c, d) in enumerate(wins):
-        total = 255 * (c - a) * (d - b)
-        picked = []
+    for i in range(n):
         for k in range(6):
             e = cands[i * 6 + k]
-            if e.kind == 0:
-                picked.append(None)
-                continue
-            s_pos = int(sums[i, k])
-            s_neg = total - s_pos
-            picked.append((1, s_neg) if s_neg < s_pos else (0, s_pos))
-        mask_list = [(k, picked[k]) for k in range(3) if picked[k] is not None]
-        otsu = sorted([(k, picked[k]) for k in range(3, 6)], key=lambda t: t[1][1])
-        mask_list.append(otsu[0])
-        mask_list.sort(key=lambda t: t[1][1])
-        for slot, (k, (inv, _)) in enumerate(mask_list):
-            src, dst = cands[i * 6 + k], order[i * 4 + slot]
-            dst.kind, dst.lo, dst.hi, dst.invert = src.kind, src.lo, src.hi, inv
+            e.kind, e.lo, e.hi, e.invert = raw[i][k]
+    sums = np.zeros((n, 6), dtype=np.uint64)
+    _lib.check(L.mit_ctd_refine_scores(*args, C.byref(cands), sums.ctypes.data, ws.data_ptr(), ws.numel(), st), "mit_ctd_refine_scores")
+    ordered = refine_merge_order(raw, sums, [(c - a) * (d - b) for a, b, c, d in wins])
+    order = (_lib.MitRefineCand * (4 * n))()
+    for i in range(n):
+        for slot, cand in enumerate(ordered[i]):
+            dst = order[i * 4 + slot]
+            dst.kind, dst.lo, dst.hi, dst.invert = cand
     _lib.check(L.mit_ctd_refine_merge(*args, C.byref(order), out.data_ptr(), ws.data_ptr(), ws.numel(), st), "mit_ctd_refine_merge")
     return out

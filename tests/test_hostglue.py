@@ -161,3 +161,57 @@ def test_native_otsu_from_histograms_matches_the_python_recurrence():
     lib.check(L.mit_otsu_from_hist(hist.ctypes.data, len(imgs), out.ctypes.data), "mit_otsu_from_hist")
     assert out.tolist() == [HG._otsu_threshold(i) for i in imgs]
     assert L.mit_otsu_from_hist(None, 1, None) != 0
+
+
+def test_refine_mask_gpu_host_logic_against_refine_mask():
+    """The host halves of the GPU refine_mask (hostglue.refine_candidates / refine_merge_order) with the three device phases
+    emulated in numpy — per-line histograms, candidate xor sums, merge_mask_list over the ordered candidates — reproduce
+    hostglue.refine_mask (the routine pinned to the reference's textmask.py) byte for byte.  The device kernels themselves are
+    checked against the same routine in tests/test_ctd_refine_gpu.py."""
+    from manga_image_translator_amd import hostglue as HG, textline as TL
+
+    rng = np.random.default_rng(3)
+    H, W = 220, 300
+    page = np.full((H, W, 3), 235, np.uint8) - rng.integers(0, 25, (H, W, 3)).astype(np.uint8)
+    pred = np.zeros((H, W), np.float32)
+    quads = []
+    for (x0, y0, bw, bh) in ((20, 15, 120, 40), (150, 80, 130, 60), (10, 150, 200, 50)):
+        for _ in range(bw // 8):
+            sx, sy = x0 + int(rng.integers(0, bw - 8)), y0 + int(rng.integers(0, bh - 10))
+            page[sy:sy + int(rng.integers(3, 10)), sx:sx + int(rng.integers(2, 7))] = int(rng.integers(0, 80))
+        pred[y0:y0 + bh, x0:x0 + bw] = rng.uniform(0.6, 1.0)
+        quads.append(TL.Quadrilateral(np.array([[x0, y0], [x0 + bw, y0], [x0 + bw, y0 + bh], [x0, y0 + bh]], np.float64)))
+    pred = (np.clip(pred + rng.normal(0, 0.05, (H, W)), 0, 1) * 255).astype(np.uint8)
+    ref = HG.refine_mask(page, pred, quads, None)
+    assert ref.any()
+
+    wins = [HG.enlarge_window(q.xyxy, W, H) for q in quads]
+    crops = [(np.ascontiguousarray(page[b:d, a:c]), np.ascontiguousarray(pred[b:d, a:c])) for a, b, c, d in wins]
+    hist = np.zeros((len(wins), 4, 256), np.int32)                       # phase A: what mit_ctd_refine_hist returns
+    for i, (im, msk) in enumerate(crops):
+        grey = HG._gray_bgr2gray(im)
+        hist[i, 0] = np.bincount(grey[HG._erode(msk, HG._RECT3) > 127], minlength=256)
+        for ch in range(3):
+            hist[i, 1 + ch] = np.bincount(im[..., ch].reshape(-1), minlength=256)
+    raw = HG.refine_candidates(hist)
+
+    def cand_mask(im, kind, lo, hi):
+        if kind == 1:
+            g = HG._gray_bgr2gray(im)
+            return np.where((g >= lo) & (g <= hi), 255, 0).astype(np.uint8)
+        return np.where(im[..., kind - 2] > lo, 255, 0).astype(np.uint8)
+
+    sums = np.zeros((len(wins), 6), np.uint64)                           # phase B: what mit_ctd_refine_scores returns
+    for i, (im, msk) in enumerate(crops):
+        for k, (kind, lo, hi, _) in enumerate(raw[i]):
+            if kind:
+                sums[i, k] = np.bitwise_xor(cand_mask(im, kind, lo, hi), msk).sum(dtype=np.uint64)
+    ordered = HG.refine_merge_order(raw, sums, [m.size for _, m in crops])
+    out = np.zeros_like(pred)                                            # phase C: merge_mask_list over the ordered candidates
+    for (a, b, c, d), (im, msk), cands in zip(wins, crops, ordered):
+        masks = []
+        for slot, (kind, lo, hi, inv) in enumerate(cands):
+            m = cand_mask(im, kind, lo, hi)
+            masks.append([255 - m if inv else m, slot])
+        out[b:d, a:c] |= HG._merge_mask_list(masks, msk, False)
+    assert np.array_equal(out, ref)
