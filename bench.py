@@ -380,7 +380,7 @@ def dropin_leg(weights, host_inputs, n_pages, device_str="cuda"):
         page, q, mask = pages[j], quads[j], masks[j]
         torch.cuda.synchronize()
         t = time.perf_counter()
-        tls, _, _ = run(det.infer(page, 1024, 0.5, 0.7, 2.3))   # network + native boxes + mask resize + refine_mask
+        tls, _, _ = run(det.infer(page, 1024, 0.5, 0.7, 2.3))   # network + native boxes + mask resize + refine_mask (GPU)
         t1 = time.perf_counter()
         lines = [Quadrilateral(np.asarray(pts)) for pts in q]     # the OCR stage is fed the generator's text lines
         run(ocr.infer(page, lines, None, False, 0, DECODE_STEPS, True))  # direction vote + warps + recognition + decode
@@ -397,7 +397,7 @@ def dropin_leg(weights, host_inputs, n_pages, device_str="cuda"):
     ms = {k: round(1e3 * float(np.mean(v)), 2) for k, v in per.items()}
     total = sum(ms.values())
     return dict(value=round(1e3 / total, 3), unit="pages/s", pages=n, batch=1, ms_per_page=round(total, 2), ms_per_stage=ms,
-                includes="host<->device copies, ctd box extraction + mask resize + refine_mask (native host glue), OCR direction vote "
+                includes="host<->device copies, ctd box extraction (native host C++), mask resize + refine_mask (GPU), OCR direction vote "
                          "and per-line planning, plugin result decoding",
                 detector_boxes_found_per_page=n_found,
                 note="synthetic weights: the detector's boxes are whatever the random network fires on, so its host-glue time is not "
