@@ -40,7 +40,8 @@ constexpr int kCfgSmall = 26, kCfgGemv16 = 27, kCfgGemv4 = 28, kCfgGemv16N1 = 29
 
 // conv_gemv_kernel preconditions: <= 4 output columns, plain (unbatched, unsplit) maps, the whole weight panel in LDS
 bool gemv_eligible(const MitConvGemm &p, int lpr) {
-    if (p.N > 4 || p.Z != 1 || p.Cin % (4 * lpr) || (int64_t)p.ntaps * p.Cin > 8192 || (int64_t)p.NB * p.Ho > 65535) return false;  // one output row per blockIdx.y
+    if (p.N > 4 || p.Z != 1 || p.Cin % (4 * lpr) || (int64_t)p.NB * p.Ho > 65535) return false;  // one output row per blockIdx.y
+    if ((int64_t)p.ntaps * p.Cin * (p.N == 1 ? 1 : 4) * 4 > 60 * 1024) return false;            // the transposed weight panel must fit the default dynamic-LDS limit
     if (p.c.nsplit || p.pre.nsplit || p.post.nsplit) return false;
     return true;
 }
