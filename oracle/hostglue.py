@@ -8,8 +8,10 @@ WITHOUT border following: contours are characterised through connected component
 ordered by where a raster scan would start tracing them, reversed (OpenCV's list order).  Min-area rectangles by brute
 force over hull edges; the pyclipper round offset follows ClipperOffset (DoOffset / OffsetPoint / DoRound).
 
-Parity status: **unpinned** — OpenCV, pyclipper and shapely are not installed anywhere this can run; the two
-implementations (this one and the native one) only pin each other plus closed-form cases (tests/test_hostglue.py).
+Parity status: the PRIMITIVES are **unpinned** — OpenCV, pyclipper and shapely are not installed anywhere this can run.  The
+control flow around them is pinned: oracle/ref_import.segdet runs the reference's own SegDetectorRepresenter Python of both
+detectors with stand-ins built from this file and oracle/contours.py, oracle/make_golden.golden_boxes records its output
+(tests/golden/boxes.npz), and the native routine reproduces it row for row (tests/test_hostglue.py).
 """
 from __future__ import annotations
 

@@ -532,6 +532,50 @@ def golden_esrgan():
     print("esrgan", y.shape, float(y.mean()), float(y.std()))
 
 
+def boxes_scene(seed: int, H: int = 128, W: int = 160) -> np.ndarray:
+    """A probability map with rotated text-line blobs of different confidence, a speck, a blob with a hole and one touching the
+    border: every branch of boxes_from_bitmap (size filters, score filter, hole contours, clipping to the destination size)."""
+    from PIL import Image, ImageDraw
+
+    rng = np.random.default_rng(seed)
+    im = Image.new("F", (W, H), 0.02)
+    d = ImageDraw.Draw(im)
+    for _ in range(7):
+        cx, cy = int(rng.integers(10, W - 10)), int(rng.integers(8, H - 8))
+        w, h, a = int(rng.integers(8, 50)), int(rng.integers(3, 14)), float(rng.uniform(0, np.pi))
+        c, s_ = np.cos(a), np.sin(a)
+        d.polygon([(cx + c * x - s_ * y, cy + s_ * x + c * y) for x, y in ((-w, -h), (w, -h), (w, h), (-w, h))],
+                  fill=float(rng.uniform(0.45, 0.97)))
+    arr = np.asarray(im).copy()
+    arr[5:7, 5:8] = 0.9                               # a speck (short side < 2 / 3)
+    arr[H - 4:, W // 3:W // 3 + 40] = 0.88            # a blob on the bottom border
+    ys, xs = np.nonzero(arr > 0.6)
+    if len(ys):
+        k = len(ys) // 2
+        arr[max(ys[k] - 2, 0):ys[k] + 2, max(xs[k] - 2, 0):xs[k] + 2] = 0.05  # a hole inside a blob
+    return arr.astype(np.float32)
+
+
+def golden_boxes():
+    """SegDetectorRepresenter of both detectors — the reference's own Python (db_utils.py:127-216, dbnet_utils.py:97-190) run with
+    the cv2 / pyclipper / shapely stand-ins of ref_import.segdet — on seeded probability maps."""
+    out = {}
+    ctd = R.segdet("ctd").SegDetectorRepresenter(thresh=0.3)                      # ctd.py:102
+    dbn = R.segdet("default")
+    for i, (seed, dh, dw) in enumerate(((3, 256, 320), (4, 128, 160), (5, 300, 333))):
+        pred = boxes_scene(seed)
+        lm = np.stack([pred, pred])[None]
+        b, s = ctd(None, lm, height=dh, width=dw)
+        out[f"pred{i}"], out[f"dest{i}"] = pred, np.array([dh, dw])
+        out[f"ctd_boxes{i}"], out[f"ctd_scores{i}"] = np.asarray(b[0], dtype=np.int64), np.asarray(s[0], dtype=np.float32)
+        for j, (tt, bt, ur) in enumerate(((0.5, 0.7, 2.3), (0.3, 0.5, 1.5))):      # default.py:73-77 (config defaults) + a looser set
+            det = dbn.SegDetectorRepresenter(tt, bt, unclip_ratio=ur)
+            b2, s2 = det({"shape": [(dh, dw)]}, lm)
+            out[f"dbnet_boxes{i}_{j}"], out[f"dbnet_scores{i}_{j}"] = np.asarray(b2[0], dtype=np.int64), np.asarray(s2[0], dtype=np.float32)
+    out["dbnet_params"] = np.array([[0.5, 0.7, 2.3], [0.3, 0.5, 1.5]])
+    np.savez_compressed(os.path.join(GOLDEN, "boxes.npz"), **out)
+
+
 def main():
     if not R.available():
         raise SystemExit("/root/reference is not present: fixtures can only be regenerated in the build container")
@@ -550,6 +594,7 @@ def main():
     golden_refine_mask()
     golden_textline_merge()
     golden_mask_refinement()
+    golden_boxes()
 
 
 if __name__ == "__main__":

@@ -343,6 +343,71 @@ def mask_refinement(refine_stub=None, bilateral_stub=None):
     return mr, tmu, G
 
 
+def segdet(kind: str = "ctd"):
+    """The reference's box extraction, ``SegDetectorRepresenter`` of detection/ctd_utils/utils/db_utils.py (kind "ctd") or
+    detection/default_utils/dbnet_utils.py ("default"), with stand-ins for the three libraries it drives — cv2 (findContours,
+    minAreaRect, boxPoints, fillPoly, mean), pyclipper (round offset) and shapely (polygon area / length) — built from the oracle's
+    restatements (oracle/contours.py, oracle/hostglue.py).  What this pins is the reference's own control flow around them:
+    get_mini_boxes' corner order, box_score_fast's window arithmetic, the unclip distance, the size filters, rounding, clipping and
+    scaling to the destination size."""
+    import numpy as np
+
+    from . import contours as OCt, hostglue as OH
+
+    _prepare()
+    cv = types.SimpleNamespace(RETR_LIST=1, CHAIN_APPROX_SIMPLE=2)
+
+    def find_contours(img, mode, method):
+        return OCt.find_contours_list(img), None
+
+    def min_area_rect(contour):
+        pts = np.asarray(contour, dtype=np.float64).reshape(-1, 2)
+        box, _ = OH.min_area_rect(pts)
+        b = box.astype(np.float64)
+        w, h = float(np.hypot(*(b[1] - b[0]))), float(np.hypot(*(b[2] - b[1])))
+        return (tuple(b.mean(0)), (w, h), 0.0, box)
+
+    cv.findContours = find_contours
+    cv.minAreaRect = min_area_rect
+    cv.boxPoints = lambda rect: np.asarray(rect[3], dtype=np.float32)
+    cv.fillPoly = lambda mask, pts, color: OCt.fill_poly(mask, np.asarray(pts)[0], color)
+    cv.mean = lambda arr, mask: (float(np.asarray(arr)[np.asarray(mask) > 0].astype(np.float64).mean()) if (np.asarray(mask) > 0).any() else 0.0, 0, 0, 0)
+
+    class _Offset:
+        def __init__(self):
+            self.path = None
+
+        def AddPath(self, path, jt, et):
+            self.path = np.asarray(path)
+
+        def Execute(self, delta):
+            out = OH.clipper_offset_round(self.path, float(delta))
+            return [out.astype(np.int64).tolist()] if len(out) else []
+
+    clip = types.SimpleNamespace(PyclipperOffset=_Offset, JT_ROUND=1, ET_CLOSEDPOLYGON=0)
+
+    class _Poly:
+        def __init__(self, pts):
+            self.p = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+
+        @property
+        def area(self):
+            x, y = self.p[:, 0], self.p[:, 1]
+            return float(abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))) / 2)
+
+        @property
+        def length(self):
+            return float(np.hypot(*(np.roll(self.p, -1, 0) - self.p).T).sum())
+
+    if kind == "ctd":
+        mod = _load("manga_translator.detection.ctd_utils.utils.db_utils", "detection/ctd_utils/utils/db_utils.py")
+    else:
+        _pkg("manga_translator.detection.default_utils")
+        mod = _load("manga_translator.detection.default_utils.dbnet_utils", "detection/default_utils/dbnet_utils.py")
+    mod.cv2, mod.pyclipper, mod.Polygon = cv, clip, _Poly
+    return mod
+
+
 def shapely_shim():
     """Minimal ``shapely.geometry`` stand-in (Polygon / MultiPoint with area, length, distance, convex_hull) so the reference's
     own ``quadrilateral_can_merge_region`` / ``Quadrilateral.polygon`` (utils/generic.py) can be executed here.  Geometry by

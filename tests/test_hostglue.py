@@ -215,3 +215,28 @@ def test_refine_mask_gpu_host_logic_against_refine_mask():
             masks.append([255 - m if inv else m, slot])
         out[b:d, a:c] |= HG._merge_mask_list(masks, msk, False)
     assert np.array_equal(out, ref)
+
+
+def _rows(boxes, scores):
+    return sorted((tuple(map(tuple, b.tolist())), round(float(s), 6)) for b, s in zip(boxes, scores) if s > 0)
+
+
+def test_native_box_extraction_against_the_references_own_flow():
+    """csrc/hostglue.hip (contours -> min-area rectangle -> score -> round offset -> rectangle -> scale) against the reference's OWN
+    SegDetectorRepresenter Python of both detectors, executed by oracle/make_golden.py with stand-ins for cv2 / pyclipper / shapely
+    (tests/golden/boxes.npz): same boxes (integer-exact), same scores, same skipped contours — and, row for row, the same order."""
+    import os
+
+    from manga_image_translator_amd import hostglue as HG
+
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "boxes.npz"))
+    for i in range(3):
+        pred, (dh, dw) = G[f"pred{i}"], G[f"dest{i}"]
+        lm = np.stack([pred, pred])[None]
+        b, s = HG.ctd_boxes(lm, int(dh), int(dw))
+        assert b.shape == G[f"ctd_boxes{i}"].shape and np.array_equal(b, G[f"ctd_boxes{i}"]), i
+        assert np.abs(s - G[f"ctd_scores{i}"]).max() < 1e-6
+        assert any(sc == 0 for sc in s) or i == 2          # the scenes exercise the size filter
+        for j, (tt, bt, ur) in enumerate(G["dbnet_params"]):
+            b2, s2 = HG.dbnet_boxes(lm, int(dh), int(dw), float(tt), float(bt), float(ur))
+            assert _rows(b2, s2) == _rows(G[f"dbnet_boxes{i}_{j}"], G[f"dbnet_scores{i}_{j}"]), (i, j)
