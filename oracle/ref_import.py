@@ -343,22 +343,15 @@ def mask_refinement(refine_stub=None, bilateral_stub=None):
     return mr, tmu, G
 
 
-def segdet(kind: str = "ctd"):
-    """The reference's box extraction, ``SegDetectorRepresenter`` of detection/ctd_utils/utils/db_utils.py (kind "ctd") or
-    detection/default_utils/dbnet_utils.py ("default"), with stand-ins for the three libraries it drives — cv2 (findContours,
-    minAreaRect, boxPoints, fillPoly, mean), pyclipper (round offset) and shapely (polygon area / length) — built from the oracle's
-    restatements (oracle/contours.py, oracle/hostglue.py).  What this pins is the reference's own control flow around them:
-    get_mini_boxes' corner order, box_score_fast's window arithmetic, the unclip distance, the size filters, rounding, clipping and
-    scaling to the destination size."""
+def box_shims():
+    """(cv2, pyclipper, Polygon) stand-ins for the reference's SegDetectorRepresenter, built from the oracle's restatements:
+    cv2.findContours = a Suzuki-Abe border follower, minAreaRect / boxPoints, fillPoly, mean (oracle/contours.py,
+    oracle/hostglue.py); pyclipper's round offset; shapely's polygon area / length."""
     import numpy as np
 
     from . import contours as OCt, hostglue as OH
 
-    _prepare()
     cv = types.SimpleNamespace(RETR_LIST=1, CHAIN_APPROX_SIMPLE=2)
-
-    def find_contours(img, mode, method):
-        return OCt.find_contours_list(img), None
 
     def min_area_rect(contour):
         pts = np.asarray(contour, dtype=np.float64).reshape(-1, 2)
@@ -367,11 +360,15 @@ def segdet(kind: str = "ctd"):
         w, h = float(np.hypot(*(b[1] - b[0]))), float(np.hypot(*(b[2] - b[1])))
         return (tuple(b.mean(0)), (w, h), 0.0, box)
 
-    cv.findContours = find_contours
+    def mean(arr, mask):
+        sel = np.asarray(mask) > 0
+        return (float(np.asarray(arr)[sel].astype(np.float64).mean()) if sel.any() else 0.0, 0, 0, 0)
+
+    cv.findContours = lambda img, mode, method: (OCt.find_contours_list(img), None)
     cv.minAreaRect = min_area_rect
     cv.boxPoints = lambda rect: np.asarray(rect[3], dtype=np.float32)
     cv.fillPoly = lambda mask, pts, color: OCt.fill_poly(mask, np.asarray(pts)[0], color)
-    cv.mean = lambda arr, mask: (float(np.asarray(arr)[np.asarray(mask) > 0].astype(np.float64).mean()) if (np.asarray(mask) > 0).any() else 0.0, 0, 0, 0)
+    cv.mean = mean
 
     class _Offset:
         def __init__(self):
@@ -399,12 +396,21 @@ def segdet(kind: str = "ctd"):
         def length(self):
             return float(np.hypot(*(np.roll(self.p, -1, 0) - self.p).T).sum())
 
+    return cv, clip, _Poly
+
+
+def segdet(kind: str = "ctd"):
+    """The reference's box extraction, ``SegDetectorRepresenter`` of detection/ctd_utils/utils/db_utils.py (kind "ctd") or
+    detection/default_utils/dbnet_utils.py ("default"), with the stand-ins of ``box_shims`` for the three libraries it drives.
+    What this pins is the reference's own control flow around them: get_mini_boxes' corner order, box_score_fast's window
+    arithmetic, the unclip distance, the size filters, rounding, clipping and scaling to the destination size."""
+    _prepare()
     if kind == "ctd":
         mod = _load("manga_translator.detection.ctd_utils.utils.db_utils", "detection/ctd_utils/utils/db_utils.py")
     else:
         _pkg("manga_translator.detection.default_utils")
         mod = _load("manga_translator.detection.default_utils.dbnet_utils", "detection/default_utils/dbnet_utils.py")
-    mod.cv2, mod.pyclipper, mod.Polygon = cv, clip, _Poly
+    mod.cv2, mod.pyclipper, mod.Polygon = box_shims()
     return mod
 
 

@@ -5,7 +5,9 @@ oracle.ref_boundary.install() makes ``manga_translator.{utils,config,detection,o
 reference's own OfflineDetector / OfflineOCR / OfflineInpainter / OfflineUpscaler (utils/inference.py ModelWrapper) and is driven
 through the reference's own callers (CommonDetector.detect, CommonOCR.recognize, CommonInpainter.inpaint, get_detector ...).
 No GPU: where a call would reach the dense engine, a stand-in engine returns fixed tensors — what is under test is the boundary
-(types, lifecycle, registry, checkpoint lookup, download flow, error propagation), not the kernels.
+(types, lifecycle, registry, checkpoint lookup, download flow, error propagation), not the kernels.  Three checks go further and
+run the reference's REAL ``_infer`` of the ctd detector, the default detector and the LaMa inpainter with a stubbed network beside
+the plugin's ``_infer`` with the same stub: everything either side does around the network must produce identical bytes.
 """
 import asyncio
 import hashlib
@@ -210,6 +212,218 @@ def _():
     assert len(tls_r) == 2 and raw_r.shape == (840, 1200)
     run(det.unload())
     assert det.engine is None and not det.is_loaded()
+
+
+@check("the reference's REAL ComicTextDetector._infer (network stubbed) == HipComicTextDetector._infer (engine stubbed identically)")
+def _():
+    """Both sides see the same network outputs; everything after the network is each side's own code: the reference's letterbox
+    crop, postprocess_mask, SegDetectorRepresenter, 0.6 filter, cv2.resize and textmask.refine_mask (its own Python over the
+    cv2 / pyclipper / shapely stand-ins) against the plugin's native box extraction, table-driven resize and refine_mask."""
+    from PIL import Image, ImageDraw
+
+    import manga_translator.detection.ctd as RC
+    import manga_translator.detection.ctd_utils.utils.db_utils as DBU
+    from manga_image_translator_amd import hostglue, imgproc
+    from oracle import ref_import as R
+
+    DBU.cv2, DBU.pyclipper, DBU.Polygon = R.box_shims()
+    imgproc.resize_u8 = lambda t, dsize, exact=False: torch.from_numpy(np.stack([imgproc.resize_u8_host(x, dsize, exact) for x in t.numpy()]))
+    hostglue.refine_mask_gpu = lambda pg, pm, quads, mode=None: torch.from_numpy(hostglue.refine_mask(pg.numpy(), pm.numpy(), quads, mode))
+
+    H, W = 1200, 840                                   # letterbox: r = 1024 / 1200, un-padded area 1024 x 717
+    r = min(1024 / H, 1024 / W)
+    nh, nw = int(round(H * r)), int(round(W * r))
+    rng = np.random.default_rng(11)
+    page = np.full((H, W, 3), 238, np.uint8) - rng.integers(0, 20, (H, W, 3)).astype(np.uint8)
+    lines_im, mask_im = Image.new("F", (1024, 1024), 0.03), Image.new("F", (1024, 1024), 0.0)
+    dl, dm = ImageDraw.Draw(lines_im), ImageDraw.Draw(mask_im)
+    boxes = [(60, 40, 420, 90), (500, 200, 560, 520), (100, 600, 600, 660), (80, 800, 300, 830), (640, 700, 700, 1000)]
+    for k, (x0, y0, x1, y1) in enumerate(boxes):
+        dl.rectangle([x0 + 6, y0 + 6, x1 - 6, y1 - 6], fill=[0.95, 0.9, 0.8, 0.55, 0.7][k])   # one below the 0.6 score filter
+        dm.rectangle([x0, y0, x1, y1], fill=0.85)
+        X0, Y0, X1, Y1 = [int(v / r) for v in (x0, y0, x1, y1)]
+        for _ in range(40):                            # dark strokes on the page under the line
+            sx, sy = int(rng.integers(X0, max(X1 - 10, X0 + 1))), int(rng.integers(Y0, max(Y1 - 12, Y0 + 1)))
+            page[sy:sy + int(rng.integers(4, 12)), sx:sx + int(rng.integers(3, 9))] = int(rng.integers(0, 70))
+    lines_f = np.asarray(lines_im).copy()
+    mask_f = np.asarray(mask_im).copy()
+    lines_f[:, nw:] = 0.0
+    mask_f[:, nw:] = 0.0
+    lines_map = np.stack([lines_f, lines_f * 0.5])[None].astype(np.float32)       # [1, 2, 1024, 1024]
+    mask_map = mask_f[None, None].astype(np.float32)                              # [1, 1, 1024, 1024]
+
+    ref = RC.ComicTextDetector.__new__(RC.ComicTextDetector)                       # the reference's own class, no checkpoint
+    ref.model = lambda img_in: (None, torch.from_numpy(mask_map.copy()), torch.from_numpy(lines_map.copy()))
+    ref.backend, ref.half, ref.device, ref.input_size = "torch", False, "cpu", (1024, 1024)
+    ref.seg_rep = DBU.SegDetectorRepresenter(thresh=0.3)
+    tls_ref, mask_ref, extra = run(RC.ComicTextDetector._infer(ref, page.copy(), 1024, 0.5, 0.7, 2.3))
+    assert extra is None and len(tls_ref) == 4 and mask_ref.shape == (H, W) and mask_ref.any()
+
+    class SameMapsEngine:
+        device = torch.device("cpu")
+
+        def forward(self, pg):                         # what CtdEngine returns for these network outputs (ctd.py:30-44,152-153)
+            m = torch.from_numpy((mask_map[0, 0, :nh, :nw] * 255).astype(np.uint8))[None]
+            return m, torch.from_numpy(lines_map[..., :nh, :nw].copy()), None
+
+        def release_workspace(self):
+            pass
+
+    det = P.HipComicTextDetector(weights={})
+    det.engine, det._loaded = SameMapsEngine(), True
+    tls, mask, extra = run(det.infer(page.copy(), 1024, 0.5, 0.7, 2.3))
+    assert extra is None and len(tls) == len(tls_ref)
+    for a, b in zip(tls, tls_ref):
+        assert type(a) is type(b) is U.Quadrilateral and np.array_equal(a.pts, b.pts) and abs(a.prob - b.prob) < 1e-6
+    assert mask.dtype == mask_ref.dtype and np.array_equal(mask, mask_ref)
+    run(det.unload())
+
+
+@check("the reference's REAL LamaMPEInpainter._infer (network stubbed) == HipLamaMPEInpainter._infer (engine stubbed identically)")
+def _():
+    """Pages that are aligned, not a multiple of 8, and larger than inpainting_size: the reference's resize_keep_aspect /
+    cv2.resize / tensor prep / uint8 truncation / resize back / composite (inpainting_lama_mpe.py:56-118, its own code over the cv2
+    stand-in) against the plugin's table-driven resizes, engine contract and select composite — same stub network on both sides."""
+    import logging
+
+    import manga_translator.inpainting.inpainting_lama_mpe as RL
+    from manga_image_translator_amd import imgproc
+
+    def net(x, m):  # any deterministic map [1,3,H,W] x [1,1,H,W] -> [1,3,H,W] in [0, 1]; the same function object on both sides
+        p = torch.nn.functional.avg_pool2d(x, 3, 1, 1)
+        return (0.55 * x + 0.35 * p + 0.1 * m).clamp(0, 1)
+
+    class StubLama(RL.LamaFourier):
+        def __init__(self):      # not the reference's constructor: no generator is built
+            pass
+
+        def __call__(self, img, mask):
+            return net(img, mask)
+
+    ref = RL.LamaMPEInpainter.__new__(RL.LamaMPEInpainter)
+    ref.model, ref.device, ref.logger = StubLama(), "cpu", logging.getLogger("ref-lama")
+
+    class SameNetEngine:
+        device = torch.device("cpu")
+
+        def forward(self, img, msk, composite=True):   # LamaEngine's contract: u8 [B,H,W,3] + u8 [B,H,W] -> u8 [B,H,W,3]
+            x = img.permute(0, 3, 1, 2).float() / 255.0
+            m = msk[:, None].float() / 255.0
+            m[m < 0.5] = 0
+            m[m >= 0.5] = 1
+            x = x * (1 - m)
+            out = torch.from_numpy((net(x, m).permute(0, 2, 3, 1).numpy() * 255.0).astype(np.uint8))
+            if composite:                               # img_inpainted * mask_original + img_original * (1 - mask_original) (:57-61,117)
+                out = torch.where((msk >= 127)[..., None], out, img)
+            return out
+
+        def release_workspace(self):
+            pass
+
+    imgproc.resize_u8 = lambda t, dsize, exact=False: torch.from_numpy(np.stack([imgproc.resize_u8_host(x, dsize, exact) for x in t.numpy()]))
+    imgproc.select_u8 = lambda mask, thr, a, b: torch.where((mask >= thr)[..., None], a, b)
+    inp = P.HipLamaMPEInpainter(weights={})
+    inp.engine, inp._loaded = SameNetEngine(), True
+    rng = np.random.default_rng(21)
+    for (H, W, size) in ((64, 72, 1024), (250, 187, 1024), (300, 232, 256), (260, 520, 256)):
+        page = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        mask = np.zeros((H, W), np.uint8)
+        mask[H // 4:H // 2, W // 5:3 * W // 4] = 255
+        mask[rng.random((H, W)) < 0.02] = int(rng.integers(100, 160))   # values around the 127 threshold
+        want = run(RL.LamaMPEInpainter._infer(ref, page.copy(), mask.copy(), None, size))
+        got = run(inp.infer(page.copy(), mask.copy(), None, size))
+        assert got.shape == want.shape == (H, W, 3) and got.dtype == np.uint8
+        assert np.array_equal(got, want.astype(np.uint8)), (H, W, size, int((got != want).sum()))
+    run(inp.unload())
+
+
+@check("the reference's REAL DefaultDetector._infer (network stubbed) == HipDefaultDetector._infer (engine stubbed identically)")
+def _():
+    """bilateralFilter + resize_aspect_ratio, SegDetectorRepresenter with the caller's thresholds, adjustResultCoordinates, the
+    area > 16 filter (and the reference's pairing of the filtered boxes with the unfiltered score list), the x2 mask resize, the
+    padding crop and the uint8 clip (default.py:56-103) — the reference's own code over the stand-ins against the plugin."""
+    import logging
+
+    import manga_translator.detection.default as RDf
+    import manga_translator.detection.default_utils.dbnet_utils as DBN
+    from manga_image_translator_amd import imgproc
+    from oracle import imgproc as OI, make_golden as MG, ref_import as R
+
+    DBN.cv2, DBN.pyclipper, DBN.Polygon = R.box_shims()
+    cv = sys.modules["cv2"]
+    base_resize = cv.resize
+
+    def resize(src, dsize, interpolation=1, **kw):     # the float32 x2 map resize of default.py:89 (plain bilinear at pixel centres)
+        if src.dtype != np.float32:
+            return base_resize(src, dsize, interpolation=interpolation, **kw)
+        h, w = src.shape
+        out = np.empty((dsize[1], dsize[0]), np.float32)
+        fy = ((np.arange(dsize[1]) + 0.5) * (h / dsize[1]) - 0.5).astype(np.float32)
+        fx = ((np.arange(dsize[0]) + 0.5) * (w / dsize[0]) - 0.5).astype(np.float32)
+        y0, x0 = np.floor(fy).astype(int), np.floor(fx).astype(int)
+        wy, wx = (fy - y0).astype(np.float32), (fx - x0).astype(np.float32)
+        wy[(y0 < 0) | (y0 >= h - 1)] = 0
+        wx[(x0 < 0) | (x0 >= w - 1)] = 0
+        y0, x0 = np.clip(y0, 0, h - 1), np.clip(x0, 0, w - 1)
+        y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+        rows = src[:, x0] * (np.float32(1) - wx)[None] + src[:, x1] * wx[None]
+        return (rows[y0] * (np.float32(1) - wy)[:, None] + rows[y1] * wy[:, None]).astype(np.float32)
+
+    cv.resize = RDf.cv2.resize = resize
+    cv.bilateralFilter = RDf.cv2.bilateralFilter = lambda img, d, sc, ss: OI.bilateral_filter_u8(img, d, float(sc), float(ss))
+    try:
+        H, W, size = 300, 210, 512                     # long side -> 512: 512 x 358, padded to 512 x 512 (pad_w 154)
+        rng = np.random.default_rng(5)
+        page = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        pred = MG.boxes_scene(6, 512, 512)
+        pred[:, 358:] = 0.0
+        db = np.stack([pred, pred * 0.5])[None].astype(np.float32)
+        mask_small = np.ascontiguousarray(pred[::2, ::2][None, None] * 1.2)    # some values clip at 255
+        seen = {}
+
+        def fake_forward(batch, device):
+            seen["batch"] = np.asarray(batch)
+            return db.copy(), mask_small.copy()
+
+        RDf.det_batch_forward_default = fake_forward
+        ref = RDf.DefaultDetector.__new__(RDf.DefaultDetector)
+        ref.device, ref.logger = "cpu", logging.getLogger("ref-default")
+        tls_ref, raw_ref, extra = run(RDf.DefaultDetector._infer(ref, page.copy(), size, 0.4, 0.6, 2.0))
+        assert extra is None and len(tls_ref) >= 3 and raw_ref.shape == (512, 358) and raw_ref.max() == 255
+
+        def pre_twin(image, detect_size):              # default_preprocess_gpu's host twin (tests/test_dbnet_gpu.py pins the device form)
+            img = image.numpy()
+            ratio = detect_size / max(img.shape[:2])
+            th, tw = int(round(img.shape[0] * ratio)), int(round(img.shape[1] * ratio))
+            proc = imgproc.resize_u8_host(OI.bilateral_filter_u8(img, 17, 80.0, 80.0), (tw, th))
+            ph, pw = (256 - th % 256) % 256, (256 - tw % 256) % 256
+            canvas = np.zeros((th + ph, tw + pw, 3), np.uint8)
+            canvas[:th, :tw] = proc
+            return torch.from_numpy(canvas)[None], ratio, pw, ph
+
+        P.default_preprocess_gpu = pre_twin
+
+        class SameMapsEngine:
+            device = torch.device("cpu")
+
+            def forward(self, pg):
+                seen["page"] = pg[0].numpy()
+                return torch.from_numpy(db.copy()), torch.from_numpy(mask_small[0].copy())
+
+            def release_workspace(self):
+                pass
+
+        det = P.HipDefaultDetector(weights={})
+        det.engine, det._loaded = SameMapsEngine(), True
+        tls, raw, extra = run(det.infer(page.copy(), size, 0.4, 0.6, 2.0))
+        assert np.array_equal(seen["page"], seen["batch"][0])          # both networks were fed the same bytes
+        assert extra is None and len(tls) == len(tls_ref)
+        for a, b in zip(tls, tls_ref):
+            assert np.array_equal(a.pts, b.pts) and abs(a.prob - b.prob) < 1e-6
+        assert raw.dtype == raw_ref.dtype and np.array_equal(raw, raw_ref)
+        run(det.unload())
+    finally:
+        cv.resize = base_resize
 
 
 @check("CommonOCR.recognize: the direction vote is the reference's own _generate_text_direction and equals the native one")
