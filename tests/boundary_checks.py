@@ -5,8 +5,8 @@ oracle.ref_boundary.install() makes ``manga_translator.{utils,config,detection,o
 reference's own OfflineDetector / OfflineOCR / OfflineInpainter / OfflineUpscaler (utils/inference.py ModelWrapper) and is driven
 through the reference's own callers (CommonDetector.detect, CommonOCR.recognize, CommonInpainter.inpaint, get_detector ...).
 No GPU: where a call would reach the dense engine, a stand-in engine returns fixed tensors — what is under test is the boundary
-(types, lifecycle, registry, checkpoint lookup, download flow, error propagation), not the kernels.  Three checks go further and
-run the reference's REAL ``_infer`` of the ctd detector, the default detector and the LaMa inpainter with a stubbed network beside
+(types, lifecycle, registry, checkpoint lookup, download flow, error propagation), not the kernels.  Four checks go further and
+run the reference's REAL ``_infer`` of the ctd detector, the default detector, the 48px OCR and the LaMa inpainter with a stubbed network beside
 the plugin's ``_infer`` with the same stub: everything either side does around the network must produce identical bytes.
 """
 import asyncio
@@ -438,6 +438,112 @@ def _():
     own = TL.generate_text_direction([TL.Quadrilateral(p) for p in pts])
     assert [(tuple(map(tuple, q.pts)), d) for q, d in got] == [(tuple(map(tuple, q.pts)), d) for q, d in own]
     assert all(type(q) is U.Quadrilateral for q, _ in got)
+
+
+@check("the reference's REAL Model48pxOCR._infer (recogniser stubbed) == HipModel48pxOCR._infer (engine stubbed identically)")
+def _():
+    """Direction vote, rectified crops, the sorted-by-width chunks of 16, the probability threshold, the token / colour decode
+    (AvgMeter means, <S> </S> <SP>), attribute assignment and the order of the returned lines (model_48px.py:67-180, the
+    reference's own code over the cv2 stand-in) against the plugin over Ocr48Engine's REAL plan_pages.  The recogniser on both
+    sides is the same function of a line's rectified pixels."""
+    import logging
+    import zlib
+
+    import manga_translator.ocr.model_48px as RM
+    from manga_image_translator_amd import ocr48
+    from oracle import textline as OT
+
+    dictionary = ["<S>", "</S>", "<SP>"] + list("abcdefghijklmnopqrstuvwxyz0123456789")
+    seen = {"ref": [], "hip": []}
+
+    def read_line(crop):  # u8 [48, w, 3] -> (token ids, prob, colour rows [T,10]); deterministic in the pixels
+        rng = np.random.default_rng(zlib.crc32(np.ascontiguousarray(crop).tobytes()))
+        T = int(rng.integers(1, 14))
+        toks = rng.integers(2, len(dictionary), T)
+        if rng.random() < 0.3:
+            toks[int(rng.integers(0, T))] = 1           # an end symbol in the middle cuts the line there
+        if rng.random() < 0.2:
+            toks[0] = 0                                  # a start symbol is skipped, its colour row too
+        cols = rng.random((T, 10)).astype(np.float32)
+        cols[:, :6] = cols[:, :6] * 1.3 - 0.15           # colour heads are unbounded: the clamp to [0, 255] must act
+        return toks.astype(np.int64), float(np.float32(rng.random())), cols  # a probability both sides hold exactly
+
+    class StubOCR:
+        def __init__(self):
+            self.dictionary = dictionary
+
+        def infer_beam_batch_tensor(self, image_tensor, widths, beams_k=5, max_seq_length=255):
+            assert beams_k == 5 and max_seq_length == 255 and image_tensor.shape[1:3] == (3, 48)
+            u8 = (image_tensor * 127.5 + 127.5).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+            assert np.all(u8[0, :, max(widths):] == 0)   # the chunk is zero padded to 4 * (max + 7) // 4 (:84-85)
+            ret = []
+            for j, w in enumerate(widths):
+                seen["ref"].append(u8[j, :, :w].copy())
+                toks, prob, cols = read_line(u8[j, :, :w])
+                c = torch.from_numpy(cols)
+                ret.append((torch.from_numpy(toks), prob, c[:, 0:3], c[:, 3:6], c[:, 6:8], c[:, 8:10]))
+            return ret
+
+    ref = RM.Model48pxOCR.__new__(RM.Model48pxOCR)
+    ref.model, ref.use_gpu, ref.device, ref.logger = StubOCR(), False, "cpu", logging.getLogger("ref-ocr")
+
+    class SameReaderEngine(ocr48.Ocr48Engine):
+        device = torch.device("cpu")
+
+        def __init__(self):      # no weights: only the host planning of the real engine is used
+            pass
+
+        def recognize_pages(self, pages_u8, quads_per_page, max_seq_length=255, suppress_eos=False, directions=None, group_pages=8):
+            assert max_seq_length == 255 and not suppress_eos and pages_u8.dtype == torch.uint8
+            P_, H, W, _ = pages_u8.shape
+            plan = self.plan_pages(quads_per_page, H, W, directions)          # Ocr48Engine's own chunking
+            n = len(plan["order"])
+            tokens, length = np.zeros((n, 16), np.int64), np.zeros(n, np.int64)
+            prob, colors = np.zeros(n, np.float32), np.zeros((n, 16, 10), np.float32)
+            for row, (p, i) in enumerate(plan["order"]):
+                crop = OT.get_transformed_region(pages_u8[p].numpy(), np.asarray(quads_per_page[p][i].pts), directions[p][i], 48)
+                seen["hip"].append(crop)
+                toks, pr, cols = read_line(crop)
+                tokens[row, 1:1 + len(toks)], length[row] = toks, len(toks) + 1   # decode()'s rows start with <S>
+                prob[row], colors[row, :len(toks)] = pr, cols
+            t = torch.from_numpy
+            return dict(tokens=t(tokens), length=t(length), prob=t(prob), colors=t(colors), order=plan["order"])
+
+        def release_workspace(self):
+            pass
+
+    rng = np.random.default_rng(33)
+    page = rng.integers(0, 256, (900, 700, 3)).astype(np.uint8)
+    boxes = []
+    for k in range(21):                                    # more than one chunk of 16; vertical, horizontal and skewed lines
+        x, y = int(rng.integers(5, 500)), int(rng.integers(5, 650))
+        if k % 3 == 0:
+            w, h = int(rng.integers(20, 40)), int(rng.integers(80, 230))
+        else:
+            w, h = int(rng.integers(60, 190)), int(rng.integers(18, 44))
+        sk = int(rng.integers(-6, 7)) if k % 4 == 0 else 0
+        boxes.append(np.array([[x, y + sk], [x + w, y], [x + w, y + h - sk], [x, y + h]]))
+    boxes[7][:, 0] = boxes[3][:, 0]                        # equal widths: the stable sort's tie order matters
+    boxes[7][:, 1] = boxes[3][:, 1] + 250
+    for prob_cfg in (None, 0.55):
+        cfg = type("Cfg", (), {"prob": prob_cfg})()
+        want_lines = [U.Quadrilateral(b.copy(), "", 1.0) for b in boxes]
+        got_lines = [U.Quadrilateral(b.copy(), "", 1.0) for b in boxes]
+        seen["ref"].clear(), seen["hip"].clear()
+        want = run(RM.Model48pxOCR._infer(ref, page.copy(), want_lines, cfg))
+        ocr = P.HipModel48pxOCR(weights={}, dictionary=dictionary)
+        ocr.engine, ocr._loaded = SameReaderEngine(), True
+        got = run(ocr.infer(page.copy(), got_lines, cfg))
+        assert len(seen["ref"]) == len(seen["hip"]) == len(boxes)
+        assert all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(seen["ref"], seen["hip"])), "crop order / pixels"
+        assert 0 < len(got) == len(want) < len(boxes), (len(got), len(want))
+        key = lambda q: (tuple(map(tuple, np.asarray(q.pts).tolist())), q.text, float(q.prob), q.fg_r, q.fg_g, q.fg_b,
+                         q.bg_r, q.bg_g, q.bg_b, q.direction)
+        for a, b in zip(got, want):
+            assert key(a) == key(b), (key(a), key(b))
+        assert all(any(q is l for l in got_lines) for q in got)       # the caller's own objects come back, mutated
+        assert any(q.text and " " not in q.text for q in got) and any(q.fg_r in (0, 255) or q.bg_r in (0, 255) for q in got)
+        run(ocr.unload())
 
 
 @check("exceptions propagate through the reference's infer()/inpaint() wrappers")
