@@ -510,6 +510,15 @@ def main():
                                       + (f" + per-step gather of {gathered['bytes']} result bytes to rank 0" if world > 1 else "")},
             "roofline": roof, "cpu_baseline": cpu, "parity_checked": parity, "dropin": dropin, "conv_gemm_by_tile": per_cfg,
         }
+        from manga_image_translator_amd import ops as _ops
+        if _ops.split_mode():  # opt-in (MIT_GEMM_SPLIT): say so wherever the number travels
+            n = _ops.split_mode()
+            out["dtype"] = f"f32 (operands as three exact bf16 planes, {n} of 9 plane pairs on the bf16 MFMA, fp32 accumulation)"
+            out["gemm_mode"] = {"MIT_GEMM_SPLIT": n, "note": "large constant-weight contractions run on conv_gemm_split_kernel; roofline.peak / frac "
+                                "are still quoted against the fp32 MFMA peak (157.3 TFLOP/s), which this mode can exceed; the bf16 MFMA peak is "
+                                "2500 TFLOP/s for N x the algorithmic FLOPs"}
+        else:
+            out["gemm_mode"] = {"MIT_GEMM_SPLIT": 0, "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"}
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         if leg_errors:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 2
+#define MIT_ABI_VERSION 3
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -102,6 +102,10 @@ typedef struct MitConvGemm {
     const float *scale, *bias;
     int32_t act;
     float act_alpha;
+    /* optional: W pre-split into three bf16 planes (mit_gemm_split_pack) for the split-bf16 tiles; NULL = fp32 MFMA only.
+     * ws_zs0 = uint16 elements between z0 slices (the z1 stride must be 0 when this is set). */
+    const uint16_t *w_split;
+    int64_t ws_zs0;
 } MitConvGemm;
 
 const char *mit_last_error(void);
@@ -123,6 +127,19 @@ const char *mit_conv_gemm_config_name(int cfg);
 /* the kernel's template-id as rocprofv3 prints it (without namespace), e.g. "conv_gemm_fast_kernel<128, 128, 16, 1, 4, 4, 4>":
  * lets bench.py join its per-tile probe numbers with the profiler's kernel-trace / PMC rows; NULL past the table. */
 const char *mit_conv_gemm_config_kernel(int cfg);
+
+/* Split-bf16 form of the same contraction (opt-in: MIT_GEMM_SPLIT=6|9 in the environment, or an explicit "split*" tile through
+ * mit_conv_gemm_cfg).  gfx950's bf16 MFMA runs at 16x the rate of the fp32 one; an fp32 number is EXACTLY the sum of three bf16
+ * numbers (x = hi + mid + lo, each the round-to-nearest bf16 of what the previous ones left), so
+ *     a * b = sum over plane pairs (p, q) of a_p * b_q        every such product is exact in fp32 (8 x 8 significant bits)
+ * and the contraction becomes 9 bf16 MFMA products accumulated in fp32 ("p9": the error is that of the fp32 accumulation alone, as
+ * for the fp32 MFMA chain), or 6 when the three pairs with p + q >= 3 (relative weight <= 2^-24 of the product) are dropped ("p6").
+ * Activations are split in the kernel while they are staged to LDS; the constant W operand is split once:
+ *   mit_gemm_split_pack: w [nz][Kw][ldw] fp32 (slices w_zs floats apart; Kw % 8 == 0, ldw % 4 == 0)
+ *                        -> out [nz][3 planes][Kw / 8][ldw][8] bf16 (16-byte cells of 8 consecutive k of one column),
+ *                        nz * 3 * Kw * ldw uint16 elements; pass it as MitConvGemm.w_split with ws_zs0 = 3 * Kw * ldw.
+ * Nothing in the reference corresponds to it (the reference computes these layers with fp32 torch kernels). */
+int mit_gemm_split_pack(const float *w_dev, int64_t w_zs, int nz, int Kw, int64_t ldw, uint16_t *out_dev, void *stream);
 
 /* k x k (3, 5, 7) stride-1 "same" convolution with 1..4 output channels on the fp32 VALU (an MFMA tile would idle 29 of
  * its 32 columns): out[b,y,x,n] = act(sum in[b,y+dy,x+dx,c] * w4[(ky*k+kx)*Cin + c][n] + bias[n]).  in: NHWC with pixel

@@ -1,6 +1,7 @@
 // conv_gemm.hip — configuration table, tile choice, kernel-time probe and C entry points of mit_conv_gemm.
 // The kernels are in conv_gemm_kernels.h; their instantiations are compiled in conv_gemm_inst<group>.hip.
 #include "conv_gemm_kernels.h"
+#include <string.h>
 
 using namespace mitcg;
 
@@ -15,6 +16,7 @@ const CfgEntry kCfgs[] = {
 #define KNAME_launch_cfg "conv_gemm_kernel"
 #define KNAME_launch_fast "conv_gemm_fast_kernel"
 #define KNAME_launch_gemv "conv_gemv_kernel"
+#define KNAME_launch_split "conv_gemm_split_kernel"
 #define X(g, name, fast, BM, BN, BK, fn, ...) \
     {name, BM, BN, BK, fn<BM, BN, BK, __VA_ARGS__>, fast, KNAME_##fn "<" #BM ", " #BN ", " #BK ", " #__VA_ARGS__ ">"},
 #include "conv_gemm_cfgs.inc"
@@ -37,6 +39,20 @@ bool fast_eligible(const MitConvGemm &p, int BK) {
 }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kCfgSmall = 26, kCfgGemv16 = 27, kCfgGemv4 = 28, kCfgGemv16N1 = 29, kCfgGemv4N1 = 30;
+
+int cfg_by_name(const char *name) {
+    for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i)
+        if (!strcmp(kCfgs[i].name, name)) return i;
+    return -1;
+}
+
+// conv_gemm_split_kernel preconditions: the fast kernel's, plus split planes of W laid out by mit_gemm_split_pack
+bool split_eligible(const MitConvGemm &p, int BK) {
+    if (!p.w_split || (reinterpret_cast<uintptr_t>(p.w_split) & 15) || (p.ws_zs0 & 7)) return false;
+    if (p.w_zs1 != 0 || (p.Kw & 7) || p.ntaps * p.Cin > p.Kw) return false;
+    if ((int64_t)3 * (p.Kw >> 3) * p.ldw > 0x7fffffffLL) return false;  // 32-bit cell indices
+    return fast_eligible(p, BK);
+}
 
 // conv_gemv_kernel preconditions: <= 4 output columns, plain (unbatched, unsplit) maps, the whole weight panel in LDS
 bool gemv_eligible(const MitConvGemm &p, int lpr) {
@@ -64,6 +80,16 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     if (!gemv_off && gemv_eligible(p, 16)) return p.N == 1 ? kCfgGemv16N1 : kCfgGemv16;
     if (!gemv_off && gemv_eligible(p, 4)) return p.N == 1 ? kCfgGemv4N1 : kCfgGemv4;
     if (p.N <= 32) return 2;
+    // opt-in split-bf16 tiles (MIT_GEMM_SPLIT=6|9): layers whose packer attached split planes of W, large enough to fill the chip
+    static const int split = getenv("MIT_GEMM_SPLIT") ? atoi(getenv("MIT_GEMM_SPLIT")) : 0;
+    static const int64_t split_min = getenv("MIT_GEMM_SPLIT_MIN_TILES") ? atoll(getenv("MIT_GEMM_SPLIT_MIN_TILES")) : 1280;
+    if ((split == 6 || split == 9) && p.w_split && split_eligible(p, 16) && ((M + 127) / 128) * ((p.N + 63) / 64) * p.Z >= split_min) {
+        static const int wide6 = cfg_by_name("split128x128x16p6m"), wide9 = cfg_by_name("split128x128x16p9m");
+        static const int narrow6 = cfg_by_name("split128x64x16p6m"), narrow9 = cfg_by_name("split128x64x16p9");
+        const int r = p.N % 128;
+        const int c = (p.N <= 64 || (r != 0 && r <= 64)) ? (split == 6 ? narrow6 : narrow9) : (split == 6 ? wide6 : wide9);
+        if (c >= 0) return c;
+    }
     if (f16 && m192 >= 0 && M > 128 && M <= 192) return m192;  // 2 x 128 rows would run a 40 % empty second tile
     if (f16 && bigk >= 0 && p.N % 128 == 0 && p.N <= 128 && p.ntaps * p.Cin >= 4096 && M >= 256 * 1024) return bigk;
     // under-filled launches (the decoder's GEMMs: M = lines x beams = 10240): a 128-row tiling leaves most CUs with one workgroup or
@@ -237,6 +263,8 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
         if (!gemv_eligible(p, lpr) || p.N > c.BN)
             return mit_set_error("mit_conv_gemm: cfg %s needs N <= %d, Z == 1, unsplit maps and Cin %% %d == 0", c.name, c.BN, 4 * lpr);
     }
+    if (c.fast == 4 && !split_eligible(p, c.BK))
+        return mit_set_error("mit_conv_gemm: cfg %s needs w_split (mit_gemm_split_pack, 16-byte aligned, w_zs1 == 0, Kw %% 8 == 0) and the fast tiles' preconditions", c.name);
     if ((c.fast == 1 || c.fast == 2) && !fast_eligible(p, c.BK))
         return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% %d == 0, <= %d taps and 32-bit element offsets", c.name, c.BK, FAST_MAX_TAPS);
     const int M = (int)M64;
@@ -270,3 +298,16 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
 }
 
 extern "C" int mit_conv_gemm(const MitConvGemm *d, void *stream) { return mit_conv_gemm_cfg(d, -1, stream); }
+
+extern "C" int mit_gemm_split_pack(const float *w_dev, int64_t w_zs, int nz, int Kw, int64_t ldw, uint16_t *out_dev, void *stream) {
+    if (!w_dev || !out_dev) return mit_set_error("mit_gemm_split_pack: null pointer");
+    if (nz <= 0 || Kw <= 0 || (Kw & 7) || ldw <= 0 || (ldw & 3) || ldw > 0x7fffffffLL)
+        return mit_set_error("mit_gemm_split_pack: need nz > 0, Kw %% 8 == 0, ldw %% 4 == 0 (nz=%d Kw=%d ldw=%lld)", nz, Kw, (long long)ldw);
+    if ((reinterpret_cast<uintptr_t>(out_dev) & 15)) return mit_set_error("mit_gemm_split_pack: output must be 16-byte aligned");
+    const int64_t total = (int64_t)nz * (Kw >> 3) * ldw;
+    hipLaunchKernelGGL(gemm_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       w_dev, w_zs, Kw >> 3, (int)ldw, out_dev, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mit_set_error("mit_gemm_split_pack: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}

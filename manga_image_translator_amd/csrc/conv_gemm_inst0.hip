@@ -18,6 +18,15 @@
 #ifndef MIT_INST_4
 #define MIT_INST_4(...)
 #endif
+#ifndef MIT_INST_5
+#define MIT_INST_5(...)
+#endif
+#ifndef MIT_INST_6
+#define MIT_INST_6(...)
+#endif
+#ifndef MIT_INST_7
+#define MIT_INST_7(...)
+#endif
 #define X(g, name, fast, BM, BN, BK, fn, ...) MIT_INST_##g(BM, BN, BK, fn, __VA_ARGS__)
 #include "conv_gemm_cfgs.inc"
 #undef X

@@ -1,7 +1,7 @@
-// conv_gemm_inst4.hip — instantiates the group-4 tile configurations of conv_gemm_cfgs.inc (parallel compilation).
+// conv_gemm_inst6.hip — instantiates the group-6 (split-bf16, pipelined) tile configurations of conv_gemm_cfgs.inc (parallel compilation).
 #include "conv_gemm_kernels.h"
 
-#define MIT_INST_4(BM, BN, BK, fn, ...) \
+#define MIT_INST_6(BM, BN, BK, fn, ...) \
     template void mitcg::fn<BM, BN, BK, __VA_ARGS__>(const MitConvGemm &, int, int, int, int, hipStream_t);
 #ifndef MIT_INST_0
 #define MIT_INST_0(...)
@@ -21,8 +21,8 @@
 #ifndef MIT_INST_5
 #define MIT_INST_5(...)
 #endif
-#ifndef MIT_INST_6
-#define MIT_INST_6(...)
+#ifndef MIT_INST_5
+#define MIT_INST_5(...)
 #endif
 #ifndef MIT_INST_7
 #define MIT_INST_7(...)

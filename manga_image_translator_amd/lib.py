@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 2
+MIT_ABI_VERSION = 3
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -67,6 +67,8 @@ class MitConvGemm(C.Structure):
         ("bias", C.c_void_p),
         ("act", C.c_int32),
         ("act_alpha", C.c_float),
+        ("w_split", C.c_void_p),
+        ("ws_zs0", C.c_int64),
     ]
 
 
@@ -144,6 +146,7 @@ SYMBOLS = {
     "mit_conv_gemm_cfg": (C.c_int, [C.POINTER(MitConvGemm), C.c_int, C.c_void_p]),
     "mit_conv_gemm_config_name": (C.c_char_p, [C.c_int]),
     "mit_conv_gemm_config_kernel": (C.c_char_p, [C.c_int]),
+    "mit_gemm_split_pack": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "mit_conv_small_cout": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "mit_prof_enable": (C.c_int, [C.c_int]),

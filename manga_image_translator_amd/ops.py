@@ -11,8 +11,10 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
+import weakref
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -134,6 +136,10 @@ def conv_gemm_desc(*, a: torch.Tensor, NB: int, Hi: int, Wi: int, Cin: int, a_st
     d.w = w.data_ptr()
     d.w_zs1, d.w_zs0 = w_zs
     d.ldw, d.Kw, d.Nw = ldw, Kw, Nw
+    if _SPLITS:
+        planes, zs = _split_for(w, ldw, Kw, w_zs)
+        if planes is not None:
+            d.w_split, d.ws_zs0 = planes.data_ptr(), zs
     d.N, d.Z, d.zdiv = N, Z, zdiv
     d.c = c
     d.pre = pre if pre is not None else tensor_map(None)
@@ -165,13 +171,59 @@ def fold_bn(gamma: torch.Tensor, beta: torch.Tensor, mean: torch.Tensor, var: to
     return scale.to(torch.float32), bias.to(torch.float32)
 
 
+def split_mode() -> int:
+    """``MIT_GEMM_SPLIT`` = 6 | 9: packers also build the three-bf16-plane form of their weights and ``mit_conv_gemm`` picks the
+    split-bf16 tiles for them (include/mit_hip.h, mit_gemm_split_pack).  0 / unset (default): fp32 MFMA tiles only."""
+    v = os.environ.get("MIT_GEMM_SPLIT", "0").strip() or "0"
+    return int(v) if v in ("3", "6", "9") else 0
+
+
+_SPLITS: Dict[int, Tuple["weakref.ref", torch.Tensor, int, int, int]] = {}   # data_ptr -> (weight, planes, nz, Kp, Np)
+
+
+def split_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[Kp, Np]`` or ``[nz, Kp, Np]`` (contiguous, on the GPU) -> int16 planes ``[nz, 3, Kp / 8, Np, 8]`` with
+    ``w == hi + mid + lo`` exactly (bf16 bit patterns), laid out as conv_gemm_split_kernel stages them."""
+    if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() not in (2, 3):
+        raise ValueError("split_weight: contiguous fp32 [Kp, Np] or [nz, Kp, Np] expected")
+    nz = 1 if w.dim() == 2 else w.shape[0]
+    Kp, Np = w.shape[-2], w.shape[-1]
+    if Kp % 8 or Np % 4:
+        raise ValueError(f"split_weight: Kp % 8 == 0 and Np % 4 == 0 needed (got {Kp} x {Np})")
+    out = torch.empty(nz, 3, Kp // 8, Np, 8, dtype=torch.int16, device=w.device)
+    _lib.check(_lib.load().mit_gemm_split_pack(w.data_ptr(), Kp * Np, nz, Kp, Np, out.data_ptr(), C.c_void_p(current_stream())),
+               "mit_gemm_split_pack")
+    return out
+
+
+def register_split(w: torch.Tensor, force: bool = False) -> Optional[torch.Tensor]:
+    """Attach split planes to a packed weight (no-op unless ``split_mode()`` or ``force``): ``conv_gemm_desc`` finds them by the
+    tensor's identity, so every layer built on ``pack_weight_kn`` / ``WinogradConv3x3`` gets the split tiles without further plumbing."""
+    if not (force or split_mode()) or w.device.type != "cuda":
+        return None
+    planes = split_weight(w)
+    nz = 1 if w.dim() == 2 else w.shape[0]
+    key = w.data_ptr()
+    _SPLITS[key] = (weakref.ref(w, lambda _r, k=key: _SPLITS.pop(k, None)), planes, nz, w.shape[-2], w.shape[-1])
+    return planes
+
+
+def _split_for(w: torch.Tensor, ldw: int, Kw: int, w_zs: Tuple[int, int]):
+    e = _SPLITS.get(w.data_ptr())
+    if e is None or e[0]() is not w or (e[3], e[4]) != (Kw, ldw) or w_zs[0] != 0 or (e[2] > 1 and w_zs[1] != Kw * ldw):
+        return None, 0
+    return e[1], (3 * Kw * ldw if e[2] > 1 else 0)
+
+
 def pack_weight_kn(w_kn: torch.Tensor, device) -> Tuple[torch.Tensor, int, int]:
     """Zero-pad a [K, N] matrix to [Kp(16), Np(4)] fp32 on ``device``; returns (w, Kp, Np)."""
     K, N = w_kn.shape
     Kp, Np = _round_up(K, 16), _round_up(N, 4)
     out = torch.zeros(Kp, Np, dtype=torch.float32)
     out[:K, :N] = w_kn.detach().to(torch.float32)
-    return out.to(device).contiguous(), Kp, Np
+    out = out.to(device).contiguous()
+    register_split(out)
+    return out, Kp, Np
 
 
 @dataclass
@@ -275,6 +327,7 @@ class WinogradConv3x3:
         u = torch.zeros(36, self.Kp, self.Np, dtype=torch.float32)
         u[:, :Cin, :Cout] = U.to(torch.float32)
         self.u = u.to(device).contiguous()
+        register_split(self.u)
         scale = bias_t = None
         if bn is not None:
             scale, bias_t = fold_bn(*bn, conv_bias=bias)

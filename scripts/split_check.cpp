@@ -1,0 +1,255 @@
+// split_check.cpp — stand-alone check of the split-bf16 tiles of mit_conv_gemm against its fp32 MFMA tiles and a float64 host
+// reference, with timings.  No Python / torch: links libmit_hip.so and the HIP runtime only, so it starts in seconds on a GPU box.
+//
+//   hipcc -O2 -std=c++17 scripts/split_check.cpp -o scripts/split_check -Iinclude -Lmanga_image_translator_amd -lmit_hip \
+//         -Wl,-rpath,'$ORIGIN/../manga_image_translator_amd'          (scripts/build_split_check.sh)
+//   scripts/split_check [reps]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <random>
+#include <string>
+#include <vector>
+#include "mit_hip.h"
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(2);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+struct Case {
+    const char *name;
+    int NB, H, W, Cin, N, k, stride, pad_mode, Z, act;
+    int ref_cfg;
+    std::vector<int> cfgs;
+};
+
+static int find_cfg(const char *name) {
+    for (int i = 0;; ++i) {
+        const char *n = mit_conv_gemm_config_name(i);
+        if (!n) return -1;
+        if (!strcmp(n, name)) return i;
+    }
+}
+
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);  // a GPU fault kills the process: keep what was printed
+    const int reps = argc > 1 ? atoi(argv[1]) : 10;
+    const bool ablate = argc > 2 && !strcmp(argv[2], "--ablate");  // time the xs* ablation tiles of an MIT_CONV_EXPERIMENTS build (no checks)
+    const int f_wide = find_cfg("fast128x128x16w4c"), f_narrow = find_cfg("fast128x64x16w5c");
+    const int s6 = find_cfg("split128x128x16p6"), s9 = find_cfg("split128x128x16p9"), s3 = find_cfg("split128x128x16p3");
+    const int n6 = find_cfg("split128x64x16p6"), n9 = find_cfg("split128x64x16p9"), s6k32 = find_cfg("split128x128x32p6");
+    const int s6s = find_cfg("split128x128x16p6s"), s9s = find_cfg("split128x128x16p9s"), n6s = find_cfg("split128x64x16p6s"), s6k32s = find_cfg("split128x128x32p6s");
+    const int s6m = find_cfg("split128x128x16p6m"), s9m = find_cfg("split128x128x16p9m"), n6m = find_cfg("split128x64x16p6m"), s6k32m = find_cfg("split128x128x32p6m");
+    if (s6s < 0 || s9s < 0 || n6s < 0 || s6k32s < 0 || s6m < 0 || s9m < 0 || n6m < 0 || s6k32m < 0) {
+        fprintf(stderr, "pipelined tile names not found\n");
+        return 2;
+    }
+    if (f_wide < 0 || f_narrow < 0 || s6 < 0 || s9 < 0 || s3 < 0 || n6 < 0 || n9 < 0 || s6k32 < 0) {
+        fprintf(stderr, "tile names not found\n");
+        return 2;
+    }
+    std::vector<Case> cases = {
+        {"probe: A[m][k] = (k == m % 16), W[k][n] = 1000 k + n", 1, 1, 256, 16, 128, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, s3, n6, s6s, n6s, s6m, n6m}},
+        {"1x1 320->1280 (ConvNeXt pw1), M=65536, gelu", 1, 256, 256, 320, 1280, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6, s9, s3, s6s, s6m, s9m, s6k32m}},
+        {"3x3 reflect 128->128, 2x96x160, relu", 2, 96, 160, 128, 128, 3, 1, MIT_PAD_REFLECT, 1, MIT_ACT_RELU, f_wide, {s6, s9, s6s, s6m, s9m, s6k32m}},
+        {"winograd-like Z=36, T=8192, 128->384", 1, 1, 8192, 128, 384, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6, s9, s6m, s9m}},
+        {"3x3 s2 zero 64->64, 4x128x128", 4, 128, 128, 64, 64, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_narrow, {n6, n9, n6s, n6m}},
+        {"1x1 1280->320 (pw2), M=65536", 1, 256, 256, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, n6, s6m, n6m, s6k32m}},
+        {"ragged: M=1000, 48->200 3x3 zero", 1, 25, 40, 48, 200, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s6, n6, n9, s6m, n6m}},
+    };
+    std::mt19937 rng(1234);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    int bad = 0;
+    for (auto &cs : cases) {
+        const int pad = cs.k / 2;
+        const int Ho = (cs.H + 2 * pad - cs.k) / cs.stride + 1, Wo = (cs.W + 2 * pad - cs.k) / cs.stride + 1;
+        const int ntaps = cs.k * cs.k, K = ntaps * cs.Cin, Kp = (K + 15) / 16 * 16, Np = (cs.N + 3) / 4 * 4;
+        const int64_t a_elems = (int64_t)cs.Z * cs.NB * cs.H * cs.W * cs.Cin, w_elems = (int64_t)cs.Z * Kp * Np;
+        const int64_t M = (int64_t)cs.NB * Ho * Wo, c_elems = (int64_t)cs.Z * M * cs.N;
+        std::vector<float> ha(a_elems), hw(w_elems, 0.f), hbias(Np), hscale(Np);
+        for (auto &v : ha) v = nd(rng) * (1.f + 3.f * (float)((&v - ha.data()) % 7 == 0));
+        for (int z = 0; z < cs.Z; ++z)
+            for (int k = 0; k < K; ++k)
+                for (int n = 0; n < cs.N; ++n) hw[((int64_t)z * Kp + k) * Np + n] = nd(rng) * 0.05f;
+        for (int n = 0; n < Np; ++n) hbias[n] = nd(rng) * 0.1f, hscale[n] = 1.f + 0.1f * nd(rng);
+        const bool probe = !strncmp(cs.name, "probe", 5);
+        if (probe) {  // output[m][n] must be exactly W[m % 16][n]: any row / column / k-group mix-up shows as a readable number
+            for (int64_t i = 0; i < a_elems; ++i) ha[i] = (i % cs.Cin) == (i / cs.Cin) % 16 ? 1.f : 0.f;
+            for (int k = 0; k < K; ++k)
+                for (int n = 0; n < cs.N; ++n) hw[(int64_t)k * Np + n] = 1000.f * k + n;
+            for (int n = 0; n < Np; ++n) hbias[n] = 0.f, hscale[n] = 1.f;
+        }
+        float *da, *dw, *dc, *dref, *dbias, *dscale;
+        uint16_t *dsplit;
+        CK(hipMalloc(&da, a_elems * 4));
+        CK(hipMalloc(&dw, w_elems * 4));
+        CK(hipMalloc(&dc, c_elems * 4));
+        CK(hipMalloc(&dref, c_elems * 4));
+        CK(hipMalloc(&dbias, Np * 4));
+        CK(hipMalloc(&dscale, Np * 4));
+        CK(hipMalloc(&dsplit, w_elems * 3 * 2));
+        CK(hipMemcpy(da, ha.data(), a_elems * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dw, hw.data(), w_elems * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dbias, hbias.data(), Np * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dscale, hscale.data(), Np * 4, hipMemcpyHostToDevice));
+        if (mit_gemm_split_pack(dw, (int64_t)Kp * Np, cs.Z, Kp, Np, dsplit, nullptr)) {
+            fprintf(stderr, "pack: %s\n", mit_last_error());
+            return 2;
+        }
+        CK(hipDeviceSynchronize());
+        {   // the planes must add up to the fp32 weights exactly
+            std::vector<uint16_t> hs(w_elems * 3);
+            CK(hipMemcpy(hs.data(), dsplit, w_elems * 3 * 2, hipMemcpyDeviceToHost));
+            int64_t wrong = 0;
+            const int K8 = Kp / 8;
+            for (int z = 0; z < cs.Z && wrong == 0; ++z)
+                for (int k = 0; k < Kp; ++k)
+                    for (int n = 0; n < Np; ++n) {
+                        float sum = 0.f;
+                        for (int pl = 2; pl >= 0; --pl) {
+                            const uint16_t b = hs[((((int64_t)z * 3 + pl) * K8 + k / 8) * Np + n) * 8 + (k & 7)];
+                            uint32_t u = (uint32_t)b << 16;
+                            float f;
+                            memcpy(&f, &u, 4);
+                            sum += f;
+                        }
+                        if (sum != hw[((int64_t)z * Kp + k) * Np + n]) ++wrong;
+                    }
+            printf("%-48s pack: %s\n", cs.name, wrong ? "PLANES DO NOT SUM TO W" : "hi + mid + lo == w exactly");
+            bad += wrong != 0;
+        }
+        MitConvGemm d;
+        memset(&d, 0, sizeof(d));
+        d.a = da;
+        d.a_zs0 = (int64_t)cs.NB * cs.H * cs.W * cs.Cin;
+        d.a_bs = (int64_t)cs.H * cs.W * cs.Cin, d.a_ys = (int64_t)cs.W * cs.Cin, d.a_xs = cs.Cin;
+        d.NB = cs.NB, d.Hi = cs.H, d.Wi = cs.W, d.Cin = cs.Cin, d.Ho = Ho, d.Wo = Wo, d.sy = d.sx = cs.stride;
+        d.ntaps = ntaps, d.pad_mode = cs.pad_mode;
+        for (int t = 0; t < ntaps; ++t) d.tap_dy[t] = t / cs.k - pad, d.tap_dx[t] = t % cs.k - pad, d.tap_off[t] = 0;
+        d.w = dw, d.w_zs0 = (int64_t)Kp * Np, d.ldw = Np, d.Kw = Kp, d.Nw = Np;
+        d.N = cs.N, d.Z = cs.Z, d.zdiv = 1 << 30;
+        d.c.base = dref, d.c.zs0 = M * cs.N, d.c.bs = (int64_t)Ho * Wo * cs.N, d.c.ys = (int64_t)Wo * cs.N, d.c.xs = cs.N;
+        d.scale = dscale, d.bias = dbias, d.act = cs.act, d.act_alpha = 0.1f;
+        d.w_split = dsplit, d.ws_zs0 = (int64_t)3 * Kp * Np;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        auto run = [&](int cfg, float *out, float *ms) -> int {
+            d.c.base = out;
+            if (mit_conv_gemm_cfg(&d, cfg, nullptr)) {
+                fprintf(stderr, "  cfg %s: %s\n", mit_conv_gemm_config_name(cfg), mit_last_error());
+                return 1;
+            }
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, nullptr));
+            for (int r = 0; r < reps; ++r) mit_conv_gemm_cfg(&d, cfg, nullptr);
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(ms, e0, e1));
+            *ms /= reps;
+            return 0;
+        };
+        float ms_ref = 0.f;
+        if (run(cs.ref_cfg, dref, &ms_ref)) return 2;
+        std::vector<float> href(c_elems), hc(c_elems);
+        CK(hipMemcpy(href.data(), dref, c_elems * 4, hipMemcpyDeviceToHost));
+        // float64 reference of the pre-activation sums on a sample of outputs
+        const int NS = 4000;
+        std::vector<int64_t> sm(NS);
+        std::vector<double> exact(NS);
+        double ymax = 0;
+        for (auto v : href) ymax = fmax(ymax, fabs((double)v));
+        std::uniform_int_distribution<int64_t> pick(0, c_elems - 1);
+        auto act64 = [&](double v) {
+            if (cs.act == MIT_ACT_RELU) return v > 0 ? v : 0.0;
+            if (cs.act == MIT_ACT_LEAKY) return v > 0 ? v : 0.1 * v;
+            if (cs.act == MIT_ACT_GELU) return 0.5 * v * (1.0 + erf(v * 0.70710678118654752440));
+            return v;
+        };
+        for (int s = 0; s < NS; ++s) {
+            const int64_t idx = pick(rng);
+            sm[s] = idx;
+            const int n = (int)(idx % cs.N);
+            const int64_t m = (idx / cs.N) % M;
+            const int z = (int)(idx / cs.N / M);
+            const int nb = (int)(m / ((int64_t)Ho * Wo)), oy = (int)(m / Wo % Ho), ox = (int)(m % Wo);
+            double acc = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                int iy = oy * cs.stride + t / cs.k - pad, ix = ox * cs.stride + t % cs.k - pad;
+                if (cs.pad_mode == MIT_PAD_REFLECT) {
+                    iy = iy < 0 ? -iy : (iy >= cs.H ? 2 * cs.H - 2 - iy : iy);
+                    ix = ix < 0 ? -ix : (ix >= cs.W ? 2 * cs.W - 2 - ix : ix);
+                } else if (iy < 0 || iy >= cs.H || ix < 0 || ix >= cs.W) {
+                    continue;
+                }
+                const float *ap = ha.data() + (((int64_t)z * cs.NB + nb) * cs.H + iy) * cs.W * cs.Cin + (int64_t)ix * cs.Cin;
+                const float *wp = hw.data() + ((int64_t)z * Kp + (int64_t)t * cs.Cin) * Np + n;
+                for (int c = 0; c < cs.Cin; ++c) acc += (double)ap[c] * (double)wp[(int64_t)c * Np];
+            }
+            exact[s] = act64(acc * (double)hscale[n] + (double)hbias[n]);
+        }
+        auto err64 = [&](const std::vector<float> &y) {
+            double e = 0;
+            for (int s = 0; s < NS; ++s) e = fmax(e, fabs((double)y[sm[s]] - exact[s]));
+            return e / ymax;
+        };
+        const double flops = 2.0 * M * cs.N * K * cs.Z;
+        printf("  %-22s %9.3f ms %8.1f TFLOP/s   err vs f64 %.2e (relative to max|y| = %.3g)\n", mit_conv_gemm_config_name(cs.ref_cfg), ms_ref,
+               flops / ms_ref * 1e-9, err64(href), ymax);
+        const double e_ref = err64(href);
+        for (int cfg : cs.cfgs) {
+            float ms = 0.f;
+            printf("  %-22s ...\n", mit_conv_gemm_config_name(cfg));
+            CK(hipMemset(dc, 0xff, c_elems * 4));
+            if (run(cfg, dc, &ms)) {
+                ++bad;
+                continue;
+            }
+            CK(hipMemcpy(hc.data(), dc, c_elems * 4, hipMemcpyDeviceToHost));
+            double dmax = 0;
+            int64_t nan = 0;
+            for (int64_t i = 0; i < c_elems; ++i) {
+                if (!(hc[i] == hc[i])) ++nan;
+                dmax = fmax(dmax, fabs((double)hc[i] - (double)href[i]));
+            }
+            const std::string nm = mit_conv_gemm_config_name(cfg);
+            if (probe || dmax / ymax > 1e-2) {
+                int shown = 0;
+                for (int64_t i = 0; i < c_elems && shown < 12; ++i)
+                    if (hc[i] != href[i] && (probe || fabs((double)hc[i] - href[i]) > 1e-2 * ymax)) {
+                        printf("    [%s] z %lld m %lld n %lld: got %.9g want %.9g\n", nm.c_str(), (long long)(i / cs.N / M), (long long)(i / cs.N % M),
+                               (long long)(i % cs.N), hc[i], href[i]);
+                        ++shown;
+                    }
+            }
+            const bool p3 = nm.find("p3") != std::string::npos;
+            const double e = err64(hc), tol = p3 ? 2e-2 : 4.0 * e_ref + 2e-6;
+            const bool ok = nan == 0 && e <= tol && dmax / ymax <= (p3 ? 2e-2 : 2e-5);
+            printf("  %-22s %9.3f ms %8.1f TFLOP/s   err vs f64 %.2e   vs fp32 tile %.2e   nan %lld   %s  (x%.2f)\n", nm.c_str(), ms, flops / ms * 1e-9, e,
+                   dmax / ymax, (long long)nan, ok ? "ok" : "FAIL", ms_ref / ms);
+            bad += !ok;
+        }
+        if (ablate && (strstr(cs.name, "pw1") || strstr(cs.name, "3x3 reflect"))) {
+            for (const char *nm : {"split128x128x16p6", "split128x128x16p6s", "xsAsmSub", "xsAsmSubNP", "xsNoLoad", "xsNoSplit", "xsNoWrite", "xsNoFrag", "xsNoBar",
+                                   "xsMfmaOnly", "xsNoLoadNP", "xsNoWriteNP", "xsNoFragNP", "xsNoLoadWriteNP", "xsMfmaOnlyNP"}) {
+                const int cfg = find_cfg(nm);
+                float ms = 0.f;
+                if (cfg < 0) continue;
+                printf("  ablation %-20s ...\n", nm);
+                if (run(cfg, dc, &ms)) continue;
+                printf("  ablation %-20s %9.3f ms %8.1f TFLOP/s-equivalent\n", nm, ms, flops / ms * 1e-9);
+            }
+        }
+        CK(hipFree(da)); CK(hipFree(dw)); CK(hipFree(dc)); CK(hipFree(dref)); CK(hipFree(dbias)); CK(hipFree(dscale)); CK(hipFree(dsplit));
+    }
+    printf(bad ? "SPLIT CHECK FAILED (%d)\n" : "SPLIT CHECK OK\n", bad);
+    return bad ? 1 : 0;
+}

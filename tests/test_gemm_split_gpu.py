@@ -1,0 +1,122 @@
+"""Split-bf16 tiles of mit_conv_gemm (conv_gemm_split_kernel) against the fp32 MFMA tiles and a float64 reference, through the
+layer classes the engines use (ops.Conv2d, ops.WinogradConv3x3's batched GEMM, ocr48.Linear).
+
+Tolerances, relative to max |y| of the layer: the 9-pair and 6-pair forms must be as close to float64 as the fp32 tile is (within
+4x + 2e-6: their error is fp32 accumulation, in a different order); the 3-pair form is a 16-bit-significand product (1e-2, and it
+must be visibly worse than the 6-pair form — that is what shows the pair ladder is wired as described).
+
+Opt-in until the kernels have been run on hardware: set MIT_TEST_SPLIT=1 (scripts/split_check.cpp is the torch-free twin)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("MIT_TEST_SPLIT") != "1", reason="split-bf16 tiles are opt-in (MIT_TEST_SPLIT=1)")]
+
+
+def _cfg(name):
+    from manga_image_translator_amd import lib
+    L = lib.load()
+    i = 0
+    while True:
+        n = L.mit_conv_gemm_config_name(i)
+        if n is None:
+            raise KeyError(name)
+        if n.decode() == name:
+            return i
+        i += 1
+
+
+def _rel(a, b, ymax):
+    return float((a.double() - b.double()).abs().max()) / ymax
+
+
+CASES = [
+    # B, Cin, Cout, H, W, k, stride, pad mode, act, fp32 tile, split tiles
+    (2, 128, 128, 40, 56, 3, 1, "reflect", 1, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9", "split128x128x16p3", "split128x128x32p6")),
+    (1, 320, 1280, 12, 200, 1, 1, "zero", 5, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9", "split128x128x32p6")),
+    (4, 64, 64, 64, 48, 3, 2, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p9")),
+    (1, 48, 200, 25, 40, 3, 1, "zero", 2, "fast128x128x16w4c", ("split128x128x16p6", "split128x64x16p9")),   # ragged M and N
+    (1, 16, 40, 9, 11, 1, 1, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6",)),                          # one K-tile, tiny problem
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[1]}to{c[2]}k{c[5]}s{c[6]}")
+def test_conv2d_split_tiles(case):
+    from manga_image_translator_amd import ops
+
+    B, Cin, Cout, H, W, k, s, mode, act, ref_tile, tiles = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[:, ::7] *= 4.0
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g) * 0.1
+    pad = k // 2
+    layer = ops.Conv2d(w, b, stride=s, padding=pad, pad_mode=ops.PAD_REFLECT if mode == "reflect" else ops.PAD_ZERO, act=act, alpha=0.1,
+                       device="cuda")
+    assert ops.register_split(layer.w, force=True) is not None
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    xp = F.pad(x.double(), (pad, pad, pad, pad), mode="reflect" if mode == "reflect" else "constant") if pad else x.double()
+    want = F.conv2d(xp, w.double(), b.double(), stride=s)
+    want = {0: lambda t: t, 1: torch.relu, 2: lambda t: F.leaky_relu(t, 0.1), 5: F.gelu}[act](want).permute(0, 2, 3, 1)
+    ymax = float(want.abs().max())
+    y32 = layer(xd, cfg=_cfg(ref_tile)).cpu()
+    e32 = _rel(y32, want, ymax)
+    errs = {}
+    for t in tiles:
+        y = layer(xd, cfg=_cfg(t)).cpu()
+        assert torch.isfinite(y).all(), t
+        errs[t] = _rel(y, want, ymax)
+        tol = 1e-2 if t.endswith("p3") else 4 * e32 + 2e-6
+        assert errs[t] <= tol, (t, errs[t], e32)
+        assert _rel(y, y32, ymax) <= (1e-2 if t.endswith("p3") else 2e-5), t
+    p3 = [e for t, e in errs.items() if t.endswith("p3")]
+    p6 = [e for t, e in errs.items() if t.endswith("x16p6")]
+    if p3 and p6:
+        assert p3[0] > 4 * p6[0], errs                                   # dropping the second-order pairs must show
+
+
+def test_batched_winograd_gemm_split():
+    """Z = 36 slices with their own split planes (ws_zs0): WinogradConv3x3's GEMM stage."""
+    from manga_image_translator_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(192, 128, 3, 3, generator=g) * 0.05
+    layer = ops.WinogradConv3x3(w, None, pad_mode=ops.PAD_REFLECT, device="cuda")
+    assert ops.register_split(layer.u, force=True) is not None
+    T = 1500
+    v = torch.randn(36, T, 128, generator=g).cuda()
+    m32 = torch.empty(36, T, 192, device="cuda")
+    ms = torch.empty_like(m32)
+    d = layer.gemm_desc(v, m32)
+    assert d.w_split and d.ws_zs0 == 3 * layer.Kp * layer.Np
+    ops.launch_conv_gemm(d, _cfg("fast128x64x16w5c"))
+    want = torch.einsum("ztc,zcn->ztn", v.double().cpu(), layer.u.double().cpu()[:, :128, :192])
+    ymax = float(want.abs().max())
+    e32 = _rel(m32.cpu(), want, ymax)
+    for t in ("split128x64x16p6", "split128x64x16p9", "split128x128x16p6"):
+        ms.fill_(float("nan"))
+        ops.launch_conv_gemm(layer.gemm_desc(v, ms), _cfg(t))
+        assert _rel(ms.cpu(), want, ymax) <= 4 * e32 + 2e-6, t
+
+
+def test_split_tile_refused_without_planes():
+    from manga_image_translator_amd import ops
+
+    layer = ops.Conv2d(torch.randn(32, 32, 1, 1), None, device="cuda")
+    x = torch.randn(1, 8, 8, 32, device="cuda")
+    if ops.split_mode() == 0:
+        with pytest.raises(RuntimeError, match="w_split"):
+            layer(x, cfg=_cfg("split128x64x16p6"))
+
+
+def test_planes_sum_to_the_weights():
+    from manga_image_translator_amd import ops
+
+    w = (torch.randn(3, 48, 72) * torch.exp(torch.randn(3, 48, 72) * 4)).cuda()
+    p = ops.split_weight(w).cpu()                                          # [nz, 3, K/8, N, 8] bf16 bit patterns
+    f = (p.to(torch.int32) << 16).view(torch.float32)                      # bf16 -> fp32 is a 16-bit shift
+    back = f.sum(dim=1, dtype=torch.float64).permute(0, 1, 3, 2).reshape(3, 48, 72)  # [nz, K/8, 8, N] -> [nz, K, N]
+    assert torch.equal(back.float(), w.cpu())
