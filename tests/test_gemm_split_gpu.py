@@ -3,17 +3,14 @@ layer classes the engines use (ops.Conv2d, ops.WinogradConv3x3's batched GEMM, o
 
 Tolerances, relative to max |y| of the layer: the 9-pair and 6-pair forms must be as close to float64 as the fp32 tile is (within
 4x + 2e-6: their error is fp32 accumulation, in a different order); the 3-pair form is a 16-bit-significand product (1e-2, and it
-must be visibly worse than the 6-pair form — that is what shows the pair ladder is wired as described).
+must be visibly (> 2x) worse than the 6-pair form — that is what shows the pair ladder is wired as described).
 
-Opt-in until the kernels have been run on hardware: set MIT_TEST_SPLIT=1 (scripts/split_check.cpp is the torch-free twin)."""
-import os
-
+scripts/split_check.cpp is the torch-free twin of these tests (it also times the tiles); profiles/r02h_* hold its output."""
 import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("MIT_TEST_SPLIT") != "1", reason="split-bf16 tiles are opt-in (MIT_TEST_SPLIT=1)")]
+pytestmark = pytest.mark.gpu
 
 
 def _cfg(name):
@@ -35,11 +32,14 @@ def _rel(a, b, ymax):
 
 CASES = [
     # B, Cin, Cout, H, W, k, stride, pad mode, act, fp32 tile, split tiles
-    (2, 128, 128, 40, 56, 3, 1, "reflect", 1, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9", "split128x128x16p3", "split128x128x32p6")),
-    (1, 320, 1280, 12, 200, 1, 1, "zero", 5, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9", "split128x128x32p6")),
-    (4, 64, 64, 64, 48, 3, 2, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p9")),
-    (1, 48, 200, 25, 40, 3, 1, "zero", 2, "fast128x128x16w4c", ("split128x128x16p6", "split128x64x16p9")),   # ragged M and N
-    (1, 16, 40, 9, 11, 1, 1, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6",)),                          # one K-tile, tiny problem
+    (2, 128, 128, 40, 56, 3, 1, "reflect", 1, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9", "split128x128x16p3", "split128x128x32p6", "split128x128x16p6s", "split128x128x16p6m",
+      "split128x128x16p9m", "split128x128x32p6m")),
+    (1, 320, 1280, 12, 200, 1, 1, "zero", 5, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9", "split128x128x32p6", "split128x128x16p6m", "split128x128x16p9s")),
+    (4, 64, 64, 64, 48, 3, 2, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p9", "split128x64x16p6s", "split128x64x16p6m")),
+    (1, 48, 200, 25, 40, 3, 1, "zero", 2, "fast128x128x16w4c", ("split128x128x16p6", "split128x64x16p9", "split128x128x16p6m", "split128x64x16p6m")),   # ragged M and N
+    (1, 16, 40, 9, 11, 1, 1, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p6m", "split128x128x16p6m", "split128x128x16p6s")),   # one K-tile, tiny problem
+    (1, 32, 96, 20, 24, 1, 1, "zero", 1, "fast128x64x16w5c", ("split128x64x16p6m", "split128x128x16p6m", "split128x128x16p6s", "split128x128x32p6m")),  # 2 K-tiles (1 of 32)
+    (1, 48, 128, 20, 24, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x128x16p6m", "split128x128x16p9m", "split128x64x16p6s")),  # 3 K-tiles: every peeled iteration kind
 ]
 
 
@@ -75,7 +75,7 @@ def test_conv2d_split_tiles(case):
     p3 = [e for t, e in errs.items() if t.endswith("p3")]
     p6 = [e for t, e in errs.items() if t.endswith("x16p6")]
     if p3 and p6:
-        assert p3[0] > 4 * p6[0], errs                                   # dropping the second-order pairs must show
+        assert p3[0] > 2 * p6[0], errs                                   # dropping the second-order pairs must show
 
 
 def test_batched_winograd_gemm_split():
@@ -96,7 +96,7 @@ def test_batched_winograd_gemm_split():
     want = torch.einsum("ztc,zcn->ztn", v.double().cpu(), layer.u.double().cpu()[:, :128, :192])
     ymax = float(want.abs().max())
     e32 = _rel(m32.cpu(), want, ymax)
-    for t in ("split128x64x16p6", "split128x64x16p9", "split128x128x16p6"):
+    for t in ("split128x64x16p6", "split128x64x16p9", "split128x128x16p6", "split128x64x16p6m", "split128x128x16p6m"):
         ms.fill_(float("nan"))
         ops.launch_conv_gemm(layer.gemm_desc(v, ms), _cfg(t))
         assert _rel(ms.cpu(), want, ymax) <= 4 * e32 + 2e-6, t
