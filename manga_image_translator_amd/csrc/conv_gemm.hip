@@ -84,8 +84,8 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     static const int split = getenv("MIT_GEMM_SPLIT") ? atoi(getenv("MIT_GEMM_SPLIT")) : 0;
     static const int64_t split_min = getenv("MIT_GEMM_SPLIT_MIN_TILES") ? atoll(getenv("MIT_GEMM_SPLIT_MIN_TILES")) : 1280;
     if ((split == 6 || split == 9) && p.w_split && split_eligible(p, 16) && ((M + 127) / 128) * ((p.N + 63) / 64) * p.Z >= split_min) {
-        static const int wide6 = cfg_by_name("split128x128x16p6m"), wide9 = cfg_by_name("split128x128x16p9m");
-        static const int narrow6 = cfg_by_name("split128x64x16p6m"), narrow9 = cfg_by_name("split128x64x16p9");
+        static const int wide6 = cfg_by_name("split128x128x16p6o"), wide9 = cfg_by_name("split128x128x16p9m");
+        static const int narrow6 = cfg_by_name("split128x64x16p6o"), narrow9 = cfg_by_name("split128x64x16p9");
         const int r = p.N % 128;
         const int c = (p.N <= 64 || (r != 0 && r <= 64)) ? (split == 6 ? narrow6 : narrow9) : (split == 6 ? wide6 : wide9);
         if (c >= 0) return c;

@@ -771,6 +771,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     constexpr bool X_NOLOAD = (VAR & 2) != 0, X_NOSPLIT = (VAR & 4) != 0, X_NOWRITE = (VAR & 8) != 0, X_NOFRAG = (VAR & 16) != 0,
                    X_NOBAR = (VAR & 32) != 0;
     constexpr bool MID = (VAR & 128) != 0;  // with PIPE: the staging cut into steps, one placed behind each MFMA (sched_barrier keeps them there)
+    constexpr bool ORD = (VAR & 256) != 0;  // with MID: fragment reads issued in the order the plane pairs consume them; next row offsets fetched in step 0
     constexpr bool ASM_SUB = (VAR & 64) != 0;  // residuals through v_sub_f32 inline asm: keeps the SLP vectoriser from packing them into v_pk_add_f32
     constexpr int SA = BM, SB = BN;
     constexpr int A_TILE = 3 * KH * SA, B_TILE = 3 * KH * SB;  // cells per buffer
@@ -911,7 +912,13 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     // per W cell write, then the loads of the following tile (row offsets, A chunks, W cells).
     constexpr int STAGE_WRITE_STEPS = 3 * A_ITERS + B_ITERS, STAGE_STEPS = STAGE_WRITE_STEPS + 1 + A_ITERS + B_ITERS;
     f32x4 rr[A_ITERS];
-    auto stage_step = [&](const int st, const int buf) {
+    int a_offn[A_ITERS];
+    auto stage_step = [&](const int st, const int buf, const bool with_loads) {
+        if (ORD && st == 0 && with_loads) {  // ahead of this tile's LDS writes: its wait does not include them
+            const int *rt = rowtab + ld_tap * BM + am;
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) a_offn[i] = rt[i * A_MSTEP];
+        }
         if (st < 3 * A_ITERS) {
             const int i = st / 3, ph = st % 3;
             const int kh = aq >> 1, half = aq & 1;
@@ -932,9 +939,14 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             const int j = st - 3 * A_ITERS;
             if ((j + 1) * 256 <= B_CELLS || tid + j * 256 < B_CELLS) (Bs + buf * B_TILE)[b_dst[j]] = b_reg[j];
         } else if (st == STAGE_WRITE_STEPS) {
-            const int *rt = rowtab + ld_tap * BM + am;
+            if (!ORD) {
+                const int *rt = rowtab + ld_tap * BM + am;
 #pragma unroll
-            for (int i = 0; i < A_ITERS; ++i) a_off[i] = rt[i * A_MSTEP];
+                for (int i = 0; i < A_ITERS; ++i) a_off[i] = rt[i * A_MSTEP];
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_ITERS; ++i) a_off[i] = a_offn[i];  // every split step of this tile has used the old offsets by now
+            }
         } else if (st <= STAGE_WRITE_STEPS + A_ITERS) {
             const int i = st - STAGE_WRITE_STEPS - 1;
             a_reg[i] = *reinterpret_cast<const f32x4 *>(a_thr + ld_ci0 + (a_off[i] < 0 ? 0 : a_off[i]));
@@ -963,12 +975,14 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int o = 0; o < 3; ++o) {
+                    const int pa = ORD ? (o == 0 ? 0 : 3 - o) : o;  // consumption order of the pairs: A planes 0, 2, 1 with W planes 2, 0, 1
+                    const int pb = ORD ? (o == 0 ? 2 : o - 1) : o;
 #pragma unroll
                     for (int mi = 0; mi < TM; ++mi)
-                        af[ks][pl][mi] = __builtin_bit_cast(bf16x8, as[(pl * KH + 2 * ks + lh) * SA + ((wm0 + mi * 32 + li) ^ split_swz<BK>(2 * ks + lh))]);
+                        af[ks][pa][mi] = __builtin_bit_cast(bf16x8, as[(pa * KH + 2 * ks + lh) * SA + ((wm0 + mi * 32 + li) ^ split_swz<BK>(2 * ks + lh))]);
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni) bf[ks][pl][ni] = __builtin_bit_cast(bf16x8, bs[(pl * KH + 2 * ks) * SB + ni * 32]);
+                    for (int ni = 0; ni < TN; ++ni) bf[ks][pb][ni] = __builtin_bit_cast(bf16x8, bs[(pb * KH + 2 * ks) * SB + ni * 32]);
                 }
         }
         if (PIPE && MID) {
@@ -978,11 +992,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             for (int i = 0; i < NM; ++i) {
                 const int ni = i % TN, mi = (i / TN) % TM, pr = 9 - NPROD + (i / (TN * TM)) % NPROD, ks = i / (TN * TM * NPROD);
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][kSplitPA[pr]][mi], bf[ks][kSplitPB[pr]][ni], acc[mi][ni], 0, 0, 0);
-                if (i >= 1 && i - 1 < NSTEP) stage_step(i - 1, cur ^ 1);
+                if (i >= 1 && i - 1 < NSTEP) stage_step(i - 1, cur ^ 1, DO_LOAD);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int st = NM - 1; st < NSTEP; ++st) stage_step(st, cur ^ 1);  // more steps than MFMAs (3-pair tiles)
+            for (int st = NM - 1; st < NSTEP; ++st) stage_step(st, cur ^ 1, DO_LOAD);  // more steps than MFMAs (3-pair tiles)
             if (!X_NOBAR) __syncthreads();
             return;
         }
