@@ -5,8 +5,9 @@ oracle.ref_boundary.install() makes ``manga_translator.{utils,config,detection,o
 reference's own OfflineDetector / OfflineOCR / OfflineInpainter / OfflineUpscaler (utils/inference.py ModelWrapper) and is driven
 through the reference's own callers (CommonDetector.detect, CommonOCR.recognize, CommonInpainter.inpaint, get_detector ...).
 No GPU: where a call would reach the dense engine, a stand-in engine returns fixed tensors — what is under test is the boundary
-(types, lifecycle, registry, checkpoint lookup, download flow, error propagation), not the kernels.  Four checks go further and
-run the reference's REAL ``_infer`` of the ctd detector, the default detector, the 48px OCR and the LaMa inpainter with a stubbed network beside
+(types, lifecycle, registry, checkpoint lookup, download flow, error propagation), not the kernels.  Five checks go further and
+run the reference's REAL ``_infer`` of the ctd detector, the default detector, the 48px OCR, the LaMa inpainter and the ESRGAN
+upscaler with a stubbed network beside
 the plugin's ``_infer`` with the same stub: everything either side does around the network must produce identical bytes.
 """
 import asyncio
@@ -544,6 +545,48 @@ def _():
         assert all(any(q is l for l in got_lines) for q in got)       # the caller's own objects come back, mutated
         assert any(q.text and " " not in q.text for q in got) and any(q.fg_r in (0, 255) or q.bg_r in (0, 255) for q in got)
         run(ocr.unload())
+
+
+@check("the reference's REAL ESRGANUpscalerPytorch._infer (network stubbed) == HipESRGANUpscaler._infer (engine stubbed identically)")
+def _():
+    """PIL -> RGB array -> BGR / 255 tensor batch -> network -> clip -> x 255 truncation -> RGB -> PIL -> bilinear resize by ratio / 4
+    (esrgan_pytorch.py:537-549, the reference's own code with the real PIL) against the plugin's u8-in / u8-out engine contract."""
+    from PIL import Image
+
+    import manga_translator.upscaling.esrgan_pytorch as RE
+
+    def net(x):  # BGR [B,3,h,w] in [0,1] -> [B,3,4h,4w], deliberately leaving [0,1] so the clip acts
+        up = torch.nn.functional.interpolate(x, scale_factor=4, mode="bilinear", align_corners=False)
+        return up * 1.15 - 0.05 + 0.02 * up.flip(1)
+
+    ref = RE.ESRGANUpscalerPytorch.__new__(RE.ESRGANUpscalerPytorch)
+    ref.model, ref.device = net, "cpu"
+
+    class SameNetEngine:
+        device = torch.device("cpu")
+
+        def forward(self, rgb_u8):                       # EsrganEngine's contract: u8 RGB [B,h,w,3] -> u8 RGB [B,4h,4w,3]
+            x = rgb_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
+            y = net(x).clip(0, 1).permute(0, 2, 3, 1).flip(-1)
+            return torch.from_numpy((y.numpy() * 255.0).astype(np.uint8))
+
+        def release_workspace(self):
+            pass
+
+    up = P.HipESRGANUpscaler(weights={})
+    up.engine, up._loaded = SameNetEngine(), True
+    rng = np.random.default_rng(5)
+    for ratio in (2, 3, 4):
+        batch = [Image.fromarray(rng.integers(0, 256, (37, 52, 3)).astype(np.uint8)) for _ in range(2)]
+        batch.append(Image.fromarray(rng.integers(0, 256, (37, 52)).astype(np.uint8)))          # a grey page: convert("RGB") on both sides
+        want = run(RE.ESRGANUpscalerPytorch._infer(ref, batch, ratio))
+        got = run(up.infer(batch, ratio))
+        assert len(got) == len(want) == 3
+        for g, w in zip(got, want):
+            assert g.size == w.size == (int(round(52 * ratio)), int(round(37 * ratio))) and g.mode == w.mode == "RGB"
+            assert np.array_equal(np.asarray(g), np.asarray(w)), ratio
+    assert run(up.infer([], 2)) == [] and run(RE.ESRGANUpscalerPytorch._infer(ref, [], 2)) == []
+    run(up.unload())
 
 
 @check("exceptions propagate through the reference's infer()/inpaint() wrappers")
