@@ -384,14 +384,28 @@ class HipModel48pxCTCOCR(HipModel48pxOCR):
         self.engine = ocr_ctc.OcrCtcEngine(self._weights, len(self.dictionary), device=dev)
         self.device = device
 
+    def _rectify(self, page: torch.Tensor, quads, dirs, idx, records: np.ndarray, wp: int) -> torch.Tensor:
+        """Lines ``idx`` of the page rectified into one zero-padded chunk tensor u8 [n, 48, wp, 3] on the device (mit_ocr_warp_lines:
+        get_transformed_region + the chunk packing of model_48px_ctc.py:83-91).  ``quads`` / ``dirs`` are not needed by the kernel — the
+        records carry the geometry — they are there for host stand-ins in tests."""
+        import ctypes as C
+
+        from . import lib as _lib, ops
+
+        dev = page.device
+        records["out_row"] = np.arange(len(idx))
+        lines_dev = torch.frombuffer(bytearray(records.tobytes()), dtype=torch.uint8).to(dev)
+        region = torch.empty(len(idx), 48, wp, 3, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.load().mit_ocr_warp_lines(page.data_ptr(), page.shape[1], page.shape[2], lines_dev.data_ptr(), len(idx), region.data_ptr(), 48, wp,
+                                                  C.c_void_p(ops.current_stream())), "mit_ocr_warp_lines")
+        return region
+
     @torch.no_grad()
     async def _infer(self, image: np.ndarray, textlines: List, config=None, verbose: bool = False):
         """Same contract as the 48px plugin; chunks are padded to max_w + 7 + 128 (:84), the line probability is
         exp(mean log-prob) against a 0.5 default threshold (:66,:124), colours average over non-space characters (:116-123).
         The bubble filter (``config.ignore_bubble``, an OpenCV heuristic, :91-93) is not applied."""
-        import ctypes as C
-
-        from . import lib as _lib, ops, textline as TL
+        from . import textline as TL
 
         threshold = 0.5 if config is None or getattr(config, "prob", None) is None else config.prob
         pairs = self._directions(textlines)
@@ -405,16 +419,10 @@ class HipModel48pxCTCOCR(HipModel48pxOCR):
         own = [Quadrilateral(np.asarray(q.pts)) for q in quads]
         rec = TL.warp_plans(own, dirs, H, W, 48)
         widths = np.where(rec["vertical"] != 0, rec["dh"], rec["dw"]).tolist()
-        lib = _lib.load()
         out = []
         for idx, ws, wp in TL.chunk_plan(widths):
             wp += 128
-            r = rec[idx].copy()
-            r["out_row"] = np.arange(len(idx))
-            lines_dev = torch.frombuffer(bytearray(r.tobytes()), dtype=torch.uint8).to(dev)
-            region = torch.empty(len(idx), 48, wp, 3, dtype=torch.uint8, device=dev)
-            _lib.check(lib.mit_ocr_warp_lines(page.data_ptr(), H, W, lines_dev.data_ptr(), len(idx), region.data_ptr(), 48, wp,
-                                              C.c_void_p(ops.current_stream())), "mit_ocr_warp_lines")
+            region = self._rectify(page, own, dirs, idx, rec[idx].copy(), wp)
             logits, colors = self.engine.forward(region)
             for j, line in enumerate(self.engine.decode(logits, colors, 0)):
                 q = quads[idx[j]]

@@ -5,8 +5,8 @@ oracle.ref_boundary.install() makes ``manga_translator.{utils,config,detection,o
 reference's own OfflineDetector / OfflineOCR / OfflineInpainter / OfflineUpscaler (utils/inference.py ModelWrapper) and is driven
 through the reference's own callers (CommonDetector.detect, CommonOCR.recognize, CommonInpainter.inpaint, get_detector ...).
 No GPU: where a call would reach the dense engine, a stand-in engine returns fixed tensors — what is under test is the boundary
-(types, lifecycle, registry, checkpoint lookup, download flow, error propagation), not the kernels.  Five checks go further and
-run the reference's REAL ``_infer`` of the ctd detector, the default detector, the 48px OCR, the LaMa inpainter and the ESRGAN
+(types, lifecycle, registry, checkpoint lookup, download flow, error propagation), not the kernels.  Six checks go further and
+run the reference's REAL ``_infer`` of the ctd detector, the default detector, both OCRs, the LaMa inpainter and the ESRGAN
 upscaler with a stubbed network beside
 the plugin's ``_infer`` with the same stub: everything either side does around the network must produce identical bytes.
 """
@@ -587,6 +587,83 @@ def _():
             assert np.array_equal(np.asarray(g), np.asarray(w)), ratio
     assert run(up.infer([], 2)) == [] and run(RE.ESRGANUpscalerPytorch._infer(ref, [], 2)) == []
     run(up.unload())
+
+
+@check("the reference's REAL Model48pxCTCOCR._infer (recogniser stubbed) == HipModel48pxCTCOCR._infer (engine stubbed identically)")
+def _():
+    """Same idea for the CTC recogniser (model_48px_ctc.py:62-160): chunks padded to max + 7 + 128, exp(mean log-prob) against the 0.5
+    default threshold, colours averaged over non-space characters only.  The recogniser on both sides is a function of the WHOLE padded
+    chunk row, so a different padding width or zero fill would show; the plugin's device rectification is replaced by its host twin."""
+    import logging
+    import zlib
+
+    import manga_translator.ocr.model_48px_ctc as RC
+    from oracle import textline as OT
+
+    dictionary = ["<blank>", "<SP>"] + list("abcdefghijklmnopqrstuvwxyz")
+
+    def read_row(row):  # u8 [48, wp, 3] -> [(chid, logprob, fr, fg, fb, br, bg, bb)]
+        rng = np.random.default_rng(zlib.crc32(np.ascontiguousarray(row).tobytes()))
+        n = int(rng.integers(0, 9))                        # empty lines are dropped on both sides
+        out = []
+        for _ in range(n):
+            cols = rng.random(6).astype(np.float32)
+            out.append((int(rng.integers(1, len(dictionary))), float(np.float32(-rng.random() * 1.5)), *[float(c) for c in cols]))
+        return out
+
+    class StubCTC:
+        def __init__(self):
+            self.dictionary = dictionary
+
+        def decode(self, images, widths, blank, verbose=False):
+            assert blank == 0 and images.shape[1:3] == (3, 48) and images.shape[3] == 4 * (max(widths) + 7) // 4 + 128
+            u8 = (images * 127.5 + 127.5).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+            return [read_row(u8[j]) for j in range(len(widths))]
+
+    ref = RC.Model48pxCTCOCR.__new__(RC.Model48pxCTCOCR)
+    ref.model, ref.use_gpu, ref.device, ref.logger = StubCTC(), False, "cpu", logging.getLogger("ref-ctc")
+
+    class SameReaderEngine:
+        device = torch.device("cpu")
+
+        def forward(self, region_u8):                      # OcrCtcEngine: chunk tensor -> (logits, colours); here the rows themselves
+            return region_u8, None
+
+        def decode(self, logits, colors, blank):
+            assert blank == 0
+            return [read_row(r.numpy()) for r in logits]
+
+        def release_workspace(self):
+            pass
+
+    def host_rectify(page, quads, dirs, idx, records, wp):  # the device routine's host twin (tests/test_ocr_gpu.py pins the kernel to it)
+        region = np.zeros((len(idx), 48, wp, 3), np.uint8)
+        for j, i in enumerate(idx):
+            crop = OT.get_transformed_region(page[0].numpy(), np.asarray(quads[i].pts), dirs[i], 48)
+            region[j, :, :crop.shape[1]] = crop
+        return torch.from_numpy(region)
+
+    rng = np.random.default_rng(44)
+    page = rng.integers(0, 256, (700, 640, 3)).astype(np.uint8)
+    boxes = []
+    for k in range(19):
+        x, y = int(rng.integers(5, 430)), int(rng.integers(5, 450))
+        w, h = (int(rng.integers(20, 40)), int(rng.integers(80, 230))) if k % 3 == 0 else (int(rng.integers(60, 190)), int(rng.integers(18, 44)))
+        boxes.append(np.array([[x, y], [x + w, y], [x + w, y + h], [x, y + h]]))
+    for prob_cfg in (None, 0.3):
+        cfg = type("Cfg", (), {"prob": prob_cfg, "ignore_bubble": 0})()
+        want_lines = [U.Quadrilateral(b.copy(), "", 1.0) for b in boxes]
+        got_lines = [U.Quadrilateral(b.copy(), "", 1.0) for b in boxes]
+        want = run(RC.Model48pxCTCOCR._infer(ref, page.copy(), want_lines, cfg))
+        ocr = P.HipModel48pxCTCOCR(weights={}, dictionary=dictionary)
+        ocr.engine, ocr._loaded, ocr._rectify = SameReaderEngine(), True, host_rectify
+        got = run(ocr.infer(page.copy(), got_lines, cfg))
+        key = lambda q: (tuple(map(tuple, np.asarray(q.pts).tolist())), q.text, float(q.prob), q.fg_r, q.fg_g, q.fg_b, q.bg_r, q.bg_g, q.bg_b)
+        assert 0 < len(got) == len(want) < len(boxes), (len(got), len(want))
+        for a, b in zip(got, want):
+            assert key(a) == key(b), (key(a), key(b))
+        assert all(any(q is l for l in got_lines) for q in got) and any(" " in q.text for q in got)
+        run(ocr.unload())
 
 
 @check("exceptions propagate through the reference's infer()/inpaint() wrappers")
