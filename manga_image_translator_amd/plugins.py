@@ -404,10 +404,12 @@ class HipModel48pxCTCOCR(HipModel48pxOCR):
     async def _infer(self, image: np.ndarray, textlines: List, config=None, verbose: bool = False):
         """Same contract as the 48px plugin; chunks are padded to max_w + 7 + 128 (:84), the line probability is
         exp(mean log-prob) against a 0.5 default threshold (:66,:124), colours average over non-space characters (:116-123).
-        The bubble filter (``config.ignore_bubble``, an OpenCV heuristic, :91-93) is not applied."""
+        ``config.ignore_bubble`` in 1..50 applies the reference's frame / colour heuristic to every rectified crop (:91-93, utils/bubble.py):
+        a rejected line's row of the chunk stays zero and is recognised as such, exactly as the reference's ``continue`` leaves it."""
         from . import textline as TL
 
         threshold = 0.5 if config is None or getattr(config, "prob", None) is None else config.prob
+        ignore_bubble = int(getattr(config, "ignore_bubble", 0) or 0) if config is not None else 0
         pairs = self._directions(textlines)
         if not pairs:
             return []
@@ -423,6 +425,11 @@ class HipModel48pxCTCOCR(HipModel48pxOCR):
         for idx, ws, wp in TL.chunk_plan(widths):
             wp += 128
             region = self._rectify(page, own, dirs, idx, rec[idx].copy(), wp)
+            if 1 <= ignore_bubble <= 50:
+                host = region.cpu().numpy()
+                for j, w_line in enumerate(ws):
+                    if TL.is_ignore(host[j, :, :w_line], ignore_bubble):
+                        region[j] = 0
             logits, colors = self.engine.forward(region)
             for j, line in enumerate(self.engine.decode(logits, colors, 0)):
                 q = quads[idx[j]]

@@ -413,3 +413,22 @@ def warp_plans(quads: Sequence[Quadrilateral], directions: Sequence[str], im_h: 
     for q, d in zip(quads, directions):
         q.assigned_direction = d
     return rec
+
+
+def is_ignore(region_img: np.ndarray, ignore_bubble: int = 0) -> bool:
+    """``--ignore-bubble`` filter on a rectified line crop (utils/bubble.py:28-84): share of dark (<= 127) values in the 2-pixel frame of
+    the crop; inside [ignore_bubble, 100 - ignore_bubble] % the line is taken for text on artwork and skipped, and so is any crop with
+    more than 10 coloured pixels (squared distance to its own luma > 100).  Values outside 1..50 switch the filter off."""
+    if ignore_bubble < 1 or ignore_bubble > 50:
+        return False
+    dark = np.asarray(region_img) <= 127                       # cv2.threshold(img, 127, 255, THRESH_BINARY) == 0
+    h, w = dark.shape[:2]
+    frame = [dark[0:2, 0:w], dark[h - 2:h, 0:w], dark[2:h - 2, 0:2], dark[2:h - 2, w - 2:w]]
+    val0 = sum(int(f.sum()) for f in frame)
+    total = sum(f.size for f in frame)
+    ratio = round(val0 / total, 6) * 100
+    if ignore_bubble <= ratio <= 100 - ignore_bubble:
+        return True
+    img = np.asarray(region_img)
+    gray = np.dot(img[..., :3], [0.299, 0.587, 0.114])[..., np.newaxis]
+    return bool(np.sum(np.sum((img - gray) ** 2, axis=-1) > 100) > 10)

@@ -556,6 +556,49 @@ def boxes_scene(seed: int, H: int = 128, W: int = 160) -> np.ndarray:
     return arr.astype(np.float32)
 
 
+def bubble_crops(n=40, seed=23):
+    """Rectified-line-like crops for the ignore-bubble filter: white / black bubbles with glyph strokes inside, artwork-like noise, a
+    clean frame with a coloured interior, and frames whose dark share sits exactly on the thresholds."""
+    rng = np.random.default_rng(seed)
+    crops = []
+    for k in range(n):
+        w = int(rng.integers(24, 120))
+        kind = k % 5
+        if kind == 0:    # white bubble, dark strokes away from the frame
+            img = np.full((48, w, 3), int(rng.integers(200, 256)), np.uint8)
+            img[8:40, 6:w - 6][rng.random((32, w - 12)) < 0.3] = int(rng.integers(0, 60))
+        elif kind == 1:  # black bubble
+            img = np.full((48, w, 3), int(rng.integers(0, 100)), np.uint8)
+            img[8:40, 6:w - 6][rng.random((32, w - 12)) < 0.3] = int(rng.integers(180, 256))
+        elif kind == 2:  # artwork: grey noise everywhere (frame share near 50 %)
+            g = rng.integers(0, 256, (48, w, 1)).astype(np.uint8)
+            img = np.repeat(g, 3, axis=2)
+        elif kind == 3:  # white frame, coloured interior
+            img = np.full((48, w, 3), 250, np.uint8)
+            img[10:38, 8:w - 8] = rng.integers(0, 256, (28, w - 16, 3)).astype(np.uint8)
+        else:            # a frame with a controlled share of dark values (thresholds 10 / 90 % and around)
+            img = np.full((48, w, 3), 255, np.uint8)
+            frame = np.zeros((48, w), bool)
+            frame[:2] = frame[-2:] = True
+            frame[:, :2] = frame[:, -2:] = True
+            ys, xs = np.nonzero(frame)
+            share = [0.05, 0.1, 0.100001, 0.5, 0.9, 0.95, 0.0999][(k // 5) % 7]
+            pick = rng.permutation(len(ys))[:int(round(share * len(ys)))]
+            img[ys[pick], xs[pick]] = 0
+        crops.append(img)
+    return crops
+
+
+def golden_bubble():
+    """utils/bubble.py is_ignore — the reference's own function (cv2.threshold from the stand-in) — on bubble_crops() for several
+    --ignore-bubble values, including the out-of-range ones that switch the filter off."""
+    B = R.bubble()
+    crops = bubble_crops()
+    levels = [0, 1, 5, 10, 25, 50, 51]
+    want = np.array([[bool(B.is_ignore(c, lv)) for lv in levels] for c in crops])
+    np.savez_compressed(os.path.join(GOLDEN, "bubble.npz"), levels=np.array(levels), want=want, widths=np.array([c.shape[1] for c in crops]))
+
+
 def golden_boxes():
     """SegDetectorRepresenter of both detectors — the reference's own Python (db_utils.py:127-216, dbnet_utils.py:97-190) run with
     the cv2 / pyclipper / shapely stand-ins of ref_import.segdet — on seeded probability maps."""
@@ -595,6 +638,7 @@ def main():
     golden_textline_merge()
     golden_mask_refinement()
     golden_boxes()
+    golden_bubble()
 
 
 if __name__ == "__main__":

@@ -302,6 +302,14 @@ def textmask():
     return tm
 
 
+def bubble():
+    """reference module manga_translator/utils/bubble.py (is_ignore, check_color) with the cv2 stand-in (cv2.threshold only)."""
+    _prepare()
+    m = _load("manga_translator.utils.bubble", "utils/bubble.py")
+    m.cv2 = cv2_shim()
+    return m
+
+
 def mask_refinement(refine_stub=None, bilateral_stub=None):
     """reference modules manga_translator/mask_refinement/{text_mask_utils,__init__}.py with the cv2 / shapely stand-ins and the
     reference's own Quadrilateral.  ``pydensecrf`` exists nowhere this can run: the DenseCRF call (text_mask_utils.refine_mask) and

@@ -608,7 +608,8 @@ def _():
         out = []
         for _ in range(n):
             cols = rng.random(6).astype(np.float32)
-            out.append((int(rng.integers(1, len(dictionary))), float(np.float32(-rng.random() * 1.5)), *[float(c) for c in cols]))
+            chid = 1 if rng.random() < 0.2 else int(rng.integers(1, len(dictionary)))   # <SP> often enough: its colours do not count
+            out.append((chid, float(np.float32(-rng.random() * 1.5)), *[float(c) for c in cols]))
         return out
 
     class StubCTC:
@@ -650,8 +651,14 @@ def _():
         x, y = int(rng.integers(5, 430)), int(rng.integers(5, 450))
         w, h = (int(rng.integers(20, 40)), int(rng.integers(80, 230))) if k % 3 == 0 else (int(rng.integers(60, 190)), int(rng.integers(18, 44)))
         boxes.append(np.array([[x, y], [x + w, y], [x + w, y + h], [x, y + h]]))
-    for prob_cfg in (None, 0.3):
-        cfg = type("Cfg", (), {"prob": prob_cfg, "ignore_bubble": 0})()
+    for k, b in enumerate(boxes):                          # every other line sits in a clean white bubble: the bubble filter keeps those
+        if k % 2 == 0:
+            x0, y0, x1, y1 = b[0, 0], b[0, 1], b[2, 0], b[2, 1]
+            page[max(y0 - 4, 0):y1 + 5, max(x0 - 4, 0):x1 + 5] = 250
+            page[y0 + 6:y1 - 5:3, x0 + 6:x1 - 5] = 20
+    kept = {}
+    for prob_cfg, bubble in ((None, 0), (0.3, 0), (0.3, 10)):
+        cfg = type("Cfg", (), {"prob": prob_cfg, "ignore_bubble": bubble})()
         want_lines = [U.Quadrilateral(b.copy(), "", 1.0) for b in boxes]
         got_lines = [U.Quadrilateral(b.copy(), "", 1.0) for b in boxes]
         want = run(RC.Model48pxCTCOCR._infer(ref, page.copy(), want_lines, cfg))
@@ -662,8 +669,11 @@ def _():
         assert 0 < len(got) == len(want) < len(boxes), (len(got), len(want))
         for a, b in zip(got, want):
             assert key(a) == key(b), (key(a), key(b))
-        assert all(any(q is l for l in got_lines) for q in got) and any(" " in q.text for q in got)
+        assert all(any(q is l for l in got_lines) for q in got), "the caller's own objects must come back"
+        kept[(prob_cfg, bubble)] = [key(q) for q in got]
+        print("   ", prob_cfg, bubble, len(got), "lines,", sum(" " in q.text for q in got), "with spaces", flush=True)
         run(ocr.unload())
+    assert kept[(0.3, 10)] != kept[(0.3, 0)]              # the filter (the reference's own is_ignore on its side) changed what is read
 
 
 @check("exceptions propagate through the reference's infer()/inpaint() wrappers")

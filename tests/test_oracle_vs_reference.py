@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("gen,files", [("golden_textline", ["textline.npz"]), ("golden_ocr", ["ocr48.npz"]),
-                                       ("golden_ctd", ["ctd.npz"]), ("golden_lama", ["lama_mpe.npz", "lama_large.npz"]), ("golden_lama_resize", ["lama_resize.npz"]), ("golden_esrgan", ["esrgan.npz"]), ("golden_ocr_ctc", ["ocr_ctc.npz"]), ("golden_dbnet", ["dbnet.npz"]), ("golden_direction", ["direction.npz"]), ("golden_rearrange", ["rearrange.npz"]), ("golden_refine_mask", ["refine_mask.npz"]), ("golden_mask_refinement", ["mask_refinement.npz"]), ("golden_boxes", ["boxes.npz"])])
+                                       ("golden_ctd", ["ctd.npz"]), ("golden_lama", ["lama_mpe.npz", "lama_large.npz"]), ("golden_lama_resize", ["lama_resize.npz"]), ("golden_esrgan", ["esrgan.npz"]), ("golden_ocr_ctc", ["ocr_ctc.npz"]), ("golden_dbnet", ["dbnet.npz"]), ("golden_direction", ["direction.npz"]), ("golden_rearrange", ["rearrange.npz"]), ("golden_refine_mask", ["refine_mask.npz"]), ("golden_mask_refinement", ["mask_refinement.npz"]), ("golden_boxes", ["boxes.npz"]), ("golden_bubble", ["bubble.npz"])])
 def test_fixture_regenerates(tmp_path, monkeypatch, gen, files):
     from oracle import make_golden as MG
 

@@ -135,3 +135,19 @@ def test_polygon_distance_closed_form():
     a, b = TL.Quadrilateral(sq(0, 0, 10).astype(int)), TL.Quadrilateral(sq(20, 0, 10).astype(int))
     assert a.poly_distance(b) == pytest.approx(10.0) and a.is_axis_aligned and a.is_approximate_axis_aligned
     assert a.xyxy == (0, 0, 10, 10) and np.allclose(a.centroid, [5, 5])
+
+
+def test_is_ignore_matches_the_reference_function():
+    """textline.is_ignore against utils/bubble.py:28-84 itself (tests/golden/bubble.npz: the reference's function on seeded crops —
+    bubbles, artwork, coloured interiors, frames exactly on the thresholds — for --ignore-bubble in {0, 1, 5, 10, 25, 50, 51})."""
+    import os
+
+    from manga_image_translator_amd import textline as TL
+    from oracle import make_golden as MG
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bubble.npz"))
+    crops = MG.bubble_crops()
+    assert [c.shape[1] for c in crops] == g["widths"].tolist()
+    got = np.array([[TL.is_ignore(c, int(lv)) for lv in g["levels"]] for c in crops])
+    assert np.array_equal(got, g["want"])
+    assert not got[:, 0].any() and not got[:, -1].any() and got[:, 3].any() and not got[:, 3].all()   # 0 and 51 switch it off
