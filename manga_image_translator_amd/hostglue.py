@@ -141,11 +141,11 @@ _CROSS3 = ndimage.generate_binary_structure(2, 1)  # cv2.getStructuringElement(M
 
 
 def _erode(m: np.ndarray, fp: np.ndarray) -> np.ndarray:  # cv2.erode: outside the image counts as +inf
-    return ndimage.grey_erosion(m, footprint=fp, mode="constant", cval=255)
+    return ndimage.minimum_filter(m, footprint=fp, mode="constant", cval=255)  # cv2: min over src(x + x' - anchor), anchor = k // 2 (no kernel reflection)
 
 
 def _dilate(m: np.ndarray, fp: np.ndarray) -> np.ndarray:  # cv2.dilate: outside the image counts as -inf
-    return ndimage.grey_dilation(m, footprint=fp, mode="constant", cval=0)
+    return ndimage.maximum_filter(m, footprint=fp, mode="constant", cval=0)
 
 
 def _in_range_u8(src: np.ndarray, lo: float, hi: float) -> np.ndarray:

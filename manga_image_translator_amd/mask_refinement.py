@@ -127,10 +127,11 @@ def ellipse_kernel(k: int) -> np.ndarray:
 
 
 def dilate(img: np.ndarray, kernel: np.ndarray) -> np.ndarray:
-    """cv2.dilate with the default anchor / border: maximum over the kernel support, pixels outside the image ignored."""
+    """cv2.dilate with the default anchor / border: dst(x) = max over kernel taps x' of src(x + x' - k // 2), pixels outside the image
+    ignored.  ``maximum_filter`` has exactly these offsets; ``grey_dilation`` reflects the footprint and is one pixel off for even sizes."""
     if img.size == 0:
         return img
-    return _nd.grey_dilation(img, footprint=kernel, mode="constant", cval=0)
+    return _nd.maximum_filter(img, footprint=kernel, mode="constant", cval=0)
 
 
 def _clip_quad_to_rect_area(pts: np.ndarray, x0: float, y0: float, x1: float, y1: float) -> float:
@@ -278,14 +279,44 @@ def HG_area(pts: np.ndarray) -> float:
     return float(abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))) / 2)
 
 
+def bubble_filter(final_mask: np.ndarray, raw_image: np.ndarray, ignore_bubble: int) -> np.ndarray:
+    """The ``--ignore-bubble`` stage of mask_refinement.dispatch (:34-50): dilate the mask by a square of 2.5 % of the longer page side,
+    and for every outer contour of the result look at the page inside the contour's bounding rectangle (one pixel larger to the right /
+    bottom: ``cv2.rectangle`` corners are inclusive) through ``is_ignore`` — the 2-pixel frame of the WHOLE page with everything outside
+    the rectangle black, then the colour test — and erase the contour's filled polygon (component + enclosed holes) when it says so."""
+    H, W = final_mask.shape
+    k = int(max(H, W) * 0.025)
+    out = dilate(final_mask, np.ones((k, k), np.uint8)) if k > 0 else final_mask.copy()
+    filled = _nd.binary_fill_holes(out > 0)                                    # RETR_EXTERNAL: components nested in holes do not get their own contour
+    labels, n = _nd.label(filled, structure=np.ones((3, 3)))
+    if n == 0:
+        return out
+    # is_ignore() of a page that is black outside a rectangle, without building that page per contour: the frame statistics only need
+    # the bright frame values inside the rectangle, the colour test only the rectangle's pixels (black pixels have no colour distance)
+    img = np.asarray(raw_image)
+    bright = img > 127
+    frame = np.zeros((H, W), bool)
+    frame[:2] = frame[H - 2:] = True
+    frame[:, :2] = frame[:, W - 2:] = True
+    total = int(frame.sum()) * (img.shape[2] if img.ndim == 3 else 1)
+    gray = np.dot(img[..., :3], [0.299, 0.587, 0.114])[..., np.newaxis]
+    coloured = np.sum((img - gray) ** 2, axis=-1) > 100
+    for lab, sl in enumerate(_nd.find_objects(labels), start=1):
+        y0, y1, x0, x1 = sl[0].start, min(sl[0].stop + 1, H), sl[1].start, min(sl[1].stop + 1, W)
+        fr = frame[y0:y1, x0:x1]
+        val0 = total - int((bright[y0:y1, x0:x1] & (fr[..., None] if img.ndim == 3 else fr)).sum())
+        ratio = round(val0 / total, 6) * 100
+        if ignore_bubble <= ratio <= 100 - ignore_bubble or int(coloured[y0:y1, x0:x1].sum()) > 10:
+            out[labels == lab] = 0
+    return out
+
+
 def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, method: str = "fit_text", dilation_offset: int = 0,
                   ignore_bubble: int = 0, verbose: bool = False, kernel_size: int = 3, refine: Optional[RefineFn] = None,
                   bilateral: Optional[BilateralFn] = None, backend=None) -> np.ndarray:
-    """mask_refinement.dispatch (:9-33) for ``method='fit_text'`` without the bubble filter (ignore_bubble outside 1..50, the default)."""
+    """mask_refinement.dispatch (:9-50) for ``method='fit_text'``; ``ignore_bubble`` in 1..50 adds the bubble stage (``bubble_filter``)."""
     if method != "fit_text":
         raise NotImplementedError("mask refinement: only method='fit_text' is native (the reference's 'fill' path references an unset variable)")
-    if 1 <= ignore_bubble <= 50:
-        raise NotImplementedError("mask refinement: the ignore_bubble filter (utils/bubble.py) is not part of the native path")
     h, w = raw_image.shape[:2]
     scale = max(min((raw_mask.shape[0] - h / 3) / raw_mask.shape[0], 1), 0.5)
     size = (int(w * scale), int(h * scale))
@@ -296,9 +327,12 @@ def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, met
     lines = [Quadrilateral(np.asarray(l) * scale, "", 0) for region in text_regions for l in region.lines]
     final = complete_mask(img_small, mask_small, lines, dilation_offset=dilation_offset, kernel_size=kernel_size, backend=be)
     if final is None:
-        return np.zeros((h, w), dtype=np.uint8)
-    final = be.resize_mask(final, (w, h)).copy()
-    final[final > 0] = 255
+        final = np.zeros((h, w), dtype=np.uint8)
+    else:
+        final = be.resize_mask(final, (w, h)).copy()
+        final[final > 0] = 255
+    if 1 <= ignore_bubble <= 50:
+        final = bubble_filter(final, np.asarray(raw_image), ignore_bubble)
     return final
 
 

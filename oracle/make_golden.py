@@ -458,6 +458,13 @@ def mask_refinement_scene(seed=3, H=360, W=300):
     return img, mask, np.stack(lines)
 
 
+def mask_refinement_bubble_page(img):
+    g = np.repeat(img[..., :1], 3, axis=2).copy()
+    g[44:70, 60:140] = img[44:70, 60:140]          # colour under the first text line
+    g[330:, :] = 240                                # bright band reaching the bottom frame, under the last line
+    return g
+
+
 def mask_refinement_stubs():
     refine = lambda rgb, m: np.where(rgb[..., 1] > 40, m, 0).astype(np.uint8)  # stands in for the DenseCRF (uses both crops)
     bilateral = lambda img, *a: (img // 4) * 4                                   # stands in for cv2.bilateralFilter
@@ -482,6 +489,14 @@ def golden_mask_refinement():
         out[f"dispatch_{tag}"] = asyncio.run(mr.dispatch([region], img.copy(), mask.copy(), "fit_text", off, 0, False, ks))
     out["dispatch_none"] = asyncio.run(mr.dispatch([type("Region", (), {"lines": np.zeros((0, 4, 2), np.int32)})()], img.copy(),
                                                    np.zeros_like(mask), "fit_text", 0, 0, False, 3))
+    # the --ignore-bubble stage (dispatch :34-50) with the reference's own is_ignore: a grey page (no colour anywhere) with a coloured
+    # patch under the first line and a bright band along the bottom frame under the last one
+    mrb, _, _ = R.mask_refinement(refine_stub=refine, bilateral_stub=bilateral, with_bubble=True)
+    img_b = mask_refinement_bubble_page(img)
+    out["img_bubble"] = img_b
+    region = type("Region", (), {"lines": lines})()
+    for lv in (10, 40):
+        out[f"dispatch_bubble{lv}"] = asyncio.run(mrb.dispatch([region], img_b.copy(), mask.copy(), "fit_text", 0, lv, False, 3))
     np.savez_compressed(os.path.join(GOLDEN, "mask_refinement.npz"), **out)
     print("mask_refinement", {k: (v.shape, int(v.sum() // 255) if v.dtype == np.uint8 and v.ndim == 2 else "") for k, v in out.items()})
 

@@ -189,7 +189,7 @@ def cv2_shim():
     def _morph(src, kernel, iterations, dil):
         out = src
         for _ in range(iterations):
-            fn = _nd.grey_dilation if dil else _nd.grey_erosion
+            fn = _nd.maximum_filter if dil else _nd.minimum_filter  # OpenCV: extreme of src(x + x' - anchor), anchor = k // 2, kernel not reflected
             out = fn(out, footprint=np.asarray(kernel, bool), mode="constant", cval=0 if dil else 255)
         return out
 
@@ -310,7 +310,7 @@ def bubble():
     return m
 
 
-def mask_refinement(refine_stub=None, bilateral_stub=None):
+def mask_refinement(refine_stub=None, bilateral_stub=None, with_bubble=False):
     """reference modules manga_translator/mask_refinement/{text_mask_utils,__init__}.py with the cv2 / shapely stand-ins and the
     reference's own Quadrilateral.  ``pydensecrf`` exists nowhere this can run: the DenseCRF call (text_mask_utils.refine_mask) and
     cv2.bilateralFilter are replaced by the caller's deterministic stubs, so what gets pinned is everything AROUND them — component
@@ -323,7 +323,7 @@ def mask_refinement(refine_stub=None, bilateral_stub=None):
     utils.Quadrilateral, utils.TextBlock = G.Quadrilateral, type("TextBlock", (), {})
     utils.image_resize = lambda *a, **k: None
     bubble = types.ModuleType("manga_translator.utils.bubble")
-    bubble.is_ignore = lambda *a, **k: False
+    bubble.is_ignore = globals()["bubble"]().is_ignore if with_bubble else (lambda *a, **k: False)   # the reference's own function on request
     saved = {k: sys.modules.get(k) for k in ("manga_translator.utils", "manga_translator.utils.bubble")}
     sys.modules["manga_translator.utils"], sys.modules["manga_translator.utils.bubble"] = utils, bubble
     try:
@@ -343,6 +343,44 @@ def mask_refinement(refine_stub=None, bilateral_stub=None):
     cv = cv2_shim()
     if bilateral_stub is not None:
         cv.bilateralFilter = bilateral_stub
+    if with_bubble:  # the calls of the --ignore-bubble stage of dispatch (:34-50), restated on scipy + oracle/contours.py
+        import numpy as np
+        from scipy import ndimage as _nd
+
+        from . import contours as OCt
+
+        cv.RETR_EXTERNAL, cv.CHAIN_APPROX_SIMPLE = 0, 2
+
+        def find_external(img, mode, method):
+            assert mode == cv.RETR_EXTERNAL
+            filled = _nd.binary_fill_holes(np.asarray(img) > 0)          # a component inside a hole has no external contour
+            lab, n = _nd.label(filled, structure=np.ones((3, 3)))
+            out = []
+            for k in range(1, n + 1):
+                cs = OCt.find_contours_list((lab == k).astype(np.uint8))  # hole-free component: exactly its outer border
+                assert len(cs) == 1
+                out.append(cs[0])
+            return out[::-1], None
+
+        def bounding_rect(cnt):
+            p = np.asarray(cnt).reshape(-1, 2)
+            x0, y0 = p.min(axis=0)
+            x1, y1 = p.max(axis=0)
+            return int(x0), int(y0), int(x1 - x0 + 1), int(y1 - y0 + 1)
+
+        def bitwise_and(a, b, mask=None):
+            r = np.bitwise_and(a, b)
+            if mask is not None:
+                r = np.where((np.asarray(mask) != 0)[..., None] if r.ndim == 3 else (np.asarray(mask) != 0), r, 0).astype(a.dtype)
+            return r
+
+        def draw_contours(img, cnts, idx, color, thickness):
+            assert thickness < 0 and idx == -1
+            for c in cnts:
+                OCt.fill_poly(img, np.asarray(c).reshape(-1, 2), color)
+            return img
+
+        cv.findContours, cv.boundingRect, cv.bitwise_and, cv.drawContours = find_external, bounding_rect, bitwise_and, draw_contours
     tmu.cv2 = mr.cv2 = cv
     tmu.Polygon = shp.Polygon
     tmu.tqdm = lambda it, *a, **k: it

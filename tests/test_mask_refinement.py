@@ -35,6 +35,63 @@ def test_dispatch_matches_reference(tag, offset, ksize):
     assert np.array_equal(got, G[f"dispatch_{tag}"])
 
 
+@pytest.mark.parametrize("level", [10, 40])
+def test_dispatch_with_the_bubble_filter_matches_reference(level):
+    """--ignore-bubble (dispatch :34-50 + utils/bubble.py, the reference's own Python over the cv2 stand-ins): a grey page with one
+    coloured patch and a bright band on the bottom frame; the two levels keep different components."""
+    region = type("Region", (), {"lines": G["lines"]})()
+    got = MR.dispatch_sync([region], G["img_bubble"].copy(), G["mask"].copy(), "fit_text", 0, level, False, 3, refine=REFINE, bilateral=BILATERAL)
+    assert np.array_equal(got, G[f"dispatch_bubble{level}"])
+    assert not np.array_equal(G["dispatch_bubble10"], G["dispatch_bubble40"])
+    plain = MR.dispatch_sync([region], G["img_bubble"].copy(), G["mask"].copy(), "fit_text", 0, 0, False, 3, refine=REFINE, bilateral=BILATERAL)
+    k = int(max(plain.shape) * 0.025)
+    assert (got > 0).sum() < (MR.dilate(plain, np.ones((k, k), np.uint8)) > 0).sum()          # something was erased
+
+
+def test_bubble_filter_equals_is_ignore_on_blocked_pages():
+    """bubble_filter evaluates is_ignore() of "the page, black outside the contour's rectangle" without building that page; the literal
+    form (textline.is_ignore on the blocked page) must agree, also for even dilation sizes and rectangles on the page frame."""
+    from scipy import ndimage as nd
+
+    from manga_image_translator_amd import textline as TL
+
+    rng = np.random.default_rng(3)
+    for trial in range(24):
+        H, W = (120, 160) if trial % 2 else (90, 200)
+        raw = np.repeat(rng.integers(0, 256, (H, W, 1)).astype(np.uint8), 3, 2)
+        if trial % 3 == 0:
+            raw[40:60, 50:90] = rng.integers(0, 256, (20, 40, 3))
+        if trial % 4 == 0:
+            raw[:] = 250
+        mask = np.zeros((H, W), np.uint8)
+        for _ in range(int(rng.integers(1, 5))):
+            y, x = int(rng.integers(0, H - 10)), int(rng.integers(0, W - 10))
+            mask[y:y + int(rng.integers(2, 12)), x:x + int(rng.integers(2, 14))] = 255
+        level = int(rng.integers(1, 51))
+        got = MR.bubble_filter(mask, raw, level)
+        k = int(max(H, W) * 0.025)
+        want = MR.dilate(mask, np.ones((k, k), np.uint8))
+        labels, n = nd.label(nd.binary_fill_holes(want > 0), structure=np.ones((3, 3)))
+        for lab, sl in enumerate(nd.find_objects(labels), start=1):
+            y0, y1, x0, x1 = sl[0].start, min(sl[0].stop + 1, H), sl[1].start, min(sl[1].stop + 1, W)
+            block = np.zeros_like(raw)
+            block[y0:y1, x0:x1] = raw[y0:y1, x0:x1]
+            if TL.is_ignore(block, level):
+                want[labels == lab] = 0
+        assert np.array_equal(got, want), trial
+
+
+def test_dilate_uses_opencv_anchor_for_even_kernels():
+    """cv2.dilate: dst(x) = max over taps x' of src(x + x' - k // 2) — for even k the window reaches one pixel further up / left."""
+    img = np.zeros((9, 9), np.uint8)
+    img[4, 4] = 255
+    out = MR.dilate(img, np.ones((4, 4), np.uint8))
+    ys, xs = np.nonzero(out)
+    assert (ys.min(), ys.max(), xs.min(), xs.max()) == (3, 6, 3, 6)       # x + x' - 2 == 4 for x' in 0..3  ->  x in 3..6
+    out = MR.dilate(img, np.ones((3, 3), np.uint8))
+    assert np.nonzero(out)[0].min() == 3 and np.nonzero(out)[0].max() == 5
+
+
 def test_nothing_to_keep_gives_an_empty_mask():
     region = type("Region", (), {"lines": np.zeros((0, 4, 2), np.int32)})()
     got = MR.dispatch_sync([region], G["img"], np.zeros_like(G["mask"]), refine=REFINE, bilateral=BILATERAL)
