@@ -671,9 +671,9 @@ def _():
             assert key(a) == key(b), (key(a), key(b))
         assert all(any(q is l for l in got_lines) for q in got), "the caller's own objects must come back"
         kept[(prob_cfg, bubble)] = [key(q) for q in got]
-        print("   ", prob_cfg, bubble, len(got), "lines,", sum(" " in q.text for q in got), "with spaces", flush=True)
         run(ocr.unload())
     assert kept[(0.3, 10)] != kept[(0.3, 0)]              # the filter (the reference's own is_ignore on its side) changed what is read
+    assert any(" " in k[1] for ks in kept.values() for k in ks)   # <SP> went through the text / colour rules somewhere
 
 
 @check("exceptions propagate through the reference's infer()/inpaint() wrappers")
