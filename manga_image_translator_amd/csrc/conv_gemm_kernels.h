@@ -747,6 +747,7 @@ __device__ constexpr int kSplitPB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
 template <int BK>
 __device__ __forceinline__ constexpr int split_swz(int kh) { return kh * (32 / (BK / 4)); }
 
+constexpr int SPLIT_TPB = 4;  // output tiles per workgroup of the persistent split tiles (VAR & 512)
 // VAR bit 1: software pipeline — the next tile's operands (loaded one iteration ahead) are split and written to the other LDS buffer
 // among this tile's MFMAs, and the loads of the tile after it are issued behind them.
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int NPROD, int VAR = 0>
@@ -772,6 +773,10 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
                    X_NOBAR = (VAR & 32) != 0;
     constexpr bool MID = (VAR & 128) != 0;  // with PIPE: the staging cut into steps, one placed behind each MFMA (sched_barrier keeps them there)
     constexpr bool ORD = (VAR & 256) != 0;  // with MID: fragment reads issued in the order the plane pairs consume them; next row offsets fetched in step 0
+    // 512: each workgroup computes SPLIT_TPB consecutive output tiles; the next tile's gather table and first K-tile loads are issued before
+    // the current tile's epilogue, so their latency hides behind its stores
+    constexpr bool PERSIST = (VAR & 512) != 0;
+    constexpr int TPB = PERSIST ? SPLIT_TPB : 1;
     constexpr bool ASM_SUB = (VAR & 64) != 0;  // residuals through v_sub_f32 inline asm: keeps the SLP vectoriser from packing them into v_pk_add_f32
     constexpr int SA = BM, SB = BN;
     constexpr int A_TILE = 3 * KH * SA, B_TILE = 3 * KH * SB;  // cells per buffer
@@ -791,13 +796,15 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const int lh = lane >> 5;
 
     const int nwg = MT * NT;
+    const int nblk = (nwg + TPB - 1) / TPB;  // == gridDim.x
     int bid = blockIdx.x;
     {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int mt = bid / NT, nt = bid - mt * NT;
-    const int m0 = mt * BM, n0 = nt * BN;
+    int cur_tile = bid * TPB;  // this workgroup's run of consecutive tiles (n fastest: they share the A panel)
+    const int tile_end = cur_tile + TPB < nwg ? cur_tile + TPB : nwg;
+    int m0 = 0, n0 = 0;
     const int z = blockIdx.y;
     const int z1 = z / p.zdiv, z0 = z - z1 * p.zdiv;
     const int HoWo = p.Ho * p.Wo;
@@ -807,45 +814,50 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const int K8 = p.Kw >> 3;     // cells along k per plane
     const int ldn = (int)p.ldw;   // cells per k-row
 
-    for (int idx = tid; idx < p.ntaps * BM; idx += 256) {
-        const int t = idx / BM, r = idx - t * BM;
-        const int m = m0 + r;
-        int off = -1;
-        if (m < M) {
-            const int nb = m / HoWo;
-            const int rem = m - nb * HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            int iy = oy * p.sy + p.tap_dy[t];
-            int ix = ox * p.sx + p.tap_dx[t];
-            bool ok = true;
-            if (p.pad_mode == MIT_PAD_REFLECT) {
-                iy = iy < 0 ? -iy : (iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy);
-                ix = ix < 0 ? -ix : (ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix);
-            } else {
-                ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            }
-            if (ok) off = (int)((int64_t)nb * p.a_bs + (int64_t)iy * p.a_ys + (int64_t)ix * p.a_xs + p.tap_off[t]);
-        }
-        rowtab[idx] = off;
-    }
-
     const int aq = tid % KQ;
     const int am = tid / KQ;
     const float *__restrict__ a_thr = a_base + aq * 4;
-
-    // this thread's W cells: the same (plane, kh, n) in every K-tile
-    int b_src[B_ITERS], b_dst[B_ITERS];
+    int b_src[B_ITERS], b_dst[B_ITERS];  // this thread's W cells: the same (plane, kh, n) in every K-tile of an output tile
     bool b_ok[B_ITERS];
+    int ld_tap = 0, ld_ci0 = 0, ld_k8 = 0;  // (tap, first channel, first k cell) of the tile being loaded: wave-uniform
+    auto setup_tile = [&](const int t) {  // gather table, W cell addresses and load cursor of output tile t
+        const int mt = t / NT, nt = t - mt * NT;
+        m0 = mt * BM;
+        n0 = nt * BN;
+        for (int idx = tid; idx < p.ntaps * BM; idx += 256) {
+            const int tp = idx / BM, r = idx - tp * BM;
+            const int m = m0 + r;
+            int off = -1;
+            if (m < M) {
+                const int nb = m / HoWo;
+                const int rem = m - nb * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                int iy = oy * p.sy + p.tap_dy[tp];
+                int ix = ox * p.sx + p.tap_dx[tp];
+                bool ok = true;
+                if (p.pad_mode == MIT_PAD_REFLECT) {
+                    iy = iy < 0 ? -iy : (iy >= p.Hi ? 2 * p.Hi - 2 - iy : iy);
+                    ix = ix < 0 ? -ix : (ix >= p.Wi ? 2 * p.Wi - 2 - ix : ix);
+                } else {
+                    ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                }
+                if (ok) off = (int)((int64_t)nb * p.a_bs + (int64_t)iy * p.a_ys + (int64_t)ix * p.a_xs + p.tap_off[tp]);
+            }
+            rowtab[idx] = off;
+        }
 #pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
-        const int c = tid + i * 256;
-        const int pl = c / B_CPP, rem = c - pl * B_CPP;
-        const int kh = rem / BN, n = rem - kh * BN;
-        b_ok[i] = c < B_CELLS && (n0 + n) < ldn;
-        b_src[i] = (pl * K8 + kh) * ldn + n0 + n;
-        b_dst[i] = (pl * KH + kh) * SB + n;
-    }
+        for (int i = 0; i < B_ITERS; ++i) {
+            const int c = tid + i * 256;
+            const int pl = c / B_CPP, rem = c - pl * B_CPP;
+            const int kh = rem / BN, n = rem - kh * BN;
+            b_ok[i] = c < B_CELLS && (n0 + n) < ldn;
+            b_src[i] = (pl * K8 + kh) * ldn + n0 + n;
+            b_dst[i] = (pl * KH + kh) * SB + n;
+        }
+        ld_tap = ld_ci0 = ld_k8 = 0;
+    };
+    setup_tile(cur_tile);
 
     f32x4 a_reg[A_ITERS];
     u32x4 b_reg[B_ITERS];
@@ -853,7 +865,6 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
 
     __syncthreads();  // rowtab visible
 
-    int ld_tap = 0, ld_ci0 = 0, ld_k8 = 0;  // (tap, first channel, first k cell) of the tile being loaded: wave-uniform
     // Branch-free on purpose: masked-off lanes read a valid dummy address and the value is replaced by zero afterwards, so a loop
     // iteration stays ONE basic block and the scheduler can place these loads, the split and the LDS writes among the MFMAs.
     auto load_tile = [&]() {
@@ -898,12 +909,6 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int wm0 = (wave / WAVES_N) * WM;
     const int wn0 = (wave % WAVES_N) * WN;
@@ -1030,26 +1035,43 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const std::integral_constant<bool, true> yes;
     const std::integral_constant<bool, false> no;
 
-    load_tile();
-    store_tile(0);
-    if (PIPE && KT > 1) load_tile();  // tile 1 rides in the registers across the barrier
-    __syncthreads();
-    {
-        int kt = 0;
-        if (PIPE) {
-            for (; kt + 2 < KT; ++kt) tile(kt, yes, yes);
-            if (kt + 1 < KT) tile(kt++, yes, no);
-        } else {
-            for (; kt + 1 < KT; ++kt) tile(kt, yes, no);
-        }
-        tile(kt, no, no);
-    }
-    if (X_NOBAR) __syncthreads();  // the epilogue reuses the staging area
-
     constexpr int EPI_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4 + 4 * 32 * EPI_PITCH;
     constexpr int STAGE_FLOATS = (2 * A_TILE + 2 * B_TILE) * 4;
     constexpr int SMEM_F = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
-    epilogue<BM, TM, TN, 0, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+
+    load_tile();
+    for (;;) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        store_tile(0);
+        if (PIPE && KT > 1) load_tile();  // tile 1 rides in the registers across the barrier
+        __syncthreads();
+        {
+            int kt = 0;
+            if (PIPE) {
+                for (; kt + 2 < KT; ++kt) tile(kt, yes, yes);
+                if (kt + 1 < KT) tile(kt++, yes, no);
+            } else {
+                for (; kt + 1 < KT; ++kt) tile(kt, yes, no);
+            }
+            tile(kt, no, no);
+        }
+        if (X_NOBAR) __syncthreads();  // the epilogue reuses the staging area
+        const int em0 = m0, en0 = n0;
+        const bool more = PERSIST && cur_tile + 1 < tile_end;  // workgroup-uniform
+        if (more) {  // the gather table is no longer read (the K loop ended on a barrier); the staging registers are free
+            setup_tile(++cur_tile);
+            __syncthreads();
+            load_tile();  // in flight during the epilogue below
+        }
+        epilogue<BM, TM, TN, 0, SMEM_F>(p, acc, smem, M, em0, en0, wm0, wn0, z1, z0, HoWo);
+        if (!more) break;
+        __syncthreads();  // the epilogue's row table / transpose buffers live in the staging area the next store_tile(0) overwrites
+    }
 }
 
 // W [nz][Kw][ldw] fp32 -> [nz][3][Kw / 8][ldw][8] bf16 (see conv_gemm_split_kernel); one thread per (slice, k cell, column)
@@ -1233,7 +1255,8 @@ void launch_split(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    dim3 grid(MT * NT, p.Z, 1);
+    const int tpb = (VAR & 512) ? SPLIT_TPB : 1;
+    dim3 grid((MT * NT + tpb - 1) / tpb, p.Z, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 }  // namespace mitcg
