@@ -747,7 +747,7 @@ __device__ constexpr int kSplitPB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
 template <int BK>
 __device__ __forceinline__ constexpr int split_swz(int kh) { return kh * (32 / (BK / 4)); }
 
-constexpr int SPLIT_TPB = 4;  // output tiles per workgroup of the persistent split tiles (VAR & 512)
+constexpr int split_tpb(int var) { return (var & 1024) ? 2 : (var & 512) ? 4 : 1; }  // output tiles per workgroup of the multi-tile split tiles
 // VAR bit 1: software pipeline — the next tile's operands (loaded one iteration ahead) are split and written to the other LDS buffer
 // among this tile's MFMAs, and the loads of the tile after it are issued behind them.
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int NPROD, int VAR = 0>
@@ -773,10 +773,10 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
                    X_NOBAR = (VAR & 32) != 0;
     constexpr bool MID = (VAR & 128) != 0;  // with PIPE: the staging cut into steps, one placed behind each MFMA (sched_barrier keeps them there)
     constexpr bool ORD = (VAR & 256) != 0;  // with MID: fragment reads issued in the order the plane pairs consume them; next row offsets fetched in step 0
-    // 512: each workgroup computes SPLIT_TPB consecutive output tiles; the next tile's gather table and first K-tile loads are issued before
-    // the current tile's epilogue, so their latency hides behind its stores
-    constexpr bool PERSIST = (VAR & 512) != 0;
-    constexpr int TPB = PERSIST ? SPLIT_TPB : 1;
+    // 512 / 1024: each workgroup computes 4 / 2 consecutive output tiles; the next tile's gather table and first K-tile loads are issued
+    // before the current tile's epilogue, so their latency hides behind its stores
+    constexpr int TPB = split_tpb(VAR);
+    constexpr bool PERSIST = TPB > 1;
     constexpr bool ASM_SUB = (VAR & 64) != 0;  // residuals through v_sub_f32 inline asm: keeps the SLP vectoriser from packing them into v_pk_add_f32
     constexpr int SA = BM, SB = BN;
     constexpr int A_TILE = 3 * KH * SA, B_TILE = 3 * KH * SB;  // cells per buffer
@@ -1255,7 +1255,7 @@ void launch_split(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    const int tpb = (VAR & 512) ? SPLIT_TPB : 1;
+    const int tpb = split_tpb(VAR);
     dim3 grid((MT * NT + tpb - 1) / tpb, p.Z, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
