@@ -175,7 +175,7 @@ def split_mode() -> int:
     """``MIT_GEMM_SPLIT`` = 6 | 9: packers also build the three-bf16-plane form of their weights and ``mit_conv_gemm`` picks the
     split-bf16 tiles for them (include/mit_hip.h, mit_gemm_split_pack).  0 / unset (default): fp32 MFMA tiles only."""
     v = os.environ.get("MIT_GEMM_SPLIT", "0").strip() or "0"
-    return int(v) if v in ("3", "6", "9") else 0
+    return int(v) if v in ("6", "9") else 0  # the 3-pair tiles are a test ladder (explicit tile index only), never a mode
 
 
 _SPLITS: Dict[int, Tuple["weakref.ref", torch.Tensor, int, int, int]] = {}   # data_ptr -> (weight, planes, nz, Kp, Np)
