@@ -200,3 +200,35 @@ def bilateral_filter_u8(img: torch.Tensor, d: int = 17, sigma_color: float = 80.
     _lib.check(_lib.load().mit_bilateral_u8c3(s.data_ptr(), out.data_ptr(), B, H, W, radius, ofs.numel(), ofs.data_ptr(), wts.data_ptr(),
                                               cw.data_ptr(), C.c_void_p(ops.current_stream())), "mit_bilateral_u8c3")
     return out[0] if squeeze else out
+
+
+# ---- page edges: PIL <-> the uint8 RGB arrays the stage plugins exchange (utils/generic.py:223-249) ----------------------------
+
+def load_image(img):
+    """PIL image -> (uint8 RGB array [H, W, 3], alpha channel or None): RGBA and palette pages are flattened onto white and their alpha
+    is kept for ``dump_image`` (utils/generic.py:223-239); everything else is ``convert('RGB')``."""
+    from PIL import Image
+
+    if img.mode in ("RGBA", "P"):
+        if img.mode == "P":
+            img = img.convert("RGBA")
+        img.load()  # split() needs the pixel data
+        background = Image.new("RGB", img.size, (255, 255, 255))
+        alpha = img.split()[3]
+        background.paste(img, mask=alpha)
+        return np.array(background), alpha
+    return np.array(img.convert("RGB")), None
+
+
+def dump_image(img_pil, img: np.ndarray, alpha_ch=None):
+    """Result array -> RGBA PIL image of the result's size, the page's alpha re-attached when it had one (utils/generic.py:241-249)."""
+    from PIL import Image
+
+    if alpha_ch is not None:
+        if img.shape[2] != 4:
+            img = np.concatenate([img.astype(np.uint8), np.array(alpha_ch).astype(np.uint8)[..., None]], axis=2)
+    else:
+        img = img.astype(np.uint8)
+    result = img_pil.convert("RGBA").resize((img.shape[1], img.shape[0]))
+    result.paste(Image.fromarray(img), mask=alpha_ch)
+    return result

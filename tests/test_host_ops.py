@@ -262,3 +262,54 @@ def test_rfft_row_plan_and_tables():
         back = np.empty(w)
         back[0::2], back[1::2] = zz.real, zz.imag
         assert np.abs(back - x).max() < 1e-6
+
+
+def _pil_pages():
+    from PIL import Image
+
+    rng = np.random.default_rng(8)
+    rgb = Image.fromarray(rng.integers(0, 256, (20, 28, 3)).astype(np.uint8))
+    rgba = Image.fromarray(rng.integers(0, 256, (20, 28, 4)).astype(np.uint8), "RGBA")
+    grey = Image.fromarray(rng.integers(0, 256, (20, 28)).astype(np.uint8))
+    pal = rgb.convert("P", palette=Image.Palette.ADAPTIVE, colors=16)
+    pal.info["transparency"] = 3
+    return {"RGB": rgb, "RGBA": rgba, "L": grey, "P": pal}
+
+
+def test_load_and_dump_image_round_trip():
+    """imgproc.load_image / dump_image (utils/generic.py:223-249): modes, the white flattening of transparent pixels, the alpha that
+    comes back on the result."""
+    from manga_image_translator_amd import imgproc
+
+    for mode, page in _pil_pages().items():
+        arr, alpha = imgproc.load_image(page)
+        assert arr.dtype == np.uint8 and arr.shape == (20, 28, 3) and (alpha is not None) == (mode in ("RGBA", "P"))
+        out = imgproc.dump_image(page, arr, alpha)
+        assert out.mode == "RGBA" and out.size == page.size
+        if mode == "RGBA":
+            a = np.array(page)[..., 3:4].astype(np.float64) / 255
+            want = np.array(page)[..., :3] * a + 255 * (1 - a)                      # PIL's paste-through-mask blend, to within rounding
+            assert np.abs(arr.astype(np.float64) - want).max() <= 1.0
+            assert np.array_equal(np.array(out)[..., 3], np.array(page)[..., 3])
+        if mode == "RGB":
+            assert np.array_equal(arr, np.array(page)) and np.array_equal(np.array(out)[..., :3], arr)
+    big = np.zeros((40, 56, 3), np.uint8)                                            # an upscaled result: the container follows its size
+    assert imgproc.dump_image(_pil_pages()["RGB"], big).size == (56, 40)
+
+
+def test_load_and_dump_image_match_the_reference_functions():
+    from oracle import ref_import as R
+
+    if not R.available():
+        pytest.skip("/root/reference not present")
+    from manga_image_translator_amd import imgproc
+
+    G = R.generic()
+    for mode, page in _pil_pages().items():
+        a0, al0 = G.load_image(page.copy())
+        a1, al1 = imgproc.load_image(page.copy())
+        assert np.array_equal(a0, a1) and (al0 is None) == (al1 is None)
+        if al0 is not None:
+            assert np.array_equal(np.array(al0), np.array(al1))
+        res = (a0.astype(np.int32) // 2).astype(np.uint8)
+        assert np.array_equal(np.array(G.dump_image(page, res.copy(), al0)), np.array(imgproc.dump_image(page, res.copy(), al1)))
