@@ -1,4 +1,4 @@
-"""Split-bf16 contraction (conv_gemm_split_kernel, include/mit_hip.h mit_gemm_split_pack) — what can be pinned without a GPU:
+"""Split-bf16 contraction (csrc/conv_gemm_split.h conv_gemm_split_kernel, include/mit_hip.h mit_gemm_split_pack) — what can be pinned without a GPU:
 
 * the arithmetic claim: an fp32 number is exactly hi + mid + lo of three round-to-nearest-even bf16 numbers, every plane product is
   exact in fp32, and dropping the three smallest of the nine plane pairs ("p6") costs less than fp32 rounding itself;
