@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     // 512 / 1024: each workgroup computes 4 / 2 consecutive output tiles; the next tile's gather table and first K-tile loads are issued
     // before the current tile's epilogue, so their latency hides behind its stores
     constexpr int TPB = split_tpb(VAR);
-    constexpr bool PERSIST = TPB > 1;
+    // 2048: grid-strided multi-tile form: the launcher starts one workgroup per residency slot of the chip (a multiple of 8) and workgroup b
+    // takes the virtual block ids b, b + gridDim.x, ... — same XCD every time (ids stay congruent mod 8), XCD-contiguous tiles through the
+    // usual remap, at most one tile of imbalance between workgroups
+    constexpr bool STRIDED = (VAR & 2048) != 0;
+    constexpr bool PERSIST = TPB > 1 || STRIDED;
     constexpr bool ASM_SUB = (VAR & 64) != 0;  // residuals through v_sub_f32 inline asm: keeps the SLP vectoriser from packing them into v_pk_add_f32
     constexpr int SA = BM, SB = BN;
     constexpr int A_TILE = 3 * KH * SA, B_TILE = 3 * KH * SB;  // cells per buffer
@@ -110,14 +114,14 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const int lh = lane >> 5;
 
     const int nwg = MT * NT;
-    const int nblk = (nwg + TPB - 1) / TPB;  // == gridDim.x
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    int cur_tile = bid * TPB;  // this workgroup's run of consecutive tiles (n fastest: they share the A panel)
-    const int tile_end = cur_tile + TPB < nwg ? cur_tile + TPB : nwg;
+    const int nblk = STRIDED ? nwg : (nwg + TPB - 1) / TPB;  // virtual blocks (== gridDim.x unless STRIDED)
+    auto remap = [&](int v) {  // virtual block id -> position in the XCD-contiguous order
+        const int xcd = v & 7, q = nblk >> 3, r = nblk & 7;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    };
+    int vblock = blockIdx.x;
+    int cur_tile = remap(vblock) * TPB;  // consecutive tiles (n fastest) share the A panel
+    const int tile_end = STRIDED ? nwg : (cur_tile + TPB < nwg ? cur_tile + TPB : nwg);
     int m0 = 0, n0 = 0;
     const int z = blockIdx.y;
     const int z1 = z / p.zdiv, z0 = z - z1 * p.zdiv;
@@ -376,9 +380,17 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
         }
         if (X_NOBAR) __syncthreads();  // the epilogue reuses the staging area
         const int em0 = m0, en0 = n0;
-        const bool more = PERSIST && cur_tile + 1 < tile_end;  // workgroup-uniform
+        bool more;  // workgroup-uniform
+        if (STRIDED) {
+            vblock += gridDim.x;
+            more = vblock < nwg;
+            if (more) cur_tile = remap(vblock);
+        } else {
+            more = PERSIST && cur_tile + 1 < tile_end;
+            if (more) ++cur_tile;
+        }
         if (more) {  // the gather table is no longer read (the K loop ended on a barrier); the staging registers are free
-            setup_tile(++cur_tile);
+            setup_tile(cur_tile);
             __syncthreads();
             load_tile();  // in flight during the epilogue below
         }
@@ -428,7 +440,21 @@ void launch_split(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream
         attr_set = true;
     }
     const int tpb = split_tpb(VAR);
-    dim3 grid((MT * NT + tpb - 1) / tpb, p.Z, 1);
+    int gx = (MT * NT + tpb - 1) / tpb;
+    if (VAR & 2048) {  // one workgroup per residency slot (multiple of 8 so that a workgroup's tiles stay on its XCD)
+        static int slots = 0;
+        if (!slots) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, smem) != hipSuccess || per_cu < 1) per_cu = 2;
+            (void)hipGetDevice(&dev);
+            const int cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+            slots = (per_cu * cus) / 8 * 8;
+            if (slots < 8) slots = 8;
+        }
+        if (gx > slots) gx = slots;
+    }
+    dim3 grid(gx, p.Z, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 
