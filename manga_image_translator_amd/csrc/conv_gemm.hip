@@ -17,6 +17,7 @@ const CfgEntry kCfgs[] = {
 #define KNAME_launch_fast "conv_gemm_fast_kernel"
 #define KNAME_launch_gemv "conv_gemv_kernel"
 #define KNAME_launch_split "conv_gemm_split_kernel"
+#define KNAME_launch_fast_persist "conv_gemm_fast_persist_kernel"
 #define X(g, name, fast, BM, BN, BK, fn, ...) \
     {name, BM, BN, BK, fn<BM, BN, BK, __VA_ARGS__>, fast, KNAME_##fn "<" #BM ", " #BN ", " #BK ", " #__VA_ARGS__ ">"},
 #include "conv_gemm_cfgs.inc"
