@@ -47,6 +47,18 @@ H, W = 2048, 1456
 N_BOXES = 32
 DECODE_STEPS = 32          # fixed decode length with EOS suppressed (random weights never emit EOS)
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no xf32 on gfx950
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (the split-bf16 tiles' pipe)
+
+
+def split_tile_roofline(tile_name: str, alg_tflops: float):
+    """Roofline view of a split-bf16 tile (``split…p6…`` / ``…p9…``): every algorithmic FLOP is executed as 6 (or 9) bf16 MFMA products,
+    so the pipe it runs on sees ``pairs x`` the algorithmic rate against the bf16 dense peak.  None for the fp32 tiles."""
+    if not tile_name.startswith("split"):
+        return None
+    pairs = 9 if "p9" in tile_name else 6 if "p6" in tile_name else 3
+    executed = alg_tflops * pairs
+    return dict(plane_pairs=pairs, executed_bf16_tflops=round(executed, 1), bf16_mfma_peak=BF16_MATRIX_PEAK_TFLOPS,
+                frac_of_bf16_mfma_peak=round(executed / BF16_MATRIX_PEAK_TFLOPS, 4), fp32_equivalent_tflops=round(alg_tflops, 2))
 FP32_VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: vector fp32 (the VALU output convolution is priced against it)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (about 6300 achievable)
 STAGE_NAMES = {"detect": "ctd", "ocr": "ocr48", "inpaint": "lama_mpe"}
@@ -218,6 +230,9 @@ def roofline_leg(engine, pages, quads, masks, stages, dump=""):
                 whole_step=dict(conv_exec_tflops=round(total_exec / (total_wall * 1e-3) / 1e12, 2),
                                 frac_of_fp32_mfma_peak=round(total_exec / (total_wall * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)),
                 stages=per_stage, hbm_kernels=hbm, hbm_peak_GBps=HBM_PEAK_GBS, pmc_source=src)
+    sp = split_tile_roofline(cname, achieved)
+    if sp is not None:  # opt-in split-bf16 mode: the dominant tile runs on the bf16 pipe; keep the fp32-peak figures above for comparison
+        roof["split_bf16"] = sp
     return roof, per_cfg
 
 

@@ -93,3 +93,13 @@ def test_cpu_baseline_and_parity_legs_on_a_small_page(monkeypatch):
     res.ocr_tokens[0, 1] += 1
     par = bench.parity_leg(res, [0, 1], outs, ("detect", "ocr", "inpaint"))
     assert not par["ok"] and par["ocr"]["lines_with_different_tokens"] == 1 and par["inpaint"]["max_abs_u8_diff"] == 64
+
+
+def test_split_tile_roofline_view():
+    """The opt-in split-bf16 mode prices its dominant tile against the bf16 MFMA peak with the executed (6x / 9x) FLOPs."""
+    import bench
+
+    assert bench.split_tile_roofline("fast128x128x16w4c", 114.0) is None
+    r = bench.split_tile_roofline("split128x128x16p6o", 161.8)
+    assert r["plane_pairs"] == 6 and abs(r["executed_bf16_tflops"] - 970.8) < 0.1 and abs(r["frac_of_bf16_mfma_peak"] - 0.3883) < 1e-3
+    assert bench.split_tile_roofline("split128x128x16p9m", 126.6)["plane_pairs"] == 9
