@@ -193,6 +193,27 @@ def test_descriptor_picks_up_registered_planes_by_identity():
         ops._SPLITS.pop(key, None)
 
 
+def test_descriptor_strides_for_batched_weights():
+    """[nz, Kp, Np] weights (the 36 Winograd slices): planes are found only for the plain slice stride, and ws_zs0 is one slice of planes."""
+    import weakref
+
+    u = torch.zeros(4, 16, 8)
+    a = torch.zeros(1, 1, 4, 16)
+    out = torch.zeros(1, 1, 4, 8)
+    mk = lambda w_zs: ops.conv_gemm_desc(a=a, NB=1, Hi=1, Wi=4, Cin=16, a_strides=(64, 64, 16), Ho=1, Wo=4, sy=1, sx=1, taps=[(0, 0, 0)],
+                                         pad_mode=ops.PAD_ZERO, w=u, ldw=8, Kw=16, Nw=8, N=8, c=ops.tensor_map(out), Z=4, zdiv=1 << 30, w_zs=w_zs)
+    fake = torch.zeros(4, 3, 2, 8, 8, dtype=torch.int16)
+    key = u.data_ptr()
+    ops._SPLITS[key] = (weakref.ref(u), fake, 4, 16, 8)
+    try:
+        d = mk((0, 16 * 8))
+        assert d.w_split == fake.data_ptr() and d.ws_zs0 == 3 * 16 * 8
+        assert not mk((0, 2 * 16 * 8)).w_split          # every other slice: not the packed layout
+        assert not mk((0, 0)).w_split                    # one slice broadcast over z: the planes hold four different ones
+    finally:
+        ops._SPLITS.pop(key, None)
+
+
 def test_split_mode_env(monkeypatch):
     monkeypatch.delenv("MIT_GEMM_SPLIT", raising=False)
     assert ops.split_mode() == 0
