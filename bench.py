@@ -50,6 +50,13 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense (the split-bf16 tiles' pipe)
 
 
+def split_pairs(tile_name: str) -> int:
+    """Plane products a split-bf16 tile executes per algorithmic multiply (0 for the fp32 tiles)."""
+    if not tile_name.startswith("split"):
+        return 0
+    return 9 if "p9" in tile_name else 6 if "p6" in tile_name else 3
+
+
 def split_tile_roofline(tile_name: str, alg_tflops: float):
     """Roofline view of a split-bf16 tile (``split…p6…`` / ``…p9…``): every algorithmic FLOP is executed as 6 (or 9) bf16 MFMA products,
     so the pipe it runs on sees ``pairs x`` the algorithmic rate against the bf16 dense peak.  None for the fp32 tiles."""
@@ -82,6 +89,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-MFMA sub-measurement (fp32_mfma) taken beside a split-mode headline")
+    ap.add_argument("--fp32-steps", type=int, default=3, help="timed steps of the fp32_mfma sub-measurement (after 1 warm-up step)")
     ap.add_argument("--cpu-pages", type=int, default=3, help="timed pages of the CPU baseline (after 1 warm-up page)")
     ap.add_argument("--cpu-threads", default="8,16,32,64,128", help="thread counts swept per stage")
     ap.add_argument("--prof-dump", default="", help="write one CSV line per conv_gemm launch of the instrumented passes to this path (suffix .<stage>)")
@@ -159,13 +168,17 @@ def stage_legs(engine, pages, quads, masks, stages, dump=""):
         if dump:
             L.check(lib.mit_prof_dump(f"{dump}.{s}".encode()), "mit_prof_dump")
         L.check(lib.mit_prof_enable(0), "mit_prof_enable")
-        conv_ms = conv_exec = 0.0
+        conv_ms = conv_exec = peak_ms = bf16_exec = 0.0
         for i in range(ncfg.value):
             st = stats[i]
             if not st.launches:
                 continue
             conv_ms += st.ms
             conv_exec += st.exec_flops
+            pairs = split_pairs(lib.mit_conv_gemm_config_name(i).decode())
+            # time this configuration's launches would take at the peak of the pipe they run on
+            peak_ms += (st.exec_flops * pairs / (BF16_MATRIX_PEAK_TFLOPS * 1e9)) if pairs else (st.exec_flops / (FP32_MATRIX_PEAK_TFLOPS * 1e9))
+            bf16_exec += st.exec_flops * pairs
             a = conv_tot.setdefault(i, [0, 0.0, 0.0, 0.0])
             a[0] += st.launches
             a[1] += st.ms
@@ -185,7 +198,12 @@ def stage_legs(engine, pages, quads, masks, stages, dump=""):
             ms_per_page=round(wall_ms / n, 3), conv_exec_tflops=round(exec_tflops, 2),
             frac_of_fp32_mfma_peak=round(exec_tflops / FP32_MATRIX_PEAK_TFLOPS, 4),
             conv_kernel_ms_per_page=round(conv_ms / n, 3), other_probed_kernel_ms_per_page=round(other_ms / n, 3),
-            conv_kernels_alone_tflops=round(conv_exec / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None)
+            conv_kernels_alone_tflops=round(conv_exec / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
+            # the stage against the MFMA roofline of the pipes it actually uses: (time its contractions need at peak — split launches:
+            # pairs x FLOPs at the bf16 dense peak, fp32 launches: FLOPs at the fp32 matrix peak) / the stage's wall time
+            mfma_ms_at_peak_per_page=round(peak_ms / n, 3), frac_of_mfma_roofline=round(peak_ms / wall_ms, 4),
+            executed_bf16_tflops=round(bf16_exec / (wall_ms * 1e-3) / 1e12, 1) if bf16_exec else 0.0)
+        per_stage[STAGE_NAMES.get(s, s)]["_peak_ms"] = peak_ms
     return per_stage, conv_tot, kern_tot, n
 
 
@@ -200,6 +218,10 @@ def roofline_leg(engine, pages, quads, masks, stages, dump=""):
         per_cfg[lib.mit_conv_gemm_config_name(i).decode()] = dict(
             launches=int(launches), ms=round(ms, 3), alg_tflops=round(alg / (ms * 1e-3) / 1e12, 2),
             exec_tflops=round(ex / (ms * 1e-3) / 1e12, 2), kernel=lib.mit_conv_gemm_config_kernel(i).decode())
+    for name, v in per_cfg.items():
+        sp = split_tile_roofline(name, v["alg_tflops"])
+        if sp is not None:
+            v["bf16_pipe"] = sp
     if not conv_tot:
         return None, per_cfg
     dom = max(conv_tot, key=lambda i: conv_tot[i][1])  # the tile configuration with the most GPU time
@@ -223,16 +245,25 @@ def roofline_leg(engine, pages, quads, masks, stages, dump=""):
         hbm[name] = e
     total_exec = sum(v[2] for v in conv_tot.values())
     total_wall = sum(s["ms_per_page"] for s in per_stage.values()) * n
-    roof = dict(bound="mfma", kernel=kname, tile_config=cname, achieved=round(achieved, 2), peak=FP32_MATRIX_PEAK_TFLOPS,
-                unit="TFLOP/s", frac=round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=tr, launches=int(launches),
+    total_peak_ms = sum(s.pop("_peak_ms") for s in per_stage.values())
+    pairs = split_pairs(cname)
+    if pairs:
+        # The dominant kernel is a split-bf16 tile: it is priced on the pipe it runs on.  Every algorithmic multiply-add is executed
+        # as `pairs` bf16 MFMA products, so achieved = pairs x algorithmic FLOPs / kernel time against the dense bf16 MFMA peak.
+        executed = achieved * pairs
+        head = dict(achieved=round(executed, 1), peak=BF16_MATRIX_PEAK_TFLOPS, frac=round(executed / BF16_MATRIX_PEAK_TFLOPS, 4),
+                    pipe="bf16 MFMA (v_mfma_f32_32x32x16_bf16), dense", plane_pairs=pairs, fp32_equivalent_tflops=round(achieved, 2),
+                    fp32_equivalent_frac_of_fp32_mfma_peak=round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4))
+    else:
+        head = dict(achieved=round(achieved, 2), peak=FP32_MATRIX_PEAK_TFLOPS, frac=round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+                    pipe="fp32 MFMA (v_mfma_f32_32x32x2_f32)")
+    roof = dict(bound="mfma", kernel=kname, tile_config=cname, unit="TFLOP/s", **head, traffic=tr, launches=int(launches),
                 avg_launch_us=round(ms * 1e3 / launches, 2), alg_gflop_per_launch=round(alg / launches / 1e9, 3),
                 exec_tflops=round(ex / (ms * 1e-3) / 1e12, 2), pages_probed=n,
                 whole_step=dict(conv_exec_tflops=round(total_exec / (total_wall * 1e-3) / 1e12, 2),
-                                frac_of_fp32_mfma_peak=round(total_exec / (total_wall * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)),
+                                frac_of_fp32_mfma_peak=round(total_exec / (total_wall * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                frac_of_mfma_roofline=round(total_peak_ms / total_wall, 4)),
                 stages=per_stage, hbm_kernels=hbm, hbm_peak_GBps=HBM_PEAK_GBS, pmc_source=src)
-    sp = split_tile_roofline(cname, achieved)
-    if sp is not None:  # opt-in split-bf16 mode: the dominant tile runs on the bf16 pipe; keep the fp32-peak figures above for comparison
-        roof["split_bf16"] = sp
     return roof, per_cfg
 
 
@@ -456,30 +487,60 @@ def main():
     engine = pipeline.PageEngine(weights, device=device, ctd_mb=args.ctd_mb, lama_mb=args.lama_mb, group=args.group,
                                  overlap=args.overlap)
     gathered = {"bytes": 0}
+    gather = D.PageGather()
 
     def step():
         res = engine.run(pages, quads, masks, max_seq_length=DECODE_STEPS, suppress_eos=True, stages=stages)
-        if world > 1:  # per-page result records to rank 0 (point-to-point over xGMI); any failure ends the run
-            out = D.gather_pages(res.packed_pages(N_BOXES) if "ocr" in stages else res.packed())
-            if out is not None:
-                gathered["bytes"] = out.numel()
+        if world > 1:  # per-page result records to rank 0 (point-to-point over xGMI), asynchronously: the next step's kernels do not
+            gather.submit(res.packed_pages(N_BOXES) if "ocr" in stages else res.packed())  # wait for peer traffic; any failure ends the run
+            gathered["bytes"] = max(gathered["bytes"], gather.last_bytes)
         return res
+
+    def drain():
+        if world > 1:
+            gather.wait()  # the last step's gather belongs to the timed region
 
     res = None
     for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):  # N > 1: at least one untimed step proves the gather works
         res = step()
+    drain()
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    drain()
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
     dt = D.max_over_ranks(time.perf_counter() - t0)
 
-    roof = per_cfg = cpu = parity = dropin = None
+    roof = per_cfg = cpu = parity = dropin = fp32 = None
     leg_errors = {}
+    from manga_image_translator_amd import ops as _ops
+
+    shipped_mode = _ops.split_mode()
+    if shipped_mode and not args.no_fp32_leg:
+        # the same engine (same packed weights, same batch) with the GEMM mode switched to the fp32 MFMA: timed in the same process,
+        # same barrier discipline, max over ranks (VERDICT r02 #1b)
+        _ops.set_split_mode(0)
+        for _ in range(1):
+            step()
+        drain()
+        D.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.fp32_steps):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        dt32 = D.max_over_ranks(time.perf_counter() - t1)
+        fp32 = dict(value=round(args.pages * world * args.fp32_steps / dt32, 3), unit="pages/s", steps=args.fp32_steps, warmup=1,
+                    ms_per_step=round(dt32 / args.fp32_steps * 1e3, 2), gemm_mode=0,
+                    note="the same engine and batch with mit_gemm_mode_set(0): every contraction on v_mfma_f32_32x32x2_f32")
+        _ops.set_split_mode(shipped_mode)
 
     def leg(name, fn):
         """The legs run after the timed region; a failing leg is reported in the line (``leg_errors``), it does not lose the headline."""
@@ -495,6 +556,16 @@ def main():
     if not args.no_roofline and rank == 0:
         r = leg("roofline", lambda: roofline_leg(engine, pages, quads, masks, stages, args.prof_dump))
         roof, per_cfg = r if r is not None else (None, None)
+        if fp32 is not None:
+            def fp32_roof():
+                with _ops.gemm_mode(0):
+                    return roofline_leg(engine, pages, quads, masks, stages, args.prof_dump + ".fp32" if args.prof_dump else "")
+            r = leg("fp32_mfma.roofline", fp32_roof)
+            if r is not None:
+                fr, fcfg = r
+                for k in ("hbm_kernels", "hbm_peak_GBps", "pmc_source"):
+                    fr.pop(k, None)
+                fp32["roofline"], fp32["conv_gemm_by_tile"] = fr, fcfg
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         r = leg("cpu_baseline", lambda: cpu_baseline_leg(weights, host_inputs, stages, args.cpu_pages,
                                                          [int(t) for t in args.cpu_threads.split(",") if t]))
@@ -523,17 +594,22 @@ def main():
                        "streams": 2 if args.overlap else 1,
                        "parallelism": f"pages sharded one contiguous block per GPU x{world}; RCCL weight broadcast"
                                       + (f" + per-step gather of {gathered['bytes']} result bytes to rank 0" if world > 1 else "")},
-            "roofline": roof, "cpu_baseline": cpu, "parity_checked": parity, "dropin": dropin, "conv_gemm_by_tile": per_cfg,
+            "roofline": roof, "fp32_mfma": fp32, "cpu_baseline": cpu, "parity_checked": parity, "dropin": dropin, "conv_gemm_by_tile": per_cfg,
         }
-        from manga_image_translator_amd import ops as _ops
-        if _ops.split_mode():  # opt-in (MIT_GEMM_SPLIT): say so wherever the number travels
-            n = _ops.split_mode()
-            out["dtype"] = f"f32 (operands as three exact bf16 planes, {n} of 9 plane pairs on the bf16 MFMA, fp32 accumulation)"
-            out["gemm_mode"] = {"MIT_GEMM_SPLIT": n, "note": "large constant-weight contractions run on conv_gemm_split_kernel; roofline.peak / frac "
-                                "are still quoted against the fp32 MFMA peak (157.3 TFLOP/s), which this mode can exceed; the bf16 MFMA peak is "
-                                "2500 TFLOP/s for N x the algorithmic FLOPs"}
+        if shipped_mode:  # say so wherever the number travels
+            n = shipped_mode
+            dropped = ("no plane product dropped: only the fp32 accumulation order differs from the fp32 MFMA" if n == 9 else
+                       "the three products with p + q >= 3 dropped, each <= 2^-25 |a b|: below one fp32 multiply rounding")
+            out["dtype"] = "f32"
+            out["gemm_mode"] = {"mode": n, "arithmetic": f"fp32 operands as three exact bf16 planes (x = hi + mid + lo), {n} of the 9 plane products on "
+                                f"v_mfma_f32_32x32x16_bf16, every product exact in fp32, fp32 accumulation; {dropped}",
+                                "applies_to": "contractions with constant weights that fill the chip (conv_gemm_split_kernel); all other launches and "
+                                              "every non-GEMM kernel compute in fp32 as in mode 0",
+                                "headline_and_parity_checked_in_this_mode": True, "fp32_mfma_beside_it": "fp32_mfma",
+                                "roofline_priced_on": "the bf16 MFMA pipe (2500 TFLOP/s dense) for the split tiles: executed = pairs x algorithmic FLOPs",
+                                "switch": "MIT_GEMM_SPLIT=0|6|9 or mit_gemm_mode_set()"}
         else:
-            out["gemm_mode"] = {"MIT_GEMM_SPLIT": 0, "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"}
+            out["gemm_mode"] = {"mode": 0, "arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"}
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         if leg_errors:

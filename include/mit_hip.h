@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 3
+#define MIT_ABI_VERSION 4
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -128,7 +128,7 @@ const char *mit_conv_gemm_config_name(int cfg);
  * lets bench.py join its per-tile probe numbers with the profiler's kernel-trace / PMC rows; NULL past the table. */
 const char *mit_conv_gemm_config_kernel(int cfg);
 
-/* Split-bf16 form of the same contraction (opt-in: MIT_GEMM_SPLIT=6|9 in the environment, or an explicit "split*" tile through
+/* Split-bf16 form of the same contraction (the GEMM mode: mit_gemm_mode_set / MIT_GEMM_SPLIT, or an explicit "split*" tile through
  * mit_conv_gemm_cfg).  gfx950's bf16 MFMA runs at 16x the rate of the fp32 one; an fp32 number is EXACTLY the sum of three bf16
  * numbers (x = hi + mid + lo, each the round-to-nearest bf16 of what the previous ones left), so
  *     a * b = sum over plane pairs (p, q) of a_p * b_q        every such product is exact in fp32 (8 x 8 significant bits)
@@ -140,6 +140,20 @@ const char *mit_conv_gemm_config_kernel(int cfg);
  *                        nz * 3 * Kw * ldw uint16 elements; pass it as MitConvGemm.w_split with ws_zs0 = 3 * Kw * ldw.
  * Nothing in the reference corresponds to it (the reference computes these layers with fp32 torch kernels). */
 int mit_gemm_split_pack(const float *w_dev, int64_t w_zs, int nz, int Kw, int64_t ldw, uint16_t *out_dev, void *stream);
+/* The GEMM mode of mit_conv_gemm's automatic tile choice, process-wide, switchable at run time (launches already queued keep the tile
+ * they were given):
+ *   6 (default)  layers that carry w_split and fill the chip run on the split-bf16 tiles with 6 of the 9 plane products ("p6": the
+ *                dropped terms are <= 2^-25 |a b| each, below one fp32 multiply rounding);
+ *   9            the same with all 9 plane products (no term dropped: fp32 accumulation order is the only difference to the fp32 MFMA);
+ *   0            fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere, w_split ignored.
+ * The initial value is MIT_GEMM_SPLIT from the environment (0 | 6 | 9) when set, else 6.  mit_gemm_mode_set returns non-zero for any
+ * other value.  Nothing in the reference corresponds to it. */
+int mit_gemm_mode_set(int mode);
+int mit_gemm_mode_get(void);
+/* Smallest launch, counted in 128 x 64 output tiles (x Z), that the automatic choice hands to the split tiles (default 1280 = one full
+ * wave of workgroups, or MIT_GEMM_SPLIT_MIN_TILES); n >= 0 sets it, n < 0 only queries.  Returns the previous value.  Tests lower it to 1
+ * so that small problems exercise the split tiles too. */
+int64_t mit_gemm_split_min_tiles(int64_t n);
 
 /* k x k (3, 5, 7) stride-1 "same" convolution with 1..4 output channels on the fp32 VALU (an MFMA tile would idle 29 of
  * its 32 columns): out[b,y,x,n] = act(sum in[b,y+dy,x+dx,c] * w4[(ky*k+kx)*Cin + c][n] + bias[n]).  in: NHWC with pixel

@@ -105,8 +105,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                 sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *objs]
-    subprocess.run(cmd, check=True)
+    tmp = LIB_PATH.with_name(f"{LIB_PATH.name}.tmp{os.getpid()}")  # a concurrent dlopen never sees a half-written library
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *objs]
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if tmp.exists():
+            tmp.unlink()
     _STAMP.write_text(digest)
     return LIB_PATH
 

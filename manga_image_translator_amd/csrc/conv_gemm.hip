@@ -2,6 +2,7 @@
 // The kernels are in conv_gemm_kernels.h; their instantiations are compiled in conv_gemm_inst<group>.hip.
 #include "conv_gemm_kernels.h"
 #include <string.h>
+#include <atomic>
 
 using namespace mitcg;
 
@@ -63,6 +64,33 @@ bool gemv_eligible(const MitConvGemm &p, int lpr) {
     return true;
 }
 
+// GEMM mode (include/mit_hip.h, mit_gemm_mode_set): -1 = not read yet
+std::atomic<int> g_gemm_mode{-1};
+int gemm_mode_now() {
+    int m = g_gemm_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char *v = getenv("MIT_GEMM_SPLIT");
+        m = (v && *v) ? atoi(v) : 6;
+        if (m != 6 && m != 9) m = 0;
+        g_gemm_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+// smallest launch (in 128 x 64 tiles) the automatic choice gives to the split tiles: below one full wave of workgroups their longer
+// prologue does not pay.  -1 = not read yet (MIT_GEMM_SPLIT_MIN_TILES, default 1280)
+std::atomic<long long> g_split_min{-1};
+int64_t split_min_now() {
+    long long m = g_split_min.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char *v = getenv("MIT_GEMM_SPLIT_MIN_TILES");
+        m = (v && *v) ? atoll(v) : 1280;
+        if (m < 0) m = 0;
+        g_split_min.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
 int env_cfg(const char *name, int dflt) {  // tuning knob for scripts/: replaces a default fast tile by another fast tile
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
@@ -81,9 +109,9 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     if (!gemv_off && gemv_eligible(p, 16)) return p.N == 1 ? kCfgGemv16N1 : kCfgGemv16;
     if (!gemv_off && gemv_eligible(p, 4)) return p.N == 1 ? kCfgGemv4N1 : kCfgGemv4;
     if (p.N <= 32) return 2;
-    // opt-in split-bf16 tiles (MIT_GEMM_SPLIT=6|9): layers whose packer attached split planes of W, large enough to fill the chip
-    static const int split = getenv("MIT_GEMM_SPLIT") ? atoi(getenv("MIT_GEMM_SPLIT")) : 0;
-    static const int64_t split_min = getenv("MIT_GEMM_SPLIT_MIN_TILES") ? atoll(getenv("MIT_GEMM_SPLIT_MIN_TILES")) : 1280;
+    // split-bf16 tiles (GEMM mode 6 | 9, mit_gemm_mode_set): layers whose packer attached split planes of W, large enough to fill the chip
+    const int split = gemm_mode_now();
+    const int64_t split_min = split_min_now();
     if ((split == 6 || split == 9) && p.w_split && split_eligible(p, 16) && ((M + 127) / 128) * ((p.N + 63) / 64) * p.Z >= split_min) {
         static const int wide6 = cfg_by_name("split128x128x16p6o"), wide9 = cfg_by_name("split128x128x16p9m");
         static const int narrow6 = cfg_by_name("split128x64x16p6o"), narrow9 = cfg_by_name("split128x64x16p9");
@@ -299,6 +327,20 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
 }
 
 extern "C" int mit_conv_gemm(const MitConvGemm *d, void *stream) { return mit_conv_gemm_cfg(d, -1, stream); }
+
+extern "C" int mit_gemm_mode_set(int mode) {
+    if (mode != 0 && mode != 6 && mode != 9) return mit_set_error("mit_gemm_mode_set: mode must be 0, 6 or 9 (got %d)", mode);
+    g_gemm_mode.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int mit_gemm_mode_get(void) { return gemm_mode_now(); }
+
+extern "C" int64_t mit_gemm_split_min_tiles(int64_t n) {
+    const int64_t prev = split_min_now();
+    if (n >= 0) g_split_min.store(n, std::memory_order_relaxed);
+    return prev;
+}
 
 extern "C" int mit_gemm_split_pack(const float *w_dev, int64_t w_zs, int nz, int Kw, int64_t ldw, uint16_t *out_dev, void *stream) {
     if (!w_dev || !out_dev) return mit_set_error("mit_gemm_split_pack: null pointer");

@@ -797,16 +797,28 @@ size_t smem_bytes() {
     return staging > rows ? staging : rows;
 }
 
+// Dynamic LDS beyond 64 KB needs an opt-in per kernel (and per device).  The opt-in is raised whenever a launch needs more than what
+// was granted before — a layer with more taps needs a larger gather table than the first launch of that kernel did.
+struct DynSmemOptIn {
+    size_t granted[16] = {0};
+    void ensure(const void *kern, size_t smem) {
+        if (smem <= 64 * 1024) return;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        size_t &g = granted[dev & 15];
+        if (g >= smem) return;
+        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        g = smem;
+    }
+};
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 void launch_cfg(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
     dim3 grid(MT * NT, p.Z, 1);
     size_t smem = smem_bytes<BM, BN, BK, WAVES_M, WAVES_N>();
     auto kern = conv_gemm_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
-    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set && smem > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynSmemOptIn optin;
+    optin.ensure(reinterpret_cast<const void *>(kern), smem);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 
@@ -818,11 +830,8 @@ void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
     size_t rows = ((size_t)BM * sizeof(RowOff) + 15) / 16 * 16 + (size_t)4 * 32 * EPI_PITCH * sizeof(float);  // row table + transpose buffers
     size_t smem = staging > rows ? staging : rows;
     auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, VAR>;
-    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set && smem > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynSmemOptIn optin;
+    optin.ensure(reinterpret_cast<const void *>(kern), smem);
     dim3 grid(MT * NT, p.Z, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }

@@ -16,6 +16,9 @@ namespace mitcg {
 //     bytes per lane, global -> VGPR -> LDS.
 // The MFMA pairs A element j of k-group g with B element j of k-group g, so only the (row | column, k-group) placement matters and
 // both operands use the same one.  Accumulators have the 32x32 C layout of the fp32 tiles: the epilogue is shared.
+// Range precondition: finite operands with |x| <= the largest bf16 (3.39e38).  hi = bf16(x) of a larger (or infinite) x is Inf and
+// the residual x - Inf is -Inf / NaN, so such an operand yields NaN here where the fp32 MFMA yields Inf or a finite value.  Activations
+// and weights of the networks on this path are many orders of magnitude inside the range.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -434,11 +437,8 @@ void launch_split(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream
     size_t rows = ((size_t)BM * sizeof(RowOff) + 15) / 16 * 16 + (size_t)4 * 32 * EPI_PITCH * sizeof(float);
     size_t smem = staging > rows ? staging : rows;
     auto kern = conv_gemm_split_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, NPROD, VAR>;
-    static bool attr_set = false;
-    if (!attr_set && smem > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static DynSmemOptIn optin;
+    optin.ensure(reinterpret_cast<const void *>(kern), smem);
     const int tpb = split_tpb(VAR);
     int gx = (MT * NT + tpb - 1) / tpb;
     if (VAR & 2048) {  // one workgroup per residency slot (multiple of 8 so that a workgroup's tiles stay on its XCD)

@@ -47,6 +47,64 @@ YOLO_LAYERS = [
 ]
 
 
+def layers_from_cfg(cfg: dict):
+    """The (index, kind, c1, c2, k | n, stride) table of a yolov5 model cfg as the reference builds it from the checkpoint
+    (``Model(ckpt['cfg'])``, ctd_utils/yolov5/yolo.py:286-292 -> ``parse_model`` :208-259): output channels are
+    ``ceil(c2 * width_multiple / 8) * 8``, repeat counts above 1 become ``max(round(n * depth_multiple), 1)``, Concat sums its
+    sources, Upsample / anything else keeps the channel count.  Only Conv / C3 / SPPF rows are returned (they own the weights)."""
+    import math
+
+    gd, gw = float(cfg["depth_multiple"]), float(cfg["width_multiple"])
+    anchors = cfg["anchors"]
+    na = len(anchors[0]) // 2 if isinstance(anchors, (list, tuple)) else int(anchors)
+    no = na * (int(cfg["nc"]) + 5)
+    ch = [int(cfg.get("ch", 3))]
+    rows = []
+    for i, (f, n, m, args) in enumerate(list(cfg["backbone"]) + list(cfg["head"])):
+        name = m if isinstance(m, str) else getattr(m, "__name__", str(m))
+        args = [no if a == "no" else a for a in args]
+        n = max(round(n * gd), 1) if n > 1 else n
+        if name in ("Conv", "C3", "SPPF"):
+            c1, c2 = ch[f], args[0]
+            if c2 != no:
+                c2 = int(math.ceil(c2 * gw / 8) * 8)
+            if name == "Conv":
+                rows.append((i, "conv", c1, c2, args[1] if len(args) > 1 else 1, args[2] if len(args) > 2 else 1))
+            elif name == "C3":
+                rows.append((i, "c3", c1, c2, n, 1))
+            else:
+                rows.append((i, "sppf", c1, c2, args[1] if len(args) > 1 else 5, 1))
+        elif name == "Concat":
+            c2 = sum(ch[x] for x in f)
+        elif name == "Detect":
+            c2 = ch[f[0]] if isinstance(f, (list, tuple)) else ch[f]
+        else:
+            c2 = ch[f]
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return rows
+
+
+# stride of the Conv rows of YOLO_LAYERS (the yolov5s-v6 graph): every 3x3 / 6x6 Conv of the backbone and the two PAN down-convolutions
+_YOLO_STRIDES = {0: 2, 1: 2, 3: 2, 5: 2, 7: 2, 10: 1, 14: 1, 18: 2, 21: 2}
+
+
+def check_yolo_cfg(cfg) -> None:
+    """Raise unless the checkpoint's own model cfg (``ckpt['blk_det']['cfg']``) describes the graph ``CtdEngine`` executes: the engine —
+    like the reference's ``UnetHead`` / ``DBHead``, which hard-code the channel counts of the five tapped features (basemodel.py:41-72) —
+    is built for the yolov5s-v6 layout; a checkpoint with another layout must fail here, loudly, not late or silently."""
+    if not isinstance(cfg, dict):
+        raise ValueError(f"comictextdetector.pt: blk_det.cfg is {type(cfg).__name__}, expected the yolov5 model dict")
+    want = [(i, k, c1, c2, kn, _YOLO_STRIDES.get(i, 1)) for i, k, c1, c2, kn in YOLO_LAYERS]
+    got = layers_from_cfg(cfg)
+    if got != want:
+        diff = [f"layer {g[0]}: checkpoint {g[1:]} != engine {w[1:]}" for g, w in zip(got, want) if g != w]
+        if len(got) != len(want):
+            diff.append(f"{len(got)} weighted layers in the checkpoint, {len(want)} in the engine")
+        raise ValueError("comictextdetector.pt: the checkpoint's yolov5 cfg is not the yolov5s-v6 graph this engine implements: " + "; ".join(diff[:6]))
+
+
 def yolo_schema() -> Schema:
     s: Schema = []
     for i, kind, c1, c2, kn in YOLO_LAYERS:

@@ -114,6 +114,50 @@ def gather_pages(packed: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
     return None
 
 
+class PageGather:
+    """The per-step result gather with one step of slack: ``submit(packed)`` issues the gather asynchronously (RCCL runs it on its own
+    stream, ordered after the work that produced ``packed``) and returns the PREVIOUS step's gathered tensor; the caller's stream never
+    waits for peer traffic before launching the next step's kernels — rank 0 receives ``world - 1`` result blocks (0.8 GB each at 64
+    pages) over its xGMI links while its next batch is already computing.  ``wait()`` drains the last one (call it before the end of a
+    timed region).  At most one gather is in flight, so at most two result blocks per rank are alive.  Same semantics on gloo."""
+
+    def __init__(self, dst: int = 0):
+        self.dst = dst
+        self._work = None
+        self._out: Optional[torch.Tensor] = None
+        self._keep = None
+        self.last_bytes = 0
+
+    def submit(self, packed: torch.Tensor) -> Optional[torch.Tensor]:
+        prev = self.wait()
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            self._out = packed.unsqueeze(0)
+            self.last_bytes = self._out.numel() * self._out.element_size()
+            return prev
+        world, rank = dist.get_world_size(), dist.get_rank()
+        packed = packed.contiguous()
+        if dist.get_backend() != "nccl" and packed.is_cuda:  # gloo rehearsal: stage through host memory
+            packed = packed.cpu()
+        if rank == self.dst:
+            out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+            self._work = dist.gather(packed, list(out.unbind(0)), dst=self.dst, async_op=True)
+            self._out = out
+            self.last_bytes = out.numel() * out.element_size()
+        else:
+            self._work = dist.gather(packed, None, dst=self.dst, async_op=True)
+            self._out = None
+        self._keep = packed  # alive until the gather has been waited for
+        return prev
+
+    def wait(self) -> Optional[torch.Tensor]:
+        """Result of the gather in flight ([world, *shape] on ``dst``, None elsewhere or when nothing was submitted); a failure raises."""
+        if self._work is not None:
+            self._work.wait()  # nccl: the current stream waits for the collective (no host block); gloo: blocks
+            self._work = None
+        out, self._out, self._keep = self._out, None, None
+        return out
+
+
 def max_over_ranks(value: float) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value

@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 3
+MIT_ABI_VERSION = 4
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -147,6 +147,9 @@ SYMBOLS = {
     "mit_conv_gemm_config_name": (C.c_char_p, [C.c_int]),
     "mit_conv_gemm_config_kernel": (C.c_char_p, [C.c_int]),
     "mit_gemm_split_pack": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mit_gemm_mode_set": (C.c_int, [C.c_int]),
+    "mit_gemm_mode_get": (C.c_int, []),
+    "mit_gemm_split_min_tiles": (C.c_int64, [C.c_int64]),
     "mit_conv_small_cout": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "mit_prof_enable": (C.c_int, [C.c_int]),
@@ -248,8 +251,17 @@ def lib_path() -> Path:
 def _stale(path: Path, want: str) -> bool:
     """True when the binary at ``path`` was built from other sources than the tree's.  The digest is read from the marker
     string in the file, not through dlopen: a stale library must not stay mapped when its replacement is loaded."""
+    needle = b"MIT_SOURCE_DIGEST=" + want.encode()
     try:
-        return (b"MIT_SOURCE_DIGEST=" + want.encode()) not in path.read_bytes()
+        with open(path, "rb") as f:  # chunked scan: the library is ~10 MB and every process start checks it
+            tail = b""
+            while True:
+                chunk = f.read(1 << 20)
+                if not chunk:
+                    return True
+                if needle in tail + chunk:
+                    return False
+                tail = chunk[-len(needle):]
     except OSError:
         return True
 
@@ -269,7 +281,17 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         if not build_if_missing:
             what = "is missing" if not path.exists() else "was built from different sources than this tree"
             raise RuntimeError(f"{path} {what}: run `python -m manga_image_translator_amd.build`")
-        _build.build(force=True)
+        # several processes (the ranks of a multi-GPU launch, pytest workers) may find the library stale at the same moment: one of
+        # them builds under an exclusive file lock, the others wait and re-check; the build links to a temporary name and renames
+        import fcntl
+
+        with open(str(path) + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not path.exists() or _stale(path, want):
+                    _build.build(force=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(str(path))
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

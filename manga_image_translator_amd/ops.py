@@ -24,7 +24,7 @@ from .lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_POST_FIRST, ACT_RELU, ACT_S
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "ACT_LEAKY", "ACT_SILU", "ACT_SIGMOID", "ACT_GELU", "ACT_POST_FIRST", "PAD_ZERO", "PAD_REFLECT",
-    "Conv2d", "ConvSmallCout", "ConvTranspose2d", "UpsampleConv2d", "fold_bn", "conv_gemm_desc", "launch_conv_gemm", "current_stream",
+    "Conv2d", "ConvSmallCout", "split_mode", "set_split_mode", "gemm_mode", "ConvTranspose2d", "UpsampleConv2d", "fold_bn", "conv_gemm_desc", "launch_conv_gemm", "current_stream",
 ]
 
 
@@ -172,10 +172,39 @@ def fold_bn(gamma: torch.Tensor, beta: torch.Tensor, mean: torch.Tensor, var: to
 
 
 def split_mode() -> int:
-    """``MIT_GEMM_SPLIT`` = 6 | 9: packers also build the three-bf16-plane form of their weights and ``mit_conv_gemm`` picks the
-    split-bf16 tiles for them (include/mit_hip.h, mit_gemm_split_pack).  0 / unset (default): fp32 MFMA tiles only."""
-    v = os.environ.get("MIT_GEMM_SPLIT", "0").strip() or "0"
-    return int(v) if v in ("6", "9") else 0  # the 3-pair tiles are a test ladder (explicit tile index only), never a mode
+    """The GEMM mode of ``mit_conv_gemm`` (include/mit_hip.h, ``mit_gemm_mode_get``): 6 (default) | 9 = packers also build the
+    three-bf16-plane form of their weights and the automatic tile choice takes the split-bf16 tiles for them; 0 = fp32 MFMA tiles
+    only.  The initial value comes from ``MIT_GEMM_SPLIT`` in the environment when set."""
+    return int(_lib.load().mit_gemm_mode_get())  # the 3-pair tiles are a test ladder (explicit tile index only), never a mode
+
+
+def set_split_mode(mode: int) -> int:
+    """Switch the GEMM mode at run time; returns the previous one.  Weights packed while the mode was 0 carry no planes and stay on the
+    fp32 tiles; weights packed in mode 6 | 9 carry them and follow the mode of the moment (so one engine can be timed in both)."""
+    lib = _lib.load()
+    prev = int(lib.mit_gemm_mode_get())
+    _lib.check(lib.mit_gemm_mode_set(int(mode)), "mit_gemm_mode_set")
+    return prev
+
+
+class gemm_mode:
+    """``with ops.gemm_mode(0): ...`` — the GEMM mode (and, optionally, the smallest launch the split tiles take, in 128 x 64 tiles)
+    inside the block, the previous values restored after it."""
+
+    def __init__(self, mode: int, min_tiles: Optional[int] = None):
+        self.mode, self.min_tiles, self.prev, self.prev_min = int(mode), min_tiles, None, None
+
+    def __enter__(self):
+        self.prev = set_split_mode(self.mode)
+        if self.min_tiles is not None:
+            self.prev_min = int(_lib.load().mit_gemm_split_min_tiles(int(self.min_tiles)))
+        return self
+
+    def __exit__(self, *exc):
+        set_split_mode(self.prev)
+        if self.prev_min is not None:
+            _lib.load().mit_gemm_split_min_tiles(self.prev_min)
+        return False
 
 
 _SPLITS: Dict[int, Tuple["weakref.ref", torch.Tensor, int, int, int]] = {}   # data_ptr -> (weight, planes, nz, Kp, Np)
@@ -199,7 +228,7 @@ def split_weight(w: torch.Tensor) -> torch.Tensor:
 def register_split(w: torch.Tensor, force: bool = False) -> Optional[torch.Tensor]:
     """Attach split planes to a packed weight (no-op unless ``split_mode()`` or ``force``): ``conv_gemm_desc`` finds them by the
     tensor's identity, so every layer built on ``pack_weight_kn`` / ``WinogradConv3x3`` gets the split tiles without further plumbing."""
-    if not (force or split_mode()) or w.device.type != "cuda":
+    if w.device.type != "cuda" or not (force or split_mode()):
         return None
     planes = split_weight(w)
     nz = 1 if w.dim() == 2 else w.shape[0]

@@ -604,7 +604,7 @@ class HipESRGANUpscaler(_UpBase):
         from . import esrgan
 
         dev = _gpu_device(device)
-        sd = self._weights or torch.load(_ckpt_path(self, "4xESRGAN.pth"), map_location="cpu")
+        sd = self._weights or _load_esrgan_checkpoint(self)
         nb = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("model.1.sub.") and ".RDB" in k)  # infer_params (:470-509)
         self.engine = esrgan.EsrganEngine(sd, nb=nb, device=dev)
         self.device = device
@@ -777,31 +777,62 @@ def _ckpt_path(plugin, name: str) -> str:
 
 def _load_ctd_checkpoint(plugin):
     """comictextdetector.pt = {'blk_det': {'cfg','weights'}, 'text_seg', 'text_det'} (ctd_utils/basemodel.py:205-214)."""
+    from . import ctd_schema as S, synth
+
     ck = torch.load(_ckpt_path(plugin, "comictextdetector.pt"), map_location="cpu")
-    return {"ctd.yolo": ck["blk_det"]["weights"], "ctd.seg": ck["text_seg"], "ctd.det": ck["text_det"]}
+    S.check_yolo_cfg(ck["blk_det"]["cfg"])  # the reference builds the backbone from it (yolov5/yolo.py:286-292)
+    return {"ctd.yolo": synth.check_state_dict(ck["blk_det"]["weights"], S.yolo_schema(), "comictextdetector.pt blk_det.weights"),
+            "ctd.seg": synth.check_state_dict(ck["text_seg"], S.unet_head_schema(), "comictextdetector.pt text_seg"),
+            "ctd.det": synth.check_state_dict(ck["text_det"], S.db_head_schema(), "comictextdetector.pt text_det")}
+
+
+def _read_dictionary(path: str):
+    with open(path, "r", encoding="utf-8") as fp:
+        return [s[:-1] for s in fp.readlines()]  # model_48px.py:47-48: every line loses its last character (the newline)
 
 
 def _load_ocr_checkpoint(plugin):
-    with open(_ckpt_path(plugin, "alphabet-all-v7.txt"), "r", encoding="utf-8") as fp:
-        dictionary = [s[:-1] for s in fp.readlines()]
-    return torch.load(_ckpt_path(plugin, "ocr_ar_48px.ckpt"), map_location="cpu"), dictionary
+    """ocr_ar_48px.ckpt (a bare state_dict) + alphabet-all-v7.txt (model_48px.py:46-52)."""
+    from . import ocr_schema, synth
+
+    dictionary = _read_dictionary(_ckpt_path(plugin, "alphabet-all-v7.txt"))
+    sd = torch.load(_ckpt_path(plugin, "ocr_ar_48px.ckpt"), map_location="cpu")
+    return synth.check_state_dict(sd, ocr_schema.ocr48_schema(len(dictionary)), "ocr_ar_48px.ckpt"), dictionary
 
 
 def _load_ocr_ctc_checkpoint(plugin):
-    """ocr-ctc.ckpt + alphabet-all-v5.txt (model_48px_ctc.py:19-28,40-52)."""
-    with open(_ckpt_path(plugin, "alphabet-all-v5.txt"), "r", encoding="utf-8") as fp:
-        dictionary = [s[:-1] for s in fp.readlines()]
+    """ocr-ctc.ckpt ({'model': state_dict} or bare; its three ``encoders.layers.N.pe.pe`` tables are dropped by the reference and
+    unused here) + alphabet-all-v5.txt (model_48px_ctc.py:19-28,38-48)."""
+    from . import ocr_ctc_schema, synth
+
+    dictionary = _read_dictionary(_ckpt_path(plugin, "alphabet-all-v5.txt"))
     sd = torch.load(_ckpt_path(plugin, "ocr-ctc.ckpt"), map_location="cpu")
-    return sd.get("model", sd), dictionary
+    sd = sd["model"] if "model" in sd else sd
+    return synth.check_state_dict(sd, ocr_ctc_schema.ocr_ctc_schema(len(dictionary)), "ocr-ctc.ckpt"), dictionary
 
 
 def _load_lama_checkpoint(plugin):
     """{'gen_state_dict', 'str_state_dict'?} (inpainting_lama_mpe.py:818-825)."""
+    from . import lama_schema, synth
+
     ck = torch.load(_ckpt_path(plugin, plugin.CKPT), map_location="cpu")
-    out = {"lama.gen": ck["gen_state_dict"]}
+    out = {"lama.gen": synth.check_state_dict(ck["gen_state_dict"], lama_schema.lama_generator_schema(plugin.N_BLOCKS), plugin.CKPT)}
     if "str_state_dict" in ck:
         out["lama.mpe"] = ck["str_state_dict"]
+        if plugin.USE_MPE:
+            synth.check_state_dict(out["lama.mpe"], lama_schema.lama_mpe_schema(), plugin.CKPT + " str_state_dict")
     return out
+
+
+def _load_esrgan_checkpoint(plugin):
+    """4xESRGAN.pth: a bare RRDBNet state_dict; the block count comes from its keys (esrgan_pytorch.py:526-528, infer_params :476-510)."""
+    from . import esrgan_schema, synth
+
+    sd = torch.load(_ckpt_path(plugin, "4xESRGAN.pth"), map_location="cpu")
+    nb = 1 + max((int(k.split(".")[3]) for k in sd if k.startswith("model.1.sub.") and ".RDB" in k), default=-1)
+    if nb <= 0:
+        raise ValueError("4xESRGAN.pth: no RRDB trunk (model.1.sub.<n>.…) in the state_dict")
+    return synth.check_state_dict(sd, esrgan_schema.rrdbnet_schema(nb), "4xESRGAN.pth")
 
 
 def register() -> None:

@@ -27,6 +27,18 @@ def _gen(seed: int, name: str) -> torch.Generator:
     return g
 
 
+def check_state_dict(sd: Dict[str, torch.Tensor], schema: Schema, what: str) -> Dict[str, torch.Tensor]:
+    """Raise ValueError unless ``sd`` holds every tensor of ``schema`` at its shape (extra keys — ``num_batches_tracked``, positional
+    tables a reference loader deletes — are ignored).  Run on every checkpoint before an engine is built from it, so a file with another
+    layout fails at load time with the list of differences instead of a KeyError or a silent mis-shape deep inside the packers."""
+    missing = [n for n, _, k in schema if n not in sd and not k.startswith("nbt")]
+    wrong = [f"{n}: {tuple(sd[n].shape)} != {tuple(shape)}" for n, shape, _ in schema if n in sd and tuple(sd[n].shape) != tuple(shape)]
+    if missing or wrong:
+        raise ValueError(f"{what}: not the expected state_dict layout — {len(missing)} missing tensors (e.g. {missing[:4]}), "
+                         f"{len(wrong)} with another shape (e.g. {wrong[:4]})")
+    return sd
+
+
 def synth_state_dict(schema: Schema, seed: int = 0, gain: float = 1.0) -> Dict[str, torch.Tensor]:
     sd: Dict[str, torch.Tensor] = {}
     for name, shape, kind in schema:

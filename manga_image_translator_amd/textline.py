@@ -213,8 +213,11 @@ def quadrilateral_can_merge_region(a: Quadrilateral, b: Quadrilateral, ratio=1.9
     x2, y2, w2, h2 = b2.x, b2.y, b2.w, b2.h
     # the gap between the axis-aligned boxes is a lower bound of the polygon distance: far-apart pairs (most of the O(K^2)
     # pairs of a page) fail the first test of the reference without the exact distance being needed — same decisions, always
-    gx = max(0, max(x1, x2) - min(x1 + w1, x2 + w2))
-    gy = max(0, max(y1, y2) - min(y1 + h1, y2 + h2))
+    # (the gap is taken from the float extents of the points, not from ``aabb``: its int() truncation can fall short of the true
+    # extent for non-integer points, and the bound must never exceed the real distance)
+    pa, pb = np.asarray(a.pts, dtype=np.float64), np.asarray(b.pts, dtype=np.float64)
+    gx = max(0.0, max(pa[:, 0].min(), pb[:, 0].min()) - min(pa[:, 0].max(), pb[:, 0].max()))
+    gy = max(0.0, max(pa[:, 1].min(), pb[:, 1].min()) - min(pa[:, 1].max(), pb[:, 1].max()))
     if gx * gx + gy * gy > (discard_connection_gap * char_size) ** 2:
         return False
     dist = polygon_distance(a.pts, b.pts)  # Polygon(a.pts).distance(Polygon(b.pts))

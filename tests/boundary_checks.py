@@ -155,6 +155,74 @@ def _():
     assert set(w) == {"lama.gen", "lama.mpe"} and torch.equal(w["lama.gen"]["model.1.ffc.convl2l.weight"], sd["model.1.ffc.convl2l.weight"])
 
 
+@check("checkpoint files in the reference's own layouts load through every plugin's loader; other layouts fail at load time")
+def _():
+    import copy
+
+    from manga_image_translator_amd import ctd_schema as CS, esrgan_schema, ocr_ctc_schema, ocr_schema, synth
+
+    # comictextdetector.pt: {'blk_det': {'cfg', 'weights'}, 'text_seg', 'text_det'} (ctd_utils/basemodel.py:205-214, yolov5/yolo.py:286-292)
+    det = P.HipComicTextDetector()
+    ck = {"blk_det": {"cfg": copy.deepcopy(CS.YOLOV5S_CFG), "weights": synth.synth_state_dict(CS.yolo_schema())},
+          "text_seg": synth.synth_state_dict(CS.unet_head_schema()), "text_det": synth.synth_state_dict(CS.db_head_schema())}
+    torch.save(ck, det._get_file_path("comictextdetector.pt"))
+    w = P._load_ctd_checkpoint(det)
+    assert set(w) == {"ctd.yolo", "ctd.seg", "ctd.det"} and torch.equal(w["ctd.yolo"]["model.0.conv.weight"], ck["blk_det"]["weights"]["model.0.conv.weight"])
+    # the reference's own parse_model accepts the cfg and yields the channel table the engine was built for
+    ref_rows = CS.layers_from_cfg(ck["blk_det"]["cfg"])
+    assert [r[:5] for r in ref_rows] == CS.YOLO_LAYERS
+    bad = copy.deepcopy(ck)
+    bad["blk_det"]["cfg"]["width_multiple"] = 0.75            # yolov5m-like widths: the heads' hard-coded channels no longer match
+    torch.save(bad, det._get_file_path("comictextdetector.pt"))
+    try:
+        P._load_ctd_checkpoint(det)
+        raise SystemExit("a checkpoint with another yolov5 cfg must be refused")
+    except ValueError as e:
+        assert "yolov5s-v6" in str(e)
+    bad = copy.deepcopy(ck)
+    del bad["text_seg"]["down_conv1.conv.cv1.conv.weight"]
+    torch.save(bad, det._get_file_path("comictextdetector.pt"))
+    try:
+        P._load_ctd_checkpoint(det)
+        raise SystemExit("a checkpoint with a missing tensor must be refused")
+    except ValueError as e:
+        assert "text_seg" in str(e) and "missing" in str(e)
+
+    # ocr_ar_48px.ckpt (bare state_dict) + alphabet-all-v7.txt, one entry per line (model_48px.py:46-52)
+    ocr = P.HipModel48pxOCR()
+    dictionary = ocr_schema.synth_dictionary(97)
+    with open(ocr._get_file_path("alphabet-all-v7.txt"), "w", encoding="utf-8") as fp:
+        fp.write("".join(c + "\n" for c in dictionary))
+    sd = synth.synth_state_dict(ocr_schema.ocr48_schema(len(dictionary)))
+    torch.save(sd, ocr._get_file_path("ocr_ar_48px.ckpt"))
+    got_sd, got_dict = P._load_ocr_checkpoint(ocr)
+    assert got_dict == dictionary and torch.equal(got_sd["embd.weight"], sd["embd.weight"])
+    with open(ocr._get_file_path("alphabet-all-v7.txt"), "a", encoding="utf-8") as fp:
+        fp.write("extra\n")                                    # dictionary and embedding rows out of step
+    try:
+        P._load_ocr_checkpoint(ocr)
+        raise SystemExit("dictionary / checkpoint size mismatch must be refused")
+    except ValueError as e:
+        assert "another shape" in str(e)
+
+    # ocr-ctc.ckpt = {'model': state_dict incl. the pe.pe tables the reference deletes} + alphabet-all-v5.txt (model_48px_ctc.py:38-48)
+    ctc = P.HipModel48pxCTCOCR()
+    with open(ctc._get_file_path("alphabet-all-v5.txt"), "w", encoding="utf-8") as fp:
+        fp.write("".join(c + "\n" for c in dictionary))
+    sd = synth.synth_state_dict(ocr_ctc_schema.ocr_ctc_schema(len(dictionary)))
+    assert all(f"encoders.layers.{i}.pe.pe" in sd for i in range(3))   # the tables the reference's loader deletes are part of the file
+    torch.save({"model": sd}, ctc._get_file_path("ocr-ctc.ckpt"))
+    got_sd, got_dict = P._load_ocr_ctc_checkpoint(ctc)
+    assert got_dict == dictionary and all(torch.equal(got_sd[k], v) for k, v in list(sd.items())[:8])
+
+    # 4xESRGAN.pth: bare old-arch RRDBNet state_dict, block count inferred from the keys (esrgan_pytorch.py:476-528)
+    up = P.HipESRGANUpscaler()
+    sd = synth.synth_state_dict(esrgan_schema.rrdbnet_schema(3))
+    torch.save(sd, up._get_file_path("4xESRGAN.pth"))
+    got = P._load_esrgan_checkpoint(up)
+    assert set(got) == set(sd) and 1 + max(int(k.split(".")[3]) for k in got if ".RDB" in k) == 3
+
+
 @check("register() writes into the reference's registries; get_* constructs and caches our classes")
 def _():
     P.register()

@@ -55,6 +55,20 @@ def _worker(rank, world, port, q):
             assert out.reshape(-1).tolist() == [p for p in range(n_pages) for _ in range(4)]
         else:
             assert out is None
+        # the asynchronous form bench.py uses: submit() returns the previous step's block, wait() drains the last one
+        pg = D.PageGather()
+        seen = []
+        for stepno in range(3):
+            prev = pg.submit(packed + stepno)
+            seen.append(prev)
+        seen.append(pg.wait())
+        assert pg.wait() is None                                    # nothing left in flight
+        if rank == 0:
+            assert seen[0] is None and pg.last_bytes == world * packed.numel()
+            for stepno, blk in enumerate(seen[1:]):
+                assert blk.reshape(-1).tolist() == [p + stepno for p in range(n_pages) for _ in range(4)]
+        else:
+            assert all(x is None for x in seen)
         assert D.max_over_ranks(float(rank + 1)) == float(world)
         D.barrier()
         torch.distributed.destroy_process_group()
@@ -85,4 +99,6 @@ def test_single_process_paths():
         D.broadcast_weights(None)
     t = torch.arange(4)
     assert torch.equal(D.gather_pages(t), t[None])
+    pg = D.PageGather()
+    assert pg.submit(t) is None and torch.equal(pg.submit(t + 1), t[None]) and torch.equal(pg.wait(), (t + 1)[None]) and pg.wait() is None
     assert D.max_over_ranks(2.5) == 2.5

@@ -9,12 +9,15 @@
 * the host plumbing that attaches split planes to a descriptor (identity-checked registry).
 The kernel itself is compared with the fp32 tiles in tests/test_gemm_split_gpu.py."""
 import gc
+import os
 
 import numpy as np
 import pytest
 import torch
 
 from manga_image_translator_amd import ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def bf16_rne(x):
@@ -214,11 +217,31 @@ def test_descriptor_strides_for_batched_weights():
         ops._SPLITS.pop(key, None)
 
 
-def test_split_mode_env(monkeypatch):
-    monkeypatch.delenv("MIT_GEMM_SPLIT", raising=False)
-    assert ops.split_mode() == 0
-    for v, want in (("6", 6), ("9", 9), ("3", 0), ("1", 0), ("", 0), ("x", 0)):
-        monkeypatch.setenv("MIT_GEMM_SPLIT", v)
-        assert ops.split_mode() == want
-    monkeypatch.setenv("MIT_GEMM_SPLIT", "6")
+def test_gemm_mode_switch_and_initial_value():
+    """mit_gemm_mode_set / _get (include/mit_hip.h): 6 unless MIT_GEMM_SPLIT says otherwise, switchable at run time, anything but
+    0 | 6 | 9 refused (the 3-pair tiles are a test ladder reachable by explicit tile index only)."""
+    import subprocess
+    import sys
+
+    prev = ops.split_mode()
+    try:
+        for m in (0, 9, 6):
+            ops.set_split_mode(m)
+            assert ops.split_mode() == m
+        for bad in (3, 1, -1, 12):
+            with pytest.raises(RuntimeError, match="mode must be"):
+                ops.set_split_mode(bad)
+        assert ops.split_mode() == 6
+        with ops.gemm_mode(0):
+            assert ops.split_mode() == 0
+        assert ops.split_mode() == 6
+    finally:
+        ops.set_split_mode(prev)
     assert ops.register_split(torch.zeros(16, 4)) is None                   # CPU tensors are never split (no GPU, no planes)
+    code = "from manga_image_translator_amd import lib; print(lib.load(build_if_missing=False).mit_gemm_mode_get())"
+    for env, want in ((None, 6), ("0", 0), ("9", 9), ("6", 6), ("3", 0), ("x", 0), ("", 6)):
+        e = {k: v for k, v in os.environ.items() if k != "MIT_GEMM_SPLIT"}
+        if env is not None:
+            e["MIT_GEMM_SPLIT"] = env
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, cwd=ROOT, check=True).stdout
+        assert int(out.strip().splitlines()[-1]) == want, (env, out)

@@ -45,7 +45,7 @@ def test_fourier_unit_parity(cuda):
                                                  (9, True, 1, 2048, 1456),    # the BASELINE page, shipped path (Winograd FFC blocks, LDS FFT)
                                                  (18, False, 1, 512, 512)],   # lama_large at its nominal 512 px
                          ids=["large-64x88", "mpe-264x272", "mpe-256x320x2", "mpe-BASELINE-2048x1456", "large-512x512"])
-def test_lama_page_parity(cuda, n_blocks, mpe, B, H, W):
+def test_lama_page_parity(cuda, gemm_mode, oracle_memo, n_blocks, mpe, B, H, W):
     from manga_image_translator_amd import synth
     from oracle import lama as OL
 
@@ -63,8 +63,13 @@ def test_lama_page_parity(cuda, n_blocks, mpe, B, H, W):
     torch.cuda.synchronize()
     out = out.cpu().numpy()
     for i in range(B):
-        otaps = {}
-        ref = OL.infer(sd, mpe_sd, pages[i], masks[i], n_blocks, otaps)
+        def run_oracle(i=i):
+            ot = {}
+            r = OL.infer(sd, mpe_sd, pages[i], masks[i], n_blocks, ot)
+            keep = ("stem", f"block{n_blocks - 1}_l", f"block{n_blocks - 1}_g", "out_float")
+            return r, {k: ot[k] for k in keep}
+
+        ref, otaps = oracle_memo(("lama", n_blocks, mpe, B, H, W, i), run_oracle)
         if mpe:
             rel, _, direct = OL.load_masked_position_encoding((masks[i].astype(np.float32) / 255.0 >= 0.5).astype(np.float32))
             ymap = np.minimum(np.floor(np.arange(H) * (256 / H)).astype(np.int64), 255)
@@ -96,7 +101,7 @@ def test_lama_page_parity(cuda, n_blocks, mpe, B, H, W):
             frac = np.abs(of - np.round(of))
             assert all(frac[tuple(b)] < 0.05 for b in bad), "uint8 mismatch away from a truncation boundary"
             assert len(bad) < 1e-3 * diff.size
-        print(f"lama {n_blocks} blocks {H}x{W} page {i}: stem {stem_err:.2e}, last block {blk_err:.2e} (range {blk.abs().max().item():.2f}), "
+        print(f"lama {n_blocks} blocks {H}x{W} page {i} gemm mode {gemm_mode}: stem {stem_err:.2e}, last block {blk_err:.2e} (range {blk.abs().max().item():.2f}), "
               f"sigmoid {ferr:.2e}, u8 diffs {len(bad)} of {diff.size}")
 
 

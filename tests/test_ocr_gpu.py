@@ -12,12 +12,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def ocr_setup(cuda):
+def ocr_setup(cuda, shipped_mode):
     from manga_image_translator_amd import ocr48, ocr_schema, synth
 
     D = 300
     sd = synth.synth_state_dict(ocr_schema.ocr48_schema(D))
-    return sd, D, ocr48.Ocr48Engine(sd, D, device=cuda)
+    with shipped_mode():
+        return sd, D, ocr48.Ocr48Engine(sd, D, device=cuda)
 
 
 def _crops(widths, seed=0):
@@ -25,7 +26,7 @@ def _crops(widths, seed=0):
     return [rng.integers(0, 256, size=(48, w, 3), dtype=np.uint8) for w in widths]
 
 
-def test_encoder_memory_parity(cuda, ocr_setup):
+def test_encoder_memory_parity(cuda, gemm_mode, ocr_setup):
     from oracle import ocr48 as OO
 
     sd, D, eng = ocr_setup
@@ -47,7 +48,7 @@ def test_encoder_memory_parity(cuda, ocr_setup):
         assert klen.cpu().tolist() == [min((w + 3) // 4 + 2, L) for w in widths]
 
 
-def _check_beam_parity(cuda, sd, D, eng, crops, T, suppress):
+def _check_beam_parity(cuda, sd, D, eng, crops, T, suppress, memo=None):
     from oracle import ocr48 as OO
 
     chunks = list(eng.make_chunks(crops))
@@ -57,9 +58,13 @@ def _check_beam_parity(cuda, sd, D, eng, crops, T, suppress):
     out = eng.decode(mem_k, mem_v, klen, max_seq_length=T, suppress_eos=suppress, trace=True)
     torch.cuda.synchronize()
     img = ((torch.from_numpy(region).float() - 127.5) / 127.5).permute(0, 3, 1, 2)
-    trace = []
-    with torch.no_grad():
-        ref = OO.infer_beam_batch_tensor(sd, img, ws, max_seq_length=T, trace=trace, suppress_eos=suppress)
+    def run_oracle():
+        tr = []
+        with torch.no_grad():
+            r = OO.infer_beam_batch_tensor(sd, img, ws, max_seq_length=T, trace=tr, suppress_eos=suppress)
+        return r, tr
+
+    ref, trace = memo[0](memo[1], run_oracle) if memo is not None else run_oracle()
     N = len(ws)
     tl = out["trace_logits"].cpu()
     worst = 0.0
@@ -97,12 +102,12 @@ def _check_beam_parity(cuda, sd, D, eng, crops, T, suppress):
 
 
 @pytest.mark.parametrize("widths,T,suppress", [([50, 77, 120, 121], 12, False), ([200, 33, 90], 10, True)])
-def test_beam_search_parity(cuda, ocr_setup, widths, T, suppress):
+def test_beam_search_parity(cuda, gemm_mode, ocr_setup, widths, T, suppress):
     sd, D, eng = ocr_setup
     _check_beam_parity(cuda, sd, D, eng, _crops(widths, seed=3), T, suppress)
 
 
-def test_beam_search_parity_at_bench_config(cuda):
+def test_beam_search_parity_at_bench_config(cuda, gemm_mode, oracle_memo):
     """The bench's OCR workload: the 32 text lines of a synthetic 2048x1456 page (two chunks of 16, crop widths 180..600 px),
     dictionary of 6004 entries, 32 decode steps with EOS suppressed — per-step log-probs within 5e-4 of the oracle, token ids,
     probabilities and colour heads identical / within tolerance (model_48px.py:678-801)."""
@@ -120,8 +125,8 @@ def test_beam_search_parity_at_bench_config(cuda):
     order = sorted(range(len(crops)), key=lambda i: crops[i].shape[1])
     assert len(crops) == 32 and crops[order[0]].shape[1] >= 150 and crops[order[-1]].shape[1] <= 640
     for c in range(0, 32, 16):
-        worst = _check_beam_parity(cuda, sd, D, eng, [crops[i] for i in order[c:c + 16]], 32, True)
-        print(f"bench-config chunk {c // 16}: widths {crops[order[c]].shape[1]}..{crops[order[c + 15]].shape[1]}, worst per-step log-prob error {worst:.2e}")
+        worst = _check_beam_parity(cuda, sd, D, eng, [crops[i] for i in order[c:c + 16]], 32, True, memo=(oracle_memo, ("ocr-bench", c)))
+        print(f"gemm mode {gemm_mode} bench-config chunk {c // 16}: widths {crops[order[c]].shape[1]}..{crops[order[c + 15]].shape[1]}, worst per-step log-prob error {worst:.2e}")
 
 
 def test_pooled_decode_equals_per_chunk(cuda, ocr_setup):

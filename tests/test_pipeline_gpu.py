@@ -85,19 +85,32 @@ def test_recognize_pages_matches_host_chunking(cuda):
     assert torch.allclose(got["prob"].cpu(), ref["prob"].cpu(), rtol=1e-5, atol=0)
 
 
-def test_page_pipeline_parity(cuda):
+def test_page_pipeline_parity(cuda, gemm_mode):
     from manga_image_translator_amd import pipeline, synth
     from oracle import ctd as OC, lama as OL, ocr48 as OO, textline as OT
 
     D = 211
     weights = pipeline.synthetic_weights(dict_size=D)
+    from manga_image_translator_amd import lib as L, ops
+
     eng = pipeline.PageEngine(weights, device=cuda, dict_size=D, ctd_mb=2, lama_mb=2, group=2)
     B, H, W, T = 3, 256, 192, 5
     pages, quads, masks = zip(*[synth.synth_page(i, H, W, n_boxes=4) for i in range(B)])
     qobjs = [pipeline.quads_from_array(q) for q in quads]
-    res = eng.run(torch.from_numpy(np.stack(pages)).to(cuda), qobjs, torch.from_numpy(np.stack(masks)).to(cuda),
-                  max_seq_length=T, suppress_eos=True)
-    torch.cuda.synchronize()
+    # these pages are far below the launch size the split tiles normally take: lower the threshold so that in the split mode every
+    # eligible layer runs on them, and check with the launch probe which tiles ran
+    lib = L.load()
+    with ops.gemm_mode(gemm_mode, min_tiles=1):
+        L.check(lib.mit_prof_enable(1), "mit_prof_enable")
+        res = eng.run(torch.from_numpy(np.stack(pages)).to(cuda), qobjs, torch.from_numpy(np.stack(masks)).to(cuda),
+                      max_seq_length=T, suppress_eos=True)
+        torch.cuda.synchronize()
+        stats = (L.MitProfStat * 64)()
+        ncfg = C.c_int(0)
+        L.check(lib.mit_prof_read(stats, 64, C.byref(ncfg)), "mit_prof_read")
+        L.check(lib.mit_prof_enable(0), "mit_prof_enable")
+    split_launches = sum(stats[i].launches for i in range(ncfg.value) if lib.mit_conv_gemm_config_name(i).decode().startswith("split"))
+    assert (split_launches > 100) if gemm_mode else (split_launches == 0), (gemm_mode, split_launches)
     toks, probs = res.ocr_tokens.cpu().numpy(), res.ocr_prob.cpu().numpy()
     row = 0
     for b in range(B):

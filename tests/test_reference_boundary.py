@@ -19,6 +19,6 @@ def test_plugins_against_the_real_reference_boundary(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "boundary_checks.py")], capture_output=True, text=True, timeout=600,
                          cwd=str(tmp_path), env=env)
     assert out.returncode == 0, out.stdout[-3000:] + "\n" + out.stderr[-3000:]
-    assert "ALL 15 BOUNDARY CHECKS PASSED" in out.stdout
+    assert "ALL 16 BOUNDARY CHECKS PASSED" in out.stdout
     for name in ("ComicTextDetector._infer", "DefaultDetector._infer", "LamaMPEInpainter._infer"):   # the end-to-end stubs ran
         assert f"ok the reference's REAL {name}" in out.stdout, name
