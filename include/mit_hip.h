@@ -150,9 +150,9 @@ int mit_gemm_split_pack(const float *w_dev, int64_t w_zs, int nz, int Kw, int64_
  * other value.  Nothing in the reference corresponds to it. */
 int mit_gemm_mode_set(int mode);
 int mit_gemm_mode_get(void);
-/* Smallest launch, counted in 128 x 64 output tiles (x Z), that the automatic choice hands to the split tiles (default 1280 = one full
- * wave of workgroups, or MIT_GEMM_SPLIT_MIN_TILES); n >= 0 sets it, n < 0 only queries.  Returns the previous value.  Tests lower it to 1
- * so that small problems exercise the split tiles too. */
+/* Smallest launch, counted in 128 x 64 output tiles (x Z), that the automatic choice hands to the split tiles (default 0 — every
+ * eligible launch, which keeps a page's result independent of the batch it is part of — or MIT_GEMM_SPLIT_MIN_TILES); n >= 0 sets it,
+ * n < 0 only queries.  Returns the previous value.  A tuning knob: 1280 = one full wave of workgroups. */
 int64_t mit_gemm_split_min_tiles(int64_t n);
 
 /* k x k (3, 5, 7) stride-1 "same" convolution with 1..4 output channels on the fp32 VALU (an MFMA tile would idle 29 of
@@ -255,6 +255,23 @@ int mit_ctd_refine_merge(const uint8_t *page_dev, const uint8_t *pred_dev, int H
 typedef struct MitCrfCrop {
     int x, y, w, h; /* crop rectangle inside the page, pixels */
 } MitCrfCrop;
+
+/* Elliptical dilation of byte masks, batched over jobs (cv2.dilate with cv2.getStructuringElement(MORPH_ELLIPSE, (k, k)), k odd, default
+ * anchor and border: text_mask_utils.py:178-195).  Job j reads the source rectangle (sx, sy, sw, sh) — page coordinates — whose pixels
+ * live at src_dev + src_off with row pitch spitch, and writes the window (dx, dy, dw, dh) of dst_dev [H, W]: source pixels outside the
+ * source rectangle or outside the window count as 0 (the host form dilates the window as a sub-array).  merge = 0: dst = dilated;
+ * merge = 1: dst |= dilated for {0, 255} masks (the union over the lines of a page; windows may overlap).  jobs_host is copied to
+ * jobs_dev (n_jobs entries of device scratch) on the stream. */
+typedef struct MitDilateJob {
+    int32_t sx, sy, sw, sh;
+    int32_t dx, dy, dw, dh;
+    int32_t k, spitch;
+    int64_t src_off;
+} MitDilateJob;
+int mit_mask_dilate_jobs(const uint8_t *src_dev, const MitDilateJob *jobs_host, int n_jobs, uint8_t *dst_dev, int H, int W, int merge,
+                         MitDilateJob *jobs_dev, void *stream);
+/* buf[i] = buf[i] ? 255 : 0 in place (mask_refinement/__init__.py:29 after the resize back to page size). */
+int mit_binarize_u8(uint8_t *buf_dev, int64_t n, void *stream);
 
 /* Bytes of device workspace mit_densecrf_refine needs for these crops (-1: bad crops / batch too large). */
 int64_t mit_densecrf_workspace_bytes(const MitCrfCrop *crops, int n_crops);
@@ -399,11 +416,13 @@ typedef struct MitXposTables {
     int32_t imax, pmax;
 } MitXposTables;
 
-/* A packed nn.Linear: w [Kp][ldw] (k-major), out = act((x @ w) * scale + bias); scale may be NULL. */
+/* A packed nn.Linear: w [Kp][ldw] (k-major), out = act((x @ w) * scale + bias); scale may be NULL.  w_split: the same matrix as
+ * three bf16 planes (mit_gemm_split_pack) for the split-bf16 tiles, or NULL (fp32 MFMA only). */
 typedef struct MitLinear {
     const float *w, *scale, *bias;
     int64_t ldw;
     int32_t K, N, Kp, Np;
+    const uint16_t *w_split;
 } MitLinear;
 
 typedef struct MitOcrDecoderLayer {

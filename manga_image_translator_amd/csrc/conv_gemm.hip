@@ -77,14 +77,15 @@ int gemm_mode_now() {
     return m;
 }
 
-// smallest launch (in 128 x 64 tiles) the automatic choice gives to the split tiles: below one full wave of workgroups their longer
-// prologue does not pay.  -1 = not read yet (MIT_GEMM_SPLIT_MIN_TILES, default 1280)
+// smallest launch (in 128 x 64 tiles) the automatic choice gives to the split tiles.  Default 0: every eligible launch takes them, so
+// that a layer's arithmetic — and with it a page's result — does not depend on how many pages share the batch (a size threshold made
+// the same layer run on the fp32 tiles at B = 1 and on the split tiles at B = 16).  -1 = not read yet (MIT_GEMM_SPLIT_MIN_TILES)
 std::atomic<long long> g_split_min{-1};
 int64_t split_min_now() {
     long long m = g_split_min.load(std::memory_order_relaxed);
     if (m < 0) {
         const char *v = getenv("MIT_GEMM_SPLIT_MIN_TILES");
-        m = (v && *v) ? atoll(v) : 1280;
+        m = (v && *v) ? atoll(v) : 0;
         if (m < 0) m = 0;
         g_split_min.store(m, std::memory_order_relaxed);
     }
@@ -112,14 +113,22 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     // split-bf16 tiles (GEMM mode 6 | 9, mit_gemm_mode_set): layers whose packer attached split planes of W, large enough to fill the chip
     const int split = gemm_mode_now();
     const int64_t split_min = split_min_now();
-    if ((split == 6 || split == 9) && p.w_split && split_eligible(p, 16) && ((M + 127) / 128) * ((p.N + 63) / 64) * p.Z >= split_min) {
+    const int64_t tiles128 = ((M + 127) / 128) * ((p.N + 63) / 64);
+    if ((split == 6 || split == 9) && p.w_split && split_eligible(p, 16) && tiles128 * p.Z >= split_min) {
         static const int wide6 = cfg_by_name("split128x128x16p6o"), wide9 = cfg_by_name("split128x128x16p9m");
         static const int narrow6 = cfg_by_name("split128x64x16p6o"), narrow9 = cfg_by_name("split128x64x16p9");
+        static const int small6 = getenv("MIT_CONV_NO_SMALL_TILE") ? -1 : cfg_by_name("split64x64x16p6o");
+        static const int small9 = getenv("MIT_CONV_NO_SMALL_TILE") ? -1 : cfg_by_name("split64x64x16p9m");
+        static const int64_t ssmall_max = getenv("MIT_CONV_SPLIT_SMALL_MAX") ? atoll(getenv("MIT_CONV_SPLIT_SMALL_MAX")) : 768;  // one wave of 128-row split tiles (3 workgroups per CU)
         const int r = p.N % 128;
-        const int c = (p.N <= 64 || (r != 0 && r <= 64)) ? (split == 6 ? narrow6 : narrow9) : (split == 6 ? wide6 : wide9);
+        int c = (p.N <= 64 || (r != 0 && r <= 64)) ? (split == 6 ? narrow6 : narrow9) : (split == 6 ? wide6 : wide9);
+        // under-filled launches (one page through the plugins, the decoder's Linears): 64 x 64 tiles quadruple the workgroup count;
+        // the arithmetic per output element is that of the large tiles, so a result does not depend on the choice
+        const int sm = split == 6 ? small6 : small9;
+        if (sm >= 0 && p.Z == 1 && tiles128 < ssmall_max) c = sm;
         if (c >= 0) return c;
     }
-    if (f16 && m192 >= 0 && M > 128 && M <= 192) return m192;  // 2 x 128 rows would run a 40 % empty second tile
+    if (f16 && m192 >= 0 && M > 128 && M <= 192 && p.Z >= 8) return m192;  // batched launches (Z entries of M = 184 rows: W-axis DFTs): 2 x 128 rows would run a 40 % empty second tile.  Unbatched, one row of 192 x 64 tiles leaves the chip empty (the decoder at B = 1: M = 160)
     if (f16 && bigk >= 0 && p.N % 128 == 0 && p.N <= 128 && p.ntaps * p.Cin >= 4096 && M >= 256 * 1024) return bigk;
     // under-filled launches (the decoder's GEMMs: M = lines x beams = 10240): a 128-row tiling leaves most CUs with one workgroup or
     // none, 64 x 64 tiles double the count

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/mit_hip.h"
 #include "common.h"
@@ -22,9 +23,17 @@ constexpr int E = 320;
 constexpr int FF = 2048;
 
 struct Ws {
-    float *tgt, *nrm, *qkv, *krot, *qrot, *att, *q2, *ffh, *decoded, *p1, *logits, *vals, *logp, *cfeat;
+    float *tgt, *nrm, *qkv, *krot, *qrot, *att, *q2, *ffh, *decoded, *p1, *logits, *vals, *logp, *cfeat, *part;
     int *idx, *hist, *done, *done_count;
 };
+
+// Few rows, long contraction (the FFN's second Linear, K = 2048, at one page: R = lines x beams = 160 rows): a 64-row tiling is
+// (R / 64) x (320 / 64) = 15 workgroups that each walk all 128 K-tiles — 45 us of a 256-CU chip for 0.2 GFLOP.  Up to SPLITK_MAX_M
+// rows such a GEMM is cut along K into slices of SPLITK_SLICE, computed as batch entries of ONE launch into a partial buffer
+// [S][M][Np], and summed in slice order by splitk_reduce_kernel, which applies the epilogue.  Deterministic; the sum order differs
+// from the k-sequential chain of the single-launch form (fp32 rounding only), so results of a decode with more rows than
+// SPLITK_MAX_M (a pooled beam search over > 409 lines) differ from a smaller one in the last bits of the logits.
+constexpr int SPLITK_MAX_M = 2048, SPLITK_MIN_K = 1024, SPLITK_SLICE = 128;
 
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
@@ -51,26 +60,76 @@ int64_t carve(Ws *w, char *base, int N, int T, int D) {
     float *vals = (float *)take(R * 5 * 4);
     float *logp = (float *)take(2 * R * 4);
     float *cfeat = (float *)take(R * T * 64 * 4);
+    float *part = (float *)take(R <= SPLITK_MAX_M ? (int64_t)(FF / SPLITK_SLICE) * R * E * 4 : 0);
     int *idx = (int *)take(R * 5 * 4);
     int *hist = (int *)take(2 * R * (T + 1) * 4);
     int *done = (int *)take((int64_t)N * 4);
     int *done_count = (int *)take(256);
-    if (w) *w = Ws{tgt, nrm, qkv, krot, qrot, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, idx, hist, done, done_count};
+    if (w) *w = Ws{tgt, nrm, qkv, krot, qrot, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, part, idx, hist, done, done_count};
     return off;
 }
 
-// C[M x N] = act((A[M x K] @ W) * scale + bias) + post, rows of A / C / post strided.
+// sum of the S partial products in slice order + the epilogue of mit_conv_gemm: C = act(sum * scale + bias) + post
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, const int S, const int M, const int N4, const int Np,
+                                                           float *C, const int64_t ldc, const float *__restrict__ scale,
+                                                           const float *__restrict__ bias, const int act, const float *post, const int64_t ldpost) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * N4) return;
+    const int m = idx / N4, n = (idx - m * N4) * 4;
+    const int64_t slice = (int64_t)M * Np;
+    const float *p = part + (int64_t)m * Np + n;
+    float4 v = *reinterpret_cast<const float4 *>(p);
+    for (int z = 1; z < S; ++z) {
+        const float4 t = *reinterpret_cast<const float4 *>(p + z * slice);
+        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+    }
+    if (scale) {
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + n);
+        v.x *= sc.x, v.y *= sc.y, v.z *= sc.z, v.w *= sc.w;
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(bias + n);
+        v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+    }
+    if (act == MIT_ACT_RELU) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    if (post) {
+        const float4 r = *reinterpret_cast<const float4 *>(post + (int64_t)m * ldpost + n);
+        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+    }
+    *reinterpret_cast<float4 *>(C + (int64_t)m * ldc + n) = v;
+}
+
+// C[M x N] = act((A[M x K] @ W) * scale + bias) + post, rows of A / C / post strided.  ``part``: partial-sum scratch for the
+// split-K form (NULL = never split).
 int gemm(const MitLinear &lin, const float *A, int64_t lda, float *Cp, int64_t ldc, int M, int act, const float *post,
-         int64_t ldpost, hipStream_t s, int nsplit = 0, int64_t nhi = 0) {
+         int64_t ldpost, hipStream_t s, int nsplit = 0, int64_t nhi = 0, float *part = nullptr) {
     MitConvGemm d;
     memset(&d, 0, sizeof(d));
     d.a = A;
     d.a_xs = lda;
-    d.NB = 1; d.Hi = 1; d.Wi = M; d.Cin = lin.K;
-    d.Ho = 1; d.Wo = M; d.sy = 1; d.sx = 1;
+    d.NB = 1; d.Hi = 1; d.Wi = M; d.Ho = 1; d.Wo = M; d.sy = 1; d.sx = 1;
     d.ntaps = 1; d.pad_mode = MIT_PAD_ZERO;
-    d.w = lin.w; d.ldw = lin.ldw; d.Kw = lin.Kp; d.Nw = lin.Np;
-    d.N = lin.N; d.Z = 1; d.zdiv = 1;
+    d.w = lin.w; d.ldw = lin.ldw; d.Nw = lin.Np;
+    d.N = lin.N;
+    static const bool splitk_off = getenv("MIT_OCR_NO_SPLITK") != nullptr;  // A/B knob for scripts/
+    if (part && !splitk_off && M <= SPLITK_MAX_M && lin.K >= SPLITK_MIN_K && lin.K % SPLITK_SLICE == 0 && lin.Kp == lin.K && !nsplit &&
+        (lin.N & 3) == 0 && (act == MIT_ACT_NONE || act == MIT_ACT_RELU) && !(ldc & 3) && !(ldpost & 3)) {
+        const int S = lin.K / SPLITK_SLICE;
+        d.Cin = SPLITK_SLICE; d.Kw = SPLITK_SLICE;
+        d.Z = S; d.zdiv = 1 << 30;                       // z1 = 0, z0 = slice
+        d.a_zs0 = SPLITK_SLICE;                          // A rows are k-contiguous: slice z starts SPLITK_SLICE floats further
+        d.w_zs0 = (int64_t)SPLITK_SLICE * lin.ldw;
+        d.c.base = part; d.c.xs = lin.Np; d.c.zs0 = (int64_t)M * lin.Np;
+        d.act = MIT_ACT_NONE;
+        if (mit_conv_gemm(&d, s)) return 1;
+        const int N4 = lin.N / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((M * N4 + 255) / 256), dim3(256), 0, s, part, S, M, N4, lin.Np, Cp, ldc, lin.scale,
+                           lin.bias, act, post, ldpost);
+        return 0;
+    }
+    d.Cin = lin.K; d.Kw = lin.Kp;
+    d.Z = 1; d.zdiv = 1;
+    d.w_split = lin.w_split;  // planes attached by the packer in a split GEMM mode (NULL otherwise); the launcher decides by the mode of the moment
     d.c.base = Cp; d.c.xs = ldc; d.c.nsplit = nsplit; d.c.nhi = nhi;
     if (post) {
         d.post.base = const_cast<float *>(post);
@@ -153,9 +212,9 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
             ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, s);
             if (gemm(ly.ff1, w.nrm, E, w.ffh, FF, R, MIT_ACT_RELU, nullptr, 0, s)) return 1;
             if (l < 4) {
-                if (gemm(ly.ff2, w.ffh, FF, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, s)) return 1;
+                if (gemm(ly.ff2, w.ffh, FF, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, s, 0, 0, w.part)) return 1;
             } else {  // last layer writes the step's output straight into the activation cache (:570)
-                if (gemm(ly.ff2, w.ffh, FF, w.decoded + (int64_t)step * E, TE, R, MIT_ACT_NONE, w.tgt, E, s)) return 1;
+                if (gemm(ly.ff2, w.ffh, FF, w.decoded + (int64_t)step * E, TE, R, MIT_ACT_NONE, w.tgt, E, s, 0, 0, w.part)) return 1;
             }
         }
         if (gemm(dec->pred1, w.decoded + (int64_t)step * E, TE, w.p1, E, R, MIT_ACT_GELU, nullptr, 0, s)) return 1;

@@ -43,14 +43,17 @@ class DenseCrfRefiner:
         self._ws = None
 
     def refine(self, page_dev: torch.Tensor, rects: Sequence[Tuple[int, int, int, int]], masks: Sequence[np.ndarray],
-               return_q: bool = False, iterations: int = ITERATIONS):
+               return_q: bool = False, iterations: int = ITERATIONS, packed: bool = False):
         """page_dev u8 [H,W,3] (device), rects (x, y, w, h) per crop, masks u8 [h, w] per crop (host) -> list of u8 [h, w] masks in
-        {0, 255} (and the final marginals [h, w, 2] per crop when ``return_q``)."""
+        {0, 255} (and the final marginals [h, w, 2] per crop when ``return_q``).  ``packed``: the refined crops stay on the device —
+        returns (u8 device tensor with the crops back to back, row-major, [offset of each crop])."""
         if page_dev.dtype != torch.uint8 or page_dev.dim() != 3 or page_dev.shape[2] != 3 or not page_dev.is_cuda:
             raise ValueError(f"DenseCrfRefiner.refine expects a uint8 device page [H,W,3], got {page_dev.dtype} {tuple(page_dev.shape)}")
         if len(rects) != len(masks):
             raise ValueError("one mask per crop rectangle")
         if not rects:
+            if packed:
+                return torch.empty(0, dtype=torch.uint8, device=self.device), []
             return ([], []) if return_q else []
         page_dev = page_dev.contiguous()
         H, W, _ = page_dev.shape
@@ -76,6 +79,12 @@ class DenseCrfRefiner:
                                          q_dev.data_ptr() if return_q else None, GAUSS_SXY, GAUSS_COMPAT, BILATERAL_SXY, BILATERAL_SRGB,
                                          BILATERAL_COMPAT, int(iterations), self._lut.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
                                          C.c_void_p(ops.current_stream())), "mit_densecrf_refine")
+        if packed:
+            offs, o = [], 0
+            for (x, y, w, h) in rects:
+                offs.append(o)
+                o += w * h
+            return out_dev, offs
         out = out_dev.cpu().numpy()
         res, qs, o = [], [], 0
         qh = q_dev.cpu().numpy() if return_q else None

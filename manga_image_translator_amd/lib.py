@@ -79,7 +79,7 @@ class MitXposTables(C.Structure):
 
 class MitLinear(C.Structure):
     _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("ldw", C.c_int64), ("K", C.c_int32),
-                ("N", C.c_int32), ("Kp", C.c_int32), ("Np", C.c_int32)]
+                ("N", C.c_int32), ("Kp", C.c_int32), ("Np", C.c_int32), ("w_split", C.c_void_p)]
 
 
 class MitOcrDecoderLayer(C.Structure):
@@ -120,6 +120,11 @@ class MitWarpLine(C.Structure):
 
 class MitCrfCrop(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class MitDilateJob(C.Structure):
+    _fields_ = [("sx", C.c_int32), ("sy", C.c_int32), ("sw", C.c_int32), ("sh", C.c_int32), ("dx", C.c_int32), ("dy", C.c_int32),
+                ("dw", C.c_int32), ("dh", C.c_int32), ("k", C.c_int32), ("spitch", C.c_int32), ("src_off", C.c_int64)]
 
 
 class MitRefineWindow(C.Structure):
@@ -173,6 +178,8 @@ SYMBOLS = {
                                  C.c_float, C.c_void_p]),
     "mit_bilateral_u8c3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "mit_mask_dilate_jobs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mit_binarize_u8": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "mit_densecrf_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int]),
     "mit_densecrf_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -51,11 +51,14 @@ class CallableMaskBackend:
 class GpuMaskBackend:
     """Default backend: bilateral filter + batched DenseCRF on the device (imgproc.bilateral_filter_u8, densecrf.DenseCrfRefiner)."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, gpu_tail: bool = True):
+        """``gpu_tail``: the per-line dilations, their union and the closing dilation run on the device too (``refine_dilate_union``);
+        False keeps them on the host (scipy) — bit-identical, for A/B runs and tests."""
         import torch
 
         from . import densecrf, lib
 
+        self.gpu_tail = gpu_tail
         lib.load()  # fails loudly without the HIP library
         if device is None:
             if not torch.cuda.is_available():
@@ -82,6 +85,16 @@ class GpuMaskBackend:
 
         return imgproc.resize_u8(self._dev(mask)[None], size)[0].cpu().numpy()
 
+    def resize_binarize(self, mask_dev, size):
+        """cv2.resize(mask, (w, h), INTER_LINEAR) then mask[mask > 0] = 255 (mask_refinement/__init__.py:28-29), on the device."""
+        import ctypes as C
+
+        from . import imgproc, lib as _lib, ops
+
+        out = imgproc.resize_u8(mask_dev[None].contiguous(), size)[0]
+        _lib.check(_lib.load().mit_binarize_u8(out.data_ptr(), out.numel(), C.c_void_p(ops.current_stream())), "mit_binarize_u8")
+        return out
+
     def filter_page(self, img):
         from . import imgproc
 
@@ -89,6 +102,37 @@ class GpuMaskBackend:
 
     def refine(self, page, rects, masks):
         return self._crf.refine(page, rects, masks)
+
+    def refine_dilate_union(self, page, jobs, masks, H: int, W: int, kernel_size: int):
+        """The tail of complete_mask (text_mask_utils.py:172-195) without leaving the device: batched DenseCRF of the lines' crops, each
+        refined crop dilated by its own ellipse inside its window and OR-ed into the page mask, then the closing dilation.
+        jobs: (crop rectangle (x, y, w, h), window rectangle, dilation size) per line; masks: the crops' component masks (host).
+        Returns the u8 [H, W] mask as a device tensor."""
+        import ctypes as C
+
+        import torch
+
+        from . import lib as _lib, ops
+
+        L = _lib.load()
+        out_dev, offs = self._crf.refine(page, [r for r, _, _ in jobs], masks, packed=True)
+        n = len(jobs)
+        final = torch.zeros(2, H, W, dtype=torch.uint8, device=self.device)
+        scratch = torch.empty((n + 1) * C.sizeof(_lib.MitDilateJob), dtype=torch.uint8, device=self.device)
+        stream = C.c_void_p(ops.current_stream())
+        arr = (_lib.MitDilateJob * max(n, 1))()
+        for j, ((x1, y1, w1, h1), (x2, y2, w2, h2), k) in enumerate(jobs):
+            a = arr[j]
+            a.sx, a.sy, a.sw, a.sh, a.dx, a.dy, a.dw, a.dh, a.k, a.spitch, a.src_off = x1, y1, w1, h1, x2, y2, w2, h2, k, w1, offs[j]
+        if n:
+            _lib.check(L.mit_mask_dilate_jobs(out_dev.data_ptr(), C.byref(arr), n, final[0].data_ptr(), H, W, 1, scratch.data_ptr(), stream),
+                       "mit_mask_dilate_jobs")
+        one = (_lib.MitDilateJob * 1)()
+        a = one[0]
+        a.sx, a.sy, a.sw, a.sh, a.dx, a.dy, a.dw, a.dh, a.k, a.spitch, a.src_off = 0, 0, W, H, 0, 0, W, H, kernel_size, W, 0
+        _lib.check(L.mit_mask_dilate_jobs(final[0].data_ptr(), C.byref(one), 1, final[1].data_ptr(), H, W, 0,
+                                          scratch.data_ptr() + n * C.sizeof(_lib.MitDilateJob), stream), "mit_mask_dilate_jobs")
+        return final[1]
 
     def release_workspace(self):
         self._crf.release_workspace()
@@ -194,7 +238,7 @@ def _xywh(q: Quadrilateral):  # BBox.xywh (utils/generic.py:319-321): int32 trun
 
 def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadrilateral], keep_threshold: float = 1e-2,
                   dilation_offset: int = 0, kernel_size: int = 3, refine: Optional[RefineFn] = None,
-                  bilateral: Optional[BilateralFn] = None, backend=None) -> Optional[np.ndarray]:
+                  bilateral: Optional[BilateralFn] = None, backend=None, device_result: bool = False) -> Optional[np.ndarray]:
     """text_mask_utils.complete_mask (:96-195).  ``mask`` is modified in place exactly like the reference's (line boxes are
     outlined with zeros before labelling).  The per-line DenseCRF calls of :172-176 are independent of each other (each line owns
     its component image, all read the same filtered page), so they are collected and refined as one batch."""
@@ -264,7 +308,15 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
         if cc[y1:y1 + h1, x1:x1 + w1].size == 0:
             continue
         jobs.append((i, (x1, y1, w1, h1), dilate_size))
-    refined = be.refine(page, [r for _, r, _ in jobs], [np.ascontiguousarray(ccs[i][y:y + h, x:x + w]) for i, (x, y, w, h), _ in jobs])
+    crops = [np.ascontiguousarray(ccs[i][y:y + h, x:x + w]) for i, (x, y, w, h), _ in jobs]
+    if getattr(be, "gpu_tail", False) and kernel_size % 2 == 1:
+        # device tail: the windows are the host form's own rectangles; inside a window every non-zero pixel of the line's component
+        # image lies in its crop rectangle (the crop is the components' bounding box, extended), so the refined crop is all the
+        # dilation has to read
+        dev_jobs = [(r, _extend_rect(*r, W, H, -(-k // 2)), k) for _, r, k in jobs]
+        out = be.refine_dilate_union(page, dev_jobs, crops, H, W, kernel_size)
+        return out if device_result else out.cpu().numpy()   # device_result: the caller (dispatch) resizes it on the device
+    refined = be.refine(page, [r for _, r, _ in jobs], crops)
     for (i, (x1, y1, w1, h1), dilate_size), region in zip(jobs, refined):
         cc = ccs[i]
         cc[y1:y1 + h1, x1:x1 + w1] = region
@@ -325,12 +377,15 @@ def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, met
     mask_small = be.resize_mask(raw_mask, size).copy()
     mask_small[mask_small > 0] = 255
     lines = [Quadrilateral(np.asarray(l) * scale, "", 0) for region in text_regions for l in region.lines]
-    final = complete_mask(img_small, mask_small, lines, dilation_offset=dilation_offset, kernel_size=kernel_size, backend=be)
+    final = complete_mask(img_small, mask_small, lines, dilation_offset=dilation_offset, kernel_size=kernel_size, backend=be,
+                          device_result=True)
     if final is None:
         final = np.zeros((h, w), dtype=np.uint8)
-    else:
+    elif isinstance(final, np.ndarray):
         final = be.resize_mask(final, (w, h)).copy()
         final[final > 0] = 255
+    else:  # device tensor from the GPU tail: resize and binarise there, one download
+        final = be.resize_binarize(final, (w, h)).cpu().numpy()
     if 1 <= ignore_bubble <= 50:
         final = bubble_filter(final, np.asarray(raw_image), ignore_bubble)
     return final

@@ -54,6 +54,8 @@ class Linear:
         m.w, m.ldw, m.K, m.N, m.Kp, m.Np = self.w.data_ptr(), self.Np, self.K, self.N, self.Kp, self.Np
         m.scale = None if self.scale is None else self.scale.data_ptr()
         m.bias = None if self.bias is None else self.bias.data_ptr()
+        planes, _ = ops._split_for(self.w, self.Np, self.Kp, (0, 0))   # packed in a split GEMM mode: the decoder's launches use them too
+        m.w_split = None if planes is None else planes.data_ptr()
         return m
 
     def __call__(self, x: torch.Tensor, out: torch.Tensor, act: int = ACT_NONE, post: Optional[torch.Tensor] = None,

@@ -13,6 +13,7 @@ size and the inverse homography that ``mit_ocr_warp_lines`` (csrc/ocr_warp.hip) 
 from __future__ import annotations
 
 import functools
+import math
 from dataclasses import dataclass
 from typing import List, Sequence, Tuple
 
@@ -99,6 +100,12 @@ class Quadrilateral:
         return BBox(int(mn[0]), int(mn[1]), int(mx[0] - mn[0]), int(mx[1] - mn[1]))
 
     @functools.cached_property
+    def extent(self) -> Tuple[float, float, float, float]:
+        """(xmin, ymin, xmax, ymax) of the points as floats (``aabb`` truncates to int)."""
+        p = np.asarray(self.pts, dtype=np.float64)
+        return float(p[:, 0].min()), float(p[:, 1].min()), float(p[:, 0].max()), float(p[:, 1].max())
+
+    @functools.cached_property
     def area(self) -> float:
         x, y = self.pts[:, 0].astype(np.float64), self.pts[:, 1].astype(np.float64)
         return float(abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))) / 2)  # convex quad: hull area = shoelace
@@ -161,10 +168,12 @@ def _convex_hull(pts: np.ndarray) -> np.ndarray:
 
 
 def _seg_point_dist(p, a, b) -> float:
-    ab, ap = b - a, p - a
-    den = float(ab @ ab)
-    t = 0.0 if den == 0 else min(1.0, max(0.0, float(ap @ ab) / den))
-    return float(np.linalg.norm(ap - t * ab))
+    """Distance of point p from segment ab (plain Python floats: this runs O(lines^2 x 32) times per page)."""
+    abx, aby, apx, apy = b[0] - a[0], b[1] - a[1], p[0] - a[0], p[1] - a[1]
+    den = abx * abx + aby * aby
+    t = 0.0 if den == 0 else min(1.0, max(0.0, (apx * abx + apy * aby) / den))
+    dx, dy = apx - t * abx, apy - t * aby
+    return math.sqrt(dx * dx + dy * dy)
 
 
 def _segs_intersect(a, b, c, d) -> bool:
@@ -189,7 +198,7 @@ def _point_in_polygon(p, poly) -> bool:
 def polygon_distance(pa: np.ndarray, pb: np.ndarray) -> float:
     """Minimum distance between two simple polygons given as vertex rings (0 when they touch or overlap) — what
     shapely's ``Polygon.distance`` returns for the quads of utils/generic.py:660-662."""
-    pa, pb = np.asarray(pa, dtype=np.float64), np.asarray(pb, dtype=np.float64)
+    pa, pb = np.asarray(pa, dtype=np.float64).tolist(), np.asarray(pb, dtype=np.float64).tolist()  # lists of Python floats
     na, nb = len(pa), len(pb)
     for i in range(na):
         for j in range(nb):
@@ -215,9 +224,9 @@ def quadrilateral_can_merge_region(a: Quadrilateral, b: Quadrilateral, ratio=1.9
     # pairs of a page) fail the first test of the reference without the exact distance being needed — same decisions, always
     # (the gap is taken from the float extents of the points, not from ``aabb``: its int() truncation can fall short of the true
     # extent for non-integer points, and the bound must never exceed the real distance)
-    pa, pb = np.asarray(a.pts, dtype=np.float64), np.asarray(b.pts, dtype=np.float64)
-    gx = max(0.0, max(pa[:, 0].min(), pb[:, 0].min()) - min(pa[:, 0].max(), pb[:, 0].max()))
-    gy = max(0.0, max(pa[:, 1].min(), pb[:, 1].min()) - min(pa[:, 1].max(), pb[:, 1].max()))
+    ea, eb = a.extent, b.extent
+    gx = max(0.0, max(ea[0], eb[0]) - min(ea[2], eb[2]))
+    gy = max(0.0, max(ea[1], eb[1]) - min(ea[3], eb[3]))
     if gx * gx + gy * gy > (discard_connection_gap * char_size) ** 2:
         return False
     dist = polygon_distance(a.pts, b.pts)  # Polygon(a.pts).distance(Polygon(b.pts))
@@ -254,6 +263,22 @@ def quadrilateral_can_merge_region(a: Quadrilateral, b: Quadrilateral, ratio=1.9
     return False
 
 
+def near_pairs(quads: Sequence[Quadrilateral], discard_connection_gap: float = 2) -> List[Tuple[int, int]]:
+    """The pairs (u < v, in itertools.combinations order) that pass ``quadrilateral_can_merge_region``'s own first test — bounding-box
+    gap against ``discard_connection_gap`` x the smaller font size — evaluated for all pairs at once: of the O(n^2) pairs of a page
+    only the handful of neighbours has to go through the Python predicate (which repeats the test)."""
+    n = len(quads)
+    if n < 2:
+        return []
+    ext = np.array([q.extent for q in quads], dtype=np.float64)
+    fs = np.array([q.font_size for q in quads], dtype=np.float64)
+    gx = np.maximum(0.0, np.maximum(ext[:, None, 0], ext[None, :, 0]) - np.minimum(ext[:, None, 2], ext[None, :, 2]))
+    gy = np.maximum(0.0, np.maximum(ext[:, None, 1], ext[None, :, 1]) - np.minimum(ext[:, None, 3], ext[None, :, 3]))
+    near = np.triu(gx * gx + gy * gy <= (discard_connection_gap * np.minimum(fs[:, None], fs[None, :])) ** 2, 1)
+    us, vs = np.nonzero(near)
+    return list(zip(us.tolist(), vs.tolist()))
+
+
 def generate_text_direction(quads: Sequence[Quadrilateral]):
     """CommonOCR._generate_text_direction (ocr/common.py:12-39): connected components of the merge graph
     (aspect_ratio_tol = 1), majority direction per component, lines ordered top-to-bottom ('h') or right-to-left ('v').
@@ -267,12 +292,11 @@ def generate_text_direction(quads: Sequence[Quadrilateral]):
             i = parent[i]
         return i
 
-    for u in range(n):
-        for v in range(u + 1, n):
-            if quadrilateral_can_merge_region(quads[u], quads[v], aspect_ratio_tol=1):
-                ru, rv = find(u), find(v)
-                if ru != rv:
-                    parent[max(ru, rv)] = min(ru, rv)
+    for u, v in near_pairs(quads):
+        if quadrilateral_can_merge_region(quads[u], quads[v], aspect_ratio_tol=1):
+            ru, rv = find(u), find(v)
+            if ru != rv:
+                parent[max(ru, rv)] = min(ru, rv)
     comps = {}
     for i in range(n):  # components in order of their first node, nodes ascending (networkx + CPython set order for small ints)
         comps.setdefault(find(i), []).append(i)

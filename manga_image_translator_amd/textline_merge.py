@@ -146,7 +146,7 @@ def split_text_region(bboxes: Sequence[Quadrilateral], indices: Iterable[int], w
 def merge_bboxes_text_region(bboxes: Sequence[Quadrilateral], width, height):
     """textline_merge/__init__.py:112-184: yields (lines in reading order, fg colour, bg colour) per text region."""
     n = len(bboxes)
-    edges = [(u, v) for u, v in itertools.combinations(range(n), 2)
+    edges = [(u, v) for u, v in TL.near_pairs(bboxes)   # the pairs of itertools.combinations(range(n), 2) that can pass the predicate's first test
              if TL.quadrilateral_can_merge_region(bboxes[u], bboxes[v], aspect_ratio_tol=1.3, font_size_ratio_tol=2,
                                                   char_gap_tolerance=1, char_gap_tolerance2=3)]
     regions: List[Set[int]] = []

@@ -11,6 +11,17 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fp32_mfma_tiles():
+    """These are tests of the fp32 tiles (bit-equality between tile shapes, the generic and the fast kernel): the layers are packed and
+    launched in GEMM mode 0.  The split-bf16 tiles have their own file (test_gemm_split_gpu.py)."""
+    from manga_image_translator_amd import ops
+
+    with ops.gemm_mode(0):
+        yield
+
+
+
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 

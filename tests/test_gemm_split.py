@@ -72,7 +72,7 @@ def test_pair_ladder_error_against_fp32_rounding():
     assert 1e-7 < err["p3"] < 2e-5            # three pairs is a 16-bit-significand product: not an fp32 substitute
 
 
-TILES = [(128, 128, 16, 2, 2), (128, 64, 16, 2, 2), (128, 128, 32, 2, 2)]    # conv_gemm_cfgs.inc group 5
+TILES = [(128, 128, 16, 2, 2), (128, 64, 16, 2, 2), (128, 128, 32, 2, 2), (64, 64, 16, 2, 2)]    # conv_gemm_cfgs.inc groups 5 / 6
 
 
 @pytest.mark.parametrize("BM,BN,BK,WAVES_M,WAVES_N", TILES)

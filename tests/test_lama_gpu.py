@@ -219,6 +219,13 @@ def test_rfft_rows_rejects_unsupported_widths(cuda):
 
 @pytest.mark.parametrize("H,W,B", [(64, 72, 2), (256, 184, 1), (16, 24, 1)])
 def test_row_packed_stem_is_bit_identical(cuda, H, W, B):
+    from manga_image_translator_amd import ops
+
+    with ops.gemm_mode(0):  # a statement about the fp32 tiles: the row-packed form (fast kernel) against the plain one (generic kernel)
+        _row_packed_stem_check(cuda, H, W, B)
+
+
+def _row_packed_stem_check(cuda, H, W, B):
     """The 7x7 4->64 stem as 7 taps of one contiguous 32-float read on the reflect-padded input (fast kernel) == the plain
     reflect-padded Conv2d on the generic kernel: same (ky, kx, c) accumulation order, the surplus terms are exact zeros."""
     from manga_image_translator_amd import lama, lama_schema, synth

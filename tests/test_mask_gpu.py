@@ -147,3 +147,37 @@ def test_complete_mask_default_backend_matches_oracle_backend(cuda):
     d1 = MR.dispatch_sync([region], G["img"].copy(), G["mask"].copy())  # default backend
     d2 = MR.dispatch_sync([region], G["img"].copy(), G["mask"].copy(), refine=OD.refine_mask, bilateral=OI.bilateral_filter_u8)
     assert d1.shape == G["mask"].shape and (d1 != d2).mean() < 2e-3
+
+
+def test_gpu_tail_of_complete_mask_is_bit_identical_to_the_host_tail(cuda):
+    """The per-line elliptical dilations, their union, the closing dilation and the resize + binarisation back to page size on the
+    device (mit_mask_dilate_jobs, mit_binarize_u8) against the same steps on the host (scipy maximum_filter with
+    cv2.getStructuringElement's ellipse rows, pinned to the reference's Python by tests/golden/mask_refinement.npz): same bytes —
+    on the golden scene and on a bench-like page (32 lines, dilation sizes 13..23, windows overlapping and touching the borders)."""
+    from manga_image_translator_amd import mask_refinement as MR, synth
+    from manga_image_translator_amd.textline import Quadrilateral
+
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_refinement.npz"))
+    dev_be, host_be = MR.GpuMaskBackend(cuda), MR.GpuMaskBackend(cuda, gpu_tail=False)
+    quads = [Quadrilateral(l.astype(np.float64), "", 0) for l in G["lines"]]
+    for off, ks in ((0, 3), (20, 3), (7, 5)):
+        a = MR.complete_mask(G["img"].copy(), G["mask"].copy(), quads, dilation_offset=off, kernel_size=ks, backend=dev_be)
+        b = MR.complete_mask(G["img"].copy(), G["mask"].copy(), quads, dilation_offset=off, kernel_size=ks, backend=host_be)
+        assert a is not None and a.dtype == np.uint8 and np.array_equal(a, b), (off, ks, int((a != b).sum()))
+    H, W = 1024, 728
+    page, boxes, mask = synth.synth_page(3, H, W, n_boxes=32)
+    boxes = np.asarray(boxes).copy()
+    boxes[0][:, 0] = np.clip(boxes[0][:, 0] + (W - boxes[0][:, 0].max()), 0, W)     # one line flush with the right border
+    boxes[1][:, 1] = np.clip(boxes[1][:, 1] + (H - boxes[1][:, 1].max()), 0, H)     # one flush with the bottom
+    rng = np.random.default_rng(5)
+    raw = np.zeros((H, W), np.uint8)
+    for q in boxes:                                                                   # glyph-like blobs inside every line box
+        x0, y0, x1, y1 = int(q[:, 0].min()), int(q[:, 1].min()), int(q[:, 0].max()), int(q[:, 1].max())
+        for _ in range(max((x1 - x0) * (y1 - y0) // 300, 6)):
+            sx, sy = int(rng.integers(x0, max(x1 - 6, x0 + 1))), int(rng.integers(y0, max(y1 - 8, y0 + 1)))
+            raw[sy:sy + int(rng.integers(3, 9)), sx:sx + int(rng.integers(2, 7))] = 255
+    region = type("Region", (), {"lines": boxes.astype(np.int64)})()
+    for off in (0, 20):
+        d1 = MR.dispatch_sync([region], page, raw.copy(), dilation_offset=off, backend=dev_be)
+        d2 = MR.dispatch_sync([region], page, raw.copy(), dilation_offset=off, backend=host_be)
+        assert d1.shape == (H, W) and set(np.unique(d1)) <= {0, 255} and d1.any() and np.array_equal(d1, d2), int((d1 != d2).sum())
