@@ -89,6 +89,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--no-coupled", action="store_true", help="skip the coupled (glue-inclusive) secondary measurement")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-MFMA sub-measurement (fp32_mfma) taken beside a split-mode headline")
     ap.add_argument("--fp32-steps", type=int, default=3, help="timed steps of the fp32_mfma sub-measurement (after 1 warm-up step)")
     ap.add_argument("--cpu-pages", type=int, default=3, help="timed pages of the CPU baseline (after 1 warm-up page)")
@@ -450,6 +451,133 @@ def dropin_leg(weights, host_inputs, n_pages, device_str="cuda"):
                      "representative of real pages; OCR gets the generator's 32 lines, the inpainter the generator's mask")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the coupled path: every stage consumes what the previous one produced, host glue included (manga_translator.py:432-622)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _coupled_inputs(n_pages, distinct, device):
+    """Pages for the coupled path: the generator's text boxes kept apart from each other (synth_page(disjoint=True)) — a detector cannot
+    separate the overlapping boxes of the headline pages, which are fed to the stages as ground-truth quads instead."""
+    from manga_image_translator_amd import synth
+
+    distinct = max(1, min(distinct, n_pages))
+    gen = [synth.synth_page(i, H, W, n_boxes=N_BOXES, disjoint=True) for i in range(distinct)]
+    idx = [i % distinct for i in range(n_pages)]
+    pages_dev = torch.from_numpy(np.stack([gen[i][0] for i in idx])).to(device)
+    return pages_dev, ([g[0] for g in gen], [g[1] for g in gen], [g[2] for g in gen]), idx
+
+
+def _injection(host_inputs, idx, device, map_hw):
+    """Per-page maps a trained ctd head would emit for the synthetic pages (coupled.synthetic_head_outputs): random-init weights fire
+    on nothing, so the coupled path would otherwise time empty glue.  The network still runs in full; the maps are max-ed over its output."""
+    from manga_image_translator_amd import coupled
+
+    pages, quads, _ = host_inputs
+    per = [coupled.synthetic_head_outputs(pages[g], quads[g], map_hw) for g in range(len(pages))]
+    prob = torch.from_numpy(np.stack([per[g][0] for g in idx])).to(device)
+    mask = torch.from_numpy(np.stack([per[g][1] for g in idx])).to(device)
+    return {"prob": prob, "mask": mask}
+
+
+def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4):
+    """(1) batch: coupled.CoupledPageEngine over the same resident pages as the headline — detector -> native box extraction on a host
+    thread pool -> GPU refine_mask -> OCR of the DETECTED lines -> text-line merge -> mask refinement (bilateral + DenseCRF + dilations
+    on the GPU) -> LaMa with the REFINED mask; (2) B = 1: the same chain through the plugins, page by page, host copies included."""
+    import asyncio
+    import warnings
+
+    from manga_image_translator_amd import coupled, ctd as CTD, mask_refinement as MR, plugins as P, textline_merge as TM
+
+    pages_dev, host_inputs, idx = _coupled_inputs(n_pages, distinct, device)
+    dict_size = weights["ocr48"]["embd.weight"].shape[0]
+    dictionary = ["<PAD>", "<S>", "</S>", "<SP>"] + [chr(0x4E00 + i) for i in range(dict_size - 4)]
+    nh, nw, dw, dh = CTD.CtdEngine.letterbox_geometry(H, W)
+    map_hw = (CTD.INPUT_SIZE - dh, CTD.INPUT_SIZE - dw)
+    inj = _injection(host_inputs, idx, device, map_hw)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)   # log(prob) of random-weight recognitions underflows in the region statistics
+        eng = coupled.CoupledPageEngine(weights, dictionary, device=device)
+        res = eng.run(pages_dev, max_seq_length=DECODE_STEPS, suppress_eos=True, prob_threshold=0.0, inject=inj)   # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        phases = {}
+        for _ in range(steps):
+            res = eng.run(pages_dev, max_seq_length=DECODE_STEPS, suppress_eos=True, prob_threshold=0.0, inject=inj)
+            for k, v in res.seconds.items():
+                phases[k] = phases.get(k, 0.0) + v
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        n = pages_dev.shape[0]
+        found = [len(t) for t in res.textlines]
+        out["batch"] = dict(value=round(n / dt, 3), unit="pages/s", pages=n, steps=steps, ms_per_page=round(dt / n * 1e3, 2),
+                            host_ms_per_page_by_phase={k: round(v / steps / n * 1e3, 2) for k, v in phases.items()},
+                            lines_per_page_after_ocr={"min": min(found), "mean": round(float(np.mean(found)), 1), "max": max(found)},
+                            text_regions_per_page=round(float(np.mean([len(r) for r in res.regions])), 1),
+                            refined_mask_coverage=round(float((res.mask > 0).float().mean()), 4),
+                            note="host phases overlap the GPU work queued before them; the last phase only enqueues LaMa")
+        eng.close()
+        del eng, res
+        torch.cuda.empty_cache()
+
+        # ---- B = 1 through the plugins ----
+        pages, quads, _ = host_inputs
+        run = asyncio.new_event_loop().run_until_complete
+        det = P.HipComicTextDetector(weights=weights)
+        ocr = P.HipModel48pxOCR(weights=weights["ocr48"], dictionary=dictionary)
+        inp = P.HipLamaMPEInpainter(weights=weights)
+        for p in (det, ocr, inp):
+            run(p.load("cuda"))
+        cur = {"g": 0}
+        plain_forward = det.engine.forward
+
+        def forward_with_trained_head(pages_u8, taps=None):   # the network runs in full; a trained head's maps are max-ed over its output
+            m, lines, pad = plain_forward(pages_u8, taps)
+            k = idx.index(cur["g"])
+            lines[:, 0] = torch.maximum(lines[:, 0], inj["prob"][k:k + 1])
+            return torch.maximum(m, inj["mask"][k:k + 1]), lines, pad
+
+        det.engine.forward = forward_with_trained_head
+
+        class Cfg:
+            prob = 0.0
+
+        per = {k: [] for k in ("detect", "ocr", "textline_merge", "mask_refinement", "inpaint")}
+        n_found = []
+        distinct = sorted(set(idx))[:b1_pages]
+        for it, g in enumerate([distinct[0]] + distinct):   # the first page twice: the first call is the warm-up
+            cur["g"] = g
+            page = pages[g]
+            torch.cuda.synchronize()
+            t = [time.perf_counter()]
+            tls, mask_raw, _ = run(det.infer(page, 1024, 0.5, 0.7, 2.3))
+            t.append(time.perf_counter())
+            lines = run(ocr.infer(page, tls, Cfg(), False, 0, DECODE_STEPS, True))
+            lines = [l for l in lines if l.text.strip()]
+            t.append(time.perf_counter())
+            regions = TM.dispatch_sync(lines, W, H)
+            t.append(time.perf_counter())
+            mask = MR.dispatch_sync(regions, page, mask_raw, "fit_text", 20, 0, False, 3)
+            t.append(time.perf_counter())
+            run(inp.infer(page, mask, None, max(H, W)))
+            torch.cuda.synchronize()
+            t.append(time.perf_counter())
+            if it:
+                for k, (a, b) in zip(per, zip(t, t[1:])):
+                    per[k].append(b - a)
+                n_found.append(len(tls))
+        for p in (det, ocr, inp):
+            run(p.unload())
+        ms = {k: round(1e3 * float(np.mean(v)), 2) for k, v in per.items()}
+        tot = sum(ms.values())
+        out["b1_plugins"] = dict(value=round(1e3 / tot, 3), unit="pages/s", pages=len(distinct), ms_per_page=round(tot, 2), ms_per_stage=ms,
+                                 detector_boxes_found_per_page=n_found)
+    out["order"] = "detect -> boxes -> refine_mask -> OCR (detected lines) -> textline merge -> mask refinement (dilation offset 20, kernel 3) -> inpaint (manga_translator.py:432-622)"
+    out["detector_head"] = ("random-init weights fire on nothing: the maps a trained head would emit for the synthetic page (DB shrink map 0.9 inside the "
+                            "shrunk text boxes, glyph mask) are max-ed over the network's output after it has run in full (coupled.synthetic_head_outputs)")
+    return out
+
+
 def main():
     args = parse()
     from manga_image_translator_amd import dist as D
@@ -572,10 +700,15 @@ def main():
         if r is not None:
             cpu, oracle_out = r
             parity = leg("parity_checked", lambda: parity_leg(res, idx, oracle_out, stages))
+    coupled = None
     if not args.no_dropin and rank == 0 and world == 1 and set(stages) == {"detect", "ocr", "inpaint"}:
         del engine
         torch.cuda.empty_cache()
         dropin = leg("dropin", lambda: dropin_leg(weights, host_inputs, args.dropin_pages))
+        if not args.no_coupled:
+            del pages, masks
+            torch.cuda.empty_cache()
+            coupled = leg("coupled", lambda: coupled_leg(weights, args.pages, args.distinct, device))
     D.barrier()
 
     if rank == 0:
@@ -594,7 +727,8 @@ def main():
                        "streams": 2 if args.overlap else 1,
                        "parallelism": f"pages sharded one contiguous block per GPU x{world}; RCCL weight broadcast"
                                       + (f" + per-step gather of {gathered['bytes']} result bytes to rank 0" if world > 1 else "")},
-            "roofline": roof, "fp32_mfma": fp32, "cpu_baseline": cpu, "parity_checked": parity, "dropin": dropin, "conv_gemm_by_tile": per_cfg,
+            "roofline": roof, "fp32_mfma": fp32, "cpu_baseline": cpu, "parity_checked": parity, "dropin": dropin, "coupled": coupled,
+            "conv_gemm_by_tile": per_cfg,
         }
         if shipped_mode:  # say so wherever the number travels
             n = shipped_mode

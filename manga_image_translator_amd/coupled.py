@@ -1,0 +1,193 @@
+"""The COUPLED page path: detector -> boxes -> refine_mask -> OCR -> text-line merge -> mask refinement -> inpainting, for a batch
+of pages, in the order and with the arguments the reference's orchestrator uses for one page
+(/root/reference/manga_translator/manga_translator.py:432-622: ``_run_detection`` :1208, ``_run_ocr`` :745,
+``_run_textline_merge`` :772, ``_run_mask_refinement`` :1356-1358 with ``mask_dilation_offset`` = 20 and ``kernel_size`` = 3
+(config.py:342-344), ``_run_inpainting`` :1360-1364).
+
+``pipeline.PageEngine`` times the three dense stages fed independently; here each stage consumes what the previous one
+produced, so the glue between them — box extraction (a4), the detector's ``refine_mask`` (a5), the merge graph (f3), the mask
+refinement with its DenseCRF (f1) — is inside the measured path.  Dense work runs batched on the GPU; the per-page host steps
+(contours -> boxes in native C++, direction vote, merge graph, component labelling) run on a thread pool (ctypes / numpy / scipy
+release the GIL) while the stream keeps executing.
+
+Random-init networks fire on nothing, so a benchmark passes ``inject``: per-page maps a trained head would have produced for the
+synthetic page (``synthetic_head_outputs``); they are max-ed into the network's own outputs AFTER the network has run (its cost is
+paid in full) — a stand-in for trained weights, never part of the product path (the plugins do not know about it).
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ctd, hostglue, imgproc, lama, mask_refinement as MR, ocr48, textline_merge as TM
+from .textline import Quadrilateral
+
+BOX_THRESH = 0.6          # ctd.py:157-159
+MASK_DILATION_OFFSET = 20  # config.py:344
+KERNEL_SIZE = 3            # config.py:342
+
+
+@dataclass
+class CoupledResult:
+    textlines: List[List[Quadrilateral]]      # per page: the detector's lines with OCR text / prob / colours set
+    regions: List[list]                        # per page: TextBlocks of the merge
+    mask: torch.Tensor                         # u8 [B,H,W] final inpainting mask (device)
+    inpainted: torch.Tensor                    # u8 [B,H,W,3] (device)
+    seconds: Dict[str, float] = field(default_factory=dict)   # host wall time per phase (the GPU runs asynchronously underneath)
+
+
+def synthetic_head_outputs(page: np.ndarray, quads: np.ndarray, map_hw, shrink_ratio: float = 0.4, unclip_ratio: float = 1.5):
+    """What a TRAINED ctd head would emit for a synthetic page (benchmark stand-in for weights, see the module docstring):
+    * the DB shrink map [h, w] float32: 0.9 inside every text box shrunk so that SegDetectorRepresenter's unclip
+      (distance = area * 1.5 / perimeter, db_utils.py:150-155) grows it back to the box — d solves d * 2(w + h - 4d) = 1.5 (w - 2d)(h - 2d);
+    * the text mask [h, w] uint8: 255 on the dark (glyph) pixels inside the boxes.
+    ``map_hw`` = the network's un-padded output size (page / 2 for a 2048 x 1456 page)."""
+    H, W = page.shape[:2]
+    h, w = map_hw
+    sy, sx = h / H, w / W
+    prob = np.zeros((h, w), np.float32)
+    box = np.zeros((H, W), bool)
+    for q in np.asarray(quads):
+        x0, y0, x1, y1 = q[:, 0].min() * sx, q[:, 1].min() * sy, q[:, 0].max() * sx, q[:, 1].max() * sy
+        bw, bh = x1 - x0, y1 - y0
+        S = bw + bh
+        disc = 25 * S * S - 84 * bw * bh
+        d = (5 * S - math.sqrt(max(disc, 0.0))) / 28 if bw > 0 and bh > 0 else 0.0
+        d = min(d, 0.45 * min(bw, bh))
+        ya, yb, xa, xb = int(round(y0 + d)), int(round(y1 - d)), int(round(x0 + d)), int(round(x1 - d))
+        if yb > ya and xb > xa:
+            prob[ya:yb, xa:xb] = 0.9
+        box[int(q[:, 1].min()):int(q[:, 1].max()), int(q[:, 0].min()):int(q[:, 0].max())] = True
+    glyph = ((page.min(-1) < 128) & box).astype(np.uint8) * 255
+    mask = imgproc.resize_u8_host(glyph, (w, h))
+    mask[mask > 0] = 255
+    return prob, mask
+
+
+class CoupledPageEngine:
+    """Owns the stage engines of one GPU and a host thread pool."""
+
+    def __init__(self, weights: Dict[str, Dict[str, torch.Tensor]], dictionary: Sequence[str], device="cuda", lama_blocks: int = 9,
+                 ctd_mb: int = 16, lama_mb: int = 16, host_workers: int = 16):
+        self.device = torch.device(device)
+        self.dictionary = list(dictionary)
+        self.ctd = ctd.CtdEngine(weights["ctd.yolo"], weights["ctd.seg"], weights["ctd.det"], device=self.device)
+        self.ocr = ocr48.Ocr48Engine(weights["ocr48"], len(self.dictionary), device=self.device)
+        self.lama = lama.LamaEngine(weights["lama.gen"], weights.get("lama.mpe"), n_blocks=lama_blocks, device=self.device)
+        self.mask_backend = MR.GpuMaskBackend(self.device)
+        self.ctd_mb, self.lama_mb = ctd_mb, lama_mb
+        self.pool = cf.ThreadPoolExecutor(max_workers=host_workers, thread_name_prefix="mit-host")
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+    # ---- stage 1: detector network + boxes (host pool) + mask resize + refine_mask ------------------------------------------
+    @torch.no_grad()
+    def detect(self, pages_u8: torch.Tensor, inject=None):
+        """-> (textlines per page, refined mask u8 [B,H,W] on the device): ComicTextDetector._infer (ctd.py:129-179) for a batch."""
+        B, H, W, _ = pages_u8.shape
+        futures: List[Optional[cf.Future]] = [None] * B
+        mask_full = torch.empty(B, H, W, dtype=torch.uint8, device=self.device)
+        keep = []
+        for i in range(0, B, self.ctd_mb):
+            j = min(B, i + self.ctd_mb)
+            mask_u8, lines, _ = self.ctd.forward(pages_u8[i:j])
+            if inject is not None:   # benchmark stand-in for trained weights: the maps a trained head would emit, over the network's own
+                lines[:, 0] = torch.maximum(lines[:, 0], inject["prob"][i:j])
+                mask_u8 = torch.maximum(mask_u8, inject["mask"][i:j])
+            host = torch.empty(lines.shape, dtype=torch.float32, pin_memory=True)   # [b,2,h,w]: box_score_fast needs the float map
+            host.copy_(lines, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            mask_full[i:j] = imgproc.resize_u8(mask_u8.contiguous(), (W, H))          # cv2.resize(mask, (w, h), INTER_LINEAR) (ctd.py:162)
+            keep.append(host)
+            for b in range(i, j):
+                futures[b] = self.pool.submit(self._boxes_of_page, host, b - i, ev, H, W)
+        textlines = [f.result() for f in futures]
+        refined = torch.empty_like(mask_full)
+        for b in range(B):  # refine_mask(img, mask, textlines) (ctd.py:177): batched over the page's lines on the device
+            refined[b] = hostglue.refine_mask_gpu(pages_u8[b], mask_full[b], textlines[b], None)
+        return textlines, refined
+
+    @staticmethod
+    def _boxes_of_page(host_lines: torch.Tensor, k: int, ev, H: int, W: int) -> List[Quadrilateral]:
+        ev.synchronize()
+        boxes, scores = hostglue.ctd_boxes(host_lines[k:k + 1].numpy(), H, W)    # SegDetectorRepresenter (db_utils.py:40-216), native C++
+        keep = scores > BOX_THRESH
+        return [Quadrilateral(pts.astype(np.int64), "", float(s)) for pts, s in zip(boxes[keep], scores[keep])]
+
+    # ---- stage 2: OCR ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def recognize(self, pages_u8: torch.Tensor, textlines: List[List[Quadrilateral]], max_seq_length: int, suppress_eos: bool,
+                  prob_threshold: float):
+        """Model48pxOCR._infer (model_48px.py:67-180) for a batch: direction vote per page (host pool), rectification + recognition
+        + one pooled beam search on the GPU, text / probability / colours written back into the lines; lines under the threshold dropped."""
+        from . import plugins as P, textline as TL
+
+        def vote(lines):
+            return list(TL.generate_text_direction(lines))
+
+        pairs = list(self.pool.map(vote, textlines))
+        quads = [[q for q, _ in pr] for pr in pairs]
+        dirs = [[d for _, d in pr] for pr in pairs]
+        r = self.ocr.recognize_pages(pages_u8, quads, max_seq_length=max_seq_length, suppress_eos=suppress_eos, directions=dirs)
+        out: List[List[Quadrilateral]] = [[] for _ in textlines]
+        if not r["order"]:
+            return out
+        toks, lens = r["tokens"].cpu().numpy(), r["length"].cpu().numpy()
+        probs, cols = r["prob"].cpu().numpy(), r["colors"].cpu().numpy()
+        for row, (p, i) in enumerate(r["order"]):
+            q, prob = quads[p][i], float(probs[row])
+            q.assigned_direction = dirs[p][i]
+            if prob < prob_threshold:
+                continue
+            n = int(lens[row]) - 1
+            q.text, (q.fg_r, q.fg_g, q.fg_b), (q.bg_r, q.bg_g, q.bg_b) = P.decode_line(toks[row, 1:1 + n], cols[row, :n], self.dictionary)
+            q.prob = prob
+            if q.text.strip():                   # manga_translator.py:762-770: lines without text are dropped after OCR
+                out[p].append(q)
+        return out
+
+    # ---- stages 3 + 4: text-line merge, mask refinement -------------------------------------------------------------------
+    def merge_and_refine(self, pages_u8: torch.Tensor, textlines: List[List[Quadrilateral]], mask_raw: torch.Tensor):
+        B, H, W, _ = pages_u8.shape
+        regions = list(self.pool.map(lambda ls: TM.dispatch_sync(ls, W, H) if ls else [], textlines))
+        final = torch.zeros(B, H, W, dtype=torch.uint8, device=self.device)
+        for b in range(B):
+            if not regions[b]:
+                continue     # no text: the orchestrator returns the page as it is (manga_translator.py:500-504)
+            m = MR.dispatch_device(regions[b], pages_u8[b], mask_raw[b], dilation_offset=MASK_DILATION_OFFSET, kernel_size=KERNEL_SIZE,
+                                   backend=self.mask_backend)
+            final[b] = m
+        return regions, final
+
+    # ---- the whole path -----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def run(self, pages_u8: torch.Tensor, max_seq_length: int = 255, suppress_eos: bool = False, prob_threshold: float = 0.2,
+            inject=None) -> CoupledResult:
+        if pages_u8.dtype != torch.uint8 or pages_u8.dim() != 4 or pages_u8.shape[-1] != 3 or not pages_u8.is_cuda:
+            raise ValueError(f"CoupledPageEngine.run expects a uint8 device tensor [B,H,W,3], got {pages_u8.dtype} {tuple(pages_u8.shape)}")
+        B = pages_u8.shape[0]
+        sec = {}
+        t = time.perf_counter()
+        textlines, mask_raw = self.detect(pages_u8, inject)
+        sec["detect+boxes+refine_mask"] = time.perf_counter() - t
+        t = time.perf_counter()
+        textlines = self.recognize(pages_u8, textlines, max_seq_length, suppress_eos, prob_threshold)
+        sec["ocr"] = time.perf_counter() - t
+        t = time.perf_counter()
+        regions, mask = self.merge_and_refine(pages_u8, textlines, mask_raw)
+        sec["textline_merge+mask_refinement"] = time.perf_counter() - t
+        t = time.perf_counter()
+        inpainted = torch.empty_like(pages_u8)
+        for i in range(0, B, self.lama_mb):
+            j = min(B, i + self.lama_mb)
+            inpainted[i:j].copy_(self.lama.forward(pages_u8[i:j], mask[i:j]))
+        sec["inpaint (enqueue)"] = time.perf_counter() - t
+        return CoupledResult(textlines, regions, mask, inpainted, sec)

@@ -31,8 +31,8 @@ struct Ws {
 // (R / 64) x (320 / 64) = 15 workgroups that each walk all 128 K-tiles — 45 us of a 256-CU chip for 0.2 GFLOP.  Up to SPLITK_MAX_M
 // rows such a GEMM is cut along K into slices of SPLITK_SLICE, computed as batch entries of ONE launch into a partial buffer
 // [S][M][Np], and summed in slice order by splitk_reduce_kernel, which applies the epilogue.  Deterministic; the sum order differs
-// from the k-sequential chain of the single-launch form (fp32 rounding only), so results of a decode with more rows than
-// SPLITK_MAX_M (a pooled beam search over > 409 lines) differ from a smaller one in the last bits of the logits.
+// from the k-sequential chain of the single-launch form (fp32 rounding only) — which is why it is an opt-in experiment
+// (MIT_OCR_SPLITK=1, see gemm()): measured 44 -> 50 ms per page of the B = 1 OCR call without it.
 constexpr int SPLITK_MAX_M = 2048, SPLITK_MIN_K = 1024, SPLITK_SLICE = 128;
 
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -111,8 +111,11 @@ int gemm(const MitLinear &lin, const float *A, int64_t lda, float *Cp, int64_t l
     d.ntaps = 1; d.pad_mode = MIT_PAD_ZERO;
     d.w = lin.w; d.ldw = lin.ldw; d.Nw = lin.Np;
     d.N = lin.N;
-    static const bool splitk_off = getenv("MIT_OCR_NO_SPLITK") != nullptr;  // A/B knob for scripts/
-    if (part && !splitk_off && M <= SPLITK_MAX_M && lin.K >= SPLITK_MIN_K && lin.K % SPLITK_SLICE == 0 && lin.Kp == lin.K && !nsplit &&
+    // Opt-in (MIT_OCR_SPLITK=1): the slice-wise sum is deterministic but rounds differently from the k-sequential chain of the
+    // single-launch form, and with it a page decoded alone would no longer give bit for bit the logits it gives inside a batch — beam
+    // search turns such last-bit differences into different tokens whenever two hypotheses score within them.  Off by default.
+    static const bool splitk_on = getenv("MIT_OCR_SPLITK") != nullptr && atoi(getenv("MIT_OCR_SPLITK")) != 0;
+    if (part && splitk_on && M <= SPLITK_MAX_M && lin.K >= SPLITK_MIN_K && lin.K % SPLITK_SLICE == 0 && lin.Kp == lin.K && !nsplit &&
         (lin.N & 3) == 0 && (act == MIT_ACT_NONE || act == MIT_ACT_RELU) && !(ldc & 3) && !(ldpost & 3)) {
         const int S = lin.K / SPLITK_SLICE;
         d.Cin = SPLITK_SLICE; d.Kw = SPLITK_SLICE;

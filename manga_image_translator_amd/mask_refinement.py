@@ -365,8 +365,12 @@ def bubble_filter(final_mask: np.ndarray, raw_image: np.ndarray, ignore_bubble: 
 
 def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, method: str = "fit_text", dilation_offset: int = 0,
                   ignore_bubble: int = 0, verbose: bool = False, kernel_size: int = 3, refine: Optional[RefineFn] = None,
-                  bilateral: Optional[BilateralFn] = None, backend=None) -> np.ndarray:
-    """mask_refinement.dispatch (:9-50) for ``method='fit_text'``; ``ignore_bubble`` in 1..50 adds the bubble stage (``bubble_filter``)."""
+                  bilateral: Optional[BilateralFn] = None, backend=None, device_result: bool = False) -> np.ndarray:
+    """mask_refinement.dispatch (:9-50) for ``method='fit_text'``; ``ignore_bubble`` in 1..50 adds the bubble stage (``bubble_filter``).
+    With the GPU backend ``raw_image`` / ``raw_mask`` may be device tensors (a batch engine keeps pages and masks resident), and
+    ``device_result`` returns the final mask as a device tensor (no bubble stage then: it needs the page on the host)."""
+    if device_result and 1 <= ignore_bubble <= 50:
+        raise NotImplementedError("mask refinement: the --ignore-bubble stage runs on the host (device_result=False)")
     if method != "fit_text":
         raise NotImplementedError("mask refinement: only method='fit_text' is native (the reference's 'fill' path references an unset variable)")
     h, w = raw_image.shape[:2]
@@ -385,7 +389,14 @@ def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, met
         final = be.resize_mask(final, (w, h)).copy()
         final[final > 0] = 255
     else:  # device tensor from the GPU tail: resize and binarise there, one download
-        final = be.resize_binarize(final, (w, h)).cpu().numpy()
+        final = be.resize_binarize(final, (w, h))
+        if device_result:
+            return final
+        final = final.cpu().numpy()
+    if device_result:
+        import torch
+
+        return torch.from_numpy(final).to(be.device)
     if 1 <= ignore_bubble <= 50:
         final = bubble_filter(final, np.asarray(raw_image), ignore_bubble)
     return final
@@ -394,3 +405,10 @@ def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, met
 async def dispatch(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, method: str = "fit_text", dilation_offset: int = 0,
                    ignore_bubble: int = 0, verbose: bool = False, kernel_size: int = 3, **kw) -> np.ndarray:
     return dispatch_sync(text_regions, raw_image, raw_mask, method, dilation_offset, ignore_bubble, verbose, kernel_size, **kw)
+
+
+def dispatch_device(text_regions, page_dev, mask_dev, dilation_offset: int = 0, kernel_size: int = 3, backend=None):
+    """``dispatch`` for a device-resident page (u8 [H,W,3]) and raw mask (u8 [H,W]); returns the refined mask on the device.  Only the
+    down-scaled raw mask (for the component labelling) and the per-line component crops cross PCIe."""
+    return dispatch_sync(text_regions, page_dev, mask_dev, "fit_text", dilation_offset, 0, False, kernel_size, backend=backend or default_backend(),
+                         device_result=True)

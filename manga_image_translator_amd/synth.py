@@ -108,8 +108,11 @@ def bn_entries(prefix: str, c: int, wmul: str = "") -> Schema:
 # and the dilated boxes are the inpainting mask.
 # ---------------------------------------------------------------------------------------
 
-def synth_page(index: int, height: int = 2048, width: int = 1456, n_boxes: int = 32, seed: int = 1234):
-    """Returns (page u8 [H,W,3] RGB, quads int64 [n_boxes,4,2] (x,y), mask u8 [H,W] in {0,255})."""
+def synth_page(index: int, height: int = 2048, width: int = 1456, n_boxes: int = 32, seed: int = 1234, disjoint: bool = False):
+    """Returns (page u8 [H,W,3] RGB, quads int64 [n_boxes,4,2] (x,y), mask u8 [H,W] in {0,255}).
+    ``disjoint``: text boxes keep 24 px (at 2048 x 1456) apart from each other, like speech bubbles on a real page — what a detector
+    needs to tell them apart (the coupled benchmark); the default places them independently (the stages are then fed the generator's
+    own quads)."""
     rng = np.random.default_rng(seed + index)
     page = np.clip(rng.normal(245.0, 5.0, size=(height, width, 1)), 0, 255).astype(np.uint8).repeat(3, axis=2)
     # panel borders
@@ -138,6 +141,14 @@ def synth_page(index: int, height: int = 2048, width: int = 1456, n_boxes: int =
         bw, bh = max(bw, 8), max(bh, 8)
         x0 = int(rng.integers(8, max(9, width - bw - 8)))
         y0 = int(rng.integers(8, max(9, height - bh - 8)))
+        if disjoint:
+            gap = max(int(24 * min(sh, sw)), 2)
+            for _ in range(400):   # rejection sampling against the boxes placed so far
+                prev = quads[:b]
+                if not np.any((prev[:, 0, 0] - gap < x0 + bw) & (prev[:, 2, 0] + gap > x0) & (prev[:, 0, 1] - gap < y0 + bh) & (prev[:, 2, 1] + gap > y0)):
+                    break
+                x0 = int(rng.integers(8, max(9, width - bw - 8)))
+                y0 = int(rng.integers(8, max(9, height - bh - 8)))
         page[y0:y0 + bh, x0:x0 + bw] = 250
         # glyph-like blobs on a 1.2x pitch, 70 % density
         g = int(rng.integers(3, 8))

@@ -246,7 +246,7 @@ int main(int argc, char **argv) {
                    dmax / ymax, (long long)nan, ok ? "ok" : "FAIL", ms_ref / ms);
             bad += !ok;
         }
-        if (ablate && (strstr(cs.name, "pw1") || strstr(cs.name, "3x3 reflect"))) {
+        if (ablate && (strstr(cs.name, "pw1") || strstr(cs.name, "3x3 reflect") || strstr(cs.name, "pw2"))) {
             for (const char *nm : {"split128x128x16p6", "split128x128x16p6s", "xsAsmSub", "xsAsmSubNP", "xsNoLoad", "xsNoSplit", "xsNoWrite", "xsNoFrag", "xsNoBar",
                                    "xsMfmaOnly", "xsNoLoadNP", "xsNoWriteNP", "xsNoFragNP", "xsNoLoadWriteNP", "xsMfmaOnlyNP"}) {
                 const int cfg = find_cfg(nm);
