@@ -78,12 +78,17 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pages", type=int, default=64, help="pages per GPU per step (BASELINE config 3: 64)")
     ap.add_argument("--config4", action="store_true", help="BASELINE config 4 preset: 128 pages per GPU (1024 pages over 8 GPUs)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5 on one GPU: ESRGAN 4x + lama_large (its own line)")
+    ap.add_argument("--config1", action="store_true", help="BASELINE config 1 on one GPU: default detector + 48px + lama_mpe at 1024^2, B = 1 (its own line)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pages (global page g shows page g %% distinct)")
     ap.add_argument("--stages", default="detect,ocr,inpaint")
     ap.add_argument("--lama-mb", type=int, default=16)
     ap.add_argument("--ctd-mb", type=int, default=16)
     ap.add_argument("--group", type=int, default=16)
-    ap.add_argument("--overlap", action="store_true", help="two streams: detector + OCR beside LaMa (+8 %% pages/s; per-kernel roofline numbers then include the stretch of concurrent kernels)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="one HIP stream instead of two (default: LaMa on the caller's stream, detector + OCR on a side stream that joins at the end of the "
+                         "step, +4 %% pages/s; the roofline legs run one stage at a time on one stream either way, so per-kernel times are never of overlapped kernels)")
+    ap.set_defaults(overlap=True)
     ap.add_argument("--mode", choices=["batch", "dropin"], default="batch", help="dropin: time the plugin path (B = 1) and print its line instead of the headline")
     ap.add_argument("--dropin-pages", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,6 +136,17 @@ def _pmc_traffic():
         return None, {}
     try:
         return os.path.relpath(files[-1], ROOT), json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None, {}
+
+
+def _mfma_busy():
+    """Newest committed MFMA-busy summary (scripts/pmc_mfma.sh): stage -> fraction of matrix-pipe cycles used (PMC)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy.json")))
+    if not files:
+        return None, {}
+    try:
+        return os.path.relpath(files[-1], ROOT), json.load(open(files[-1])).get("stages", {})
     except (OSError, ValueError):
         return None, {}
 
@@ -244,6 +260,10 @@ def roofline_leg(engine, pages, quads, masks, stages, dump=""):
         if t is not None:
             e["pmc_traffic"] = t
         hbm[name] = e
+    busy_src, busy = _mfma_busy()
+    for sname, key in (("ctd", "detect"), ("ocr48", "ocr"), ("lama_mpe", "inpaint")):
+        if sname in per_stage and key in busy:   # PMC view of the same stage (counters-only pass of scripts/pmc_mfma.sh, committed under profiles/)
+            per_stage[sname]["mfma_busy"] = dict(frac=busy[key].get("mfma_busy"), effective_clock_GHz=busy[key].get("effective_clock_GHz"), source=busy_src)
     total_exec = sum(v[2] for v in conv_tot.values())
     total_wall = sum(s["ms_per_page"] for s in per_stage.values()) * n
     total_peak_ms = sum(s.pop("_peak_ms") for s in per_stage.values())
@@ -469,7 +489,7 @@ def _coupled_inputs(n_pages, distinct, device):
 
 def _injection(host_inputs, idx, device, map_hw):
     """Per-page maps a trained ctd head would emit for the synthetic pages (coupled.synthetic_head_outputs): random-init weights fire
-    on nothing, so the coupled path would otherwise time empty glue.  The network still runs in full; the maps are max-ed over its output."""
+    on nothing, so the coupled path would otherwise time empty glue.  The network still runs in full; the maps replace its (random) output."""
     from manga_image_translator_amd import coupled
 
     pages, quads, _ = host_inputs
@@ -531,11 +551,11 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4):
         cur = {"g": 0}
         plain_forward = det.engine.forward
 
-        def forward_with_trained_head(pages_u8, taps=None):   # the network runs in full; a trained head's maps are max-ed over its output
+        def forward_with_trained_head(pages_u8, taps=None):   # the network runs in full; a trained head's maps replace its random output
             m, lines, pad = plain_forward(pages_u8, taps)
             k = idx.index(cur["g"])
-            lines[:, 0] = torch.maximum(lines[:, 0], inj["prob"][k:k + 1])
-            return torch.maximum(m, inj["mask"][k:k + 1]), lines, pad
+            lines[:, 0] = inj["prob"][k:k + 1]
+            return inj["mask"][k:k + 1], lines, pad
 
         det.engine.forward = forward_with_trained_head
 
@@ -574,8 +594,147 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4):
                                  detector_boxes_found_per_page=n_found)
     out["order"] = "detect -> boxes -> refine_mask -> OCR (detected lines) -> textline merge -> mask refinement (dilation offset 20, kernel 3) -> inpaint (manga_translator.py:432-622)"
     out["detector_head"] = ("random-init weights fire on nothing: the maps a trained head would emit for the synthetic page (DB shrink map 0.9 inside the "
-                            "shrunk text boxes, glyph mask) are max-ed over the network's output after it has run in full (coupled.synthetic_head_outputs)")
+                            "shrunk text boxes, glyph mask) are put in place of the network's output after it has run in full (coupled.synthetic_head_outputs)")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# presets for the other BASELINE configurations (one GPU; secondary lines, not the headline)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _probe_pass(fn):
+    """Run ``fn`` once under the C-ABI launch probe: (wall ms, executed conv FLOPs, ms at the MFMA peak of the pipes used)."""
+    from manga_image_translator_amd import lib as L
+
+    lib = L.load()
+    torch.cuda.synchronize()
+    L.check(lib.mit_prof_enable(1), "mit_prof_enable")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    stats = (L.MitProfStat * 64)()
+    ncfg = C.c_int(0)
+    L.check(lib.mit_prof_read(stats, 64, C.byref(ncfg)), "mit_prof_read")
+    L.check(lib.mit_prof_enable(0), "mit_prof_enable")
+    ex = peak_ms = 0.0
+    tiles = {}
+    for i in range(ncfg.value):
+        st = stats[i]
+        if not st.launches:
+            continue
+        name = lib.mit_conv_gemm_config_name(i).decode()
+        pairs = split_pairs(name)
+        ex += st.exec_flops
+        peak_ms += (st.exec_flops * pairs / (BF16_MATRIX_PEAK_TFLOPS * 1e9)) if pairs else (st.exec_flops / (FP32_MATRIX_PEAK_TFLOPS * 1e9))
+        tiles[name] = dict(launches=int(st.launches), ms=round(st.ms, 2), exec_tflops=round(st.exec_flops / (st.ms * 1e-3) / 1e12, 1))
+    return e0.elapsed_time(e1), ex, peak_ms, tiles
+
+
+def _stage_summary(ms, ex, peak_ms, tiles, per):
+    return dict(ms=round(ms / per, 2), conv_exec_tflops=round(ex / (ms * 1e-3) / 1e12, 1),
+                frac_of_fp32_mfma_peak=round(ex / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4), frac_of_mfma_roofline=round(peak_ms / ms, 4),
+                conv_gemm_by_tile=tiles)
+
+
+def config5_line(args, device):
+    """BASELINE config 5 on one GPU: a 2048 x 1440 page through ESRGAN 4x (-> 8192 x 5760, the tensor an --upscale-ratio 2 run resizes
+    to 4096 x 2880; upscaling/esrgan_pytorch.py:537-549) and a 2048 x 1456 page through lama_large (18 FFC blocks, no MPE;
+    inpainting_lama_mpe.py:121-136).  One step = ``--pages`` pages through both; prints its own line."""
+    from manga_image_translator_amd import esrgan, esrgan_schema, lama, lama_schema, ops as _ops, synth
+
+    n = max(1, min(args.pages, 4))
+    He, We = 2048, 1440
+    eng = esrgan.EsrganEngine(synth.synth_state_dict(esrgan_schema.rrdbnet_schema(23)), nb=23, device=device)
+    pages_e = torch.from_numpy(np.stack([synth.synth_page(i, He, We, n_boxes=16)[0] for i in range(n)])).to(device)
+    leng = lama.LamaEngine(synth.synth_state_dict(lama_schema.lama_generator_schema(18)), None, n_blocks=18, device=device)
+    gen = [synth.synth_page(i, H, W) for i in range(n)]
+    img = torch.from_numpy(np.stack([g[0] for g in gen])).to(device)
+    msk = torch.from_numpy(np.stack([g[2] for g in gen])).to(device)
+
+    def up():
+        for i in range(n):   # one page per call: the 4x output of a single page is 8192 x 5760 x 64 floats in its widest layer
+            eng.forward(pages_e[i:i + 1])
+
+    def inpaint():
+        leng.forward(img, msk)
+
+    def step():
+        up()
+        inpaint()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    stages = {"esrgan_4x": _stage_summary(*_probe_pass(up), per=n), "lama_large": _stage_summary(*_probe_pass(inpaint), per=n)}
+    stages["esrgan_4x"]["alg_tflops"] = round(eng.flops_per_input_pixel() * He * We / (stages["esrgan_4x"]["ms"] * 1e-3) / 1e12, 1)
+    stages["lama_large"]["alg_tflops"] = round(leng.flops_per_page(H, W) / (stages["lama_large"]["ms"] * 1e-3) / 1e12, 1)
+    return {"metric": "pages/sec, ESRGAN 4x upscale of a 2048x1440 page + lama_large inpainting at 2048x1456 (BASELINE config 5, one GPU)",
+            "value": round(n / dt, 4), "unit": "pages/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5: {n} pages per step, RRDBNet (nb = 23) 4x on 2048x1440 + lama_large (18 FFC blocks) on 2048x1456; "
+                                   "random-init weights of the reference architectures", "pages_per_gpu": n},
+            "gemm_mode": {"mode": _ops.split_mode()}, "stages_ms_per_page": stages,
+            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+
+
+def config1_line(args, device):
+    """BASELINE config 1 on one GPU: one 1024 x 1024 page at a time, --detector default (DBNet-R34 at detect_size 2048: the page is
+    upsampled 2x, detection/default.py:56-103) + --ocr 48px + --inpainter lama_mpe."""
+    from manga_image_translator_amd import dbnet, dbnet_schema, lama, lama_schema, ocr48, ocr_schema, ops as _ops, pipeline, synth
+
+    Hc = Wc = 1024
+    n = max(1, min(args.pages, 8))
+    det = dbnet.DbnetEngine(synth.synth_state_dict(dbnet_schema.text_detection_schema()), device=device)
+    D = pipeline.DICT_SIZE
+    ocr = ocr48.Ocr48Engine(synth.synth_state_dict(ocr_schema.ocr48_schema(D)), D, device=device)
+    leng = lama.LamaEngine(synth.synth_state_dict(lama_schema.lama_generator_schema(9)), synth.synth_state_dict(lama_schema.lama_mpe_schema()),
+                           n_blocks=9, device=device)
+    gen = [synth.synth_page(i, Hc, Wc, n_boxes=16) for i in range(n)]
+    pages = [torch.from_numpy(g[0][None]).to(device) for g in gen]
+    masks = [torch.from_numpy(g[2][None]).to(device) for g in gen]
+    quads = [pipeline.quads_from_array(g[1]) for g in gen]
+    from manga_image_translator_amd import imgproc
+
+    def detect():
+        for p in pages:   # resize_aspect_ratio to detect_size 2048 (default.py:62, imgproc.py:37-70): a 1024^2 page is upsampled 2x
+            det.forward(imgproc.resize_u8(p, (2048, 2048)))
+
+    def recognise():
+        for p, q in zip(pages, quads):
+            ocr.recognize_pages(p, [q], max_seq_length=DECODE_STEPS, suppress_eos=True)
+
+    def inpaint():
+        for p, m in zip(pages, masks):
+            leng.forward(p, m)
+
+    def step():
+        detect()
+        recognise()
+        inpaint()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    stages = {"default_dbnet": _stage_summary(*_probe_pass(detect), per=n), "ocr48": _stage_summary(*_probe_pass(recognise), per=n),
+              "lama_mpe": _stage_summary(*_probe_pass(inpaint), per=n)}
+    return {"metric": "pages/sec, one 1024x1024 page at a time: detector=default + ocr=48px + inpainter=lama_mpe (BASELINE config 1, one GPU)",
+            "value": round(n / dt, 3), "unit": "pages/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 1: {n} synthetic 1024x1024 pages per step, one page per call (B = 1), DBNet-R34 at detect_size 2048 + "
+                                   f"48px OCR (16 lines/page, {DECODE_STEPS} decode steps) + lama_mpe; random-init weights", "pages_per_gpu": n},
+            "gemm_mode": {"mode": _ops.split_mode()}, "stages_ms_per_page": stages}
 
 
 def main():
@@ -599,6 +758,11 @@ def main():
     from manga_image_translator_amd import lib as L, pipeline
 
     L.load(build_if_missing=False)
+    if args.config5 or args.config1:   # one-GPU presets of the other BASELINE configurations: their own line
+        if rank == 0:
+            print(json.dumps((config5_line if args.config5 else config1_line)(args, device)))
+        D.barrier()
+        return
     weights = pipeline.synthetic_weights() if rank == 0 else None
     weights = D.broadcast_weights(weights)          # RCCL broadcast of one flat arena at load
     pages, quads, masks, host_inputs, idx = make_inputs(args.pages, args.distinct, rank, device)

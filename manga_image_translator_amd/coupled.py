@@ -10,9 +10,10 @@ refinement with its DenseCRF (f1) — is inside the measured path.  Dense work r
 (contours -> boxes in native C++, direction vote, merge graph, component labelling) run on a thread pool (ctypes / numpy / scipy
 release the GIL) while the stream keeps executing.
 
-Random-init networks fire on nothing, so a benchmark passes ``inject``: per-page maps a trained head would have produced for the
-synthetic page (``synthetic_head_outputs``); they are max-ed into the network's own outputs AFTER the network has run (its cost is
-paid in full) — a stand-in for trained weights, never part of the product path (the plugins do not know about it).
+Random-init networks do not detect text (their sigmoid maps hover around 0.5 everywhere), so a benchmark passes ``inject``: per-page
+maps a trained head would have produced for the synthetic page (``synthetic_head_outputs``); they replace the network's own outputs
+AFTER the network has run (its cost is paid in full) — a stand-in for trained weights, never part of the product path (the plugins do
+not know about it).
 """
 from __future__ import annotations
 
@@ -98,9 +99,9 @@ class CoupledPageEngine:
         for i in range(0, B, self.ctd_mb):
             j = min(B, i + self.ctd_mb)
             mask_u8, lines, _ = self.ctd.forward(pages_u8[i:j])
-            if inject is not None:   # benchmark stand-in for trained weights: the maps a trained head would emit, over the network's own
-                lines[:, 0] = torch.maximum(lines[:, 0], inject["prob"][i:j])
-                mask_u8 = torch.maximum(mask_u8, inject["mask"][i:j])
+            if inject is not None:   # benchmark stand-in for trained weights: the maps a trained head would emit REPLACE the random-init
+                lines[:, 0] = inject["prob"][i:j]     # network's (its sigmoid output hovers around 0.5 everywhere: one page-sized blob);
+                mask_u8 = inject["mask"][i:j]         # the network has run in full by now, its cost is in the measurement
             host = torch.empty(lines.shape, dtype=torch.float32, pin_memory=True)   # [b,2,h,w]: box_score_fast needs the float map
             host.copy_(lines, non_blocking=True)
             ev = torch.cuda.Event()

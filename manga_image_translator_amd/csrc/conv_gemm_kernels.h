@@ -437,10 +437,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     constexpr int A_ITERS = BM * KQ / 256;
     constexpr int A_MSTEP = 256 / KQ;
     constexpr int NQ = BN / 4;
-    constexpr int B_ITERS = BK * NQ / 256;
+    constexpr int B_ITERS = (BK * NQ + 255) / 256;
     constexpr int B_KSTEP = 256 / NQ;
+    constexpr bool B_PARTIAL = (BK * NQ) < 256;  // BN = 32: 128 float4 chunks per K-tile, the upper half of the workgroup loads nothing
     static_assert(A_ITERS >= 1 && (BM * KQ) % 256 == 0, "A tile must fill the workgroup");
-    static_assert(B_ITERS >= 1 && (BK * NQ) % 256 == 0, "B tile must fill the workgroup");
+    static_assert(B_PARTIAL || (BK * NQ) % 256 == 0, "B tile must fill the workgroup or fit in one pass");
     constexpr int LDA = BM + (BK == 16 ? 2 : 1);
     constexpr int LDB = BN + 4;
     constexpr int A_TILE = BK * LDA;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     const int am = tid / KQ;
     const int bn4 = tid % NQ;
     const int bk = tid / NQ;
-    const bool b_ncol_ok = (n0 + bn4 * 4) < p.Nw;
+    const bool b_ncol_ok = (n0 + bn4 * 4) < p.Nw && (!B_PARTIAL || bk < BK);
     const float *__restrict__ a_thr = a_base + aq * 4;
     const float *__restrict__ w_thr = w_base + n0 + bn4 * 4;
 
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
             const int kl = bk + i * B_KSTEP;
-            *reinterpret_cast<f32x4 *>(bs + kl * LDB + bn4 * 4) = b_reg[i];
+            if (!B_PARTIAL || bk < BK) *reinterpret_cast<f32x4 *>(bs + kl * LDB + bn4 * 4) = b_reg[i];
         }
     };
     auto store_tile = [&](int buf) {
@@ -845,4 +846,3 @@ void launch_gemv(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
 }  // namespace mitcg
 
 #include "conv_gemm_split.h"  // conv_gemm_split_kernel, gemm_split_pack_kernel, launch_split (the opt-in split-bf16 tiles)
-#include "conv_gemm_persist.h"  // conv_gemm_fast_persist_kernel, launch_fast_persist (grid-strided multi-tile form; experiments only)

@@ -64,7 +64,6 @@ __device__ constexpr int kSplitPB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
 template <int BK>
 __device__ __forceinline__ constexpr int split_swz(int kh) { return kh * (32 / (BK / 4)); }
 
-constexpr int split_tpb(int var) { return (var & 1024) ? 2 : (var & 512) ? 4 : 1; }  // output tiles per workgroup of the multi-tile split tiles
 // VAR bit 1: software pipeline — the next tile's operands (loaded one iteration ahead) are split and written to the other LDS buffer
 // among this tile's MFMAs, and the loads of the tile after it are issued behind them.
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int MINW, int NPROD, int VAR = 0>
@@ -90,14 +89,8 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
                    X_NOBAR = (VAR & 32) != 0;
     constexpr bool MID = (VAR & 128) != 0;  // with PIPE: the staging cut into steps, one placed behind each MFMA (sched_barrier keeps them there)
     constexpr bool ORD = (VAR & 256) != 0;  // with MID: fragment reads issued in the order the plane pairs consume them; next row offsets fetched in step 0
-    // 512 / 1024: each workgroup computes 4 / 2 consecutive output tiles; the next tile's gather table and first K-tile loads are issued
-    // before the current tile's epilogue, so their latency hides behind its stores
-    constexpr int TPB = split_tpb(VAR);
-    // 2048: grid-strided multi-tile form: the launcher starts one workgroup per residency slot of the chip (a multiple of 8) and workgroup b
-    // takes the virtual block ids b, b + gridDim.x, ... — same XCD every time (ids stay congruent mod 8), XCD-contiguous tiles through the
-    // usual remap, at most one tile of imbalance between workgroups
-    constexpr bool STRIDED = (VAR & 2048) != 0;
-    constexpr bool PERSIST = TPB > 1 || STRIDED;
+    // (multi-tile forms — 2 / 4 consecutive output tiles per workgroup, and a grid-strided persistent form with the next tile's set-up
+    // issued ahead of the epilogue — were measured in round 3 and removed: 0.45-1.02x of this form, profiles/r03d_split_check_experiments.log)
     constexpr bool ASM_SUB = (VAR & 64) != 0;  // residuals through v_sub_f32 inline asm: keeps the SLP vectoriser from packing them into v_pk_add_f32
     constexpr int SA = BM, SB = BN;
     constexpr int A_TILE = 3 * KH * SA, B_TILE = 3 * KH * SB;  // cells per buffer
@@ -117,14 +110,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const int lh = lane >> 5;
 
     const int nwg = MT * NT;
-    const int nblk = STRIDED ? nwg : (nwg + TPB - 1) / TPB;  // virtual blocks (== gridDim.x unless STRIDED)
-    auto remap = [&](int v) {  // virtual block id -> position in the XCD-contiguous order
-        const int xcd = v & 7, q = nblk >> 3, r = nblk & 7;
-        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
-    };
-    int vblock = blockIdx.x;
-    int cur_tile = remap(vblock) * TPB;  // consecutive tiles (n fastest) share the A panel
-    const int tile_end = STRIDED ? nwg : (cur_tile + TPB < nwg ? cur_tile + TPB : nwg);
+    int cur_tile;  // block id -> position in the XCD-contiguous order: consecutive tiles (n fastest) share the A panel
+    {
+        const int v = blockIdx.x, xcd = v & 7, q = nwg >> 3, r = nwg & 7;
+        cur_tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    }
     int m0 = 0, n0 = 0;
     const int z = blockIdx.y;
     const int z1 = z / p.zdiv, z0 = z - z1 * p.zdiv;
@@ -361,46 +351,27 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     constexpr int SMEM_F = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
 
     load_tile();
-    for (;;) {
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        store_tile(0);
-        if (PIPE && KT > 1) load_tile();  // tile 1 rides in the registers across the barrier
-        __syncthreads();
-        {
-            int kt = 0;
-            if (PIPE) {
-                for (; kt + 2 < KT; ++kt) tile(kt, yes, yes);
-                if (kt + 1 < KT) tile(kt++, yes, no);
-            } else {
-                for (; kt + 1 < KT; ++kt) tile(kt, yes, no);
-            }
-            tile(kt, no, no);
-        }
-        if (X_NOBAR) __syncthreads();  // the epilogue reuses the staging area
-        const int em0 = m0, en0 = n0;
-        bool more;  // workgroup-uniform
-        if (STRIDED) {
-            vblock += gridDim.x;
-            more = vblock < nwg;
-            if (more) cur_tile = remap(vblock);
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    store_tile(0);
+    if (PIPE && KT > 1) load_tile();  // tile 1 rides in the registers across the barrier
+    __syncthreads();
+    {
+        int kt = 0;
+        if (PIPE) {
+            for (; kt + 2 < KT; ++kt) tile(kt, yes, yes);
+            if (kt + 1 < KT) tile(kt++, yes, no);
         } else {
-            more = PERSIST && cur_tile + 1 < tile_end;
-            if (more) ++cur_tile;
+            for (; kt + 1 < KT; ++kt) tile(kt, yes, no);
         }
-        if (more) {  // the gather table is no longer read (the K loop ended on a barrier); the staging registers are free
-            setup_tile(cur_tile);
-            __syncthreads();
-            load_tile();  // in flight during the epilogue below
-        }
-        epilogue<BM, TM, TN, 0, SMEM_F>(p, acc, smem, M, em0, en0, wm0, wn0, z1, z0, HoWo);
-        if (!more) break;
-        __syncthreads();  // the epilogue's row table / transpose buffers live in the staging area the next store_tile(0) overwrites
+        tile(kt, no, no);
     }
+    if (X_NOBAR) __syncthreads();  // the epilogue reuses the staging area
+    epilogue<BM, TM, TN, 0, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
 }
 
 // W [nz][Kw][ldw] fp32 -> [nz][3][Kw / 8][ldw][8] bf16 (see conv_gemm_split_kernel); one thread per (slice, k cell, column)
@@ -439,22 +410,7 @@ void launch_split(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream
     auto kern = conv_gemm_split_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, NPROD, VAR>;
     static DynSmemOptIn optin;
     optin.ensure(reinterpret_cast<const void *>(kern), smem);
-    const int tpb = split_tpb(VAR);
-    int gx = (MT * NT + tpb - 1) / tpb;
-    if (VAR & 2048) {  // one workgroup per residency slot (multiple of 8 so that a workgroup's tiles stay on its XCD)
-        static int slots = 0;
-        if (!slots) {
-            int per_cu = 0, dev = 0;
-            hipDeviceProp_t prop;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, smem) != hipSuccess || per_cu < 1) per_cu = 2;
-            (void)hipGetDevice(&dev);
-            const int cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
-            slots = (per_cu * cus) / 8 * 8;
-            if (slots < 8) slots = 8;
-        }
-        if (gx > slots) gx = slots;
-    }
-    dim3 grid(gx, p.Z, 1);
+    dim3 grid(MT * NT, p.Z, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p, M, MT, NT, KT);
 }
 

@@ -263,8 +263,8 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
     objs = _nd.find_objects(labels)
     counts = np.bincount(labels.reshape(-1), minlength=n + 1)
     M = len(textlines)
-    ccs = [np.zeros_like(mask) for _ in range(M)]
-    rects: List[Optional[List[int]]] = [None] * M  # [left, top, right, bottom] of the components given to each line
+    members: List[List[int]] = [[] for _ in range(M)]  # labels of the components given to each line (the reference paints them into one
+    rects: List[Optional[List[int]]] = [None] * M      # page-sized image per line; only the crop of that image is ever read: _line_crop)
     valid = False
     for label in range(1, n + 1):
         area1 = int(counts[label])
@@ -288,8 +288,7 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
             unit = max(min([textlines[avg].font_size, w1, h1]), 10)
             if dist[avg] >= 0.5 * unit:
                 continue
-        region = ccs[avg][y1:y1 + h1, x1:x1 + w1]
-        region[labels[y1:y1 + h1, x1:x1 + w1] == label] = 255
+        members[avg].append(label)
         r = rects[avg]
         rects[avg] = [x1, y1, x1 + w1, y1 + h1] if r is None else [min(r[0], x1), min(r[1], y1), max(r[2], x1 + w1), max(r[3], y1 + h1)]
         valid = True
@@ -298,17 +297,26 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
     final = np.zeros_like(mask)
     page = be.filter_page(img)
     jobs = []  # (line index, crop rectangle, dilation size)
-    for i, cc in enumerate(ccs):
+    lut = np.zeros(n + 1, dtype=np.uint8)
+
+    def _line_crop(i, x, y, w, h):
+        """The crop [y:y+h, x:x+w] of line i's component image (255 on the pixels of the components assigned to it)."""
+        lut[members[i]] = 255
+        out = lut[labels[y:y + h, x:x + w]]
+        lut[members[i]] = 0
+        return np.ascontiguousarray(out)
+
+    for i in range(M):
         if rects[i] is None:  # the reference's sentinel rectangle slices to an empty crop and is skipped (:172-173)
             continue
         x1, y1, w1, h1 = rects[i][0], rects[i][1], rects[i][2] - rects[i][0], rects[i][3] - rects[i][1]
         text_size = min(w1, h1, textlines[i].font_size)
         x1, y1, w1, h1 = _extend_rect(x1, y1, w1, h1, W, H, int(text_size * 0.1))
         dilate_size = max((int((text_size + dilation_offset) * 0.3) // 2) * 2 + 1, 3)
-        if cc[y1:y1 + h1, x1:x1 + w1].size == 0:
+        if w1 <= 0 or h1 <= 0 or x1 >= W or y1 >= H:   # an empty slice
             continue
         jobs.append((i, (x1, y1, w1, h1), dilate_size))
-    crops = [np.ascontiguousarray(ccs[i][y:y + h, x:x + w]) for i, (x, y, w, h), _ in jobs]
+    crops = [_line_crop(i, x, y, w, h) for i, (x, y, w, h), _ in jobs]
     if getattr(be, "gpu_tail", False) and kernel_size % 2 == 1:
         # device tail: the windows are the host form's own rectangles; inside a window every non-zero pixel of the line's component
         # image lies in its crop rectangle (the crop is the components' bounding box, extended), so the refined crop is all the
@@ -318,11 +326,13 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
         return out if device_result else out.cpu().numpy()   # device_result: the caller (dispatch) resizes it on the device
     refined = be.refine(page, [r for _, r, _ in jobs], crops)
     for (i, (x1, y1, w1, h1), dilate_size), region in zip(jobs, refined):
-        cc = ccs[i]
-        cc[y1:y1 + h1, x1:x1 + w1] = region
         x2, y2, w2, h2 = _extend_rect(x1, y1, w1, h1, W, H, -(-dilate_size // 2))
-        cc[y2:y2 + h2, x2:x2 + w2] = dilate(cc[y2:y2 + h2, x2:x2 + w2], ellipse_kernel(dilate_size))
-        final[y2:y2 + h2, x2:x2 + w2] |= cc[y2:y2 + h2, x2:x2 + w2]
+        # the line's component image inside the dilation window: its components (all inside the window or outside it: see the note on
+        # the device tail), with the crop replaced by its refined version
+        cc = _line_crop(i, x2, y2, w2, h2)
+        ya, yb, xa, xb = max(y1, y2), min(y1 + h1, y2 + h2), max(x1, x2), min(x1 + w1, x2 + w2)
+        cc[ya - y2:yb - y2, xa - x2:xb - x2] = region[ya - y1:yb - y1, xa - x1:xb - x1]
+        final[y2:y2 + h2, x2:x2 + w2] |= dilate(cc, ellipse_kernel(dilate_size))
     return dilate(final, ellipse_kernel(kernel_size))
 
 

@@ -562,10 +562,11 @@ class Ocr48Engine:
         P, H, W, _ = pages_u8.shape
         if len(quads_per_page) != P:
             raise ValueError("one quad list per page expected")
-        plan = self.upload_plan(self.plan_pages(quads_per_page, H, W, directions))
+        plan = self.plan_pages(quads_per_page, H, W, directions)
         n_lines = len(plan["order"])
-        if n_lines == 0:
+        if n_lines == 0:   # pages without text lines: nothing to upload or decode
             return dict(order=[], tokens=None)
+        plan = self.upload_plan(plan)
         mem_k, mem_v = self.alloc_memory(n_lines, plan["Lmax"])
         for p0 in range(0, P, group_pages):
             ids = [i for i, c in enumerate(plan["chunks"]) if p0 <= c[4] < p0 + group_pages]

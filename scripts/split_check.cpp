@@ -50,9 +50,8 @@ int main(int argc, char **argv) {
     const int s6m = find_cfg("split128x128x16p6m"), s9m = find_cfg("split128x128x16p9m"), n6m = find_cfg("split128x64x16p6m"), s6k32m = find_cfg("split128x128x32p6m");
     const int s6o = find_cfg("split128x128x16p6o"), n6o = find_cfg("split128x64x16p6o");
     if (s6o < 0 || n6o < 0) return 2;
-    const int s6t = find_cfg("split128x128x16p6t"), n6t = find_cfg("split128x64x16p6t");  // MIT_CONV_EXPERIMENTS builds only (-1 otherwise: skipped)
-    const int fwg = find_cfg("fast128x128x16w4cg"), fw3 = find_cfg("fast128x128x16w3cg"), fng = find_cfg("fast128x64x16w4cg");  // fp32 tiles, grid-strided multi-tile form (experiments builds)
-    const int s6t2 = find_cfg("split128x128x16p6t2"), s6g = find_cfg("split128x128x16p6g"), n6g = find_cfg("split128x64x16p6g");
+    const int s64 = find_cfg("split64x64x16p6o"), s32 = find_cfg("split128x32x16p6o"), f32t = find_cfg("fast128x32x16w4c");  // small / narrow tiles (-1: skipped)
+    const int gen32 = find_cfg("128x32x16");
     if (s6s < 0 || s9s < 0 || n6s < 0 || s6k32s < 0 || s6m < 0 || s9m < 0 || n6m < 0 || s6k32m < 0) {
         fprintf(stderr, "pipelined tile names not found\n");
         return 2;
@@ -62,15 +61,17 @@ int main(int argc, char **argv) {
         return 2;
     }
     std::vector<Case> cases = {
-        {"probe: A[m][k] = (k == m % 16), W[k][n] = 1000 k + n", 1, 1, 256, 16, 128, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, s3, n6, s6s, n6s, s6m, n6m, fwg, fw3, s6o, s6t, s6t2, s6g, n6o, n6t, n6g}},
-        {"1x1 320->1280 (ConvNeXt pw1), M=65536, gelu", 1, 256, 256, 320, 1280, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6, s9, s3, s6s, s6m, s9m, s6k32m, fwg, fw3, s6o, s6t, s6t2, s6g, s6m, s6o, s6m, s6o}},
-        {"3x3 reflect 128->128, 2x96x160, relu", 2, 96, 160, 128, 128, 3, 1, MIT_PAD_REFLECT, 1, MIT_ACT_RELU, f_wide, {s6, s9, s6s, s6m, s9m, s6k32m, fwg, fw3, s6o, s6t, s6t2, s6g, s6m, s6o, s6m, s6o}},
-        {"winograd-like Z=36, T=8192, 128->384", 1, 1, 8192, 128, 384, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6, s9, s6m, s9m, fwg, fw3, s6o, s6t, s6t2, s6g, n6o, n6t, n6g, s6o, n6o}},
-        {"1x1 192->384 (spectral conv2), M=131072, relu", 1, 256, 512, 192, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {fwg, fw3, s6o, s6t, s6t2, s6g, n6o, n6t, n6g, s6o, n6o}},
-        {"1x1 160->640 (ConvNeXt stage 2 pw1), M=131072, gelu", 1, 256, 512, 160, 640, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {fwg, fw3, s6o, s6t, s6t2, s6g, n6o, n6t, n6g, s6o, n6o}},
-        {"3x3 s2 zero 64->64, 4x128x128", 4, 128, 128, 64, 64, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_narrow, {fng, n6, n9, n6s, n6m, n6o, n6t, n6g, n6m, n6o}},
-        {"1x1 1280->320 (pw2), M=65536", 1, 256, 256, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, n6, s6m, n6m, s6k32m, fwg, fw3, s6o, s6t, s6t2, s6g, n6o, n6t, n6g, s6m, s6o}},
-        {"ragged: M=1000, 48->200 3x3 zero", 1, 25, 40, 48, 200, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s6, n6, n9, s6m, n6m, fwg, fw3, s6o, s6t, s6t2, s6g, n6o, n6t, n6g}},
+        {"probe: A[m][k] = (k == m % 16), W[k][n] = 1000 k + n", 1, 1, 256, 16, 128, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, s3, n6, s6s, n6s, s6m, n6m, s6o, n6o, s64}},
+        {"1x1 320->1280 (ConvNeXt pw1), M=65536, gelu", 1, 256, 256, 320, 1280, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6, s9, s3, s6s, s6m, s9m, s6k32m, s6o, s6m, s6o, s6m, s6o}},
+        {"3x3 reflect 128->128, 2x96x160, relu", 2, 96, 160, 128, 128, 3, 1, MIT_PAD_REFLECT, 1, MIT_ACT_RELU, f_wide, {s6, s9, s6s, s6m, s9m, s6k32m, s6o, s6m, s6o, s6m, s6o}},
+        {"winograd-like Z=36, T=8192, 128->384", 1, 1, 8192, 128, 384, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6, s9, s6m, s9m, s6o, n6o, s6o, n6o}},
+        {"1x1 192->384 (spectral conv2), M=131072, relu", 1, 256, 512, 192, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, n6o, s6o, n6o}},
+        {"1x1 160->640 (ConvNeXt stage 2 pw1), M=131072, gelu", 1, 256, 512, 160, 640, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, n6o, s6o, n6o}},
+        {"3x3 s2 zero 64->64, 4x128x128", 4, 128, 128, 64, 64, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_narrow, {n6, n9, n6s, n6m, n6o, n6m, n6o}},
+        {"1x1 1280->320 (pw2), M=65536", 1, 256, 256, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, n6, s6m, n6m, s6k32m, s6o, n6o, s6m, s6o}},
+        {"3x3 zero 128->32 (ESRGAN dense conv3), 2x256x256, leaky", 2, 256, 256, 128, 32, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, gen32, {f32t, s32, n6o}},
+        {"decoder-like M=160: 320->960", 1, 1, 160, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6o, n6o, s64}},
+        {"ragged: M=1000, 48->200 3x3 zero", 1, 25, 40, 48, 200, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s6, n6, n9, s6m, n6m, s6o, n6o}},
     };
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);

@@ -66,6 +66,9 @@ CASES = [
     (1, 128, 4, 9, 40, 3, 2, 1, "zero", 2, False, 27),     # N = 4, stride 2, forced onto gemv16
     (2, 320, 320, 7, 33, 1, 1, 0, "zero", 5, False, 26),   # the 64 x 64 fast tile (decoder-sized GEMM), GELU
     (1, 64, 96, 12, 10, 3, 1, 1, "reflect", 1, True, 26),  # 64 x 64 fast tile, 3x3 reflect, ragged N
+    (1, 64, 32, 31, 17, 3, 1, 1, "zero", 1, True, 49),     # 128 x 32 fast tile (ESRGAN's growth-32 convolutions)
+    (2, 160, 32, 12, 10, 3, 1, 1, "zero", 2, False, 49),
+    (1, 64, 16, 9, 40, 3, 1, 1, "reflect", 0, False, 49),  # ragged N on it
 ]
 
 
@@ -234,3 +237,21 @@ def test_large_batch_is_split_for_the_fast_kernel(cuda):
     torch.cuda.synchronize()
     assert torch.equal(fast, generic)
     assert fast[-1].abs().sum().item() > 0   # the last run of images was written
+
+
+def test_narrow_fast_tile_is_bit_identical_to_the_generic_kernel(cuda):
+    """fast128x32x16w4c (the automatic choice for N <= 32) against the generic 128x32 tile it replaces: same k-sequential chain."""
+    from manga_image_translator_amd import lib as L, ops
+
+    lib = L.load()
+    names = {lib.mit_conv_gemm_config_name(i).decode(): i for i in range(64) if lib.mit_conv_gemm_config_name(i)}
+    g = torch.Generator().manual_seed(11)
+    for (B, Cin, Cout, H, W, k) in ((2, 96, 32, 20, 24, 3), (1, 192, 32, 9, 33, 3), (1, 64, 24, 16, 16, 1)):
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        layer = ops.Conv2d(w, torch.randn(Cout, generator=g), padding=k // 2, act=ops.ACT_LEAKY, alpha=0.2, device=cuda)
+        x = torch.randn(B, H, W, Cin, generator=g).to(cuda)
+        auto = layer(x)
+        fast = layer(x, cfg=names["fast128x32x16w4c"])
+        generic = layer(x, cfg=names["128x32x16"])
+        torch.cuda.synchronize()
+        assert torch.equal(fast, generic) and torch.equal(auto, generic)
