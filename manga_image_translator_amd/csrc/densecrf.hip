@@ -25,8 +25,14 @@
 namespace {
 
 constexpr unsigned long long EMPTY = ~0ull;
-constexpr int KEY_BITS = 12;
-constexpr int KEY_HALF = 1 << (KEY_BITS - 1);
+// Bits per lattice coordinate in the packed 64-bit hash key: 5 coordinates x 12 bits for the bilateral kernel (positions / 23, colours / 7:
+// a few hundred lattice units at most), 2 x 24 bits for the Gaussian kernel (positions / 3: a crop taller than ~1100 px — a text line that
+// was given a long panel border as one of its components — leaves a 12-bit range).
+template <int D>
+struct KeyBits {
+    static constexpr int BITS = D <= 2 ? 24 : 12;
+    static constexpr int HALF = 1 << (BITS - 1);
+};
 constexpr double FIX_SCALE = 4294967296.0;  // 2^32
 
 struct LatticeConsts {
@@ -59,9 +65,9 @@ __device__ __forceinline__ bool pack_key(const int (&k)[D], unsigned long long *
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        const int v = k[i] + KEY_HALF;
-        ok = ok && v >= 0 && v < (1 << KEY_BITS);
-        p = (p << KEY_BITS) | (unsigned long long)(v & ((1 << KEY_BITS) - 1));
+        const int v = k[i] + KeyBits<D>::HALF;
+        ok = ok && v >= 0 && v < (1 << KeyBits<D>::BITS);
+        p = (p << KeyBits<D>::BITS) | (unsigned long long)(v & ((1 << KeyBits<D>::BITS) - 1));
     }
     *out = p;
     return ok;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void crf_neighbors_kernel(const unsigned long 
     const uint64_t cap = (uint64_t)(tb_off[c + 1] - base);
     int key[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) key[a] = (int)((packed >> (KEY_BITS * (D - 1 - a))) & ((1 << KEY_BITS) - 1)) - KEY_HALF;
+    for (int a = 0; a < D; ++a) key[a] = (int)((packed >> (KeyBits<D>::BITS * (D - 1 - a))) & ((1 << KeyBits<D>::BITS) - 1)) - KeyBits<D>::HALF;
 #pragma unroll
     for (int j = 0; j <= D; ++j) {
         int n1[D], n2[D];
@@ -459,6 +465,6 @@ extern "C" int mit_densecrf_refine(const uint8_t *page_dev, int H, int W, const 
     int overflow = 0;
     MIT_CHECK_HIP(hipMemcpyAsync(&overflow, d_over, 4, hipMemcpyDeviceToHost, st));
     MIT_CHECK_HIP(hipStreamSynchronize(st));
-    if (overflow) return mit_set_error("mit_densecrf_refine: a lattice coordinate left the 12-bit key range (crop too large for the packed hash key)");
+    if (overflow) return mit_set_error("mit_densecrf_refine: a lattice coordinate left the key range of the packed hash key (crop far larger than a page)");
     return 0;
 }

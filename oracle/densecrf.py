@@ -117,20 +117,25 @@ class Permutohedral:
             self.n1[j] = self._find(self._pack(a))
             self.n2[j] = self._find(self._pack(b))
 
+    def _bits(self) -> int:
+        return 24 if self.d <= 2 else KEY_BITS   # the position-only kernel of a page-tall crop needs more than 12 bits per coordinate
+
     def _pack(self, k: np.ndarray) -> np.ndarray:
-        half = 1 << (KEY_BITS - 1)
+        bits = self._bits()
+        half = 1 << (bits - 1)
         assert k.min() >= -half and k.max() < half, "lattice coordinate outside the packed-key range"
         out = np.zeros(len(k), dtype=np.int64)
         for i in range(k.shape[1]):
-            out = (out << KEY_BITS) | (k[:, i] + half)
+            out = (out << bits) | (k[:, i] + half)
         return out
 
     def _unpack(self, p: np.ndarray) -> np.ndarray:
-        half = 1 << (KEY_BITS - 1)
+        bits = self._bits()
+        half = 1 << (bits - 1)
         out = np.empty((len(p), self.d), dtype=np.int64)
         for i in range(self.d - 1, -1, -1):
-            out[:, i] = (p & ((1 << KEY_BITS) - 1)) - half
-            p = p >> KEY_BITS
+            out[:, i] = (p & ((1 << bits) - 1)) - half
+            p = p >> bits
         return out
 
     def _find(self, p: np.ndarray) -> np.ndarray:

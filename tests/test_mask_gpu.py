@@ -64,7 +64,7 @@ def _check_against_oracle(rgb, mask, got_mask, got_q, iterations=5):
     return err, int(margin.sum())
 
 
-@pytest.mark.parametrize("H,W", [(40, 120), (33, 57), (1, 64), (90, 14)])
+@pytest.mark.parametrize("H,W", [(40, 120), (33, 57), (1, 64), (90, 14), (1500, 24)])   # the last: a page-tall crop (a line that was given a panel border)
 def test_densecrf_matches_oracle_single_crop(cuda, H, W):
     """mit_densecrf_refine on one crop == the restated DenseCRF2D: final marginals within 2e-4 (the device splat sums exactly in
     fixed point, the library sequentially in fp32), argmax identical outside a 1e-3 margin."""

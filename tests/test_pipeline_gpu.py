@@ -206,27 +206,3 @@ def test_plugins_end_to_end(cuda):
     assert np.array_equal(got2[m2 < 127], p2[m2 < 127])
     run(inp.unload())
 
-
-def test_two_stream_mode_gives_the_same_bytes(cuda):
-    """PageEngine(overlap=True) — LaMa on the caller's stream, detector + OCR on a side stream (bench.py's default) — against the
-    one-stream run of the same engine weights: every result tensor identical, also when the call is repeated back to back (the
-    streams re-join at the end of a step and fork again at the start of the next)."""
-    from manga_image_translator_amd import pipeline, synth
-
-    D = 97
-    weights = pipeline.synthetic_weights(dict_size=D)
-    B, H, W, T = 4, 256, 320, 5
-    pages, quads, masks = zip(*[synth.synth_page(10 + i, H, W, n_boxes=5) for i in range(B)])
-    qobjs = [pipeline.quads_from_array(q) for q in quads]
-    pd, md = torch.from_numpy(np.stack(pages)).to(cuda), torch.from_numpy(np.stack(masks)).to(cuda)
-    outs = []
-    for overlap in (False, True):
-        eng = pipeline.PageEngine(weights, device=cuda, dict_size=D, ctd_mb=2, lama_mb=2, group=2, overlap=overlap)
-        for _ in range(2):
-            r = eng.run(pd, qobjs, md, max_seq_length=T, suppress_eos=True)
-        torch.cuda.synchronize()
-        outs.append(r)
-    a, b = outs
-    assert a.ocr_order == b.ocr_order
-    for name in ("det_mask", "det_shrink", "inpainted", "ocr_tokens", "ocr_length", "ocr_prob", "ocr_colors"):
-        assert torch.equal(getattr(a, name), getattr(b, name)), name
