@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import concurrent.futures as cf
 import math
+import threading
 import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -75,18 +76,29 @@ class CoupledPageEngine:
     """Owns the stage engines of one GPU and a host thread pool."""
 
     def __init__(self, weights: Dict[str, Dict[str, torch.Tensor]], dictionary: Sequence[str], device="cuda", lama_blocks: int = 9,
-                 ctd_mb: int = 16, lama_mb: int = 16, host_workers: int = 16):
+                 ctd_mb: int = 16, lama_mb: int = 16, host_workers: int = 16, mask_workers: int = 4):
         self.device = torch.device(device)
         self.dictionary = list(dictionary)
         self.ctd = ctd.CtdEngine(weights["ctd.yolo"], weights["ctd.seg"], weights["ctd.det"], device=self.device)
         self.ocr = ocr48.Ocr48Engine(weights["ocr48"], len(self.dictionary), device=self.device)
         self.lama = lama.LamaEngine(weights["lama.gen"], weights.get("lama.mpe"), n_blocks=lama_blocks, device=self.device)
-        self.mask_backend = MR.GpuMaskBackend(self.device)
         self.ctd_mb, self.lama_mb = ctd_mb, lama_mb
         self.pool = cf.ThreadPoolExecutor(max_workers=host_workers, thread_name_prefix="mit-host")
+        # mask refinement: a few pages in flight at once — each worker thread owns a backend (its DenseCRF workspace); their launches
+        # go to the same stream, a page's own launches stay in order on it, and the host parts (labelling, assignment) of one page
+        # run while another page's kernels execute
+        self.mask_pool = cf.ThreadPoolExecutor(max_workers=mask_workers, thread_name_prefix="mit-mask")
+        self._tls = threading.local()
+
+    def _mask_backend(self):
+        be = getattr(self._tls, "backend", None)
+        if be is None:
+            be = self._tls.backend = MR.GpuMaskBackend(self.device)
+        return be
 
     def close(self):
         self.pool.shutdown(wait=True)
+        self.mask_pool.shutdown(wait=True)
 
     # ---- stage 1: detector network + boxes (host pool) + mask resize + refine_mask ------------------------------------------
     @torch.no_grad()
@@ -112,8 +124,15 @@ class CoupledPageEngine:
                 futures[b] = self.pool.submit(self._boxes_of_page, host, b - i, ev, H, W)
         textlines = [f.result() for f in futures]
         refined = torch.empty_like(mask_full)
-        for b in range(B):  # refine_mask(img, mask, textlines) (ctd.py:177): batched over the page's lines on the device
-            refined[b] = hostglue.refine_mask_gpu(pages_u8[b], mask_full[b], textlines[b], None)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+        def refine(b):  # refine_mask(img, mask, textlines) (ctd.py:177): batched over the page's lines on the device; its three phases
+            torch.cuda.set_device(dev_index)   # alternate with host arithmetic (histograms -> candidates), so a few pages run interleaved
+            with torch.no_grad():
+                return hostglue.refine_mask_gpu(pages_u8[b], mask_full[b], textlines[b], None)
+
+        for b, m in enumerate(self.mask_pool.map(refine, range(B))):
+            refined[b] = m
         return textlines, refined
 
     @staticmethod
@@ -160,12 +179,19 @@ class CoupledPageEngine:
         B, H, W, _ = pages_u8.shape
         regions = list(self.pool.map(lambda ls: TM.dispatch_sync(ls, W, H) if ls else [], textlines))
         final = torch.zeros(B, H, W, dtype=torch.uint8, device=self.device)
-        for b in range(B):
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+        def refine(b):
             if not regions[b]:
-                continue     # no text: the orchestrator returns the page as it is (manga_translator.py:500-504)
-            m = MR.dispatch_device(regions[b], pages_u8[b], mask_raw[b], dilation_offset=MASK_DILATION_OFFSET, kernel_size=KERNEL_SIZE,
-                                   backend=self.mask_backend)
-            final[b] = m
+                return None      # no text: the orchestrator returns the page as it is (manga_translator.py:500-504)
+            torch.cuda.set_device(dev_index)
+            with torch.no_grad():
+                return MR.dispatch_device(regions[b], pages_u8[b], mask_raw[b], dilation_offset=MASK_DILATION_OFFSET, kernel_size=KERNEL_SIZE,
+                                          backend=self._mask_backend())
+
+        for b, m in enumerate(self.mask_pool.map(refine, range(B))):
+            if m is not None:
+                final[b] = m
         return regions, final
 
     # ---- the whole path -----------------------------------------------------------------------------------------------------

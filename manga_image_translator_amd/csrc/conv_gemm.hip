@@ -301,32 +301,6 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
             return 0;
         }
     }
-    static const bool colsplit_off = getenv("MIT_CONV_NO_COLSPLIT") != nullptr;  // A/B knob for scripts/
-    if (cfg < 0 && !colsplit_off && p.N > 128 && p.N % 128 == 64 && !p.c.nsplit && !p.pre.nsplit && !p.post.nsplit && M64 >= 4096 &&
-        !(reinterpret_cast<uintptr_t>(p.scale) & 15) && !(reinterpret_cast<uintptr_t>(p.bias) & 15)) {
-        // N = 128 j + 64 (320, 192): j wide column tiles + one narrow one instead of 2 j + 1 narrow ones — the 128-wide tiles run
-        // 8-13 % faster per FLOP.  Two launches over disjoint column ranges of the same problem; the arithmetic per output element
-        // is unchanged (results do not depend on the tile), large M only (the second launch's ramp-up has to be worth it).
-        const int n1 = p.N - 64;
-        MitConvGemm lo = *d, hi = *d;
-        lo.N = n1;
-        lo.Nw = n1 < d->Nw ? n1 : d->Nw;
-        hi.N = 64;
-        hi.Nw = d->Nw - n1 > 0 ? d->Nw - n1 : 0;
-        hi.w = d->w + n1;
-        if (d->w_split) hi.w_split = d->w_split + (int64_t)n1 * 8;   // cells [plane][k / 8][n][8]: n1 columns further in every (plane, k) row
-        hi.c.base = d->c.base + n1;
-        if (d->pre.base) hi.pre.base = d->pre.base + n1;
-        if (d->post.base) hi.post.base = d->post.base + n1;
-        if (d->scale) hi.scale = d->scale + n1;
-        if (d->bias) hi.bias = d->bias + n1;
-        if (hi.Nw > 0 && !(hi.Nw & 3) && !(lo.Nw & 3)) {
-            if (g_next_alg_flops >= 0.0) g_next_alg_flops = -1.0;  // a tagged cost does not survive the split
-            const int rc = mit_conv_gemm_cfg(&lo, -1, stream);
-            if (rc) return rc;
-            return mit_conv_gemm_cfg(&hi, -1, stream);
-        }
-    }
     if (cfg < 0) cfg = pick_cfg(p, M64);
     if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
     const CfgEntry &c = kCfgs[cfg];

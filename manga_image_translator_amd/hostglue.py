@@ -343,7 +343,22 @@ class _RefineWorkspace:
         return self.buf
 
 
-_REFINE_WS = _RefineWorkspace()
+class _PerThreadRefineWorkspace:
+    """One scratch slab per host thread: a batch engine refines several pages at once from a thread pool (coupled.py)."""
+
+    def __init__(self):
+        import threading
+
+        self._tls = threading.local()
+
+    def get(self, nbytes: int, device):
+        ws = getattr(self._tls, "ws", None)
+        if ws is None:
+            ws = self._tls.ws = _RefineWorkspace()
+        return ws.get(nbytes, device)
+
+
+_REFINE_WS = _PerThreadRefineWorkspace()
 
 
 def refine_mask_gpu(page_dev, pred_dev, quads: Sequence, refine_mode=None):

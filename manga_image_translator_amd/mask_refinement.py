@@ -226,6 +226,25 @@ def _polygon_point_distance(pts: np.ndarray, p) -> float:
     return best
 
 
+def _polygon_point_distances(polys: np.ndarray, p) -> np.ndarray:
+    """``_polygon_point_distance`` of one point against M polygons of equal vertex count at once (polys float64 [M, V, 2]): the
+    distance row of text_mask_utils.py:131 for one component, without M x V Python iterations."""
+    px, py = float(p[0]), float(p[1])
+    a = polys
+    b = np.roll(polys, -1, axis=1)
+    ax, ay, bx, by = a[..., 0], a[..., 1], b[..., 0], b[..., 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cross = ((ay > py) != (by > py)) & (px < (bx - ax) * (py - ay) / (by - ay) + ax)   # the crossing test of _point_in_polygon, edge by edge
+    inside = (np.count_nonzero(cross, axis=1) % 2) == 1
+    abx, aby = bx - ax, by - ay
+    den = abx * abx + aby * aby
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(den == 0, 0.0, np.minimum(1.0, np.maximum(0.0, ((px - ax) * abx + (py - ay) * aby) / den)))
+    dx, dy = px - (ax + t * abx), py - (ay + t * aby)
+    d = np.sqrt(dx * dx + dy * dy).min(axis=1)
+    return np.where(inside, 0.0, d)
+
+
 def _extend_rect(x, y, w, h, max_x, max_y, extend):  # text_mask_utils.py:56-61
     x1, y1 = max(x - extend, 0), max(y - extend, 0)
     return x1, y1, min(w + extend * 2, max_x - x1 - 1), min(h + extend * 2, max_y - y1 - 1)
@@ -247,6 +266,7 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
     boxes = [_xywh(t) for t in textlines]
     polys = [np.asarray(t.pts, dtype=np.float64) for t in textlines]
     areas2 = [HG_area(p) for p in polys]
+    poly_arr = np.stack(polys) if polys and all(p.shape == polys[0].shape for p in polys) else None   # [M, V, 2]: vectorised distance rows
     pmin = np.array([p.min(0) for p in polys]).reshape(-1, 2)
     pmax = np.array([p.max(0) for p in polys]).reshape(-1, 2)
     for x, y, w, h in boxes:  # cv2.rectangle(mask, (x, y), (x + w, y + h), 0, 1): one-pixel outline, inclusive corners, clipped
@@ -283,7 +303,8 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
         if ratio[avg] <= keep_threshold:
             # the distance matrix of :131 is only read on this branch, so it is only evaluated here
             centre = (x1 + w1 / 2.0, y1 + h1 / 2.0)
-            dist = np.array([_polygon_point_distance(polys[i], centre) for i in range(M)], dtype=np.float32)
+            dist = (_polygon_point_distances(poly_arr, centre).astype(np.float32) if poly_arr is not None
+                    else np.array([_polygon_point_distance(polys[i], centre) for i in range(M)], dtype=np.float32))
             avg = int(np.argmin(dist))
             unit = max(min([textlines[avg].font_size, w1, h1]), 10)
             if dist[avg] >= 0.5 * unit:
