@@ -18,7 +18,6 @@ const CfgEntry kCfgs[] = {
 #define KNAME_launch_fast "conv_gemm_fast_kernel"
 #define KNAME_launch_gemv "conv_gemv_kernel"
 #define KNAME_launch_split "conv_gemm_split_kernel"
-#define KNAME_launch_split_skinny "gemm_split_skinny_kernel"
 #define X(g, name, fast, BM, BN, BK, fn, ...) \
     {name, BM, BN, BK, fn<BM, BN, BK, __VA_ARGS__>, fast, KNAME_##fn "<" #BM ", " #BN ", " #BK ", " #__VA_ARGS__ ">"},
 #include "conv_gemm_cfgs.inc"
@@ -54,14 +53,6 @@ bool split_eligible(const MitConvGemm &p, int BK) {
     if (p.w_zs1 != 0 || (p.Kw & 7) || p.ntaps * p.Cin > p.Kw) return false;
     if ((int64_t)3 * (p.Kw >> 3) * p.ldw > 0x7fffffffLL) return false;  // 32-bit cell indices
     return fast_eligible(p, BK);
-}
-
-// gemm_split_skinny_kernel preconditions: a plain GEMM (one tap, rows a + m * a_xs, one batch entry, no pre map) with split planes of W
-bool skinny_eligible(const MitConvGemm &p) {
-    if (!p.w_split || (reinterpret_cast<uintptr_t>(p.w_split) & 15) || p.w_zs1 != 0 || (p.Kw & 7)) return false;
-    if (p.ntaps != 1 || p.tap_dy[0] || p.tap_dx[0] || p.tap_off[0] || p.NB != 1 || p.Ho != 1 || p.Hi != 1 || p.sx != 1 || p.Z != 1) return false;
-    if (p.Cin % 16 || p.Cin > p.Kw || (p.a_xs & 3) || p.pre.base || p.Wi != p.Wo) return false;
-    return (int64_t)3 * (p.Kw >> 3) * p.ldw <= 0x7fffffffLL;
 }
 
 // conv_gemv_kernel preconditions: <= 4 output columns, plain (unbatched, unsplit) maps, the whole weight panel in LDS
@@ -132,12 +123,6 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     const int split = gemm_mode_now();
     const int64_t split_min = split_min_now();
     const int64_t tiles128 = ((M + 127) / 128) * ((p.N + 63) / 64);
-    static const int skinny6 = getenv("MIT_CONV_NO_SKINNY") ? -1 : cfg_by_name("splitskinny32x32p6");
-    static const int skinny9 = getenv("MIT_CONV_NO_SKINNY") ? -1 : cfg_by_name("splitskinny32x32p9");
-    if ((split == 6 || split == 9) && M <= 512 && skinny_eligible(p) && tiles128 >= split_min) {  // a page's decoder Linears: latency-bound on workgroup tiles
-        const int c = split == 6 ? skinny6 : skinny9;
-        if (c >= 0) return c;
-    }
     if ((split == 6 || split == 9) && p.w_split && split_eligible(p, 16) && tiles128 * p.Z >= split_min) {
         static const int wide6 = cfg_by_name("split128x128x16p6o"), wide9 = cfg_by_name("split128x128x16p9m");
         static const int narrow6 = cfg_by_name("split128x64x16p6o"), narrow9 = cfg_by_name("split128x64x16p9");
@@ -325,8 +310,6 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
         if (!gemv_eligible(p, lpr) || p.N > c.BN)
             return mit_set_error("mit_conv_gemm: cfg %s needs N <= %d, Z == 1, unsplit maps and Cin %% %d == 0", c.name, c.BN, 4 * lpr);
     }
-    if (c.fast == 5 && !skinny_eligible(p))
-        return mit_set_error("mit_conv_gemm: cfg %s needs a plain GEMM (one tap, NB = Ho = 1, Z = 1, no pre map, Cin %% 16 == 0) with w_split", c.name);
     if (c.fast == 4 && !split_eligible(p, c.BK))
         return mit_set_error("mit_conv_gemm: cfg %s needs w_split (mit_gemm_split_pack, 16-byte aligned, w_zs1 == 0, Kw %% 8 == 0) and the fast tiles' preconditions", c.name);
     if ((c.fast == 1 || c.fast == 2) && !fast_eligible(p, c.BK))

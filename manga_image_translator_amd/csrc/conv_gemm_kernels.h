@@ -785,7 +785,7 @@ struct CfgEntry {
     const char *name;
     int BM, BN, BK;
     void (*launch)(const MitConvGemm &, int M, int MT, int NT, int KT, hipStream_t);
-    int fast;  // 1: conv_gemm_fast_kernel (needs fast_eligible()); 2: and Cin % 32 == 0; 3: conv_gemv_kernel (needs gemv_eligible()); 4: conv_gemm_split_kernel (needs split_eligible()); 5: gemm_split_skinny_kernel (needs skinny_eligible())
+    int fast;  // 1: conv_gemm_fast_kernel (needs fast_eligible()); 2: and Cin % 32 == 0; 3: conv_gemv_kernel (needs gemv_eligible()); 4: conv_gemm_split_kernel (needs split_eligible())
     const char *kernel;  // the kernel's template-id as profilers print it, e.g. "conv_gemm_fast_kernel<128, 128, 16, 1, 4, 4, 4>"
 };
 

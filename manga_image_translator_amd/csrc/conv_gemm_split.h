@@ -374,99 +374,9 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     epilogue<BM, TM, TN, 0, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
 }
 
-// ---- few rows (a page's decoder Linears: M = lines x beams = 160): one WAVE per 32 x 32 output block, no LDS, no barrier ---------
-// A 64 x 64 workgroup tile leaves such a GEMM with a handful of workgroups that each expose the full global -> LDS -> MFMA latency
-// once per K-tile (measured 0.7 us per K-tile: 88 us for K = 2048).  Here every wave owns one 32 x 32 block and streams its operands
-// straight into registers in MFMA layout — A: the lane's row, 8 consecutive k as two float4 (split into planes in registers, the same
-// split3 as the tiles); W: the lane's column cell of every plane, one 16-byte load each — DEPTH K-steps ahead.  Per output element
-// the sequence of MFMAs (k steps ascending, plane pairs smallest first) is that of conv_gemm_split_kernel, so the results are
-// bit-identical to the tiles' and a page decodes to the same logits alone as in a batch.
-// Plain GEMM only: one tap, rows a + m * a_xs (NB = Ho = 1), Z = 1, no pre map.
-template <int NPROD, int DEPTH>
-__global__ __launch_bounds__(256) void gemm_split_skinny_kernel(const MitConvGemm p, const int M, const int MT, const int NT, const int KT) {
-    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-uniform; n fastest: the waves of a workgroup share their A rows
-    if (tile >= MT * NT) return;
-    const int mt = tile / NT, nt = tile - mt * NT;
-    const int m = mt * 32 + li, n0 = nt * 32;
-    const bool row_ok = m < M;
-    const float *__restrict__ arow = p.a + (int64_t)(row_ok ? m : 0) * p.a_xs + lh * 8;
-    const int K8 = p.Kw >> 3;
-    const int64_t ldn = p.ldw;
-    const bool col_ok = (n0 + li) < ldn;
-    const u32x4 *__restrict__ wcol = reinterpret_cast<const u32x4 *>(p.w_split) + (col_ok ? n0 + li : 0) + (int64_t)lh * ldn;
-    const int64_t plane = (int64_t)K8 * ldn, kstep = 2 * ldn;  // cells per plane; cells per K-step of 16 (two k cells)
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    f32x4 ar[DEPTH][2];
-    u32x4 br[DEPTH][3];
-    auto load = [&](const int slot, const int kt) {
-        ar[slot][0] = *reinterpret_cast<const f32x4 *>(arow + kt * 16);
-        ar[slot][1] = *reinterpret_cast<const f32x4 *>(arow + kt * 16 + 4);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) br[slot][pl] = wcol[pl * plane + kt * kstep];
-    };
-#pragma unroll
-    for (int s = 0; s < DEPTH; ++s)
-        if (s < KT) load(s, s);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int kt0 = 0; kt0 < KT; kt0 += DEPTH) {
-#pragma unroll
-        for (int s = 0; s < DEPTH; ++s) {
-            const int kt = kt0 + s;
-            if (kt < KT) {  // wave-uniform
-                u32x2 h0, m0, l0, h1, m1, l1;
-                split3<false>(row_ok ? ar[s][0] : zero, h0, m0, l0);
-                split3<false>(row_ok ? ar[s][1] : zero, h1, m1, l1);
-                bf16x8 af[3], bf[3];
-                af[0] = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
-                af[1] = __builtin_bit_cast(bf16x8, u32x4{m0.x, m0.y, m1.x, m1.y});
-                af[2] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bf[pl] = __builtin_bit_cast(bf16x8, br[s][pl]);
-                if (kt + DEPTH < KT) load(s, kt + DEPTH);  // the slot is free: its operands are in af / bf
-#pragma unroll
-                for (int pr = 9 - NPROD; pr < 9; ++pr)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kSplitPA[pr]], bf[kSplitPB[pr]], acc, 0, 0, 0);
-            }
-        }
-    }
-    // epilogue: the arithmetic of epilogue_store (scale, bias, residual before / after the activation), element by element
-    const int n = n0 + li;
-    if (n >= p.N) return;
-    const float sc = p.scale ? p.scale[n] : 1.f, bi = p.bias ? p.bias[n] : 0.f;
-    const int64_t ncol_c = p.c.nsplit ? (int64_t)(n / p.c.nsplit) * p.c.nhi + (n % p.c.nsplit) : n;
-    const int64_t ncol_post = p.post.nsplit ? (int64_t)(n / p.post.nsplit) * p.post.nhi + (n % p.post.nsplit) : n;
-    const bool has_post = p.post.base != nullptr, post_first = (p.act & MIT_ACT_POST_FIRST) != 0;
-    const int act = p.act & 0xff;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mo = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (mo >= M) continue;
-        float v = acc[r];
-        v = v * sc + bi;
-        const float pv = has_post ? p.post.base[(int64_t)mo * p.post.xs + ncol_post] : 0.f;
-        if (has_post && post_first) v += pv;
-        switch (act) {
-            case MIT_ACT_RELU: v = apply_act<MIT_ACT_RELU>(v, p.act_alpha); break;
-            case MIT_ACT_LEAKY: v = apply_act<MIT_ACT_LEAKY>(v, p.act_alpha); break;
-            case MIT_ACT_SILU: v = apply_act<MIT_ACT_SILU>(v, p.act_alpha); break;
-            case MIT_ACT_SIGMOID: v = apply_act<MIT_ACT_SIGMOID>(v, p.act_alpha); break;
-            case MIT_ACT_GELU: v = apply_act<MIT_ACT_GELU>(v, p.act_alpha); break;
-            default: break;
-        }
-        if (has_post && !post_first) v += pv;
-        p.c.base[(int64_t)mo * p.c.xs + ncol_c] = v;
-    }
-}
-
-// BM = BN = 32, BK = 16 in the configuration table: MT / NT / KT arrive as blocks of 32 rows / 32 columns / 16 k
-template <int BM, int BN, int BK, int NPROD, int DEPTH>
-void launch_split_skinny(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
-    static_assert(BM == 32 && BN == 32 && BK == 16, "one 32 x 32 block per wave, K steps of 16");
-    hipLaunchKernelGGL((gemm_split_skinny_kernel<NPROD, DEPTH>), dim3((MT * NT + 3) / 4), dim3(256), 0, s, p, M, MT, NT, KT);
-}
+// (A one-wave-per-32x32-block form with register-streamed operands for few-row GEMMs — a page's decoder Linears, M = 160 — was built and
+// measured in round 3: bit-identical to the tiles but 10-20 % SLOWER than the 64 x 64 tile at every decoder shape (both sit on the launch
+// floor of ~12 us except K = 2048, where the six dependent MFMAs per K-step set the pace); removed.  profiles/r03i_split_check_small_tiles.log)
 
 // W [nz][Kw][ldw] fp32 -> [nz][3][Kw / 8][ldw][8] bf16 (see conv_gemm_split_kernel); one thread per (slice, k cell, column)
 static __global__ __launch_bounds__(256) void gemm_split_pack_kernel(const float *__restrict__ w, const int64_t w_zs, const int K8, const int ldw,

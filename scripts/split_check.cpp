@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
     const int s6o = find_cfg("split128x128x16p6o"), n6o = find_cfg("split128x64x16p6o");
     if (s6o < 0 || n6o < 0) return 2;
     const int s64 = find_cfg("split64x64x16p6o"), s32 = find_cfg("split128x32x16p6o"), f32t = find_cfg("fast128x32x16w4c");  // small / narrow tiles (-1: skipped)
-    const int gen32 = find_cfg("128x32x16"), sk = find_cfg("splitskinny32x32p6"), f64 = find_cfg("fast64x64x16w8c");
+    const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c");
     if (s6s < 0 || s9s < 0 || n6s < 0 || s6k32s < 0 || s6m < 0 || s9m < 0 || n6m < 0 || s6k32m < 0) {
         fprintf(stderr, "pipelined tile names not found\n");
         return 2;
@@ -70,9 +70,9 @@ int main(int argc, char **argv) {
         {"3x3 s2 zero 64->64, 4x128x128", 4, 128, 128, 64, 64, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_narrow, {n6, n9, n6s, n6m, n6o, n6m, n6o}},
         {"1x1 1280->320 (pw2), M=65536", 1, 256, 256, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, n6, s6m, n6m, s6k32m, s6o, n6o, s6m, s6o}},
         {"3x3 zero 128->32 (ESRGAN dense conv3), 2x256x256, leaky", 2, 256, 256, 128, 32, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, gen32, {f32t, s32, n6o}},
-        {"decoder-like M=160: 320->960", 1, 1, 160, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s6o, n6o, s64, sk}},
-        {"decoder-like M=160: 2048->320 (FFN out)", 1, 1, 160, 2048, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s64, sk}},
-        {"decoder-like M=160: 320->6004 (logits)", 1, 1, 160, 320, 6004, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s6o, s64, sk}},
+        {"decoder-like M=160: 320->960", 1, 1, 160, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s6o, n6o, s64}},
+        {"decoder-like M=160: 2048->320 (FFN out)", 1, 1, 160, 2048, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s64}},
+        {"decoder-like M=160: 320->6004 (logits)", 1, 1, 160, 320, 6004, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s6o, s64}},
         {"ragged: M=1000, 48->200 3x3 zero", 1, 25, 40, 48, 200, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s6, n6, n9, s6m, n6m, s6o, n6o}},
     };
     std::mt19937 rng(1234);

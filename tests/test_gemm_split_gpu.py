@@ -126,54 +126,3 @@ def test_planes_sum_to_the_weights():
     back = f.sum(dim=1, dtype=torch.float64).permute(0, 1, 3, 2).reshape(3, 48, 72)  # [nz, K/8, 8, N] -> [nz, K, N]
     assert torch.equal(back.float(), w.cpu())
 
-
-@pytest.mark.parametrize("M,K,N,act,with_post,nsplit", [(160, 2048, 320, 0, True, 0), (160, 320, 960, 0, False, 320), (80, 320, 2048, 1, False, 0),
-                                                     (33, 64, 40, 5, True, 0), (480, 320, 6004, 0, False, 0)])
-def test_skinny_split_kernel_is_bit_identical_to_the_tiles(M, K, N, act, with_post, nsplit):
-    """gemm_split_skinny_kernel (one wave per 32 x 32 block, operands streamed into registers: the automatic choice for M <= 512 in the
-    split modes — a page's decoder Linears) against the workgroup tiles: the same MFMA sequence per output element, hence the same bits,
-    with residual, activation, split output columns (the fused q|k|v projection) and ragged M / N."""
-    from manga_image_translator_amd import lib as L, ocr48, ops
-
-    lib = L.load()
-    names = {lib.mit_conv_gemm_config_name(i).decode(): i for i in range(80) if lib.mit_conv_gemm_config_name(i)}
-    g = torch.Generator().manual_seed(M + K + N)
-    with ops.gemm_mode(6):
-        lin = ocr48.Linear(torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1, "cuda")
-        x = torch.randn(M, K, generator=g).cuda()
-        post = torch.randn(M, N, generator=g).cuda() if with_post else None
-
-        def run(cfg):
-            if nsplit:   # q | k | v into three [M, nsplit] planes, nhi apart
-                out = torch.zeros(N // nsplit, M, nsplit, device="cuda")
-                cm = ops.MitTensorMap()
-                cm.base, cm.xs, cm.nsplit, cm.nhi = out.data_ptr(), nsplit, nsplit, M * nsplit
-            else:
-                out = torch.zeros(M, N, device="cuda")
-                cm = ops.MitTensorMap()
-                cm.base, cm.xs = out.data_ptr(), N
-            pm = None
-            if post is not None:
-                pm = ops.MitTensorMap()
-                pm.base, pm.xs = post.data_ptr(), N
-            d = ops.conv_gemm_desc(a=x, NB=1, Hi=1, Wi=M, Cin=K, a_strides=(0, 0, K), Ho=1, Wo=M, sy=1, sx=1, taps=[(0, 0, 0)], pad_mode=ops.PAD_ZERO,
-                                   w=lin.w, ldw=lin.Np, Kw=lin.Kp, Nw=lin.Np, N=N, c=cm, post=pm, scale=None, bias=lin.bias, act=act)
-            assert d.w_split
-            ops.launch_conv_gemm(d, cfg)
-            torch.cuda.synchronize()
-            return out
-
-        auto = run(-1)
-        skinny = run(names["splitskinny32x32p6"])
-        small = run(names["split64x64x16p6o"])
-        wide = run(names["split128x128x16p6o"])
-        assert torch.equal(skinny, small) and torch.equal(skinny, wide) and torch.equal(auto, skinny)
-        ref = x.double().cpu() @ lin.w[:K, :N].double().cpu() + lin.bias.double().cpu()
-        if act == 1:
-            ref = ref.relu()
-        elif act == 5:
-            ref = torch.nn.functional.gelu(ref)
-        if post is not None:
-            ref = ref + post.double().cpu()
-        got = skinny.permute(1, 0, 2).reshape(M, N) if nsplit else skinny
-        assert (got.double().cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
