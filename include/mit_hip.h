@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 4
+#define MIT_ABI_VERSION 5
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -106,6 +106,11 @@ typedef struct MitConvGemm {
      * ws_zs0 = uint16 elements between z0 slices (the z1 stride must be 0 when this is set). */
     const uint16_t *w_split;
     int64_t ws_zs0;
+    /* optional: a device-resident step counter, for launch sequences that are replayed from a hipGraph with the same arguments every
+     * time (the beam-search steps of mit_ocr48_decode): when non-NULL the A operand starts a_dyn * (*dyn) floats and the C map
+     * c_dyn * (*dyn) floats further than the descriptor says.  NULL everywhere else. */
+    const int32_t *dyn;
+    int64_t a_dyn, c_dyn;
 } MitConvGemm;
 
 const char *mit_last_error(void);
@@ -462,7 +467,8 @@ typedef struct MitOcr48DecodeArgs {
     float *trace_logits;        /* optional [T][N*5][dict] raw logits (pred(pred1(decoded)), :713); NULL in production */
     int32_t *trace_hist;        /* optional [T][N*5][T+1] beam tokens after each step */
     int32_t steps_run;          /* out: steps executed */
-    int32_t _pad;
+    int32_t graph_mode;         /* 0: replay the steps from a hipGraph when there are few rows (N * 5 <= 1024: the loop is launch-bound
+                                 * there) or as MIT_OCR_DECODE_GRAPH says; 1: always; 2: never.  Same kernels either way: identical results. */
 } MitOcr48DecodeArgs;
 
 /* One text line to rectify: cv2.warpPerspective of the page crop [y1:y1+ch, x1:x1+cw] to (dw, dh) with inverse map minv

@@ -304,6 +304,8 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     if (cfg < 0) cfg = pick_cfg(p, M64);
     if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
     const CfgEntry &c = kCfgs[cfg];
+    if (p.dyn && c.fast == 3) return mit_set_error("mit_conv_gemm: the device-side step offset (dyn) is not implemented by the N <= 4 kernel");
+    if (p.dyn && ((p.a_dyn | p.c_dyn) & 3)) return mit_set_error("mit_conv_gemm: a_dyn / c_dyn must be multiples of 4 floats");
     if (c.fast == 2 && (p.Cin % 32)) return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% 32 == 0", c.name);
     if (c.fast == 3) {
         const int lpr = (cfg == kCfgGemv16 || cfg == kCfgGemv16N1) ? 16 : 4;

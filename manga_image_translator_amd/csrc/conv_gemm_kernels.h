@@ -172,6 +172,7 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
                                          const int HoWo) {
     const int tid = threadIdx.x;
     RowOff *rowoff = reinterpret_cast<RowOff *>(smem);  // BM entries (<= A/B staging area)
+    const int64_t c_dyn = p.dyn ? (int64_t)(*p.dyn) * p.c_dyn : 0;  // device-side step offset (hipGraph-replayed sequences), else 0
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
         RowOff ro = {-1, 0, 0};
@@ -180,7 +181,7 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
             const int rem = m - nb * HoWo;
             const int oy = rem / p.Wo;
             const int ox = rem - oy * p.Wo;
-            ro.c = z1 * p.c.zs1 + z0 * p.c.zs0 + (int64_t)nb * p.c.bs + (int64_t)oy * p.c.ys + (int64_t)ox * p.c.xs;
+            ro.c = c_dyn + z1 * p.c.zs1 + z0 * p.c.zs0 + (int64_t)nb * p.c.bs + (int64_t)oy * p.c.ys + (int64_t)ox * p.c.xs;
             ro.pre = z1 * p.pre.zs1 + z0 * p.pre.zs0 + (int64_t)nb * p.pre.bs + (int64_t)oy * p.pre.ys +
                      (int64_t)ox * p.pre.xs;
             ro.post = z1 * p.post.zs1 + z0 * p.post.zs0 + (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys +
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, con
     const int z = blockIdx.y;
     const int z1 = z / p.zdiv, z0 = z - z1 * p.zdiv;
 
-    const float *__restrict__ a_base = p.a + z1 * p.a_zs1 + z0 * p.a_zs0;
+    const float *__restrict__ a_base = p.a + z1 * p.a_zs1 + z0 * p.a_zs0 + (p.dyn ? (int64_t)(*p.dyn) * p.a_dyn : 0);
     const float *__restrict__ w_base = p.w + z1 * p.w_zs1 + z0 * p.w_zs0;
 
     for (int t = tid; t < p.ntaps; t += 256) {
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     const int z1 = z / p.zdiv, z0 = z - z1 * p.zdiv;
     const int HoWo = p.Ho * p.Wo;
 
-    const float *__restrict__ a_base = p.a + z1 * p.a_zs1 + z0 * p.a_zs0;
+    const float *__restrict__ a_base = p.a + z1 * p.a_zs1 + z0 * p.a_zs0 + (p.dyn ? (int64_t)(*p.dyn) * p.a_dyn : 0);
     const float *__restrict__ w_base = p.w + z1 * p.w_zs1 + z0 * p.w_zs0;
 
     // ---- gather table ----

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const int z1 = z / p.zdiv, z0 = z - z1 * p.zdiv;
     const int HoWo = p.Ho * p.Wo;
 
-    const float *__restrict__ a_base = p.a + z1 * p.a_zs1 + z0 * p.a_zs0;
+    const float *__restrict__ a_base = p.a + z1 * p.a_zs1 + z0 * p.a_zs0 + (p.dyn ? (int64_t)(*p.dyn) * p.a_dyn : 0);
     const u32x4 *__restrict__ ws = reinterpret_cast<const u32x4 *>(p.w_split + z0 * p.ws_zs0);
     const int K8 = p.Kw >> 3;     // cells along k per plane
     const int ldn = (int)p.ldw;   // cells per k-row

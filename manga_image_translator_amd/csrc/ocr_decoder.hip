@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include "../../include/mit_hip.h"
 #include "common.h"
 #include "ocr_kernels.h"
@@ -24,7 +25,7 @@ constexpr int FF = 2048;
 
 struct Ws {
     float *tgt, *nrm, *qkv, *krot, *qrot, *att, *q2, *ffh, *decoded, *p1, *logits, *vals, *logp, *cfeat, *part;
-    int *idx, *hist, *done, *done_count;
+    int *idx, *hist, *done, *done_count, *dstep;
 };
 
 // Few rows, long contraction (the FFN's second Linear, K = 2048, at one page: R = lines x beams = 160 rows): a 64-row tiling is
@@ -65,7 +66,8 @@ int64_t carve(Ws *w, char *base, int N, int T, int D) {
     int *hist = (int *)take(2 * R * (T + 1) * 4);
     int *done = (int *)take((int64_t)N * 4);
     int *done_count = (int *)take(256);
-    if (w) *w = Ws{tgt, nrm, qkv, krot, qrot, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, part, idx, hist, done, done_count};
+    int *dstep = (int *)take(256);
+    if (w) *w = Ws{tgt, nrm, qkv, krot, qrot, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, part, idx, hist, done, done_count, dstep};
     return off;
 }
 
@@ -101,10 +103,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 
 // C[M x N] = act((A[M x K] @ W) * scale + bias) + post, rows of A / C / post strided.  ``part``: partial-sum scratch for the
 // split-K form (NULL = never split).
+// dyn / a_dyn / c_dyn: device-resident step counter and the per-step strides of A and C (MitConvGemm.dyn), for the graph-replayed steps.
 int gemm(const MitLinear &lin, const float *A, int64_t lda, float *Cp, int64_t ldc, int M, int act, const float *post,
-         int64_t ldpost, hipStream_t s, int nsplit = 0, int64_t nhi = 0, float *part = nullptr) {
+         int64_t ldpost, hipStream_t s, int nsplit = 0, int64_t nhi = 0, float *part = nullptr, const int *dyn = nullptr,
+         int64_t a_dyn = 0, int64_t c_dyn = 0) {
     MitConvGemm d;
     memset(&d, 0, sizeof(d));
+    d.dyn = dyn; d.a_dyn = a_dyn; d.c_dyn = c_dyn;
     d.a = A;
     d.a_xs = lda;
     d.NB = 1; d.Hi = 1; d.Wi = M; d.Ho = 1; d.Wo = M; d.sy = 1; d.sx = 1;
@@ -115,7 +120,7 @@ int gemm(const MitLinear &lin, const float *A, int64_t lda, float *Cp, int64_t l
     // single-launch form, and with it a page decoded alone would no longer give bit for bit the logits it gives inside a batch — beam
     // search turns such last-bit differences into different tokens whenever two hypotheses score within them.  Off by default.
     static const bool splitk_on = getenv("MIT_OCR_SPLITK") != nullptr && atoi(getenv("MIT_OCR_SPLITK")) != 0;
-    if (part && splitk_on && M <= SPLITK_MAX_M && lin.K >= SPLITK_MIN_K && lin.K % SPLITK_SLICE == 0 && lin.Kp == lin.K && !nsplit &&
+    if (part && splitk_on && !dyn && M <= SPLITK_MAX_M && lin.K >= SPLITK_MIN_K && lin.K % SPLITK_SLICE == 0 && lin.Kp == lin.K && !nsplit &&
         (lin.N & 3) == 0 && (act == MIT_ACT_NONE || act == MIT_ACT_RELU) && !(ldc & 3) && !(ldpost & 3)) {
         const int S = lin.K / SPLITK_SLICE;
         d.Cin = SPLITK_SLICE; d.Kw = SPLITK_SLICE;
@@ -156,6 +161,29 @@ __global__ void copy_hist_kernel(const int *src, int *dst, int64_t n) {
 
 inline int neg_ceil_half(int n) { return -((n + 1) / 2); }  // python: -(n) // 2
 
+// instantiated step graphs whose launches may still be in flight; destroyed once their event has completed
+struct PendingGraph {
+    hipGraphExec_t exec;
+    hipGraph_t graph;
+    hipEvent_t done;
+};
+thread_local std::vector<PendingGraph> g_pending;
+
+void reap_graphs() {
+    size_t k = 0;
+    for (size_t i = 0; i < g_pending.size(); ++i) {
+        PendingGraph &p = g_pending[i];
+        if (p.done && hipEventQuery(p.done) == hipSuccess) {
+            (void)hipGraphExecDestroy(p.exec);
+            (void)hipGraphDestroy(p.graph);
+            (void)hipEventDestroy(p.done);
+        } else {
+            g_pending[k++] = p;
+        }
+    }
+    g_pending.resize(k);
+}
+
 }  // namespace
 
 extern "C" int64_t mit_ocr48_decode_workspace_bytes(int N, int T, int dict_size) {
@@ -188,55 +216,102 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
     MIT_CHECK_HIP(hipMemsetAsync(a->res_len, 0, (size_t)N * 4, s));
 
     int cur = 0, steps = 0;
-    for (int step = 0; step < T; ++step) {
-        ocrk_embed(hist[cur] + step, hist_ld, dec->embd, w.tgt, R, E, s);
+    // One beam-search step as a launch sequence.  ``dyn`` == nullptr: the step-dependent arguments are host values (the classic form);
+    // ``dyn`` != nullptr: every kernel takes them from the device-resident counter w.dstep, so the SAME sequence serves every step and
+    // can be replayed from a hipGraph (one graph launch instead of 74 kernel launches per step: at one page — R = 160 rows — the loop
+    // was bound by launch cost, not by its kernels).  Both forms run the same kernels on the same operands: identical results.
+    auto body = [&](const int step, const int *dyn, hipStream_t st) -> int {
+        const int64_t so = dyn ? 0 : (int64_t)step * E;  // host-side step offset; the dyn form adds step * E on the device
+        if (dyn) ocrk_embed(hist[0], hist_ld, dec->embd, w.tgt, R, E, st, hist[1], dyn);
+        else ocrk_embed(hist[cur] + step, hist_ld, dec->embd, w.tgt, R, E, st);
         const int minpos = neg_ceil_half(step + 1);
+        const int Tk = dyn ? T : step + 1;  // dyn: capacity (grid / LDS); the kernels stop at *dyn + 1
         for (int l = 0; l < 5; ++l) {
             const MitOcrDecoderLayer &ly = dec->layers[l];
             float *qc = w.qkv + (int64_t)(l * 3 + 0) * R * TE;
             float *kc = w.qkv + (int64_t)(l * 3 + 1) * R * TE;
             float *vc = w.qkv + (int64_t)(l * 3 + 2) * R * TE;
             // self attention (:565)
-            ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, w.nrm, E, R, E, 1e-5f, s);
-            if (gemm(ly.qkv, w.nrm, E, qc + (int64_t)step * E, TE, R, MIT_ACT_NONE, nullptr, 0, s, E, (int64_t)R * TE)) return 1;
-            ocrk_xpos_rotate(qc + (int64_t)step * E, TE, E, w.qrot, E, E, R, 1, step, step + minpos, 0, dec->xpos, s);
-            ocrk_xpos_rotate(kc, TE, E, w.krot, TE, E, R, step + 1, 0, minpos, 1, dec->xpos, s);
-            ocrk_attention(w.qrot, E, E, w.krot, TE, E, vc, TE, E, w.att, E, E, nullptr, R, 1, step + 1, 1, s);
-            if (gemm(ly.out, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, s)) return 1;
+            ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, w.nrm, E, R, E, 1e-5f, st);
+            if (gemm(ly.qkv, w.nrm, E, qc + so, TE, R, MIT_ACT_NONE, nullptr, 0, st, E, (int64_t)R * TE, nullptr, dyn, 0, E)) return 1;
+            ocrk_xpos_rotate(qc + so, TE, E, w.qrot, E, E, R, 1, step, step + minpos, 0, dec->xpos, st, dyn, 1, E);
+            ocrk_xpos_rotate(kc, TE, E, w.krot, TE, E, R, Tk, 0, minpos, 1, dec->xpos, st, dyn, 2, 0);
+            ocrk_attention(w.qrot, E, E, w.krot, TE, E, vc, TE, E, w.att, E, E, nullptr, R, 1, Tk, 1, st, 4, 80, dyn);
+            if (gemm(ly.out, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
             // cross attention (:567)
-            ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, w.nrm, E, R, E, 1e-5f, s);
-            if (gemm(ly.q2, w.nrm, E, w.q2, E, R, MIT_ACT_NONE, nullptr, 0, s)) return 1;
-            ocrk_xpos_rotate(w.q2, E, E, w.qrot, E, E, R, 1, step, step + minpos, 0, dec->xpos, s);
+            ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, w.nrm, E, R, E, 1e-5f, st);
+            if (gemm(ly.q2, w.nrm, E, w.q2, E, R, MIT_ACT_NONE, nullptr, 0, st)) return 1;
+            ocrk_xpos_rotate(w.q2, E, E, w.qrot, E, E, R, 1, step, step + minpos, 0, dec->xpos, st, dyn, 1, 0);
             const float *mk = a->mem_k + (int64_t)l * N * L * E;
             const float *mv = a->mem_v + (int64_t)l * N * L * E;
-            ocrk_attention(w.qrot, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, w.att, E, E, a->mem_len, R, 1, L, 5, s);
-            if (gemm(ly.out2, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, s)) return 1;
+            ocrk_attention(w.qrot, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, w.att, E, E, a->mem_len, R, 1, L, 5, st);
+            if (gemm(ly.out2, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
             // feed forward (:568)
-            ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, s);
-            if (gemm(ly.ff1, w.nrm, E, w.ffh, FF, R, MIT_ACT_RELU, nullptr, 0, s)) return 1;
+            ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, st);
+            if (gemm(ly.ff1, w.nrm, E, w.ffh, FF, R, MIT_ACT_RELU, nullptr, 0, st)) return 1;
             if (l < 4) {
-                if (gemm(ly.ff2, w.ffh, FF, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, s, 0, 0, w.part)) return 1;
+                if (gemm(ly.ff2, w.ffh, FF, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st, 0, 0, w.part)) return 1;
             } else {  // last layer writes the step's output straight into the activation cache (:570)
-                if (gemm(ly.ff2, w.ffh, FF, w.decoded + (int64_t)step * E, TE, R, MIT_ACT_NONE, w.tgt, E, s, 0, 0, w.part)) return 1;
+                if (gemm(ly.ff2, w.ffh, FF, w.decoded + so, TE, R, MIT_ACT_NONE, w.tgt, E, st, 0, 0, dyn ? nullptr : w.part, dyn, 0, E)) return 1;
             }
         }
-        if (gemm(dec->pred1, w.decoded + (int64_t)step * E, TE, w.p1, E, R, MIT_ACT_GELU, nullptr, 0, s)) return 1;
-        if (gemm(dec->pred, w.p1, E, w.logits, Dp, R, MIT_ACT_NONE, nullptr, 0, s)) return 1;
+        if (gemm(dec->pred1, w.decoded + so, TE, w.p1, E, R, MIT_ACT_GELU, nullptr, 0, st, 0, 0, nullptr, dyn, E, 0)) return 1;
+        if (gemm(dec->pred, w.p1, E, w.logits, Dp, R, MIT_ACT_NONE, nullptr, 0, st)) return 1;
         if (a->trace_logits)
             MIT_CHECK_HIP(hipMemcpy2DAsync(a->trace_logits + (int64_t)step * R * D, (size_t)D * 4, w.logits, (size_t)Dp * 4,
-                                           (size_t)D * 4, R, hipMemcpyDeviceToDevice, s));
-        ocrk_logsoftmax_top5(w.logits, Dp, R, D, a->suppress_eos ? a->end_tok : -1, w.vals, w.idx, nullptr, s);
-        if (step == 0) {
-            ocrk_beam_init(w.vals, w.idx, hist[cur], hist_ld, logp[cur], N, a->start_tok, s);
+                                           (size_t)D * 4, R, hipMemcpyDeviceToDevice, st));
+        ocrk_logsoftmax_top5(w.logits, Dp, R, D, a->suppress_eos ? a->end_tok : -1, w.vals, w.idx, nullptr, st);
+        if (dyn) {
+            ocrk_beam_dyn(w.vals, w.idx, hist[0], hist[1], hist_ld, logp[0], logp[1], w.done, a->res_row, a->res_len, a->res_prob, a->res_tok,
+                          w.done_count, N, dyn, a->start_tok, a->end_tok, a->max_finished, st);
+            ocrk_step_advance(w.dstep, st);
+        } else if (step == 0) {
+            ocrk_beam_init(w.vals, w.idx, hist[cur], hist_ld, logp[cur], N, a->start_tok, st);
         } else {
             ocrk_beam_step(w.vals, w.idx, hist[cur], hist[cur ^ 1], hist_ld, logp[cur], logp[cur ^ 1], w.done, a->res_row,
-                           a->res_len, a->res_prob, a->res_tok, w.done_count, N, step, a->end_tok, a->max_finished, s);
+                           a->res_len, a->res_prob, a->res_tok, w.done_count, N, step, a->end_tok, a->max_finished, st);
             cur ^= 1;
         }
         if (a->trace_hist)
             MIT_CHECK_HIP(hipMemcpyAsync(a->trace_hist + (int64_t)step * R * hist_ld, hist[cur], (size_t)R * hist_ld * 4,
-                                         hipMemcpyDeviceToDevice, s));
+                                         hipMemcpyDeviceToDevice, st));
         MIT_CHECK_LAUNCH("mit_ocr48_decode");
+        return 0;
+    };
+
+    // Graph replay pays when the kernels are short (few rows); with thousands of rows the steps are GPU-bound and the history kernels
+    // of the device-step form (launched for the longest history) would only add work.  Not while tracing (per-step copies at host
+    // offsets) or probing (events around every launch).  MIT_OCR_DECODE_GRAPH=0 | 1 forces it off / on.
+    static const int graph_env = getenv("MIT_OCR_DECODE_GRAPH") ? atoi(getenv("MIT_OCR_DECODE_GRAPH")) : -1;
+    const int gm = a->graph_mode == 1 ? 1 : a->graph_mode == 2 ? 0 : graph_env;   // the argument wins over the environment
+    const bool use_graph = gm != 0 && !a->trace_logits && !a->trace_hist && !mit_probe_on() && T >= 4 && (gm == 1 || R <= 1024);
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+        reap_graphs();
+        static thread_local hipStream_t cap = nullptr;
+        if (!cap) MIT_CHECK_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        MIT_CHECK_HIP(hipMemsetAsync(w.dstep, 0, 4, s));
+        hipGraph_t graph = nullptr;
+        MIT_CHECK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
+        const int rc = body(0, w.dstep, cap);
+        const hipError_t ce = hipStreamEndCapture(cap, &graph);
+        if (rc || ce != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc ? rc : mit_set_error("mit_ocr48_decode: stream capture of a decode step failed: %s", hipGetErrorString(ce));
+        }
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            return mit_set_error("mit_ocr48_decode: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+        }
+        g_pending.push_back({exec, graph, nullptr});
+    }
+    for (int step = 0; step < T; ++step) {
+        if (use_graph) {
+            MIT_CHECK_HIP(hipGraphLaunch(exec, s));
+        } else if (body(step, nullptr, s)) {
+            return 1;
+        }
         steps = step + 1;
         if (!a->suppress_eos && step >= 1 && (step % 4 == 3) && step + 1 < T) {  // early exit (:765-766) without a per-step sync;
             // with EOS suppressed no hypothesis can finish, so the loop stays fully asynchronous
@@ -245,6 +320,13 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
             MIT_CHECK_HIP(hipStreamSynchronize(s));
             if (dc >= N) break;
         }
+    }
+    if (use_graph) {  // the graph stays alive until its launches have run: an event marks that point, the next call reaps it
+        cur = steps <= 1 ? 0 : ((steps - 1) & 1);  // the buffer the last executed step wrote (step 0 and 1 -> hist[0] -> hist[1] ...)
+        hipEvent_t ev = nullptr;
+        MIT_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        MIT_CHECK_HIP(hipEventRecord(ev, s));
+        g_pending.back().done = ev;
     }
     ocrk_beam_finalize(hist[cur], hist_ld, logp[cur], w.done, a->res_row, a->res_len, a->res_prob, a->res_tok, N, steps + 1, s);
     // colour heads over every beam row's activation cache (:789-799); the caller gathers rows res_row[n]

@@ -6,12 +6,19 @@
 
 void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
                     int D, float eps, hipStream_t s);
+// dstep != NULL: step-dependent arguments come from the decoder's device-resident step counter (see the kernels' comments)
 void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
-                      int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s);
+                      int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s, const int *dstep = nullptr, int dyn_mode = 0,
+                      int64_t dyn_in = 0);
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
-                    int kv_div, hipStream_t s, int heads = 4, int head_dim = 80);
-void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s);
+                    int kv_div, hipStream_t s, int heads = 4, int head_dim = 80, const int *dstep = nullptr);
+void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s, const int *tok1 = nullptr,
+                const int *dstep = nullptr);
+void ocrk_beam_dyn(const float *vals, const int *idx, int *hist0, int *hist1, int hist_ld, float *logp0, float *logp1, int *done,
+                   int *res_row, int *res_len, float *res_prob, int *res_tok, int *done_count, int N, const int *dstep, int start_tok,
+                   int end_tok, int max_finished, hipStream_t s);
+void ocrk_step_advance(int *dstep, hipStream_t s);
 void ocrk_logsoftmax_top5(const float *logits, int64_t ld, int R, int D, int suppress_tok, float *vals, int *idx,
                           float *logp_out, hipStream_t s);
 void ocrk_beam_init(const float *vals, const int *idx, int *hist, int hist_ld, float *logp, int N, int start_tok,

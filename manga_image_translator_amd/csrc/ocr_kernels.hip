@@ -358,10 +358,27 @@ __global__ void layernorm_kernel(const float *__restrict__ in, int64_t in_rs, co
 
 // ---- XPOS rotation (xpos_relative_position.py:36-39,54-71) on [R, T, heads*80] ----
 // position index i = i0 + t selects the sin/cos row, p = p0 + t the scale row (centred positions).
+// dstep (optional, the decoder's device-resident step counter — see ocr_decoder.hip): mode 1 = "the query of this step": the input row
+// starts step * dyn_in floats further, i0 = step, p0 = step + minpos; mode 2 = "the key history": rows t <= step only, p0 = minpos;
+// minpos = -((step + 2) / 2), the centred origin of the positions 0 .. step (python -(step + 1) // 2).
 __global__ void xpos_rotate_kernel(const float *__restrict__ in, int64_t in_rs, int64_t in_ts, float *__restrict__ out,
                                    int64_t out_rs, int64_t out_ts, int R, int T, int i0, int p0, int downscale,
                                    const float *__restrict__ cosT, const float *__restrict__ sinT,
-                                   const float *__restrict__ scaleT, const float *__restrict__ iscaleT, int pmax) {
+                                   const float *__restrict__ scaleT, const float *__restrict__ iscaleT, int pmax,
+                                   const int *__restrict__ dstep, int dyn_mode, int64_t dyn_in) {
+    int t_end = T;
+    if (dstep) {
+        const int step = *dstep;
+        const int minpos = -((step + 2) / 2);
+        if (dyn_mode == 1) {
+            in += (int64_t)step * dyn_in;
+            i0 = step;
+            p0 = step + minpos;
+        } else {
+            t_end = step + 1;
+            p0 = minpos;
+        }
+    }
     // one thread per (r, t, pair j of 160 pairs = 4 heads x 40)
     const int64_t total = (int64_t)R * T * 160;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -371,6 +388,7 @@ __global__ void xpos_rotate_kernel(const float *__restrict__ in, int64_t in_rs, 
         const int64_t rt = i / 160;
         const int t = (int)(rt % T);
         const int r = (int)(rt / T);
+        if (t >= t_end) continue;
         const int j = pair % 40;
         const int ii = i0 + t, pp = p0 + t + pmax;
         const float sc = downscale ? iscaleT[pp * 40 + j] : scaleT[pp * 40 + j];
@@ -389,7 +407,8 @@ __global__ void xpos_rotate_kernel(const float *__restrict__ in, int64_t in_rs, 
 __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int64_t q_ts, const float *__restrict__ K,
                                  int64_t k_rs, int64_t k_ts, const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
                                  float *__restrict__ O, int64_t o_rs, int64_t o_ts, const int *__restrict__ klen, int Tk,
-                                 int kv_div, int HD) {
+                                 int kv_div, int HD, const int *__restrict__ dstep) {
+    if (dstep) Tk = *dstep + 1;     // the decoder's self-attention over the tokens 0 .. step (LDS is sized for the longest history)
     extern __shared__ float lds[];  // [HD] q + [Tk] weights
     float *qs = lds;
     float *ws = lds + HD;
@@ -579,8 +598,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
 }
 
 // ---- embedding rows: out[r] = E[tok[r]] ----
+// dstep (optional): the token of step s is column s of the history buffer the previous step wrote — tok for s <= 1 and odd s, tok1 else
+// (the two buffers alternate, see beam_dyn_kernel)
 __global__ void embed_kernel(const int *__restrict__ tok, int64_t tok_stride, const float *__restrict__ E,
-                             float *__restrict__ out, int R, int D) {
+                             float *__restrict__ out, int R, int D, const int *__restrict__ tok1, const int *__restrict__ dstep) {
+    if (dstep) {
+        const int step = *dstep;
+        tok = ((step == 0 || !((step - 1) & 1)) ? tok : tok1) + step;
+    }
     const int64_t total = (int64_t)R * (D / 4);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -691,8 +716,8 @@ __global__ __launch_bounds__(256) void logsoftmax_top5_kernel(const float *__res
 
 // ---- beam bookkeeping: one thread per sample (25 candidates) ----
 // step 0 (:693-699): beam j of a sample takes the j-th best token of its (identical) row.
-__global__ void beam_init_kernel(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist,
-                                 int hist_ld, float *__restrict__ logp, int N, int start_tok) {
+__device__ __forceinline__ void beam_init_body(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist,
+                                               int hist_ld, float *__restrict__ logp, int N, int start_tok) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     for (int j = 0; j < 5; ++j) {
@@ -703,13 +728,18 @@ __global__ void beam_init_kernel(const float *__restrict__ vals, const int *__re
     }
 }
 
+__global__ void beam_init_kernel(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist,
+                                 int hist_ld, float *__restrict__ logp, int N, int start_tok) {
+    beam_init_body(vals, idx, hist, hist_ld, logp, N, start_tok);
+}
+
 // steps >= 1 (:716-771). hist_in/out [R][hist_ld]: tokens 0..step valid on input, 0..step+1 on output.
-__global__ void beam_step_kernel(const float *__restrict__ vals, const int *__restrict__ idx,
-                                 const int *__restrict__ hist_in, int *__restrict__ hist_out, int hist_ld,
-                                 const float *__restrict__ logp_in, float *__restrict__ logp_out, int *__restrict__ done,
-                                 int *__restrict__ res_row, int *__restrict__ res_len, float *__restrict__ res_prob,
-                                 int *__restrict__ res_tok, int *__restrict__ done_count, int N, int step, int end_tok,
-                                 int max_finished) {
+__device__ __forceinline__ void beam_step_body(const float *__restrict__ vals, const int *__restrict__ idx,
+                                               const int *__restrict__ hist_in, int *__restrict__ hist_out, int hist_ld,
+                                               const float *__restrict__ logp_in, float *__restrict__ logp_out, int *__restrict__ done,
+                                               int *__restrict__ res_row, int *__restrict__ res_len, float *__restrict__ res_prob,
+                                               int *__restrict__ res_tok, int *__restrict__ done_count, int N, int step, int end_tok,
+                                               int max_finished) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float cl[25];
@@ -753,6 +783,36 @@ __global__ void beam_step_kernel(const float *__restrict__ vals, const int *__re
     }
 }
 
+__global__ void beam_step_kernel(const float *__restrict__ vals, const int *__restrict__ idx,
+                                 const int *__restrict__ hist_in, int *__restrict__ hist_out, int hist_ld,
+                                 const float *__restrict__ logp_in, float *__restrict__ logp_out, int *__restrict__ done,
+                                 int *__restrict__ res_row, int *__restrict__ res_len, float *__restrict__ res_prob,
+                                 int *__restrict__ res_tok, int *__restrict__ done_count, int N, int step, int end_tok,
+                                 int max_finished) {
+    beam_step_body(vals, idx, hist_in, hist_out, hist_ld, logp_in, logp_out, done, res_row, res_len, res_prob, res_tok, done_count, N, step,
+                   end_tok, max_finished);
+}
+
+// The same bookkeeping with the step read from device memory (one launch sequence serves every step, so it can be replayed from a
+// hipGraph): step 0 initialises buffer 0; step s >= 1 reads buffer (s - 1) & 1 and writes buffer s & 1.
+__global__ void beam_dyn_kernel(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist0, int *__restrict__ hist1,
+                                int hist_ld, float *__restrict__ logp0, float *__restrict__ logp1, int *__restrict__ done,
+                                int *__restrict__ res_row, int *__restrict__ res_len, float *__restrict__ res_prob, int *__restrict__ res_tok,
+                                int *__restrict__ done_count, int N, const int *__restrict__ dstep, int start_tok, int end_tok, int max_finished) {
+    const int step = *dstep;
+    if (step == 0) {
+        beam_init_body(vals, idx, hist0, hist_ld, logp0, N, start_tok);
+        return;
+    }
+    const bool odd_in = ((step - 1) & 1) != 0;
+    beam_step_body(vals, idx, odd_in ? hist1 : hist0, odd_in ? hist0 : hist1, hist_ld, odd_in ? logp1 : logp0, odd_in ? logp0 : logp1, done,
+                   res_row, res_len, res_prob, res_tok, done_count, N, step, end_tok, max_finished);
+}
+
+__global__ void step_advance_kernel(int *__restrict__ dstep) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dstep += 1;
+}
+
 // fallback (:774-784): samples that never finished take the first row of their beam.
 __global__ void beam_finalize_kernel(const int *__restrict__ hist, int hist_ld, const float *__restrict__ logp,
                                      int *__restrict__ done, int *__restrict__ res_row, int *__restrict__ res_len,
@@ -781,17 +841,18 @@ void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float 
 }
 
 void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
-                      int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s) {
+                      int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s, const int *dstep, int dyn_mode,
+                      int64_t dyn_in) {
     const int64_t total = (int64_t)R * T * 160;
     MitProbeScope probe("xpos_rotate_kernel", s, 8.0 * (double)R * T * 320);
     hipLaunchKernelGGL(xpos_rotate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, in_rs, in_ts, out, out_rs, out_ts, R,
-                       T, i0, p0, downscale, tb.cos_t, tb.sin_t, tb.scale_t, tb.iscale_t, tb.pmax);
+                       T, i0, p0, downscale, tb.cos_t, tb.sin_t, tb.scale_t, tb.iscale_t, tb.pmax, dstep, dyn_mode, dyn_in);
 }
 
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
-                    int kv_div, hipStream_t s, int heads, int head_dim) {
-    if (Tq == 1 && kv_div > 1 && kv_div <= ATT_G_MAX && R % kv_div == 0 && R / kv_div <= 65535 && 2 * head_dim <= ATT_THREADS &&
+                    int kv_div, hipStream_t s, int heads, int head_dim, const int *dstep) {
+    if (!dstep && Tq == 1 && kv_div > 1 && kv_div <= ATT_G_MAX && R % kv_div == 0 && R / kv_div <= 65535 && 2 * head_dim <= ATT_THREADS &&
         ATT_KCHUNK * (head_dim / 4) <= ATT_STAGE * ATT_THREADS) {
         const size_t sm = ((size_t)kv_div * head_dim + (size_t)ATT_KCHUNK * (head_dim + 4) + (size_t)kv_div * Tk) * sizeof(float);
         if (sm <= 64 * 1024) {
@@ -807,12 +868,22 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
     MitProbeScope probe("attention_kernel", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * (double)R * Tq),
                         4.0 * (double)R * Tq * heads * Tk * head_dim);
     hipLaunchKernelGGL(attention_kernel, dim3(Tq, heads, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
-                       o_ts, klen, Tk, kv_div, head_dim);
+                       o_ts, klen, Tk, kv_div, head_dim, dstep);   // dstep: Tk = the LDS capacity, the kernel attends to *dstep + 1 keys
 }
 
-void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s) {
-    hipLaunchKernelGGL(embed_kernel, dim3(grid_for((int64_t)R * D / 4, 256)), dim3(256), 0, s, tok, tok_stride, E, out, R, D);
+void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s, const int *tok1,
+                const int *dstep) {
+    hipLaunchKernelGGL(embed_kernel, dim3(grid_for((int64_t)R * D / 4, 256)), dim3(256), 0, s, tok, tok_stride, E, out, R, D, tok1, dstep);
 }
+
+void ocrk_beam_dyn(const float *vals, const int *idx, int *hist0, int *hist1, int hist_ld, float *logp0, float *logp1, int *done,
+                   int *res_row, int *res_len, float *res_prob, int *res_tok, int *done_count, int N, const int *dstep, int start_tok,
+                   int end_tok, int max_finished, hipStream_t s) {
+    hipLaunchKernelGGL(beam_dyn_kernel, dim3((N + 63) / 64), dim3(64), 0, s, vals, idx, hist0, hist1, hist_ld, logp0, logp1, done, res_row,
+                       res_len, res_prob, res_tok, done_count, N, dstep, start_tok, end_tok, max_finished);
+}
+
+void ocrk_step_advance(int *dstep, hipStream_t s) { hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, dstep); }
 
 void ocrk_logsoftmax_top5(const float *logits, int64_t ld, int R, int D, int suppress_tok, float *vals, int *idx,
                           float *logp_out, hipStream_t s) {

@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 4
+MIT_ABI_VERSION = 5
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -69,6 +69,9 @@ class MitConvGemm(C.Structure):
         ("act_alpha", C.c_float),
         ("w_split", C.c_void_p),
         ("ws_zs0", C.c_int64),
+        ("dyn", C.c_void_p),
+        ("a_dyn", C.c_int64),
+        ("c_dyn", C.c_int64),
     ]
 
 
@@ -100,7 +103,7 @@ class MitOcr48DecodeArgs(C.Structure):
                 ("suppress_eos", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("res_tok", C.c_void_p), ("res_len", C.c_void_p), ("res_prob", C.c_void_p), ("res_row", C.c_void_p),
                 ("colors", C.c_void_p), ("trace_logits", C.c_void_p), ("trace_hist", C.c_void_p), ("steps_run", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("graph_mode", C.c_int32)]
 
 
 class MitProfStat(C.Structure):

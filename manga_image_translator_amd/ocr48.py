@@ -424,7 +424,7 @@ class Ocr48Engine:
 
     @torch.no_grad()
     def decode(self, mem_k: torch.Tensor, mem_v: torch.Tensor, mem_len: torch.Tensor, max_seq_length: int = 255,
-               suppress_eos: bool = False, trace: bool = False):
+               suppress_eos: bool = False, trace: bool = False, graph: Optional[bool] = None):
         """Beam search (:691-801) over N lines at once. mem_k/mem_v [5,N,L,320], mem_len [N] int32.
 
         Returns a dict of device tensors: tokens [N,T+1] int32, length [N], prob [N], colors [N,T,10]
@@ -445,6 +445,7 @@ class Ocr48Engine:
         a.mem_k, a.mem_v, a.mem_len = mem_k.contiguous().data_ptr(), mem_v.contiguous().data_ptr(), mem_len.data_ptr()
         a.max_seq_length, a.start_tok, a.end_tok, a.max_finished, a.suppress_eos = T, 1, 2, 2, int(suppress_eos)
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+        a.graph_mode = 0 if graph is None else (1 if graph else 2)   # None: the library decides (hipGraph replay of the steps for few rows)
         a.res_tok, a.res_len, a.res_prob, a.res_row, a.colors = (t.data_ptr() for t in (res_tok, res_len, res_prob, res_row, colors))
         out = {}
         if trace:

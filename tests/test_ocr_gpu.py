@@ -238,3 +238,28 @@ def test_dwconv_ragged_rows_equals_per_row_kernel(cuda, k, C_, H, shapes):
     ref = ref * sc.cpu().double().view(1, -1, 1, 1) + bi.cpu().double().view(1, -1, 1, 1)
     got = b[:n0 * H * w0].view(n0, H, w0, C_).permute(0, 3, 1, 2).cpu().double()
     assert (got - ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("widths,T,suppress", [([50, 77, 120, 121, 64, 200], 14, True), ([90, 33], 9, False), ([40 + 5 * i for i in range(40)], 6, True)])
+def test_graph_replayed_decode_is_bit_identical(cuda, ocr_setup, widths, T, suppress):
+    """mit_ocr48_decode with its steps replayed from a hipGraph (every step-dependent argument read from a device-resident counter)
+    against the classic launch-by-launch loop: the same kernels on the same operands, so every result tensor must be identical —
+    with EOS suppressed and with the early-exit polling, for one chunk and for a pooled decode of 40 lines."""
+    sd, D, eng = ocr_setup
+    crops = _crops(widths, seed=11)
+    mks, mvs, lens = [], [], []
+    for indices, ws, region in eng.make_chunks(crops):
+        mk, mv, kl, L = eng.encode(torch.from_numpy(region).to(cuda), ws)
+        mks.append(mk.clone()); mvs.append(mv.clone()); lens.append(kl.clone())
+    Lmax = max(m.shape[2] for m in mks)
+    pad = lambda m: m if m.shape[2] == Lmax else torch.cat([m, m.new_zeros(5, m.shape[1], Lmax - m.shape[2], 320)], 2)
+    mem_k, mem_v, klen = torch.cat([pad(m) for m in mks], 1).contiguous(), torch.cat([pad(m) for m in mvs], 1).contiguous(), torch.cat(lens)
+    outs = []
+    for graph in (False, True, True):
+        o = eng.decode(mem_k, mem_v, klen, max_seq_length=T, suppress_eos=suppress, graph=graph)
+        torch.cuda.synchronize()
+        outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    for o in outs[1:]:
+        assert o["steps_run"] == outs[0]["steps_run"]
+        for k in ("tokens", "length", "prob", "colors"):
+            assert torch.equal(o[k], outs[0][k]), k
