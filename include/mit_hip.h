@@ -467,8 +467,9 @@ typedef struct MitOcr48DecodeArgs {
     float *trace_logits;        /* optional [T][N*5][dict] raw logits (pred(pred1(decoded)), :713); NULL in production */
     int32_t *trace_hist;        /* optional [T][N*5][T+1] beam tokens after each step */
     int32_t steps_run;          /* out: steps executed */
-    int32_t graph_mode;         /* 0: replay the steps from a hipGraph when there are few rows (N * 5 <= 1024: the loop is launch-bound
-                                 * there) or as MIT_OCR_DECODE_GRAPH says; 1: always; 2: never.  Same kernels either way: identical results. */
+    int32_t graph_mode;         /* 1: replay the steps from a hipGraph (one launch per step instead of 74); 2: never; 0: as
+                                 * MIT_OCR_DECODE_GRAPH says (default off: measured 50.2 vs 50.6 ms per page, the loop is bound by its
+                                 * kernels' latency, not by launches).  Same kernels either way: identical results. */
 } MitOcr48DecodeArgs;
 
 /* One text line to rectify: cv2.warpPerspective of the page crop [y1:y1+ch, x1:x1+cw] to (dw, dh) with inverse map minv

@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
 }
 
 // (A one-wave-per-32x32-block form with register-streamed operands for few-row GEMMs — a page's decoder Linears, M = 160 — was built and
-// measured in round 3: bit-identical to the tiles but 10-20 % SLOWER than the 64 x 64 tile at every decoder shape (both sit on the launch
-// floor of ~12 us except K = 2048, where the six dependent MFMAs per K-step set the pace); removed.  profiles/r03i_split_check_small_tiles.log)
+// measured in round 3: bit-identical to the tiles but 10-20 % SLOWER than the 64 x 64 tile at every decoder shape.  Prefetch depth 4 / 8 /
+// 12 made no difference (not load latency) and 2 / 3 / 5 row blocks per wave scaled the time linearly (0.38 us per K-step and block: every
+// wave re-splits its A rows in registers — ~60 VALU per 8 floats — for 6 MFMAs); removed.  profiles/r03i_split_check_small_tiles.log)
 
 // W [nz][Kw][ldw] fp32 -> [nz][3][Kw / 8][ldw][8] bf16 (see conv_gemm_split_kernel); one thread per (slice, k cell, column)
 static __global__ __launch_bounds__(256) void gemm_split_pack_kernel(const float *__restrict__ w, const int64_t w_zs, const int K8, const int ldw,

@@ -279,12 +279,13 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
         return 0;
     };
 
-    // Graph replay pays when the kernels are short (few rows); with thousands of rows the steps are GPU-bound and the history kernels
-    // of the device-step form (launched for the longest history) would only add work.  Not while tracing (per-step copies at host
-    // offsets) or probing (events around every launch).  MIT_OCR_DECODE_GRAPH=0 | 1 forces it off / on.
-    static const int graph_env = getenv("MIT_OCR_DECODE_GRAPH") ? atoi(getenv("MIT_OCR_DECODE_GRAPH")) : -1;
+    // Graph replay is OPT-IN (graph_mode = 1 or MIT_OCR_DECODE_GRAPH=1).  Measured on one page (32 lines, R = 160 rows, 32 steps): 50.2 ms
+    // with the graph, 50.6 ms launch by launch — the loop is bound by its kernels' own latency (a 64 x 64 GEMM tile of K = 320 takes 12 us
+    // for 20 dependent K-steps whatever launches it; rocprofv3: 46.5 ms of kernel time per call), not by the launches.  Never while
+    // tracing (per-step copies at host offsets) or probing (events around every launch).
+    static const int graph_env = getenv("MIT_OCR_DECODE_GRAPH") ? atoi(getenv("MIT_OCR_DECODE_GRAPH")) : 0;
     const int gm = a->graph_mode == 1 ? 1 : a->graph_mode == 2 ? 0 : graph_env;   // the argument wins over the environment
-    const bool use_graph = gm != 0 && !a->trace_logits && !a->trace_hist && !mit_probe_on() && T >= 4 && (gm == 1 || R <= 1024);
+    const bool use_graph = gm == 1 && !a->trace_logits && !a->trace_hist && !mit_probe_on() && T >= 4;
     hipGraphExec_t exec = nullptr;
     if (use_graph) {
         reap_graphs();

@@ -445,7 +445,7 @@ class Ocr48Engine:
         a.mem_k, a.mem_v, a.mem_len = mem_k.contiguous().data_ptr(), mem_v.contiguous().data_ptr(), mem_len.data_ptr()
         a.max_seq_length, a.start_tok, a.end_tok, a.max_finished, a.suppress_eos = T, 1, 2, 2, int(suppress_eos)
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
-        a.graph_mode = 0 if graph is None else (1 if graph else 2)   # None: the library decides (hipGraph replay of the steps for few rows)
+        a.graph_mode = 0 if graph is None else (1 if graph else 2)   # None: off unless MIT_OCR_DECODE_GRAPH=1 (hipGraph replay of the steps: no gain measured)
         a.res_tok, a.res_len, a.res_prob, a.res_row, a.colors = (t.data_ptr() for t in (res_tok, res_len, res_prob, res_row, colors))
         out = {}
         if trace:
