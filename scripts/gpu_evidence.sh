@@ -9,8 +9,11 @@ if [ "${2:-}" != "skip-tests" ]; then
   tail -5 $OUT/pytest.log
 fi
 timeout 900 python bench.py --prof-dump $OUT/layers.csv > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python bench.py --no-cpu-baseline --no-dropin > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof rc=$?"
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python bench.py --no-cpu-baseline --no-dropin --no-fp32-leg > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof rc=$?"
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/prof
 bash scripts/pmc_stage.sh detect,ocr,inpaint 64 $OUT/pmc_traffic.json > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
+bash scripts/pmc_mfma.sh 16 $OUT/mfma_busy.json > $OUT/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"; tail -1 $OUT/pmc_mfma.log
+MIT_GEMM_SPLIT=0 bash scripts/pmc_mfma.sh 16 $OUT/mfma_busy_fp32.json > $OUT/pmc_mfma_fp32.log 2>&1; tail -1 $OUT/pmc_mfma_fp32.log
 head -c 1500 $OUT/bench.json; echo; tail -3 $OUT/bench.err
