@@ -30,12 +30,29 @@ def test_committed_bench_lines_follow_the_contract(path):
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     if os.path.basename(path) >= "r02a":  # round 2 lines: per-stage roofline, HBM kernel table, parity and drop-in legs
         assert set(r["stages"]) == {"ctd", "ocr48", "lama_mpe"} and all(0 < v["frac_of_fp32_mfma_peak"] < 1 for v in r["stages"].values())
-        assert 0 < r["whole_step"]["frac_of_fp32_mfma_peak"] <= r["frac"]
+        if os.path.basename(path) < "r03a":
+            assert 0 < r["whole_step"]["frac_of_fp32_mfma_peak"] <= r["frac"]
         big = [v for v in r["hbm_kernels"].values() if v.get("alg_GB_per_launch", 0) > 0.5]
         assert big and all(0 < v["frac_of_hbm_peak"] < 1 for v in big)
         assert d["parity_checked"]["ok"] is True and d["parity_checked"]["ocr"]["lines_with_different_tokens"] == 0
         assert d["dropin"]["batch"] == 1 and d["dropin"]["unit"] == "pages/s" and d["dropin"]["value"] < d["value"]
         assert "thread" in c["sample"] and c["cores"] in (8, 16, 32, 64, 128)
+
+
+    if os.path.basename(path) >= "r03a":  # round 3 lines: the GEMM mode is named, the fp32-MFMA figure is timed beside a split-mode headline,
+        gm = d["gemm_mode"]               # split tiles are priced on the bf16 pipe, the coupled (glue-inclusive) path has its own numbers
+        assert gm["mode"] in (0, 6, 9)
+        if gm["mode"]:
+            f = d["fp32_mfma"]
+            assert f["unit"] == "pages/s" and 0 < f["value"] < 1.1 * d["value"] and f["gemm_mode"] == 0
+            assert 0 < f["roofline"]["frac"] < 1 and f["roofline"]["peak"] == 157.3
+            assert r["peak"] == 2500.0 and r["plane_pairs"] == gm["mode"] and r["kernel"].startswith("conv_gemm_split_kernel")
+            assert abs(r["achieved"] - r["plane_pairs"] * r["fp32_equivalent_tflops"]) < 0.6
+        assert all(0 < v["frac_of_mfma_roofline"] < 1 for v in r["stages"].values()) and 0 < r["whole_step"]["frac_of_mfma_roofline"] < 1
+        c2 = d["coupled"]
+        assert c2["batch"]["unit"] == "pages/s" and 0 < c2["batch"]["value"] < d["value"]
+        assert c2["b1_plugins"]["value"] > 0 and min(c2["b1_plugins"]["detector_boxes_found_per_page"]) >= 28
+        assert c2["batch"]["lines_per_page_after_ocr"]["min"] >= 24
 
 
 def test_bench_cli_parses_without_a_gpu():
