@@ -501,6 +501,40 @@ def _injection(host_inputs, idx, device, map_hw):
     return {"prob": prob, "mask": mask}
 
 
+def _probe_kernels(fn):
+    """Run ``fn`` once under the C-ABI kernel probe: (wall ms, {kernel: launches, ms, algorithmic GB/s and fraction of the HBM peak})."""
+    from manga_image_translator_amd import lib as L
+
+    lib = L.load()
+    torch.cuda.synchronize()
+    L.check(lib.mit_prof_enable(1), "mit_prof_enable")
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    kst = (L.MitProfKernelStat * 64)()
+    nk = C.c_int(0)
+    L.check(lib.mit_prof_kernels_read(kst, 64, C.byref(nk)), "mit_prof_kernels_read")
+    stats = (L.MitProfStat * 64)()
+    ncfg = C.c_int(0)
+    L.check(lib.mit_prof_read(stats, 64, C.byref(ncfg)), "mit_prof_read")
+    L.check(lib.mit_prof_enable(0), "mit_prof_enable")
+    out = {}
+    for i in range(nk.value):
+        k = kst[i]
+        if not k.launches:
+            continue
+        e = dict(launches=int(k.launches), ms=round(k.ms, 3))
+        if k.alg_bytes > 0 and k.ms > 0:
+            gbs = k.alg_bytes / (k.ms * 1e-3) / 1e9
+            e.update(alg_GBps=round(gbs, 1), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
+        out[k.name.decode()] = e
+    conv_ms = sum(stats[i].ms for i in range(ncfg.value) if stats[i].launches)
+    if conv_ms:
+        out["conv_gemm (all tiles)"] = dict(launches=int(sum(stats[i].launches for i in range(ncfg.value))), ms=round(conv_ms, 3))
+    return round(wall, 2), dict(sorted(out.items(), key=lambda kv: -kv[1]["ms"]))
+
+
 def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4):
     """(1) batch: coupled.CoupledPageEngine over the same resident pages as the headline — detector -> native box extraction on a host
     thread pool -> GPU refine_mask -> OCR of the DETECTED lines -> text-line merge -> mask refinement (bilateral + DenseCRF + dilations
@@ -588,12 +622,19 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4):
                 for k, (a, b) in zip(per, zip(t, t[1:])):
                     per[k].append(b - a)
                 n_found.append(len(tls))
+        # the glue stages under the kernel probe (one more call each on the last page; probe events serialise the launches, so the wall
+        # clock of these passes is not the number above): where f1 (mask refinement) and a4 / a5 (boxes, refine_mask) spend GPU time
+        glue = {}
+        wall, kern = _probe_kernels(lambda: MR.dispatch_sync(regions, page, mask_raw, "fit_text", 20, 0, False, 3))
+        glue["mask_refinement"] = dict(probed_wall_ms=wall, gpu_kernel_ms=round(sum(v["ms"] for v in kern.values()), 3), kernels=kern)
+        wall, kern = _probe_kernels(lambda: run(det.infer(page, 1024, 0.5, 0.7, 2.3)))
+        glue["detect (network + boxes + refine_mask)"] = dict(probed_wall_ms=wall, gpu_kernel_ms=round(sum(v["ms"] for v in kern.values()), 3), kernels=kern)
         for p in (det, ocr, inp):
             run(p.unload())
         ms = {k: round(1e3 * float(np.mean(v)), 2) for k, v in per.items()}
         tot = sum(ms.values())
         out["b1_plugins"] = dict(value=round(1e3 / tot, 3), unit="pages/s", pages=len(distinct), ms_per_page=round(tot, 2), ms_per_stage=ms,
-                                 detector_boxes_found_per_page=n_found)
+                                 detector_boxes_found_per_page=n_found, glue_kernels=glue)
     out["order"] = "detect -> boxes -> refine_mask -> OCR (detected lines) -> textline merge -> mask refinement (dilation offset 20, kernel 3) -> inpaint (manga_translator.py:432-622)"
     out["detector_head"] = ("random-init weights fire on nothing: the maps a trained head would emit for the synthetic page (DB shrink map 0.9 inside the "
                             "shrunk text boxes, glyph mask) are put in place of the network's output after it has run in full (coupled.synthetic_head_outputs)")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 5
+#define MIT_ABI_VERSION 6
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -398,6 +398,28 @@ int mit_boxes_from_bitmap(const float *pred, const uint8_t *bitmap, int H, int W
                           int64_t *boxes_out, float *scores_out, int *n_out);
 /* Number of contours / border points cv2.findContours(RETR_LIST) would trace in a 0/1 bitmap (diagnostics, tests). */
 int mit_find_contours_count(const uint8_t *bitmap, int H, int W, int *n_contours, int64_t *n_points);
+
+/* Mask refinement, host half ahead of the per-line DenseCRF — complete_mask of mask_refinement/text_mask_utils.py:100-170 (host
+ * pointers only; CPU code).  mask: u8 [H,W] at the working scale, MODIFIED like the reference's (every line's bounding box outlined
+ * with zeros, cv2.rectangle).  Its 8-connected components (cv2.connectedComponentsWithStats) come back as row runs — runs[r] =
+ * {y, x0, x1 (exclusive), comp}, comp = 1..n in raster order of the component's first pixel — and assign[comp] is the text line
+ * the component belongs to, or -1 (assign[0] = -1): more than 9 pixels, smaller than the line, and either the line polygon covers
+ * more than keep_threshold of min(component pixels, line area) of the component's bounding rectangle (largest such ratio, fp32, first
+ * wins) or no line does and the nearest polygon is closer to the rectangle's centre than half of max(min(font size, w, h), 10).
+ * polys: f64 [M,V,2] (V = 4 for text lines), boxes_xywh: i32 [M,4] (BBox.xywh), font_size: f64 [M]; line_rects: i32 [M,4] = union
+ * (x1, y1, x2, y2) of the bounding rectangles of the line's components, -1 when it has none.  runs_cap <= H * ceil(W / 2) runs and
+ * assign_cap <= ceil(H / 2) * ceil(W / 2) + 1 entries always suffice. */
+typedef struct MitMaskRun {
+    int32_t y, x0, x1, comp;
+} MitMaskRun;
+int mit_mask_assign_lines(uint8_t *mask, int H, int W, const int32_t *boxes_xywh, const double *polys, const double *font_size, int M, int V,
+                          double keep_threshold, MitMaskRun *runs, int64_t runs_cap, int32_t *assign, int64_t assign_cap, int32_t *line_rects,
+                          int64_t *n_runs_out, int32_t *n_comp_out);
+/* The component image of a line inside a rectangle, for n_jobs (line, x, y, w, h) jobs at once (jobs: i32 [n_jobs,5]): out +
+ * offsets[j] receives the u8 [h,w] crop that is 255 on the pixels of the components assigned to the job's line — what the reference
+ * reads out of its page-sized per-line images (text_mask_utils.py:145,173). */
+int mit_mask_line_crops(const MitMaskRun *runs, int64_t n_runs, const int32_t *assign, const int32_t *jobs, int n_jobs, uint8_t *out,
+                        const int64_t *offsets);
 /* merge_mask_list of the ctd detector's refine_mask (detection/ctd_utils/textmask.py:74-132; filter_with_lines False), HOST
  * pointers: n_cands candidate masks [n_cands][h*w] (0 / 255) with their xor scores, the network's mask window pred_mask [h*w];
  * merged [h*w] receives the result.  Candidates in ascending score, their 8-connected components in raster order of the first

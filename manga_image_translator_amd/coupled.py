@@ -197,10 +197,16 @@ class CoupledPageEngine:
     # ---- the whole path -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, pages_u8: torch.Tensor, max_seq_length: int = 255, suppress_eos: bool = False, prob_threshold: float = 0.2,
-            inject=None) -> CoupledResult:
+            inject=None, group: Optional[int] = 16) -> CoupledResult:
+        """``group``: pages per pipeline slot.  A batch larger than one group flows through three stage threads (detector + boxes +
+        refine_mask | OCR | merge + mask refinement + LaMa), each working on a different group at a time, so the host phases of one
+        group run while the kernels of its neighbours execute; every stage sees the groups in order and owns its engines, and each
+        page's result is what the unpipelined call (``group=None``) gives."""
         if pages_u8.dtype != torch.uint8 or pages_u8.dim() != 4 or pages_u8.shape[-1] != 3 or not pages_u8.is_cuda:
             raise ValueError(f"CoupledPageEngine.run expects a uint8 device tensor [B,H,W,3], got {pages_u8.dtype} {tuple(pages_u8.shape)}")
         B = pages_u8.shape[0]
+        if group is not None and B > group:
+            return self._run_pipelined(pages_u8, max_seq_length, suppress_eos, prob_threshold, inject, int(group))
         sec = {}
         t = time.perf_counter()
         textlines, mask_raw = self.detect(pages_u8, inject)
@@ -217,4 +223,50 @@ class CoupledPageEngine:
             j = min(B, i + self.lama_mb)
             inpainted[i:j].copy_(self.lama.forward(pages_u8[i:j], mask[i:j]))
         sec["inpaint (enqueue)"] = time.perf_counter() - t
+        return CoupledResult(textlines, regions, mask, inpainted, sec)
+
+    def _inpaint(self, pages_u8: torch.Tensor, mask: torch.Tensor, out: torch.Tensor):
+        for i in range(0, pages_u8.shape[0], self.lama_mb):
+            j = min(pages_u8.shape[0], i + self.lama_mb)
+            out[i:j].copy_(self.lama.forward(pages_u8[i:j], mask[i:j]))
+
+    def _run_pipelined(self, pages_u8, max_seq_length, suppress_eos, prob_threshold, inject, group) -> CoupledResult:
+        B, H, W, _ = pages_u8.shape
+        spans = [(i, min(B, i + group)) for i in range(0, B, group)]
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        sec = {"detect+boxes+refine_mask": 0.0, "ocr": 0.0, "textline_merge+mask_refinement": 0.0, "inpaint (enqueue)": 0.0}
+        mask = torch.empty(B, H, W, dtype=torch.uint8, device=self.device)
+        inpainted = torch.empty_like(pages_u8)
+        stream = torch.cuda.current_stream()
+
+        def timed(key, fn, *a):
+            torch.cuda.set_device(dev_index)
+            with torch.no_grad(), torch.cuda.stream(stream):   # every stage thread launches into the caller's stream
+                t = time.perf_counter()
+                r = fn(*a)
+                sec[key] += time.perf_counter() - t           # one thread per key: no race
+                return r
+
+        def st_detect(a, b):
+            inj = None if inject is None else {k: v[a:b] for k, v in inject.items()}
+            return timed("detect+boxes+refine_mask", self.detect, pages_u8[a:b], inj)
+
+        def st_ocr(a, b, f_det):
+            tl, mraw = f_det.result()
+            return timed("ocr", self.recognize, pages_u8[a:b], tl, max_seq_length, suppress_eos, prob_threshold), mraw
+
+        def st_tail(a, b, f_ocr):
+            tl, mraw = f_ocr.result()
+            regions, m = timed("textline_merge+mask_refinement", self.merge_and_refine, pages_u8[a:b], tl, mraw)
+            mask[a:b] = m
+            timed("inpaint (enqueue)", self._inpaint, pages_u8[a:b], mask[a:b], inpainted[a:b])
+            return tl, regions
+
+        with cf.ThreadPoolExecutor(1, "mit-st-det") as e1, cf.ThreadPoolExecutor(1, "mit-st-ocr") as e2, cf.ThreadPoolExecutor(1, "mit-st-tail") as e3:
+            f1 = [e1.submit(st_detect, a, b) for a, b in spans]
+            f2 = [e2.submit(st_ocr, a, b, f) for (a, b), f in zip(spans, f1)]
+            f3 = [e3.submit(st_tail, a, b, f) for (a, b), f in zip(spans, f2)]
+            done = [f.result() for f in f3]
+        textlines = [t for tl, _ in done for t in tl]
+        regions = [r for _, rg in done for r in rg]
         return CoupledResult(textlines, regions, mask, inpainted, sec)

@@ -134,7 +134,16 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
         // under-filled launches (one page through the plugins, the decoder's Linears): 64 x 64 tiles quadruple the workgroup count;
         // the arithmetic per output element is that of the large tiles, so a result does not depend on the choice
         const int sm = split == 6 ? small6 : small9;
-        if (sm >= 0 && p.Z == 1 && tiles128 < ssmall_max) c = sm;
+        if (sm >= 0 && p.Z == 1 && tiles128 < ssmall_max) {
+            c = sm;
+            // launches of at most two workgroups per CU (one page through the plugins: the decoder at M = 160 rows, the detector's deep
+            // layers) are bound by the latency of a K-loop iteration, not by its throughput: two MFMA steps per barrier (BK = 32) take
+            // 10-22 % off them and cost 2 % on fuller launches (profiles/r03l_split_check_bk32.log).  Same MFMA sequence per element.
+            static const int small6k = getenv("MIT_CONV_NO_SMALL_BK32") ? -1 : cfg_by_name("split64x64x32p6o");
+            static const int small9k = getenv("MIT_CONV_NO_SMALL_BK32") ? -1 : cfg_by_name("split64x64x32p9m");
+            const int smk = split == 6 ? small6k : small9k;
+            if (smk >= 0 && ((M + 63) / 64) * ((p.N + 63) / 64) <= 512 && split_eligible(p, 32)) c = smk;
+        }
         if (c >= 0) return c;
     }
     if (f16 && m192 >= 0 && M > 128 && M <= 192 && p.Z >= 8) return m192;  // batched launches (Z entries of M = 184 rows: W-axis DFTs): 2 x 128 rows would run a 40 % empty second tile.  Unbatched, one row of 192 x 64 tiles leaves the chip empty (the decoder at B = 1: M = 160)

@@ -412,3 +412,243 @@ extern "C" int mit_find_contours_count(const uint8_t *bitmap, int H, int W, int 
     *n_points = np;
     return 0;
 }
+
+// ---- mask refinement: connected components of the working-scale mask and their assignment to text lines ----------------------
+// The host half of complete_mask (mask_refinement/text_mask_utils.py:100-170) ahead of the per-line DenseCRF: outline every line's
+// bounding box with zeros, label the 8-connected components, give each component of more than 9 pixels to the line whose polygon
+// covers most of its bounding rectangle (or, when none does, to the nearest line within half a glyph).  Components are kept as row
+// runs (no page-sized label image, no page-sized image per line): a line's component image is painted from the runs on demand.
+namespace {
+
+struct RunUF {
+    std::vector<int> parent;
+    int find(int a) {
+        while (parent[a] != a) {
+            parent[a] = parent[parent[a]];
+            a = parent[a];
+        }
+        return a;
+    }
+    void unite(int a, int b) {
+        a = find(a), b = find(b);
+        if (a != b) parent[a < b ? b : a] = a < b ? a : b;
+    }
+};
+
+// area of (polygon) ∩ (axis-aligned rectangle): Sutherland-Hodgman against the four sides in turn, shoelace formula
+double clip_poly_rect_area(const double *pts, int V, double x0, double y0, double x1, double y1) {
+    Pd a[32], b[32];
+    int na = 0;
+    for (int i = 0; i < V && i < 16; ++i) a[na++] = Pd{pts[2 * i], pts[2 * i + 1]};
+    Pd *cur = a, *nxt = b;
+    for (int side = 0; side < 4; ++side) {
+        if (na == 0) return 0.0;
+        const int axis = side >> 1;
+        const double bound = side == 0 ? x0 : side == 1 ? x1 : side == 2 ? y0 : y1;
+        const bool keep_ge = (side & 1) == 0;
+        int nn = 0;
+        for (int i = 0; i < na; ++i) {
+            const Pd p = cur[i], q = cur[(i + 1) % na];
+            const double pc = axis ? p.y : p.x, qc = axis ? q.y : q.x;
+            const double dp = keep_ge ? pc - bound : bound - pc, dq = keep_ge ? qc - bound : bound - qc;
+            if (dp >= 0 && nn < 32) nxt[nn++] = p;
+            if (((dp > 0 && dq < 0) || (dp < 0 && dq > 0)) && nn < 32) {
+                const double t = dp / (dp - dq);
+                nxt[nn++] = Pd{p.x + t * (q.x - p.x), p.y + t * (q.y - p.y)};
+            }
+        }
+        std::swap(cur, nxt);
+        na = nn;
+    }
+    if (na < 3) return 0.0;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < na; ++i) {
+        const Pd p = cur[i], q = cur[(i + 1) % na];
+        s1 += p.x * q.y;
+        s2 += p.y * q.x;
+    }
+    return fabs(s1 - s2) / 2;
+}
+
+double poly_area(const double *pts, int V) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < V; ++i) {
+        const int j = (i + 1) % V;
+        s1 += pts[2 * i] * pts[2 * j + 1];
+        s2 += pts[2 * i + 1] * pts[2 * j];
+    }
+    return fabs(s1 - s2) / 2;
+}
+
+// distance from a point to a polygon (0 inside): even-odd crossing test, then the nearest point of every edge
+double poly_point_distance(const double *pts, int V, double px, double py) {
+    bool inside = false;
+    for (int i = 0; i < V; ++i) {
+        const int j = (i + 1) % V;
+        const double ax = pts[2 * i], ay = pts[2 * i + 1], bx = pts[2 * j], by = pts[2 * j + 1];
+        if ((ay > py) != (by > py) && px < (bx - ax) * (py - ay) / (by - ay) + ax) inside = !inside;
+    }
+    if (inside) return 0.0;
+    double best = INFINITY;
+    for (int i = 0; i < V; ++i) {
+        const int j = (i + 1) % V;
+        const double ax = pts[2 * i], ay = pts[2 * i + 1], bx = pts[2 * j], by = pts[2 * j + 1];
+        const double abx = bx - ax, aby = by - ay, den = abx * abx + aby * aby;
+        double t = den == 0 ? 0.0 : ((px - ax) * abx + (py - ay) * aby) / den;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double dx = px - (ax + t * abx), dy = py - (ay + t * aby);
+        best = std::min(best, sqrt(dx * dx + dy * dy));
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int mit_mask_assign_lines(uint8_t *mask, int H, int W, const int32_t *boxes_xywh, const double *polys, const double *font_size,
+                                     int M, int V, double keep_threshold, MitMaskRun *runs, int64_t runs_cap, int32_t *assign,
+                                     int64_t assign_cap, int32_t *line_rects, int64_t *n_runs_out, int32_t *n_comp_out) {
+    if (!mask || !runs || !assign || !line_rects || !n_runs_out || !n_comp_out || (M > 0 && (!boxes_xywh || !polys || !font_size)))
+        return mit_set_error("mit_mask_assign_lines: null pointer");
+    if (H <= 0 || W <= 0 || M < 0 || V < 3 || V > 16) return mit_set_error("mit_mask_assign_lines: bad shape (H %d W %d M %d V %d)", H, W, M, V);
+    // cv2.rectangle(mask, (x, y), (x + w, y + h), 0, 1): one-pixel outline, inclusive corners, clipped (text_mask_utils.py:105-106)
+    for (int i = 0; i < M; ++i) {
+        const int x = boxes_xywh[4 * i], y = boxes_xywh[4 * i + 1], w = boxes_xywh[4 * i + 2], h = boxes_xywh[4 * i + 3];
+        const int xa = std::max(x, 0), xb = std::min(x + w, W - 1), ya = std::max(y, 0), yb = std::min(y + h, H - 1);
+        if (xa > xb || ya > yb) continue;
+        for (int yy : {y, y + h})
+            if (yy >= 0 && yy < H) memset(mask + (int64_t)yy * W + xa, 0, (size_t)(xb - xa + 1));
+        for (int xx : {x, x + w})
+            if (xx >= 0 && xx < W)
+                for (int yy = ya; yy <= yb; ++yy) mask[(int64_t)yy * W + xx] = 0;
+    }
+    // row runs, united with the runs of the row above that touch them (8-connectivity: a run reaches one pixel to either side)
+    int64_t nr = 0;
+    RunUF uf;
+    int64_t prev0 = 0, prev1 = 0;
+    for (int y = 0; y < H; ++y) {
+        const uint8_t *row = mask + (int64_t)y * W;
+        const int64_t row0 = nr;
+        int x = 0;
+        while (x < W) {
+            if (!row[x]) {
+                while (x + 8 <= W) {  // zeros, 8 bytes at a time
+                    uint64_t v;
+                    memcpy(&v, row + x, 8);
+                    if (v) break;
+                    x += 8;
+                }
+                while (x < W && !row[x]) ++x;
+                if (x >= W) break;
+            }
+            const int x0 = x;
+            while (x < W && row[x]) ++x;
+            if (nr >= runs_cap) return mit_set_error("mit_mask_assign_lines: more than %lld runs", (long long)runs_cap);
+            runs[nr] = MitMaskRun{y, x0, x, (int32_t)nr};
+            uf.parent.push_back((int)nr);
+            ++nr;
+        }
+        int64_t p = prev0;
+        for (int64_t r = row0; r < nr; ++r) {
+            while (p < prev1 && runs[p].x1 < runs[r].x0) ++p;  // ends left of the run, not even diagonally adjacent
+            for (int64_t q = p; q < prev1 && runs[q].x0 <= runs[r].x1; ++q) uf.unite((int)q, (int)r);
+        }
+        prev0 = row0, prev1 = nr;
+    }
+    // component numbers in raster order of their first pixel (1..n), area and bounding rectangle
+    std::vector<int> id(nr, 0);
+    struct Stat { int64_t area; int x0, y0, x1, y1; };
+    std::vector<Stat> st(1);
+    for (int64_t r = 0; r < nr; ++r) {
+        const int root = uf.find((int)r);
+        if (!id[root]) {
+            id[root] = (int)st.size();
+            st.push_back(Stat{0, INT32_MAX, INT32_MAX, 0, 0});
+        }
+        const int c = id[root];
+        MitMaskRun &ru = runs[r];
+        ru.comp = c;
+        Stat &s = st[c];
+        s.area += ru.x1 - ru.x0;
+        s.x0 = std::min(s.x0, ru.x0), s.x1 = std::max(s.x1, ru.x1), s.y0 = std::min(s.y0, ru.y), s.y1 = std::max(s.y1, ru.y + 1);
+    }
+    const int n = (int)st.size() - 1;
+    if (n + 1 > assign_cap) return mit_set_error("mit_mask_assign_lines: %d components, room for %lld", n, (long long)assign_cap - 1);
+    std::vector<double> area2(M), pminx(M), pminy(M), pmaxx(M), pmaxy(M);
+    for (int i = 0; i < M; ++i) {
+        const double *p = polys + (int64_t)i * V * 2;
+        area2[i] = poly_area(p, V);
+        pminx[i] = pmaxx[i] = p[0], pminy[i] = pmaxy[i] = p[1];
+        for (int v = 1; v < V; ++v) {
+            pminx[i] = std::min(pminx[i], p[2 * v]), pmaxx[i] = std::max(pmaxx[i], p[2 * v]);
+            pminy[i] = std::min(pminy[i], p[2 * v + 1]), pmaxy[i] = std::max(pmaxy[i], p[2 * v + 1]);
+        }
+    }
+    for (int i = 0; i < M; ++i) line_rects[4 * i] = line_rects[4 * i + 1] = line_rects[4 * i + 2] = line_rects[4 * i + 3] = -1;
+    assign[0] = -1;
+    std::vector<float> ratio(M);
+    for (int c = 1; c <= n; ++c) {
+        assign[c] = -1;
+        const Stat &s = st[c];
+        if (s.area <= 9 || M == 0) continue;
+        const int x1 = s.x0, y1 = s.y0, w1 = s.x1 - s.x0, h1 = s.y1 - s.y0;
+        int avg = 0;
+        float best = -1.f;
+        for (int i = 0; i < M; ++i) {  // overlap of the line polygon with the component's rectangle over the smaller of the two areas (:129-130), kept in fp32
+            float r = 0.f;
+            if (pminx[i] <= x1 + w1 && pmaxx[i] >= x1 && pminy[i] <= y1 + h1 && pmaxy[i] >= y1)
+                r = (float)(clip_poly_rect_area(polys + (int64_t)i * V * 2, V, x1, y1, x1 + w1, y1 + h1) / std::min((double)s.area, area2[i]));
+            ratio[i] = r;
+            if (r > best) best = r, avg = i;  // first maximum, like argmax
+        }
+        if ((double)s.area >= area2[avg]) continue;
+        if (ratio[avg] <= (float)keep_threshold) {
+            const double cx = x1 + w1 / 2.0, cy = y1 + h1 / 2.0;
+            float dbest = INFINITY;
+            int di = 0;
+            for (int i = 0; i < M; ++i) {
+                const float d = (float)poly_point_distance(polys + (int64_t)i * V * 2, V, cx, cy);
+                if (d < dbest) dbest = d, di = i;  // first minimum, like argmin
+            }
+            avg = di;
+            const double unit = std::max(std::min(std::min(font_size[avg], (double)w1), (double)h1), 10.0);
+            if ((double)dbest >= 0.5 * unit) continue;
+        }
+        assign[c] = avg;
+        int32_t *r = line_rects + 4 * avg;
+        if (r[0] < 0) r[0] = x1, r[1] = y1, r[2] = x1 + w1, r[3] = y1 + h1;
+        else r[0] = std::min(r[0], x1), r[1] = std::min(r[1], y1), r[2] = std::max(r[2], x1 + w1), r[3] = std::max(r[3], y1 + h1);
+    }
+    *n_runs_out = nr;
+    *n_comp_out = n;
+    return 0;
+}
+
+extern "C" int mit_mask_line_crops(const MitMaskRun *runs, int64_t n_runs, const int32_t *assign, const int32_t *jobs, int n_jobs, uint8_t *out,
+                                   const int64_t *offsets) {
+    if (!runs || !assign || !jobs || !out || !offsets) return mit_set_error("mit_mask_line_crops: null pointer");
+    int64_t total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int w = jobs[5 * j + 3], h = jobs[5 * j + 4];
+        if (w < 0 || h < 0) return mit_set_error("mit_mask_line_crops: job %d has a negative size", j);
+        total = std::max(total, offsets[j] + (int64_t)w * h);
+    }
+    memset(out, 0, (size_t)total);
+    // jobs of a line (normally one): lines are few, so a small per-line list is enough
+    int max_line = -1;
+    for (int j = 0; j < n_jobs; ++j) max_line = std::max(max_line, jobs[5 * j]);
+    std::vector<std::vector<int>> by_line(max_line + 1);
+    for (int j = 0; j < n_jobs; ++j)
+        if (jobs[5 * j] >= 0) by_line[jobs[5 * j]].push_back(j);
+    for (int64_t r = 0; r < n_runs; ++r) {
+        const MitMaskRun &ru = runs[r];
+        const int line = assign[ru.comp];
+        if (line < 0 || line > max_line) continue;
+        for (int j : by_line[line]) {
+            const int x = jobs[5 * j + 1], y = jobs[5 * j + 2], w = jobs[5 * j + 3], h = jobs[5 * j + 4];
+            if (ru.y < y || ru.y >= y + h) continue;
+            const int a = std::max(ru.x0, x), b = std::min(ru.x1, x + w);
+            if (a < b) memset(out + offsets[j] + (int64_t)(ru.y - y) * w + (a - x), 255, (size_t)(b - a));
+        }
+    }
+    return 0;
+}

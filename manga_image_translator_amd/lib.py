@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 5
+MIT_ABI_VERSION = 6
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -130,6 +130,10 @@ class MitDilateJob(C.Structure):
                 ("dw", C.c_int32), ("dh", C.c_int32), ("k", C.c_int32), ("spitch", C.c_int32), ("src_off", C.c_int64)]
 
 
+class MitMaskRun(C.Structure):
+    _fields_ = [("y", C.c_int32), ("x0", C.c_int32), ("x1", C.c_int32), ("comp", C.c_int32)]
+
+
 class MitRefineWindow(C.Structure):
     _fields_ = [("x1", C.c_int32), ("y1", C.c_int32), ("x2", C.c_int32), ("y2", C.c_int32)]
 
@@ -217,6 +221,9 @@ SYMBOLS = {
     "mit_merge_mask_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_otsu_from_hist": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mit_find_contours_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "mit_mask_assign_lines": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p,
+                                        C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "mit_mask_line_crops": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mit_ocr_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_dwconv_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p]),

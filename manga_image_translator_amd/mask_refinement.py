@@ -255,14 +255,68 @@ def _xywh(q: Quadrilateral):  # BBox.xywh (utils/generic.py:319-321): int32 trun
     return tuple(int(v) for v in np.array([mn[0], mn[1], mx[0] - mn[0], mx[1] - mn[1]], dtype=np.int32))
 
 
+def _assign_components_native(mask: np.ndarray, textlines: Sequence[Quadrilateral], keep_threshold: float):
+    """The component labelling and line assignment of complete_mask in native host code (``mit_mask_assign_lines``, csrc/hostglue.hip).
+    Returns (rects per line or None, crop(i, x, y, w, h) -> the line's component image inside a rectangle, crops(jobs) -> all at once)."""
+    import ctypes as C
+
+    from . import lib as _lib
+
+    L = _lib.load()
+    H, W = mask.shape
+    M = len(textlines)
+    boxes = np.ascontiguousarray([_xywh(t) for t in textlines], dtype=np.int32).reshape(M, 4)
+    polys = np.ascontiguousarray([np.asarray(t.pts, dtype=np.float64) for t in textlines], dtype=np.float64).reshape(M, 4, 2)
+    V = 4
+    font = np.ascontiguousarray([float(t.font_size) for t in textlines], dtype=np.float64)
+    runs = np.empty((H * ((W + 1) // 2), 4), dtype=np.int32)              # upper bounds; the pages are only touched as far as they are used
+    assign = np.empty(((H + 1) // 2) * ((W + 1) // 2) + 1, dtype=np.int32)
+    rects = np.empty((max(M, 1), 4), dtype=np.int32)
+    n_runs, n_comp = C.c_int64(0), C.c_int32(0)
+    if not mask.flags.c_contiguous or mask.dtype != np.uint8:
+        raise ValueError("complete_mask: a C-contiguous uint8 mask is required")
+    _lib.check(L.mit_mask_assign_lines(mask.ctypes.data, H, W, boxes.ctypes.data, polys.ctypes.data, font.ctypes.data, M, V,
+                                       float(keep_threshold), runs.ctypes.data, runs.shape[0], assign.ctypes.data, assign.shape[0],
+                                       rects.ctypes.data, C.byref(n_runs), C.byref(n_comp)), "mit_mask_assign_lines")
+    nr = int(n_runs.value)
+
+    def crops(jobs):  # jobs: (line, x, y, w, h)
+        if not jobs:
+            return []
+        ja = np.ascontiguousarray(jobs, dtype=np.int32).reshape(-1, 5)
+        offs = np.zeros(len(jobs) + 1, dtype=np.int64)
+        np.cumsum(ja[:, 3].astype(np.int64) * ja[:, 4], out=offs[1:])
+        out = np.empty(int(offs[-1]), dtype=np.uint8)
+        _lib.check(L.mit_mask_line_crops(runs.ctypes.data, nr, assign.ctypes.data, ja.ctypes.data, len(jobs), out.ctypes.data,
+                                         offs.ctypes.data), "mit_mask_line_crops")
+        return [out[offs[j]:offs[j + 1]].reshape(int(ja[j, 4]), int(ja[j, 3])) for j in range(len(jobs))]
+
+    line_rects = [None if rects[i, 0] < 0 else [int(v) for v in rects[i]] for i in range(M)]
+    return line_rects, (lambda i, x, y, w, h: crops([(i, x, y, w, h)])[0]), crops
+
+
 def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadrilateral], keep_threshold: float = 1e-2,
                   dilation_offset: int = 0, kernel_size: int = 3, refine: Optional[RefineFn] = None,
-                  bilateral: Optional[BilateralFn] = None, backend=None, device_result: bool = False) -> Optional[np.ndarray]:
+                  bilateral: Optional[BilateralFn] = None, backend=None, device_result: bool = False,
+                  native: Optional[bool] = None) -> Optional[np.ndarray]:
     """text_mask_utils.complete_mask (:96-195).  ``mask`` is modified in place exactly like the reference's (line boxes are
     outlined with zeros before labelling).  The per-line DenseCRF calls of :172-176 are independent of each other (each line owns
-    its component image, all read the same filtered page), so they are collected and refined as one batch."""
+    its component image, all read the same filtered page), so they are collected and refined as one batch.
+    ``native``: component labelling and line assignment in C++ (``mit_mask_assign_lines``; the default whenever every line is a
+    quadrilateral) or in numpy / scipy (the restatement the golden cases pin; same assignment, kept for A/B runs and as the statement of
+    what the native code computes)."""
     be = _backend_for(refine, bilateral, backend)
     H, W = mask.shape
+    if native is None:
+        native = all(np.asarray(t.pts).shape == (4, 2) for t in textlines)
+    if native:
+        # a device backend starts the page's bilateral filter now: it runs while the host labels and assigns the components
+        page = be.filter_page(img) if getattr(be, "gpu_tail", None) is not None else None
+        rects, _line_crop, _line_crops = _assign_components_native(mask, textlines, keep_threshold)
+        if not any(r is not None for r in rects):
+            return None
+        return _complete_mask_tail(be, img, mask, textlines, rects, _line_crop, _line_crops, dilation_offset, kernel_size, device_result,
+                                   page=page)
     boxes = [_xywh(t) for t in textlines]
     polys = [np.asarray(t.pts, dtype=np.float64) for t in textlines]
     areas2 = [HG_area(p) for p in polys]
@@ -315,9 +369,6 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
         valid = True
     if not valid:
         return None
-    final = np.zeros_like(mask)
-    page = be.filter_page(img)
-    jobs = []  # (line index, crop rectangle, dilation size)
     lut = np.zeros(n + 1, dtype=np.uint8)
 
     def _line_crop(i, x, y, w, h):
@@ -327,6 +378,18 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
         lut[members[i]] = 0
         return np.ascontiguousarray(out)
 
+    return _complete_mask_tail(be, img, mask, textlines, rects, _line_crop, lambda jobs: [_line_crop(*j) for j in jobs], dilation_offset,
+                               kernel_size, device_result)
+
+
+def _complete_mask_tail(be, img, mask, textlines, rects, _line_crop, _line_crops, dilation_offset, kernel_size, device_result, page=None):
+    """complete_mask from the per-line rectangles on (:172-195): crop, DenseCRF, per-line dilation, union, closing dilation."""
+    H, W = mask.shape
+    M = len(textlines)
+    final = np.zeros_like(mask)
+    if page is None:
+        page = be.filter_page(img)
+    jobs = []  # (line index, crop rectangle, dilation size)
     for i in range(M):
         if rects[i] is None:  # the reference's sentinel rectangle slices to an empty crop and is skipped (:172-173)
             continue
@@ -337,7 +400,7 @@ def complete_mask(img: np.ndarray, mask: np.ndarray, textlines: Sequence[Quadril
         if w1 <= 0 or h1 <= 0 or x1 >= W or y1 >= H:   # an empty slice
             continue
         jobs.append((i, (x1, y1, w1, h1), dilate_size))
-    crops = [_line_crop(i, x, y, w, h) for i, (x, y, w, h), _ in jobs]
+    crops = _line_crops([(i, x, y, w, h) for i, (x, y, w, h), _ in jobs])
     if getattr(be, "gpu_tail", False) and kernel_size % 2 == 1:
         # device tail: the windows are the host form's own rectangles; inside a window every non-zero pixel of the line's component
         # image lies in its crop rectangle (the crop is the components' bounding box, extended), so the refined crop is all the
@@ -409,8 +472,11 @@ def dispatch_sync(text_regions, raw_image: np.ndarray, raw_mask: np.ndarray, met
     size = (int(w * scale), int(h * scale))
     be = _backend_for(refine, bilateral, backend)
     img_small = be.resize_image(raw_image, size)  # a device tensor with the GPU backend: it never comes back to the host
-    mask_small = be.resize_mask(raw_mask, size).copy()
-    mask_small[mask_small > 0] = 255
+    if hasattr(be, "resize_binarize"):  # device backend: resize and "> 0 -> 255" there, one download
+        mask_small = be.resize_binarize(be._dev(raw_mask), size).cpu().numpy()
+    else:
+        mask_small = be.resize_mask(raw_mask, size).copy()
+        mask_small[mask_small > 0] = 255
     lines = [Quadrilateral(np.asarray(l) * scale, "", 0) for region in text_regions for l in region.lines]
     final = complete_mask(img_small, mask_small, lines, dilation_offset=dilation_offset, kernel_size=kernel_size, backend=be,
                           device_result=True)

@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
     const int s6o = find_cfg("split128x128x16p6o"), n6o = find_cfg("split128x64x16p6o");
     if (s6o < 0 || n6o < 0) return 2;
     const int s64 = find_cfg("split64x64x16p6o"), s32 = find_cfg("split128x32x16p6o"), f32t = find_cfg("fast128x32x16w4c");  // small / narrow tiles (-1: skipped)
-    const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c");
+    const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c"), s64k = find_cfg("split64x64x32p6o");
     if (s6s < 0 || s9s < 0 || n6s < 0 || s6k32s < 0 || s6m < 0 || s9m < 0 || n6m < 0 || s6k32m < 0) {
         fprintf(stderr, "pipelined tile names not found\n");
         return 2;
@@ -70,9 +70,14 @@ int main(int argc, char **argv) {
         {"3x3 s2 zero 64->64, 4x128x128", 4, 128, 128, 64, 64, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_narrow, {n6, n9, n6s, n6m, n6o, n6m, n6o}},
         {"1x1 1280->320 (pw2), M=65536", 1, 256, 256, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, n6, s6m, n6m, s6k32m, s6o, n6o, s6m, s6o}},
         {"3x3 zero 128->32 (ESRGAN dense conv3), 2x256x256, leaky", 2, 256, 256, 128, 32, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, gen32, {f32t, s32, n6o}},
-        {"decoder-like M=160: 320->960", 1, 1, 160, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s6o, n6o, s64}},
-        {"decoder-like M=160: 2048->320 (FFN out)", 1, 1, 160, 2048, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s64}},
-        {"decoder-like M=160: 320->6004 (logits)", 1, 1, 160, 320, 6004, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s6o, s64}},
+        {"decoder-like M=160: 320->960", 1, 1, 160, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s6o, n6o, s64, s64k, s64, s64k}},
+        {"decoder-like M=160: 320->320", 1, 1, 160, 320, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s64, s64k, s64, s64k}},
+        {"decoder-like M=160: 320->2048 (FFN in), relu", 1, 1, 160, 320, 2048, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {f64, s64, s64k, s64, s64k}},
+        {"decoder-like M=160: 2048->320 (FFN out)", 1, 1, 160, 2048, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s64, s64k, s64, s64k}},
+        {"decoder-like M=160: 320->6004 (logits)", 1, 1, 160, 320, 6004, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {f64, s6o, s64, s64k}},
+        {"decoder-like M=10240: 320->960", 1, 1, 10240, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6o, n6o, s64, s64k, s64, s64k}},
+        {"decoder-like M=10240: 2048->320", 1, 1, 10240, 2048, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s64, s64k, s64, s64k}},
+        {"detector-like 3x3 256->256, 1x32x32", 1, 32, 32, 256, 256, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s64, s64k, s64, s64k}},
         {"ragged: M=1000, 48->200 3x3 zero", 1, 25, 40, 48, 200, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s6, n6, n9, s6m, n6m, s6o, n6o}},
     };
     std::mt19937 rng(1234);
@@ -215,6 +220,7 @@ int main(int argc, char **argv) {
         printf("  %-22s %9.3f ms %8.1f TFLOP/s   err vs f64 %.2e (relative to max|y| = %.3g)\n", mit_conv_gemm_config_name(cs.ref_cfg), ms_ref,
                flops / ms_ref * 1e-9, err64(href), ymax);
         const double e_ref = err64(href);
+        std::vector<float> hfirst6;  // the first 6-pair split tile's output: every other one must reproduce it bit for bit
         for (int cfg : cs.cfgs) {
             if (cfg < 0) continue;
             float ms = 0.f;
@@ -245,8 +251,14 @@ int main(int argc, char **argv) {
             const double e = err64(hc), tol = p3 ? 2e-2 : 4.0 * e_ref + 2e-6;
             const bool fp32_tile = nm.rfind("fast", 0) == 0;  // another fp32 MFMA tile: same k-sequential chain, so the very same bits
             const bool ok = nan == 0 && e <= tol && dmax / ymax <= (p3 ? 2e-2 : 2e-5) && (!fp32_tile || dmax == 0.0);
-            printf("  %-22s %9.3f ms %8.1f TFLOP/s   err vs f64 %.2e   vs fp32 tile %.2e   nan %lld   %s  (x%.2f)\n", nm.c_str(), ms, flops / ms * 1e-9, e,
-                   dmax / ymax, (long long)nan, ok ? "ok" : "FAIL", ms_ref / ms);
+            const char *same = "";
+            if (nm.rfind("split", 0) == 0 && nm.find("p6") != std::string::npos) {
+                if (hfirst6.empty()) hfirst6 = hc;
+                else if (memcmp(hfirst6.data(), hc.data(), c_elems * 4)) same = "  BITS DIFFER from the first p6 tile", ++bad;
+                else same = "  == first p6 tile";
+            }
+            printf("  %-22s %9.3f ms %8.1f TFLOP/s   err vs f64 %.2e   vs fp32 tile %.2e   nan %lld   %s  (x%.2f)%s\n", nm.c_str(), ms, flops / ms * 1e-9, e,
+                   dmax / ymax, (long long)nan, ok ? "ok" : "FAIL", ms_ref / ms, same);
             bad += !ok;
         }
         if (ablate && (strstr(cs.name, "pw1") || strstr(cs.name, "3x3 reflect") || strstr(cs.name, "pw2"))) {

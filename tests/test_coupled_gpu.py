@@ -53,7 +53,13 @@ def test_coupled_batch_equals_the_plugin_chain_page_by_page(cuda):
         eng = coupled.CoupledPageEngine(weights, dictionary, device=cuda, ctd_mb=2, lama_mb=2, host_workers=4)
         res = eng.run(pages_dev, max_seq_length=T, suppress_eos=True, prob_threshold=0.0, inject=inj)
         torch.cuda.synchronize()
+        # the same pages as three pipeline slots of one page (stage threads working on different pages at once): identical results
+        piped = eng.run(pages_dev, max_seq_length=T, suppress_eos=True, prob_threshold=0.0, inject=inj, group=1)
+        torch.cuda.synchronize()
         eng.close()
+        assert torch.equal(piped.mask, res.mask) and torch.equal(piped.inpainted, res.inpainted)
+        assert [[(l.text, l.prob) for l in t] for t in piped.textlines] == [[(l.text, l.prob) for l in t] for t in res.textlines]
+        assert [[r.text for r in rg] for rg in piped.regions] == [[r.text for r in rg] for rg in res.regions]
         assert [len(t) for t in res.textlines] == [NB] * 3          # every generator box detected and recognised
         assert all(len(r) >= 1 for r in res.regions) and res.mask.any()
 

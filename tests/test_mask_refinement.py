@@ -17,11 +17,15 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_refinement.n
 REFINE, BILATERAL = MG.mask_refinement_stubs()
 
 
+@pytest.mark.parametrize("native", [True, False], ids=["native", "numpy"])
 @pytest.mark.parametrize("tag,offset,ksize", [("a", 0, 3), ("b", 6, 5)])
-def test_complete_mask_matches_reference(tag, offset, ksize):
+def test_complete_mask_matches_reference(tag, offset, ksize, native):
+    """Both forms of the component labelling / line assignment (C++ ``mit_mask_assign_lines``, the default; numpy / scipy) against the
+    reference's own complete_mask."""
     quads = [Quadrilateral(l.astype(np.float64), "", 0) for l in G["lines"]]
     m = G["mask"].copy()
-    got = MR.complete_mask(G["img"].copy(), m, quads, dilation_offset=offset, kernel_size=ksize, refine=REFINE, bilateral=BILATERAL)
+    got = MR.complete_mask(G["img"].copy(), m, quads, dilation_offset=offset, kernel_size=ksize, refine=REFINE, bilateral=BILATERAL,
+                           native=native)
     assert np.array_equal(m, G[f"complete_{tag}_mask_after"])      # the outlined working mask, modified in place like the reference's
     assert np.array_equal(got, G[f"complete_{tag}"])
 
@@ -122,3 +126,71 @@ def test_ellipse_kernels():
     assert MR.ellipse_kernel(3).astype(int).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
     assert MR.ellipse_kernel(5).astype(int).tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
     assert MR.ellipse_kernel(1).astype(int).tolist() == [[1]]
+
+
+def _random_scene(rng, H, W, n_lines):
+    """Blobs of every kind the assignment distinguishes: glyph-sized ones inside rotated line quads, a few far away (nearest-line branch
+    and its distance cut-off), tiny ones (<= 9 pixels), blobs larger than their line, blobs touching diagonally, blobs on the frame."""
+    mask = np.zeros((H, W), np.uint8)
+    quads = []
+    for _ in range(n_lines):
+        cx, cy = rng.uniform(30, W - 30), rng.uniform(30, H - 30)
+        hw, hh = rng.uniform(20, 70), rng.uniform(6, 14)
+        if rng.random() < 0.4:
+            hw, hh = hh, hw
+        a = rng.uniform(-0.5, 0.5) if rng.random() < 0.5 else 0.0
+        c, s_ = np.cos(a), np.sin(a)
+        pts = np.array([[-hw, -hh], [hw, -hh], [hw, hh], [-hw, hh]]) @ np.array([[c, s_], [-s_, c]]) + [cx, cy]
+        quads.append(Quadrilateral(pts.astype(np.float64), "", 0))
+        for _ in range(int(rng.integers(2, 9))):   # glyphs along the line
+            t = rng.uniform(-0.9, 0.9)
+            gx, gy = (np.array([t * hw, rng.uniform(-0.5, 0.5) * hh]) @ np.array([[c, s_], [-s_, c]]) + [cx, cy]).astype(int)
+            g = int(rng.integers(2, 7))
+            mask[max(gy - g, 0):gy + g, max(gx - g, 0):gx + g] = 255
+    for _ in range(12):   # strays
+        x, y, w, h = int(rng.integers(0, W - 4)), int(rng.integers(0, H - 4)), int(rng.integers(1, 30)), int(rng.integers(1, 30))
+        mask[y:y + h, x:x + w] = 255
+    for _ in range(40):   # specks and diagonal chains
+        x, y = int(rng.integers(1, W - 6)), int(rng.integers(1, H - 6))
+        for d in range(int(rng.integers(1, 6))):
+            mask[y + d, x + d] = 255
+    mask[rng.random((H, W)) < 0.002] = 255
+    return mask, quads
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_native_component_assignment_equals_the_numpy_form(seed):
+    """``mit_mask_assign_lines`` + ``mit_mask_line_crops`` against the numpy / scipy restatement (itself pinned to the reference above) on
+    random scenes: the outlined mask, the final refined mask and — through a recording refine stub — every line's crop must be identical."""
+    rng = np.random.default_rng(100 + seed)
+    H, W = int(rng.integers(120, 260)), int(rng.integers(150, 330))
+    mask, quads = _random_scene(rng, H, W, int(rng.integers(1, 9)))
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    res = {}
+    for native in (True, False):
+        seen = []
+        m = mask.copy()
+        out = MR.complete_mask(img.copy(), m, quads, dilation_offset=int(seed % 3) * 4, kernel_size=3, bilateral=BILATERAL,
+                               refine=lambda rgb, cm: seen.append(cm.copy()) or REFINE(rgb, cm), native=native)
+        res[native] = (m, out, seen)
+    assert np.array_equal(res[True][0], res[False][0])
+    assert (res[True][1] is None) == (res[False][1] is None)
+    if res[True][1] is not None:
+        assert np.array_equal(res[True][1], res[False][1])
+    assert len(res[True][2]) == len(res[False][2]) and all(np.array_equal(a, b) for a, b in zip(res[True][2], res[False][2]))
+
+
+def test_native_component_assignment_edge_cases():
+    """An empty mask, a full mask, a one-pixel-wide page: the native form agrees with the numpy form (None or the same mask); no lines: None."""
+    q = [Quadrilateral(np.array([[10, 10], [60, 10], [60, 30], [10, 30]], np.float64), "", 0)]
+    for mask, quads in [(np.zeros((40, 80), np.uint8), q), (np.full((40, 80), 255, np.uint8), q), (np.full((40, 80), 255, np.uint8), []),
+                        (np.full((64, 1), 255, np.uint8), q), (np.full((1, 64), 255, np.uint8), q)]:
+        img = np.zeros(mask.shape + (3,), np.uint8)
+        a_m, b_m = mask.copy(), mask.copy()
+        a = MR.complete_mask(img, a_m, quads, refine=REFINE, bilateral=BILATERAL, native=True)
+        if not quads:   # the numpy form (like the reference) takes an argmax over zero lines and raises; the native form keeps nothing
+            assert a is None
+            continue
+        b = MR.complete_mask(img, b_m, quads, refine=REFINE, bilateral=BILATERAL, native=False)
+        assert np.array_equal(a_m, b_m)
+        assert (a is None and b is None) or np.array_equal(a, b)
