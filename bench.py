@@ -97,6 +97,9 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--no-coupled", action="store_true", help="skip the coupled (glue-inclusive) secondary measurement")
+    ap.add_argument("--coupled-group", type=int, default=16, help="pages per pipeline slot of the coupled batch path (0: one unpipelined pass)")
+    ap.add_argument("--coupled-mask-workers", type=int, default=4, help="host threads of the coupled path's per-page mask stages")
+    ap.add_argument("--coupled-only", action="store_true", help="only the coupled batch measurement (A/B runs of its knobs)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-MFMA sub-measurement (fp32_mfma) taken beside a split-mode headline")
     ap.add_argument("--fp32-steps", type=int, default=3, help="timed steps of the fp32_mfma sub-measurement (after 1 warm-up step)")
     ap.add_argument("--cpu-pages", type=int, default=3, help="timed pages of the CPU baseline (after 1 warm-up page)")
@@ -535,7 +538,7 @@ def _probe_kernels(fn):
     return round(wall, 2), dict(sorted(out.items(), key=lambda kv: -kv[1]["ms"]))
 
 
-def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4):
+def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4, group=16, mask_workers=4, batch_only=False):
     """(1) batch: coupled.CoupledPageEngine over the same resident pages as the headline — detector -> native box extraction on a host
     thread pool -> GPU refine_mask -> OCR of the DETECTED lines -> text-line merge -> mask refinement (bilateral + DenseCRF + dilations
     on the GPU) -> LaMa with the REFINED mask; (2) B = 1: the same chain through the plugins, page by page, host copies included."""
@@ -553,13 +556,14 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4):
     out = {}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)   # log(prob) of random-weight recognitions underflows in the region statistics
-        eng = coupled.CoupledPageEngine(weights, dictionary, device=device)
-        res = eng.run(pages_dev, max_seq_length=DECODE_STEPS, suppress_eos=True, prob_threshold=0.0, inject=inj)   # warm-up
+        eng = coupled.CoupledPageEngine(weights, dictionary, device=device, mask_workers=mask_workers)
+        kw = dict(max_seq_length=DECODE_STEPS, suppress_eos=True, prob_threshold=0.0, inject=inj, group=group or None)
+        res = eng.run(pages_dev, **kw)   # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         phases = {}
         for _ in range(steps):
-            res = eng.run(pages_dev, max_seq_length=DECODE_STEPS, suppress_eos=True, prob_threshold=0.0, inject=inj)
+            res = eng.run(pages_dev, **kw)
             for k, v in res.seconds.items():
                 phases[k] = phases.get(k, 0.0) + v
         torch.cuda.synchronize()
@@ -571,10 +575,13 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4):
                             lines_per_page_after_ocr={"min": min(found), "mean": round(float(np.mean(found)), 1), "max": max(found)},
                             text_regions_per_page=round(float(np.mean([len(r) for r in res.regions])), 1),
                             refined_mask_coverage=round(float((res.mask > 0).float().mean()), 4),
-                            note="host phases overlap the GPU work queued before them; the last phase only enqueues LaMa")
+                            pipeline=dict(pages_per_slot=group or n, stage_threads=3 if group and n > group else 1, mask_workers=mask_workers),
+                            note="host wall time per stage thread; the stages work on different page groups at the same time and share one stream")
         eng.close()
         del eng, res
         torch.cuda.empty_cache()
+        if batch_only:
+            return out
 
         # ---- B = 1 through the plugins ----
         pages, quads, _ = host_inputs
@@ -810,6 +817,13 @@ def main():
     weights = D.broadcast_weights(weights)          # RCCL broadcast of one flat arena at load
     pages, quads, masks, host_inputs, idx = make_inputs(args.pages, args.distinct, rank, device)
 
+    if args.coupled_only:   # A/B runs of the coupled batch path's knobs: its own line
+        if rank == 0:
+            c = coupled_leg(weights, args.pages, args.distinct, device, steps=max(args.steps, 1), group=args.coupled_group,
+                            mask_workers=args.coupled_mask_workers, batch_only=True)
+            print(json.dumps({"metric": "pages/sec, coupled batch path (detect -> boxes -> OCR -> merge -> mask refinement -> inpaint), 2048x1456",
+                              **c["batch"], "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic"}))
+        return
     if args.mode == "dropin":
         if rank == 0:
             d = dropin_leg(weights, host_inputs, args.dropin_pages)
@@ -915,7 +929,8 @@ def main():
         if not args.no_coupled:
             del pages, masks
             torch.cuda.empty_cache()
-            coupled = leg("coupled", lambda: coupled_leg(weights, args.pages, args.distinct, device))
+            coupled = leg("coupled", lambda: coupled_leg(weights, args.pages, args.distinct, device, group=args.coupled_group,
+                                                         mask_workers=args.coupled_mask_workers))
     D.barrier()
 
     if rank == 0:

@@ -185,25 +185,30 @@ __global__ __launch_bounds__(256) void refine_label_init_kernel(const uint8_t *_
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = p < g.P;
     const int l = ok ? line_of[p] : 0;
-    int t = 1;
-    if (!ok) {
-    } else if (mode == 0) {
-        const MitRefineCand c = order[l * 4 + slot];
-        if (c.kind == 0) t = 0;
-        else {
-            const MitRefineWindow w = g.win[l];
-            const int cw = w.x2 - w.x1;
-            const int local = (int)(p - g.pt_off[l]);
-            const int y = local / cw, x = local - y * cw;
-            t = cand_bit(c, grey[p], page + ((int64_t)(w.y1 + y) * W + w.x1 + x) * 3);
+    int t = 1, x = 0;
+    if (ok) {
+        const MitRefineWindow w = g.win[l];
+        const int cw = w.x2 - w.x1;
+        const int local = (int)(p - g.pt_off[l]);
+        const int y = local / cw;
+        x = local - y * cw;
+        if (mode == 0) {
+            const MitRefineCand c = order[l * 4 + slot];
+            t = c.kind == 0 ? 0 : cand_bit(c, grey[p], page + ((int64_t)(w.y1 + y) * W + w.x1 + x) * 3);
+        } else {
+            t = merged[p] ? 0 : 1;
         }
-    } else {
-        t = merged[p] ? 0 : 1;
     }
     if (mode == 1) wave_count(zero_area, l, ok && !t);
+    // The 64 pixels of a wave are consecutive: a horizontal run of candidates inside it starts its life already linked (every pixel
+    // points at the run's first pixel), so refine_label_link_kernel only has to join runs across wave boundaries and rows.
+    const int lane = threadIdx.x & 63;
+    const unsigned long long cm = __ballot(ok && t);
+    const bool start = ok && t && (lane == 0 || !((cm >> (lane - 1)) & 1ull) || x == 0);
+    const unsigned long long sm = __ballot(start);
     if (!ok) return;
     cand[p] = (uint8_t)t;
-    L[p] = t ? (int)p : -1;
+    L[p] = t ? (int)p - (lane - (63 - __clzll((long long)(sm & ((2ull << lane) - 1ull))))) : -1;
     st.area[p] = 0;
     st.gain[p] = 0;
     st.loss[p] = 0;
@@ -219,12 +224,25 @@ __global__ __launch_bounds__(256) void refine_label_link_kernel(Geo g, const int
     const int cw = w.x2 - w.x1;
     const int local = (int)(p - g.pt_off[l]);
     const int y = local / cw, x = local - y * cw;
-    if (x > 0 && cand[p - 1]) uf_union(L, (int)p, (int)p - 1);
+    // Only the unions that can join two sets: (left) runs are pre-linked inside a wave, so only its first lane looks left; (up) not
+    // when the left neighbour and the pixel above it are candidates too — the left neighbour (or a pixel further left along the two
+    // solid rows) makes that link; (diagonals) only when neither the pixel above nor the horizontal neighbour below the diagonal can.
+    const bool left = x > 0 && cand[p - 1];
+    if (left && (threadIdx.x & 63) == 0) uf_union(L, (int)p, (int)p - 1);
     if (y > 0) {
-        if (cand[p - cw]) uf_union(L, (int)p, (int)p - cw);
-        if (x > 0 && cand[p - cw - 1]) uf_union(L, (int)p, (int)p - cw - 1);
-        if (x + 1 < cw && cand[p - cw + 1]) uf_union(L, (int)p, (int)p - cw + 1);
+        const bool up = cand[p - cw] != 0, ul = x > 0 && cand[p - cw - 1], ur = x + 1 < cw && cand[p - cw + 1];
+        if (up && !(left && ul)) uf_union(L, (int)p, (int)p - cw);
+        if (ul && !up && !left) uf_union(L, (int)p, (int)p - cw - 1);
+        if (ur && !up && !(x + 1 < cw && cand[p + 1])) uf_union(L, (int)p, (int)p - cw + 1);
     }
+}
+
+// every pixel points at its root: the statistics and apply passes then find it in one step
+__global__ __launch_bounds__(256) void refine_label_flatten_kernel(int64_t P, const uint8_t *__restrict__ cand, int *__restrict__ L) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P || !cand[p]) return;
+    const int r = uf_find(L, (int)p);
+    if (r != (int)p) __atomic_store_n(&L[p], r, __ATOMIC_RELAXED);
 }
 
 __global__ __launch_bounds__(256) void refine_label_stats_kernel(Geo g, const int *__restrict__ line_of, const uint8_t *__restrict__ cand,
@@ -469,12 +487,14 @@ extern "C" int mit_ctd_refine_merge(const uint8_t *page_dev, const uint8_t *pred
             hipLaunchKernelGGL(refine_label_init_kernel, dim3(nb), dim3(256), 0, st, page_dev, W, g, line_of, grey, order, s, 0, merged, cand, lab, cs,
                                zero_area);
             hipLaunchKernelGGL(refine_label_link_kernel, dim3(nb), dim3(256), 0, st, g, line_of, cand, lab);
+            hipLaunchKernelGGL(refine_label_flatten_kernel, dim3(nb), dim3(256), 0, st, L.P, cand, lab);
             hipLaunchKernelGGL(refine_label_stats_kernel, dim3(nb), dim3(256), 0, st, g, line_of, cand, lab, merged, pred_bin, cs);
             hipLaunchKernelGGL(refine_apply_kernel, dim3(nb), dim3(256), 0, st, L.P, cand, lab, cs, merged);
         }
         hipLaunchKernelGGL(refine_label_init_kernel, dim3(nb), dim3(256), 0, st, page_dev, W, g, line_of, grey, order, 0, 1, merged, cand, lab, cs,
                            zero_area);
         hipLaunchKernelGGL(refine_label_link_kernel, dim3(nb), dim3(256), 0, st, g, line_of, cand, lab);
+        hipLaunchKernelGGL(refine_label_flatten_kernel, dim3(nb), dim3(256), 0, st, L.P, cand, lab);
         hipLaunchKernelGGL(refine_label_stats_kernel, dim3(nb), dim3(256), 0, st, g, line_of, cand, lab, merged, pred_bin, cs);
         hipLaunchKernelGGL(refine_hole_max_kernel, dim3(nb), dim3(256), 0, st, L.P, line_of, cand, lab, cs, max1);
         hipLaunchKernelGGL(refine_hole_second_kernel, dim3(nb), dim3(256), 0, st, L.P, line_of, cand, lab, cs, max1, cnt_eq, max_lt);
