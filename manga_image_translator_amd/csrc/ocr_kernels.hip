@@ -849,6 +849,106 @@ void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out,
                        T, i0, p0, downscale, tb.cos_t, tb.sin_t, tb.scale_t, tb.iscale_t, tb.pmax, dstep, dyn_mode, dyn_in);
 }
 
+// ---- the same attention for ALL query positions of a row (the encoder's self-attention: Tq = Tk = the line's memory length): one
+// workgroup per (head, row, block of 32 queries) stages the row's keys and values in LDS once — attention_kernel re-reads them
+// from L2 for every query (32 x the bytes) — and each wave takes eight queries, so a key / value element read from LDS feeds eight
+// dot products / weighted sums.  Per (query, key) dot product, per query the lane-strided softmax sums, per (query, d) the t-ordered
+// weighted sum: evaluated in exactly the order of attention_kernel, so both give bitwise identical results.
+constexpr int ATTR_GQ = 8;
+constexpr int ATTR_THREADS = 256;
+
+__global__ __launch_bounds__(ATTR_THREADS) void attention_rows_kernel(const float *__restrict__ Q, int64_t q_rs, int64_t q_ts,
+                                                                      const float *__restrict__ K, int64_t k_rs, int64_t k_ts,
+                                                                      const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
+                                                                      float *__restrict__ O, int64_t o_rs, int64_t o_ts,
+                                                                      const int *__restrict__ klen, int Tq, int Tk, int HD) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KP = HD + 4;  // 16-byte aligned rows; lane t reads row t as float4s
+    const int HD4 = HD / 4;
+    float *kv = lds;                                   // [Tk][KP]: the keys, then (same buffer) the values
+    float *qs_all = kv + (size_t)Tk * KP;              // [waves][GQ][HD]
+    float *ws_all = qs_all + (ATTR_THREADS / 64) * ATTR_GQ * HD;  // [waves][GQ][Tk]
+    const int h = blockIdx.x, r = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int valid = klen ? min(klen[r], Tk) : Tk;
+    auto stage = [&](const float *base, int64_t ts) {
+        for (int i = tid; i < valid * HD4; i += ATTR_THREADS) {
+            const int t = i / HD4, d4 = i - t * HD4;
+            *reinterpret_cast<float4 *>(kv + t * KP + d4 * 4) = *reinterpret_cast<const float4 *>(base + (int64_t)t * ts + d4 * 4);
+        }
+    };
+    stage(K + (int64_t)r * k_rs + h * HD, k_ts);
+    float *qs = qs_all + wave * ATTR_GQ * HD;
+    float *ws = ws_all + (size_t)wave * ATTR_GQ * Tk;
+    // blockIdx.z: this workgroup's block of 4 x 8 query positions (the grid, not a loop, covers the row's queries — a chunk of 16 lines
+    // x 4 heads alone would leave three quarters of the CUs without a workgroup)
+    const int qa = ((int)blockIdx.z * (ATTR_THREADS / 64) + wave) * ATTR_GQ;
+    const int ng = max(0, min(ATTR_GQ, Tq - qa));
+    for (int i = lane; i < ATTR_GQ * HD; i += 64) {
+        const int g = i / HD, d = i - g * HD;
+        qs[i] = g < ng ? Q[(int64_t)r * q_rs + (int64_t)(qa + g) * q_ts + h * HD + d] : 0.f;
+    }
+    __syncthreads();  // keys and queries staged
+    float mx[ATTR_GQ];
+#pragma unroll
+    for (int g = 0; g < ATTR_GQ; ++g) mx[g] = -INFINITY;
+    for (int t = lane; t < Tk; t += 64) {
+        float dot[ATTR_GQ];
+#pragma unroll
+        for (int g = 0; g < ATTR_GQ; ++g) dot[g] = t < valid ? 0.f : -INFINITY;
+        if (t < valid) {
+            const float4 *kp = reinterpret_cast<const float4 *>(kv + t * KP);
+            for (int d4 = 0; d4 < HD4; ++d4) {  // d ascending, one rounding per product and per sum, as in attention_kernel
+                const float4 kk = kp[d4];
+#pragma unroll
+                for (int g = 0; g < ATTR_GQ; ++g) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(qs + g * HD + d4 * 4);  // same address in every lane: broadcast
+                    dot[g] += qv.x * kk.x;
+                    dot[g] += qv.y * kk.y;
+                    dot[g] += qv.z * kk.z;
+                    dot[g] += qv.w * kk.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < ATTR_GQ; ++g) {
+            ws[(size_t)g * Tk + t] = dot[g];
+            mx[g] = fmaxf(mx[g], dot[g]);
+        }
+    }
+    __syncthreads();  // every wave is done with the keys; this wave's scores are visible to all its lanes
+    stage(V + (int64_t)r * v_rs + h * HD, v_ts);  // the values take the keys' place (their loads fly while the softmax runs)
+#pragma unroll
+    for (int g = 0; g < ATTR_GQ; ++g) {  // softmax: lanes strided over the keys exactly as attention_kernel's single wave
+        float *w = ws + (size_t)g * Tk;
+        float m = mx[g];
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int t = lane; t < Tk; t += 64) {
+            const float e = expf(w[t] - m);
+            w[t] = e;
+            sum += e;
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        for (int t = lane; t < Tk; t += 64) w[t] *= inv;
+    }
+    __syncthreads();
+    for (int d = lane; d < HD; d += 64) {  // weighted sum of the values, t-ordered per (query, d)
+        float acc[ATTR_GQ];
+#pragma unroll
+        for (int g = 0; g < ATTR_GQ; ++g) acc[g] = 0.f;
+        for (int t = 0; t < valid; ++t) {
+            const float v = kv[t * KP + d];
+#pragma unroll
+            for (int g = 0; g < ATTR_GQ; ++g) acc[g] += ws[(size_t)g * Tk + t] * v;
+        }
+#pragma unroll
+        for (int g = 0; g < ATTR_GQ; ++g)
+            if (g < ng) O[(int64_t)r * o_rs + (int64_t)(qa + g) * o_ts + h * HD + d] = acc[g];
+    }
+}
+
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
                     int kv_div, hipStream_t s, int heads, int head_dim, const int *dstep) {
@@ -861,6 +961,27 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
                                 4.0 * (double)R * heads * Tk * head_dim);
             hipLaunchKernelGGL(attention_shared_kv_kernel, dim3(heads, R / kv_div), dim3(ATT_THREADS), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts,
                                O, o_rs, klen, Tk, kv_div, head_dim);
+            return;
+        }
+    }
+    static const bool no_rows = getenv("MIT_ATT_NO_ROWS") != nullptr;
+    if (!no_rows && !dstep && kv_div == 1 && Tq >= 2 * ATTR_GQ && R <= 65535 && Tq <= 65535 * 32 && head_dim <= 128 && ((q_rs | q_ts | k_rs | k_ts | v_rs | v_ts) & 3) == 0) {
+        const size_t sm = ((size_t)Tk * (head_dim + 4) + (size_t)(ATTR_THREADS / 64) * ATTR_GQ * (head_dim + Tk)) * sizeof(float);
+        if (sm <= 150 * 1024 && head_dim % 8 == 0) {
+            // algorithmic bytes: q, k, v read once and o written once per row; FLOPs 4 Tk d per query and head
+            MitProbeScope probe("attention_rows_kernel", s, 4.0 * (double)R * heads * head_dim * (2.0 * Tq + 2.0 * Tk),
+                                4.0 * (double)R * Tq * heads * Tk * head_dim);
+            static size_t granted[16] = {0};
+            if (sm > 64 * 1024) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (granted[dev & 15] < sm) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attention_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+                    granted[dev & 15] = sm;
+                }
+            }
+            hipLaunchKernelGGL(attention_rows_kernel, dim3(heads, R, (Tq + (ATTR_THREADS / 64) * ATTR_GQ - 1) / ((ATTR_THREADS / 64) * ATTR_GQ)), dim3(ATTR_THREADS), sm, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
+                               o_ts, klen, Tq, Tk, head_dim);
             return;
         }
     }

@@ -201,6 +201,39 @@ def test_shared_kv_attention_bitwise_equals_per_row(cuda, G, Tk, heads, hd):
     assert (out_a.double().cpu() - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("T,heads,hd", [(70, 4, 80), (142, 4, 80), (33, 8, 40), (16, 2, 16), (150, 1, 128)])
+def test_row_attention_bitwise_equals_per_query(cuda, T, heads, hd):
+    """The encoder's self-attention (every query position of a row at once, keys / values staged in LDS once per (head, row):
+    attention_rows_kernel) must give bit for bit what the one-wave-per-query kernel gives when it is called one query position at a
+    time, and match a float64 softmax(q k^T) v; padded keys (klen) masked, padded queries still computed."""
+    import ctypes as C
+
+    from manga_image_translator_amd import lib as L, ops
+
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    R, E = 6, heads * hd
+    q = torch.randn(R, T, E, generator=g).to(cuda)
+    k = torch.randn(R, T, E, generator=g).to(cuda)
+    v = torch.randn(R, T, E, generator=g).to(cuda)
+    klen = torch.tensor([T, 1, T // 2, T - 1, 3, 17][:R], dtype=torch.int32, device=cuda).clamp_(max=T)
+    out_a, out_b = torch.full_like(q, float("nan")), torch.full_like(q, float("nan"))
+    st = C.c_void_p(ops.current_stream())
+    L.check(lib.mit_attention_heads(q.data_ptr(), T * E, E, k.data_ptr(), T * E, E, v.data_ptr(), T * E, E, out_a.data_ptr(), T * E, E,
+                                    klen.data_ptr(), R, T, T, 1, heads, hd, st), "rows")
+    for t in range(T):   # Tq = 1: the per-query kernel
+        L.check(lib.mit_attention_heads(q[:, t].data_ptr(), T * E, E, k.data_ptr(), T * E, E, v.data_ptr(), T * E, E, out_b[:, t].data_ptr(),
+                                        T * E, E, klen.data_ptr(), R, 1, T, 1, heads, hd, st), "per-query")
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    qd, kd, vd = (x.double().cpu().view(R, T, heads, hd) for x in (q, k, v))
+    sc = torch.einsum("nqhd,nthd->nhqt", qd, kd)
+    mask = torch.arange(T)[None, :] >= klen.cpu()[:, None]
+    sc = sc.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = torch.einsum("nhqt,nthd->nqhd", sc.softmax(-1), vd).reshape(R, T, E)
+    assert (out_a.double().cpu() - ref).abs().max() < 5e-5   # fp32 dot products of 80-128 N(0,1) terms, outputs of order 1
+
+
 @pytest.mark.parametrize("k,C_,H,shapes", [(7, 80, 24, [(2, 37), (1, 64), (3, 9)]), (7, 160, 12, [(1, 150), (2, 5)]), (5, 320, 6, [(2, 33), (1, 70)]),
                                            (3, 320, 3, [(2, 40)]), (5, 16, 8, [(1, 3), (1, 4)])])
 def test_dwconv_ragged_rows_equals_per_row_kernel(cuda, k, C_, H, shapes):
