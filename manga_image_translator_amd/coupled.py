@@ -8,7 +8,8 @@ of pages, in the order and with the arguments the reference's orchestrator uses 
 produced, so the glue between them — box extraction (a4), the detector's ``refine_mask`` (a5), the merge graph (f3), the mask
 refinement with its DenseCRF (f1) — is inside the measured path.  Dense work runs batched on the GPU; the per-page host steps
 (contours -> boxes in native C++, direction vote, merge graph, component labelling) run on a thread pool (ctypes / numpy / scipy
-release the GIL) while the stream keeps executing.
+release the GIL) while the stream keeps executing.  A batch larger than one group of 16 pages flows through three stage threads
+(detector + boxes + refine_mask | OCR | merge + mask refinement + LaMa) that work on different groups at the same time (``run(group=)``).
 
 Random-init networks do not detect text (their sigmoid maps hover around 0.5 everywhere), so a benchmark passes ``inject``: per-page
 maps a trained head would have produced for the synthetic page (``synthetic_head_outputs``); they replace the network's own outputs

@@ -16,6 +16,8 @@
 //                                                     integer coordinates (pyclipper truncates the float box)
 //   shapely Polygon.area / .length                    shoelace area, perimeter
 // It lives in the C-ABI library so the plugins need no Python-level OpenCV stand-in on the per-page path.
+// Further down: the host half of the mask refinement (mit_mask_assign_lines / mit_mask_line_crops — connected components as row runs
+// and their assignment to text lines, mask_refinement/text_mask_utils.py:100-170).
 
 #include <math.h>
 #include <stdint.h>
