@@ -285,6 +285,12 @@ class LamaEngine:
         return self._mpe_tabs.get((H, W), make)
 
     # -- FourierUnit (:214-257): LDS-butterfly FFTs (dense DFT GEMMs for the sizes they do not cover) ---------------------------------------------------
+    _dbg: Optional[dict] = None  # diagnostics only (scripts/diag_ffc_load.py): intermediate tensors of the FIRST FFC layer of a forward
+
+    def _dbg_put(self, name: str, t: torch.Tensor):
+        if self._dbg is not None and name not in self._dbg:
+            self._dbg[name] = t.clone()
+
     def _fourier_unit(self, ffc: _FFC, t1: torch.Tensor, t2: torch.Tensor):
         """t2 = t1 + irfft2(relu(bn(conv1x1(rfft2(t1)))))   (x + fu(x), :305)."""
         B, h, w, Cc = t1.shape
@@ -318,6 +324,7 @@ class LamaEngine:
                 a=F1, NB=1, Hi=2, Wi=wk, Cin=F1.shape[1], a_strides=(0, wk * F1.shape[1], F1.shape[1]), Ho=2, Wo=wk, sy=1,
                 sx=1, taps=one, pad_mode=PAD_ZERO, w=t1, ldw=Cc, Kw=w, Nw=Cc, N=Cc, c=cm, Z=B * h, zdiv=h,
                 w_zs=(h * w * Cc, w * Cc)))
+        self._dbg_put("fu1_rfft_rows", Y)
         # S2: complex DFT along H on planar re/im: LDS-butterfly FFT when h is a power of two (H/8 = 256 for the BASELINE
         # page), else the dense [2h x 2h] DFT GEMM  Z[b] = G2 @ Y[b]
         if use_fft:
@@ -330,6 +337,7 @@ class LamaEngine:
                 a=G2, NB=1, Hi=1, Wi=2 * h, Cin=G2.shape[1], a_strides=(0, 0, G2.shape[1]), Ho=1, Wo=2 * h, sy=1, sx=1, taps=one,
                 pad_mode=PAD_ZERO, w=Y, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
                 w_zs=(0, 2 * plane)))
+        self._dbg_put("fu2_fft_cols", Zf)
         # spectral 1x1 conv + BN + ReLU: two taps = re plane, im plane; planar output via the column split
         cm = ops.MitTensorMap()
         cm.base, cm.zs1, cm.zs0, cm.bs, cm.ys, cm.xs = Z2.data_ptr(), 0, 0, 2 * plane, wk * Cc, Cc
@@ -338,6 +346,7 @@ class LamaEngine:
             a=Zf, NB=B, Hi=h, Wi=wk, Cin=Cc, a_strides=(2 * plane, wk * Cc, Cc), Ho=h, Wo=wk, sy=1, sx=1,
             taps=[(0, 0, 0), (0, 0, plane)], pad_mode=PAD_ZERO, w=ffc.fu_w, ldw=ffc.fu_Np, Kw=ffc.fu_Kp, Nw=ffc.fu_Np,
             N=2 * Cc, c=cm, scale=ffc.fu_scale, bias=ffc.fu_bias, act=ACT_RELU))
+        self._dbg_put("fu3_spectral_conv", Z2)
         # S3: inverse complex DFT along H.  U[b,h,t] rows (t,h) = G2i @ Z2[b]
         if use_fft:
             self._fft_h(Z2, U, (2 * plane, wk * Cc, 2 * wk * Cc), B, h, wk * Cc, plane, True)
@@ -349,6 +358,7 @@ class LamaEngine:
                 a=G2i, NB=1, Hi=2, Wi=h, Cin=G2i.shape[1], a_strides=(0, h * G2i.shape[1], G2i.shape[1]), Ho=2, Wo=h, sy=1, sx=1, taps=one,
                 pad_mode=PAD_ZERO, w=Z2, ldw=wk * Cc, Kw=2 * h, Nw=wk * Cc, N=wk * Cc, c=cm, Z=B, zdiv=1 << 30,
                 w_zs=(0, 2 * plane)))
+        self._dbg_put("fu4_ifft_cols", U)
         # S4: complex->real inverse DFT along W, + t1.  t2[b,h] = Fi @ U[b,h] ([2wk] x [C]) + t1[b,h]
         if use_fft_w:
             _lib.check(lib.mit_irfft_rows(U.data_ptr(), 2 * plane, wk * Cc, 2 * wk * Cc, Cc, t2.data_ptr(), h * w * Cc, w * Cc,
@@ -376,16 +386,24 @@ class LamaEngine:
             T = ops.WinogradConv3x3.tiles(B, h, w)
             V = self._buf("wino_v", 36, T, LOCAL_C + GLOBAL_C)
             ffc.to_l.transform_input(x, V)
+            self._dbg_put("w1_wino_input", V)
             ffc.to_l.gemm_output(V, self._buf("wino_ml", 36, T, LOCAL_C), out[..., :LOCAL_C], post=res_l)
+            self._dbg_put("w2_wino_products_l", self._buf("wino_ml", 36, T, LOCAL_C))
+            self._dbg_put("w3_out_local", out[..., :LOCAL_C])
             ffc.l2g.gemm_output(V, self._buf("wino_mg", 36, T, GLOBAL_C), P)
+            self._dbg_put("w4_wino_products_g", self._buf("wino_mg", 36, T, GLOBAL_C))
+            self._dbg_put("w5_P", P)
         else:
             ffc.to_l(x, out=out[..., :LOCAL_C], post=res_l)  # convl2l(x_l) + convg2l(x_g) -> bn_l -> relu (+ id_l)
             ffc.l2g(x_l, out=P)  # convl2g(x_l), raw
         t1 = self._buf("ffc_t1", B, h, w, SPEC_C)
         t2 = self._buf("ffc_t2", B, h, w, SPEC_C)
         ffc.st_in(x_g, out=t1)  # SpectralTransform.conv1 (:272-277)
+        self._dbg_put("s1_st_in", t1)
         self._fourier_unit(ffc, t1, t2)
-        ffc.st_out(t2, out=out[..., LOCAL_C:], pre=P, post=res_g)  # conv2(x + fu(x)) + convl2g -> bn_g -> relu (+ id_g)
+        self._dbg_put("fu5_irfft_rows_plus_t1", t2)
+        ffc.st_out(t2, out=out[..., LOCAL_C:], pre=P, post=res_g)
+        self._dbg_put("s2_out_global", out[..., LOCAL_C:])  # conv2(x + fu(x)) + convl2g -> bn_g -> relu (+ id_g)
 
     # -- full generator ------------------------------------------------------------------------
     @torch.no_grad()

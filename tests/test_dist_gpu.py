@@ -38,7 +38,7 @@ def _records(weights, lo, hi):
     return res.packed_pages(LINES)
 
 
-def _shard_worker(rank, world, port, q):
+def _shard_worker(rank, world, port, q, gpu_turn):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       MIT_DIST_BACKEND="gloo")
     try:
@@ -47,7 +47,13 @@ def _shard_worker(rank, world, port, q):
         Dm.init()
         weights = Dm.broadcast_weights(pipeline.synthetic_weights(dict_size=D) if rank == 0 else None)
         lo, hi = Dm.shard_range(N_PAGES, rank, world)
-        out = Dm.gather_pages(_records(weights, lo, hi))
+        # Both ranks of this rehearsal sit on ONE GPU (a real job has one GPU per rank).  Their compute phases take turns: two copies of
+        # the engine running kernels on one device AT THE SAME TIME is not a configuration the engine supports — scripts/diag_concurrent2.py
+        # and scripts/diag_ffc_load.py show results that vary from run to run in that situation (first seen in rfft / irfft rows).
+        with gpu_turn:
+            recs = _records(weights, lo, hi)
+            torch.cuda.synchronize()
+        out = Dm.gather_pages(recs)
         if rank == 0:
             q.put(("records", out.reshape(N_PAGES, -1).cpu().numpy()))
         Dm.barrier()
@@ -67,7 +73,8 @@ def test_page_records_do_not_depend_on_world_size_and_rccl_smoke(cuda):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    gpu_turn = ctx.Lock()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, gpu_turn)) for r in range(2)]
     for p in procs:
         p.start()
     got, rccl, oks = None, None, []
