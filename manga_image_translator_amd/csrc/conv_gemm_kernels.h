@@ -74,8 +74,8 @@ __device__ __forceinline__ float apply_act(float v, float alpha) {
 // wave: a per-element switch costs more than the stores on the small-K layers.
 template <int TM, int TN, int ACT, bool HAS_POST, int XE>
 __device__ __forceinline__ void epilogue_store(const MitConvGemm &p, f32x16 (&acc)[TM][TN], const RowOff *rowoff, const int n0,
-                                               const int wm0, const int wn0) {
-    const int lane = threadIdx.x & 63;
+                                               const int wm0, const int wn0, const int tid) {
+    const int lane = tid & 63;
     const int li = lane & 31;
     const int lh = lane >> 5;
     const bool has_pre = p.pre.base != nullptr;
@@ -122,8 +122,8 @@ constexpr int EPI_PITCH = 36;
 
 template <int TM, int TN, int ACT, bool HAS_POST, int XE>
 __device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 (&acc)[TM][TN], const RowOff *rowoff, float *tbuf,
-                                                   const int n0, const int wm0, const int wn0) {
-    const int lane = threadIdx.x & 63;
+                                                   const int n0, const int wm0, const int wn0, const int tid) {
+    const int lane = tid & 63;
     const int li = lane & 31;
     const int lh = lane >> 5;
     const int vr = lane >> 3, vc = (lane & 7) * 4;
@@ -169,8 +169,9 @@ __device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 
 template <int BM, int TM, int TN, int XE = 0, int SMEM_FLOATS = 0>
 __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM][TN], float *smem, const int M, const int m0,
                                          const int n0, const int wm0, const int wn0, const int z1, const int z0,
-                                         const int HoWo) {
-    const int tid = threadIdx.x;
+                                         const int HoWo, const int tid) {
+    // tid: the caller's thread index — threadIdx.x, or the same number rebuilt after the K loop (wave index kept in an SGPR, lane from
+    // mbcnt) so that no thread-index-derived register has to stay live, or be spilled to scratch, across the loop
     RowOff *rowoff = reinterpret_cast<RowOff *>(smem);  // BM entries (<= A/B staging area)
     const int64_t c_dyn = p.dyn ? (int64_t)(*p.dyn) * p.c_dyn : 0;  // device-side step offset (hipGraph-replayed sequences), else 0
     for (int r = tid; r < BM; r += 256) {
@@ -198,10 +199,10 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
     const bool vec = VEC_FITS && (p.act & MIT_ACT_VEC_OK);
 #define MIT_EPI(A)                                                                                   \
     if (VEC_FITS && vec) {                                                                           \
-        if (has_post) epilogue_store_vec<TM, TN, A, true, XE>(p, acc, rowoff, tbuf, n0, wm0, wn0);      \
-        else epilogue_store_vec<TM, TN, A, false, XE>(p, acc, rowoff, tbuf, n0, wm0, wn0);              \
-    } else if (has_post) epilogue_store<TM, TN, A, true, XE>(p, acc, rowoff, n0, wm0, wn0);           \
-    else epilogue_store<TM, TN, A, false, XE>(p, acc, rowoff, n0, wm0, wn0)
+        if (has_post) epilogue_store_vec<TM, TN, A, true, XE>(p, acc, rowoff, tbuf, n0, wm0, wn0, tid); \
+        else epilogue_store_vec<TM, TN, A, false, XE>(p, acc, rowoff, tbuf, n0, wm0, wn0, tid);         \
+    } else if (has_post) epilogue_store<TM, TN, A, true, XE>(p, acc, rowoff, n0, wm0, wn0, tid);      \
+    else epilogue_store<TM, TN, A, false, XE>(p, acc, rowoff, n0, wm0, wn0, tid)
     switch (p.act & 0xff) {
         case MIT_ACT_RELU: MIT_EPI(MIT_ACT_RELU); break;
         case MIT_ACT_LEAKY: MIT_EPI(MIT_ACT_LEAKY); break;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const MitConvGemm p, con
         __syncthreads();
     }
 
-    epilogue<BM, TM, TN, 0, 2 * A_TILE + 2 * B_TILE>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+    epilogue<BM, TM, TN, 0, 2 * A_TILE + 2 * B_TILE>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo, (int)threadIdx.x);
 }
 
 // ---- fast path: Cin % BK == 0, so every K-tile lies inside ONE tap ----------------------------
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
     // buffers, so small tiles (64 x 64) get the dwordx4 store path too
     constexpr int EPI_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4 + 4 * 32 * EPI_PITCH;
     constexpr int SMEM_F = (2 * A_TILE + 2 * B_TILE) > EPI_FLOATS ? (2 * A_TILE + 2 * B_TILE) : EPI_FLOATS;
-    epilogue<BM, TM, TN, (VAR >> 12) & 3, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+    epilogue<BM, TM, TN, (VAR >> 12) & 3, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo, (int)threadIdx.x);
 }
 // ---- N <= 4: one output column group per row — a dot product, not a tile ------------------------------------------------
 // An MFMA tile would idle >= 28 of its 32 columns (the ctd heads' last ConvTranspose2d 64 -> 1 and 16 -> 1 ran at 2 TFLOP/s on

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR (wm0 / wn0 with it)
     const int li = lane & 31;
     const int lh = lane >> 5;
 
@@ -128,8 +128,16 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const int aq = tid % KQ;
     const int am = tid / KQ;
     const float *__restrict__ a_thr = a_base + aq * 4;
-    int b_src[B_ITERS], b_dst[B_ITERS];  // this thread's W cells: the same (plane, kh, n) in every K-tile of an output tile
-    bool b_ok[B_ITERS];
+    // this thread's W cells: the same (plane, kh, n) in every K-tile of an output tile.  B_UNI (a plane of the K-tile is exactly one
+    // cell per thread: the 128 x 128 x 16 tile): the thread's cells differ only by the plane, so one source index, one LDS index and one
+    // flag stand for all of them (the other planes are a wave-uniform stride away) — six registers less on the tile that needs them
+    constexpr bool B_UNI = B_CPP == 256;
+    constexpr int B_IDX = B_UNI ? 1 : B_ITERS;
+    int b_src[B_IDX], b_dst[B_IDX];
+    bool b_ok[B_IDX];
+    auto bsrc = [&](const int i) { return B_UNI ? b_src[0] + i * K8 * ldn : b_src[B_UNI ? 0 : i]; };
+    auto bdst = [&](const int i) { return B_UNI ? b_dst[0] + i * KH * SB : b_dst[B_UNI ? 0 : i]; };
+    auto bok = [&](const int i) { return b_ok[B_UNI ? 0 : i]; };
     int ld_tap = 0, ld_ci0 = 0, ld_k8 = 0;  // (tap, first channel, first k cell) of the tile being loaded: wave-uniform
     auto setup_tile = [&](const int t) {  // gather table, W cell addresses and load cursor of output tile t
         const int mt = t / NT, nt = t - mt * NT;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             rowtab[idx] = off;
         }
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
+        for (int i = 0; i < B_IDX; ++i) {
             const int c = tid + i * 256;
             const int pl = c / B_CPP, rem = c - pl * B_CPP;
             const int kh = rem / BN, n = rem - kh * BN;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             a_reg[i] = *reinterpret_cast<const f32x4 *>(ak + (a_off[i] < 0 ? 0 : a_off[i]));  // on the loaded value would wait for the load
         const u32x4 *wk = ws + (int64_t)ld_k8 * ldn;  // split_eligible(): every K-tile lies inside the packed planes
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) b_reg[i] = wk[b_ok[i] ? b_src[i] : 0];  // columns past ldw get arbitrary finite-or-not values: never stored
+        for (int i = 0; i < B_ITERS; ++i) b_reg[i] = wk[bok(i) ? bsrc(i) : 0];  // columns past ldw get arbitrary finite-or-not values: never stored
         ld_k8 += KH;
         ld_ci0 += BK;
         const bool wrap = ld_ci0 >= p.Cin;
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
         u32x4 *bs = Bs + buf * B_TILE;
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i)
-            if ((i + 1) * 256 <= B_CELLS || tid + i * 256 < B_CELLS) bs[b_dst[i]] = b_reg[i];
+            if ((i + 1) * 256 <= B_CELLS || tid + i * 256 < B_CELLS) bs[bdst(i)] = b_reg[i];
     };
 
     f32x16 acc[TM][TN];
@@ -227,48 +235,50 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     // The staging of one tile as a sequence of small steps (MID): per A chunk three (pack a plane, write it, form the residual), one
     // per W cell write, then the loads of the following tile (row offsets, A chunks, W cells).
     constexpr int STAGE_WRITE_STEPS = 3 * A_ITERS + B_ITERS, STAGE_STEPS = STAGE_WRITE_STEPS + 1 + A_ITERS + B_ITERS;
-    f32x4 rr[A_ITERS];
-    int a_offn[A_ITERS];
     auto stage_step = [&](const int st, const int buf, const bool with_loads) {
-        if (ORD && st == 0 && with_loads) {  // ahead of this tile's LDS writes: its wait does not include them
-            const int *rt = rowtab + ld_tap * BM + am;
+        if (ORD && st == 3 * (A_ITERS - 1) + 1 && with_loads) {  // the last use of the current offsets (the zero mask of the last chunk) is behind:
+            const int *rt = rowtab + ld_tap * BM + am;            // the next tile's take their registers, ahead of most of this tile's LDS writes
 #pragma unroll
-            for (int i = 0; i < A_ITERS; ++i) a_offn[i] = rt[i * A_MSTEP];
+            for (int i = 0; i < A_ITERS; ++i) a_off[i] = rt[i * A_MSTEP];
         }
         if (st < 3 * A_ITERS) {
             const int i = st / 3, ph = st % 3;
             const int kh = aq >> 1, half = aq & 1;
-            const int ml = (am + i * A_MSTEP) ^ split_swz<BK>(kh);
+            // one index register for every chunk and plane: the swizzle only touches row bits below A_MSTEP, so chunk i sits
+            // i * A_MSTEP rows (an immediate) behind chunk 0
+            static_assert((A_MSTEP & (A_MSTEP - 1)) == 0 && (BK / 4) * (32 / (BK / 4)) <= A_MSTEP || A_ITERS == 1, "row swizzle must stay inside a chunk's rows");
+            const int ml = ((am ^ split_swz<BK>(kh)) + i * A_MSTEP);
+            f32x4 &r = a_reg[i];  // the residuals replace the loaded values in place: the chunk is reloaded only after its last split step
             if (ph == 0) {
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                rr[i] = a_off[i] < 0 ? zero : a_reg[i];
+                const unsigned int keep = ~(unsigned int)(a_off[i] >> 31);  // rows that contribute zeros (offset -1): all bits cleared
+                r.x = __uint_as_float(__float_as_uint(r.x) & keep);
+                r.y = __uint_as_float(__float_as_uint(r.y) & keep);
+                r.z = __uint_as_float(__float_as_uint(r.z) & keep);
+                r.w = __uint_as_float(__float_as_uint(r.w) & keep);
             }
-            const u32x2 pk = {pack_bf16(rr[i].x, rr[i].y), pack_bf16(rr[i].z, rr[i].w)};
+            const u32x2 pk = {pack_bf16(r.x, r.y), pack_bf16(r.z, r.w)};
             reinterpret_cast<u32x2 *>(As + buf * A_TILE)[((ph * KH + kh) * SA + ml) * 2 + half] = pk;
             if (ph < 2) {
-                rr[i].x = sub_f32<ASM_SUB>(rr[i].x, bf16_lo(pk.x));
-                rr[i].y = sub_f32<ASM_SUB>(rr[i].y, bf16_hi(pk.x));
-                rr[i].z = sub_f32<ASM_SUB>(rr[i].z, bf16_lo(pk.y));
-                rr[i].w = sub_f32<ASM_SUB>(rr[i].w, bf16_hi(pk.y));
+                r.x = sub_f32<ASM_SUB>(r.x, bf16_lo(pk.x));
+                r.y = sub_f32<ASM_SUB>(r.y, bf16_hi(pk.x));
+                r.z = sub_f32<ASM_SUB>(r.z, bf16_lo(pk.y));
+                r.w = sub_f32<ASM_SUB>(r.w, bf16_hi(pk.y));
             }
         } else if (st < STAGE_WRITE_STEPS) {
             const int j = st - 3 * A_ITERS;
-            if ((j + 1) * 256 <= B_CELLS || tid + j * 256 < B_CELLS) (Bs + buf * B_TILE)[b_dst[j]] = b_reg[j];
+            if ((j + 1) * 256 <= B_CELLS || tid + j * 256 < B_CELLS) (Bs + buf * B_TILE)[bdst(j)] = b_reg[j];
         } else if (st == STAGE_WRITE_STEPS) {
             if (!ORD) {
                 const int *rt = rowtab + ld_tap * BM + am;
 #pragma unroll
                 for (int i = 0; i < A_ITERS; ++i) a_off[i] = rt[i * A_MSTEP];
-            } else {
-#pragma unroll
-                for (int i = 0; i < A_ITERS; ++i) a_off[i] = a_offn[i];  // every split step of this tile has used the old offsets by now
             }
         } else if (st <= STAGE_WRITE_STEPS + A_ITERS) {
             const int i = st - STAGE_WRITE_STEPS - 1;
             a_reg[i] = *reinterpret_cast<const f32x4 *>(a_thr + ld_ci0 + (a_off[i] < 0 ? 0 : a_off[i]));
         } else if (st < STAGE_STEPS) {
             const int j = st - STAGE_WRITE_STEPS - 1 - A_ITERS;
-            b_reg[j] = (ws + (int64_t)ld_k8 * ldn)[b_ok[j] ? b_src[j] : 0];
+            b_reg[j] = (ws + (int64_t)ld_k8 * ldn)[bok(j) ? bsrc(j) : 0];
             if (st == STAGE_STEPS - 1) {
                 ld_k8 += KH;
                 ld_ci0 += BK;
@@ -371,7 +381,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
         tile(kt, no, no);
     }
     if (X_NOBAR) __syncthreads();  // the epilogue reuses the staging area
-    epilogue<BM, TM, TN, 0, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo);
+    // the thread index rebuilt from the SGPR wave index and mbcnt: nothing derived from threadIdx.x has to survive the K loop (the
+    // 128 x 128 tile otherwise spilled eight such registers to scratch memory; see DESIGN §7 on why no kernel of this library may use
+    // scratch)
+    const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    epilogue<BM, TM, TN, 0, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo, tid_e);
 }
 
 // (A one-wave-per-32x32-block form with register-streamed operands for few-row GEMMs — a page's decoder Linears, M = 160 — was built and

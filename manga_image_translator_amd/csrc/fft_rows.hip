@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/mit_hip.h"
 #include "common.h"
@@ -171,10 +173,14 @@ constexpr int LD_UNROLL = 3;  // (row pair) loads in flight per thread: 3 x 32 p
 __global__ __launch_bounds__(256) void rfft_rows_kernel(const float *__restrict__ in, int64_t in_bs, int64_t in_hs, int64_t in_ws,
                                                          float *__restrict__ out, int64_t out_bs, int64_t out_ts, int64_t out_hs,
                                                          int64_t out_ks, const float2 *__restrict__ tables, RowPlan plan, int N,
-                                                         int Cn, float scale) {
+                                                         int Cn, float scale, int dbg_zero) {
     extern __shared__ __attribute__((aligned(16))) float2 lds2[];
     float2 *bufA = lds2;                    // [N + 1][CC]
     float2 *bufB = lds2 + (N + 1) * CC;     // [N + 1][CC]
+    if (dbg_zero) {  // diagnostics (scripts/diag_rfft_load.py): start from a cleared LDS image
+        for (int j = threadIdx.x; j < 2 * (N + 1) * CC + 2 * N + 1; j += 256) lds2[j] = make_float2(0.f, 0.f);
+        __syncthreads();
+    }
     float2 *tw = lds2 + 2 * (N + 1) * CC;   // [N]      (cos, sin)(2 pi j / N)
     float2 *tw2 = tw + N;                   // [N + 1]  (cos, sin)(2 pi k / w), w = 2 N
     const int c0 = blockIdx.x * CC;
@@ -349,7 +355,12 @@ extern "C" int mit_rfft_rows(const float *in_dev, int64_t in_bs, int64_t in_hs, 
         !aligned4(out_ks) || (reinterpret_cast<uintptr_t>(in_dev) & 15) || (reinterpret_cast<uintptr_t>(out_dev) & 15))
         return mit_set_error("mit_rfft_rows: strides and bases must be multiples of 4 floats");
     const int N = w / 2;
-    const size_t smem = ((size_t)2 * (N + 1) * CC + 2 * N + 1) * sizeof(float2);
+    size_t smem = ((size_t)2 * (N + 1) * CC + 2 * N + 1) * sizeof(float2);
+    int dbg_zero = 0;
+    if (const char *e = getenv("MIT_FFT_ROWS_DEBUG")) {  // diagnostics: "<extra LDS bytes>,<clear LDS first 0|1>"
+        int pad = 0;
+        if (sscanf(e, "%d,%d", &pad, &dbg_zero) >= 1 && pad > 0) smem += (size_t)pad;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rfft_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -361,7 +372,7 @@ extern "C" int mit_rfft_rows(const float *in_dev, int64_t in_bs, int64_t in_hs, 
     MitProbeScope probe("rfft_rows_kernel", st, 4.0 * rows * (w + 2.0 * (N + 1)), 2.5 * w * log2((double)w) * rows);
     dim3 grid(mit_div_up(C, CC), h, B), block(256);
     hipLaunchKernelGGL(rfft_rows_kernel, grid, block, smem, st, in_dev, in_bs, in_hs, in_ws, out_dev, out_bs, out_ts, out_hs, out_ks,
-                       reinterpret_cast<const float2 *>(tables_dev), plan, N, C, scale);
+                       reinterpret_cast<const float2 *>(tables_dev), plan, N, C, scale, dbg_zero);
     MIT_CHECK_LAUNCH("mit_rfft_rows");
     return 0;
 }
