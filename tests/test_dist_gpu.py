@@ -48,8 +48,9 @@ def _shard_worker(rank, world, port, q, gpu_turn):
         weights = Dm.broadcast_weights(pipeline.synthetic_weights(dict_size=D) if rank == 0 else None)
         lo, hi = Dm.shard_range(N_PAGES, rank, world)
         # Both ranks of this rehearsal sit on ONE GPU (a real job has one GPU per rank).  Their compute phases take turns: two copies of
-        # the engine running kernels on one device AT THE SAME TIME is not a configuration the engine supports — scripts/diag_concurrent2.py
-        # and scripts/diag_ffc_load.py show results that vary from run to run in that situation (first seen in rfft / irfft rows).
+        # the engine running kernels on one device AT THE SAME TIME is not a configuration the engine supports — scripts/diag_concurrent2.py,
+        # diag_ffc_load.py and diag_rfft_culprit.py: the 128 x 128 split GEMM tile of one process disturbs kernels of the other that share a
+        # CU with it (rfft / irfft rows most visibly); cause open, DESIGN §7.
         with gpu_turn:
             recs = _records(weights, lo, hi)
             torch.cuda.synchronize()
