@@ -847,4 +847,4 @@ void launch_gemv(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
 }
 }  // namespace mitcg
 
-#include "conv_gemm_split.h"  // conv_gemm_split_kernel, gemm_split_pack_kernel, launch_split (the opt-in split-bf16 tiles)
+#include "conv_gemm_split.h"  // conv_gemm_split_kernel, gemm_split_pack_kernel, launch_split (the split-bf16 tiles: GEMM mode 6 | 9)

@@ -1,4 +1,5 @@
-// conv_gemm_split.h — the split-bf16 tiles of mit_conv_gemm (opt-in, MIT_GEMM_SPLIT): kernel, weight packer and launcher.
+// conv_gemm_split.h — the split-bf16 tiles of mit_conv_gemm (GEMM mode 6, the default, and 9: mit_gemm_mode_set / MIT_GEMM_SPLIT): kernel,
+// weight packer and launcher.  No kernel here may spill to scratch memory (check .amdhsa_private_segment_fixed_size after changes).
 // Included at the end of conv_gemm_kernels.h (it shares that header's epilogue, RowOff and launch conventions); instantiated by
 // conv_gemm_inst5 / 6 / 7.hip through conv_gemm_cfgs.inc.
 #pragma once
