@@ -193,6 +193,28 @@ __global__ __launch_bounds__(256) void lanes_kernel(const float *in, float *out)
     for (int i = 0; i < 16; ++i) out[(size_t)blockIdx.x * 4096 + tid + 256 * i] = v[i];
 }
 
+// UNBALANCED phases: in every round ONE wave works for a long time and publishes 64 values through LDS, the other three go straight to the
+// barrier and then read them.  A barrier that lets a wave through early shows up as stale values (the FFT rows kernels are unbalanced in
+// the same way: a radix-4 stage of a 12-point row has work for three of the eight half-wave slots).
+__global__ __launch_bounds__(256) void unbalanced_kernel(const float *in, float *out, int spin) {
+    __shared__ float t[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc = in[(size_t)blockIdx.x * 256 + tid];
+    if (tid < 64) t[tid] = 0.f;
+    __syncthreads();
+    for (int round = 0; round < 16; ++round) {
+        if (wave == (round & 3)) {
+            float x = acc + (float)round;
+            for (int i = 0; i < spin; ++i) x = x * 0.999f + 0.001f;
+            t[lane] = x;
+        }
+        __syncthreads();
+        acc += t[(lane + round) & 63];
+        __syncthreads();
+    }
+    out[(size_t)blockIdx.x * 256 + tid] = acc;
+}
+
 int main(int argc, char **argv) {
     setvbuf(stdout, nullptr, _IOLBF, 0);
     const int launches = argc > 1 ? atoi(argv[1]) : 200;
@@ -252,17 +274,19 @@ int main(int argc, char **argv) {
     };
     auto run_k = [&](int which, std::vector<float> &host) {
         if (which == 0) hipLaunchKernelGGL(exchange128_kernel, dim3(XWG), dim3(256), 16384, 0, xin, xout);
+        else if (which == 2) hipLaunchKernelGGL(unbalanced_kernel, dim3(4096), dim3(256), 0, 0, xin, xout, 400);
         else hipLaunchKernelGGL(lanes_kernel, dim3(XWG), dim3(256), 0, 0, xin, xout);
         CK(hipDeviceSynchronize());
         host.resize((size_t)XWG * 4096);
         CK(hipMemcpy(host.data(), xout, host.size() * 4, hipMemcpyDeviceToHost));
     };
-    std::vector<float> ref_r, ref_x, ref_b, ref_l, got;
+    std::vector<float> ref_r, ref_x, ref_b, ref_l, ref_u, got;
     run_rfft(ref_r);
     run_x(ref_x);
     run_k(0, ref_b);
     run_k(1, ref_l);
-    printf("%-66s %-22s %s\n", "co-tenant (another process)", "rfft_rows launches bad", "LDS-exchange b32 / dynamic b128 / b32 + readlane launches bad");
+    run_k(2, ref_u);
+    printf("%-66s %-22s %s\n", "co-tenant (another process)", "rfft_rows launches bad", "LDS-exchange b32 / dynamic b128 / b32 + readlane / UNBALANCED waves: launches bad");
     for (int a = 0; a < kNumAggressors; ++a) {
         if (a && a < first) continue;
         if (a) {
@@ -270,7 +294,7 @@ int main(int argc, char **argv) {
             if (write(go[a][1], &c, 1) != 1 || read(ready[a][0], &c, 1) != 1) return 2;
             usleep(300 * 1000);
         }
-        int bad_r = 0, bad_x = 0, bad_b = 0, bad_l = 0;
+        int bad_r = 0, bad_x = 0, bad_b = 0, bad_l = 0, bad_u = 0;
         for (int i = 0; i < launches; ++i) {
             run_rfft(got);
             bad_r += memcmp(got.data(), ref_r.data(), n_out * 4) != 0;
@@ -280,8 +304,10 @@ int main(int argc, char **argv) {
             bad_b += memcmp(got.data(), ref_b.data(), got.size() * 4) != 0;
             run_k(1, got);
             bad_l += memcmp(got.data(), ref_l.data(), got.size() * 4) != 0;
+            run_k(2, got);
+            bad_u += memcmp(got.data(), ref_u.data(), (size_t)4096 * 256 * 4) != 0;
         }
-        printf("%-66s %4d of %-14d %4d / %d / %d of %d\n", kAggressors[a].name, bad_r, launches, bad_x, bad_b, bad_l, launches);
+        printf("%-66s %4d of %-14d %4d / %d / %d / %d of %d\n", kAggressors[a].name, bad_r, launches, bad_x, bad_b, bad_l, bad_u, launches);
         if (a) {
             kill(pids[a], SIGKILL);
             waitpid(pids[a], nullptr, 0);
