@@ -194,3 +194,43 @@ def test_native_component_assignment_edge_cases():
         b = MR.complete_mask(img, b_m, quads, refine=REFINE, bilateral=BILATERAL, native=False)
         assert np.array_equal(a_m, b_m)
         assert (a is None and b is None) or np.array_equal(a, b)
+
+
+def test_native_assignment_reports_capacity_and_shape_errors():
+    """The C-ABI entry points of the host half refuse bad shapes and too small output buffers with a message (no writes past the caller's
+    buffers), and two crop jobs of the same line both get painted."""
+    import ctypes as C
+
+    from manga_image_translator_amd import lib as L
+
+    lib = L.load()
+    H, W = 8, 16
+    mask = np.zeros((H, W), np.uint8)
+    mask[1, 1:5] = 255          # 4 pixels: a speck (<= 9 pixels is never assigned)
+    mask[3:7, 2:12] = 255       # 40 pixels inside the line below
+    polys = np.array([[[0, 2], [15, 2], [15, 7], [0, 7]]], np.float64)
+    boxes = np.array([[-2, -2, 0, 0]], np.int32)   # outline off the page: leaves the mask alone
+    font = np.array([5.0])
+    runs = np.empty((64, 4), np.int32)
+    assign = np.empty(16, np.int32)
+    rects = np.empty((1, 4), np.int32)
+    n_runs, n_comp = C.c_int64(), C.c_int32()
+    args = lambda m, rc, ac: (m.ctypes.data, H, W, boxes.ctypes.data, polys.ctypes.data, font.ctypes.data, 1, 4, 1e-2, runs.ctypes.data, rc,
+                              assign.ctypes.data, ac, rects.ctypes.data, C.byref(n_runs), C.byref(n_comp))
+    assert lib.mit_mask_assign_lines(*args(mask.copy(), 64, 16)) == 0
+    assert (n_runs.value, n_comp.value) == (5, 2) and assign[:3].tolist() == [-1, -1, 0] and rects[0].tolist() == [2, 3, 12, 7]
+    assert lib.mit_mask_assign_lines(*args(mask.copy(), 3, 16)) != 0 and b"runs" in lib.mit_last_error()
+    assert lib.mit_mask_assign_lines(*args(mask.copy(), 64, 2)) != 0 and b"components" in lib.mit_last_error()
+    assert lib.mit_mask_assign_lines(mask.ctypes.data, H, W, boxes.ctypes.data, polys.ctypes.data, font.ctypes.data, 1, 2, 1e-2, runs.ctypes.data, 64,
+                                     assign.ctypes.data, 16, rects.ctypes.data, C.byref(n_runs), C.byref(n_comp)) != 0
+    assert lib.mit_mask_assign_lines(*args(mask.copy(), 64, 16)) == 0
+    jobs = np.array([[0, 2, 3, 10, 4], [0, 0, 0, 16, 8], [3, 0, 0, 4, 4]], np.int32)   # the line's rectangle, the whole page, a line without components
+    offs = np.array([0, 40, 40 + 128], np.int64)
+    out = np.full(40 + 128 + 16, 7, np.uint8)
+    assert lib.mit_mask_line_crops(runs.ctypes.data, n_runs.value, assign.ctypes.data, jobs.ctypes.data, 3, out.ctypes.data, offs.ctypes.data) == 0
+    assert (out[:40] == 255).all()
+    page = out[40:168].reshape(8, 16)
+    assert (page[3:7, 2:12] == 255).all() and page.sum() == 40 * 255      # the speck belongs to no line
+    assert not out[168:].any()
+    bad = np.array([[0, 0, 0, -1, 4]], np.int32)
+    assert lib.mit_mask_line_crops(runs.ctypes.data, n_runs.value, assign.ctypes.data, bad.ctypes.data, 1, out.ctypes.data, offs.ctypes.data) != 0
