@@ -30,6 +30,9 @@ core = core.replace("x[i] = src[(q + s * (p + m * i)) * CC + c];", "x[i] = MIT_L
 n2 = core.count("float2 w = tw[p * k * tws];")
 core = core.replace("float2 w = tw[p * k * tws];", "float2 w = MIT_TW(tw, p * k * tws, N);")
 assert n1 == 1 and n2 == 1, (n1, n2)
+# third hook: where the workgroup's coordinates come from (a 3-D grid, or one flat index decoded in the kernel)
+for ax in "xyz":
+    core = core.replace("blockIdx." + ax, "MIT_BID_" + ax.upper())
 assert "MIT_RUN_STAGES" in core and "run_fixed12" in core
 open("scripts/_fft_rows_core.inc", "w").write(core + "\n")
 PY
