@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 6
+#define MIT_ABI_VERSION 7
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -159,6 +159,56 @@ int mit_gemm_mode_get(void);
  * eligible launch, which keeps a page's result independent of the batch it is part of — or MIT_GEMM_SPLIT_MIN_TILES); n >= 0 sets it,
  * n < 0 only queries.  Returns the previous value.  A tuning knob: 1280 = one full wave of workgroups. */
 int64_t mit_gemm_split_min_tiles(int64_t n);
+
+/* ---- planar operands: the plain GEMMs of the split-bf16 mode with activations that ARRIVE split ---------------------------------
+ * In mit_conv_gemm's split tiles the activations are split into their three bf16 planes by VALU work inside the K loop, once per
+ * output-column tile.  When the producer of an activation tensor writes the planes itself (mit_split_planes, the planar forms of
+ * mit_dwconv_nhwc_ragged_rows / mit_wino43_input, or mit_pgemm's own planar epilogue) a plain GEMM (1x1 convolution, nn.Linear, the 36
+ * Winograd products) needs no VALU work in its K loop at all: both operands go global -> LDS by the LDS-DMA (global_load_lds_dwordx4)
+ * in the cell layout the bf16 MFMA consumes, a ring of stages keeps the loads one or two K-tiles ahead behind counted vmcnt waits, and
+ * a workgroup walks several output tiles so that the next tile's loads are in flight during an epilogue.
+ *
+ * "planes" of a row-major fp32 matrix X[R][K] (K % 8 == 0), ld >= R:   P[3][K / 8][ld][8] bf16 (uint16 bit patterns),
+ *     X[r][8 c + j] == bf16(P[0][c][r][j]) + bf16(P[1][c][r][j]) + bf16(P[2][c][r][j])      exactly, each plane the
+ *     round-to-nearest-even bf16 of what the previous ones left (the same split as conv_gemm_split_kernel and mit_gemm_split_pack:
+ *     the weights' planes [3][Kw / 8][ldw][8] ARE this layout with r = output column).
+ * mit_pgemm:  C[z][m][n] = epilogue( sum_k A[z][m][k] * W[z][k][n] ),  the sum taken as NPROD (6 | 9) bf16 MFMA products per 16-wide k
+ *     step in the order of the split tiles: results are bit-identical to mit_conv_gemm on a "split*p6*" / "split*p9*" tile for the
+ *     same operands.  epilogue(v) = act((v + pre) * scale[n] + bias[n]) + post   (MIT_ACT_POST_FIRST as in MitConvGemm).
+ *     Output either fp32 row-major (c, ldc) or planes (c_planes, ld_cp: N % 8 == 0; pre / post must be NULL), or both NULL = error.
+ * Replaces the same reference calls as mit_conv_gemm for these layers: the pointwise convolutions of ConvNeXtBlock
+ * (ocr/model_48px.py:203-214) and the convl2l / convl2g / convg2l products of the FFC blocks (inpainting_lama_mpe.py:349-369). */
+typedef struct MitPGemm {
+    const uint16_t *a_planes; /* [Z][3][K/8][lda][8] */
+    int64_t a_zs;             /* uint16 elements between z slices of A (0 for Z == 1) */
+    int64_t lda;              /* rows per (plane, k-cell) slab, >= M */
+    const uint16_t *w_planes; /* [Z][3][K/8][ldw][8] (mit_gemm_split_pack) */
+    int64_t w_zs;             /* uint16 elements between z slices of W (0: shared) */
+    int64_t ldw;              /* columns per slab, >= N */
+    int32_t M, N, K, Z;       /* K % 16 == 0 */
+    float *c;                 /* fp32 output [Z][M][ldc] or NULL */
+    int64_t ldc, c_zs;
+    const float *pre;         /* optional fp32 operands of the epilogue, row-major like c (own strides) */
+    int64_t ld_pre, pre_zs;
+    const float *post;
+    int64_t ld_post, post_zs;
+    uint16_t *c_planes;       /* planar output [Z][3][N/8][ld_cp][8] or NULL */
+    int64_t ld_cp, cp_zs;
+    const float *scale, *bias;
+    int32_t act;
+    float act_alpha;
+    int32_t nprod;            /* 6 | 9 (0 = follow mit_gemm_mode_get(), which must then be 6 or 9) */
+    int32_t tile;             /* -1 = automatic; else an index into mit_pgemm_tile_name() (tests / tuning) */
+} MitPGemm;
+int mit_pgemm(const MitPGemm *desc, void *stream);
+const char *mit_pgemm_tile_name(int tile); /* NULL past the table */
+/* 1 when mit_pgemm accepts the problem (sizes / alignment); 0 otherwise, with the reason in mit_last_error(). */
+int mit_pgemm_supported(const MitPGemm *desc);
+/* X fp32 [R][K] (row stride ldx floats, ldx % 4 == 0, K % 8 == 0) -> planes [3][K/8][ld][8] as above.  The stand-alone producer
+ * (tests, and tensors whose producer has no planar form). */
+int mit_split_planes(const float *x_dev, int64_t ldx, int R, int K, uint16_t *planes_dev, int64_t ld, void *stream);
+/* planes -> fp32 (the exact sum hi + mid + lo): tests and debugging. */
+int mit_join_planes(const uint16_t *planes_dev, int64_t ld, int R, int K, float *x_dev, int64_t ldx, void *stream);
 
 /* k x k (3, 5, 7) stride-1 "same" convolution with 1..4 output channels on the fp32 VALU (an MFMA tile would idle 29 of
  * its 32 columns): out[b,y,x,n] = act(sum in[b,y+dy,x+dx,c] * w4[(ky*k+kx)*Cin + c][n] + bias[n]).  in: NHWC with pixel

@@ -69,6 +69,17 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
     return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x));
 }
 
+// A (re, im) pair out of LDS as TWO 4-byte loads.  The butterfly inputs of a stage sit a constant stride apart, which hipcc merges into
+// two-address 8-byte reads (ds_read2_b64 / ds_read2st64_b64); launches of these kernels then returned wrong workgroups whenever ANOTHER
+// queue's kernel that mixes MFMAs with LDS traffic was resident on the same CU (7-15 of 60 launches; scripts/cotenant_check,
+// profiles/r04a_cotenant_check.log), while the same kernel with these reads as 4-byte loads — and every other victim tried, including
+// single-address 8- and 16-byte LDS reads — stayed bit-exact (0 of 60).  The volatile keeps the two loads from being merged again.  The
+// kernels are HBM-bound: the narrower reads cost nothing measurable.
+__device__ __forceinline__ float2 lds_pair(const float2 *p) {
+    const volatile float *f = reinterpret_cast<const volatile float *>(p);
+    return make_float2(f[0], f[1]);
+}
+
 // y_k = sum_i x_i exp(-/+ 2 pi i ik / P), in place.
 template <int P, bool INV>
 __device__ __forceinline__ void butterfly(float2 (&x)[P]) {
@@ -127,7 +138,7 @@ __device__ __forceinline__ void stage(const float2 *__restrict__ src, float2 *__
         const int q = bf % s, p = bf / s;
         float2 x[P];
 #pragma unroll
-        for (int i = 0; i < P; ++i) x[i] = src[(q + s * (p + m * i)) * CC + c];
+        for (int i = 0; i < P; ++i) x[i] = lds_pair(src + (q + s * (p + m * i)) * CC + c);
         butterfly<P, INV>(x);
         if (m > 1) {
 #pragma unroll
@@ -219,8 +230,8 @@ __global__ __launch_bounds__(256) void rfft_rows_kernel(const float *__restrict_
     const bool sok = c0 + c < Cn;
     const float hs = 0.5f * scale;
     for (int k = slot; k <= N; k += NSLOT) {
-        const float2 zk = Z[(k == N ? 0 : k) * CC + c];
-        const float2 zr = Z[(k == 0 ? 0 : N - k) * CC + c];
+        const float2 zk = lds_pair(Z + (k == N ? 0 : k) * CC + c);
+        const float2 zr = lds_pair(Z + (k == 0 ? 0 : N - k) * CC + c);
         const float2 zn = make_float2(zr.x, -zr.y);
         const float2 e = cadd(zk, zn), d = csub(zk, zn);
         const float2 w = tw2[k];                                  // (cos, sin); e^{-i th} = (cos, -sin)
@@ -278,8 +289,8 @@ __global__ __launch_bounds__(256) void irfft_rows_kernel(const float *__restrict
     const int slot = threadIdx.x >> 5, c = threadIdx.x & 31;
     // tangle: Z[k] = (X[k] + conj X[N-k]) + i e^{+2 pi i k / w} (X[k] - conj X[N-k]),  k < N
     for (int k = slot; k < N; k += NSLOT) {
-        const float2 xk = bufA[k * CC + c];
-        const float2 xr = bufA[(N - k) * CC + c];
+        const float2 xk = lds_pair(bufA + k * CC + c);
+        const float2 xr = lds_pair(bufA + (N - k) * CC + c);
         const float2 xn = make_float2(xr.x, -xr.y);
         const float2 e = cadd(xk, xn), d = csub(xk, xn);
         const float2 o = cmul(make_float2(-d.y, d.x), tw2[k]);  // i d e^{+i th}

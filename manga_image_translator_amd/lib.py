@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 6
+MIT_ABI_VERSION = 7
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -72,6 +72,21 @@ class MitConvGemm(C.Structure):
         ("dyn", C.c_void_p),
         ("a_dyn", C.c_int64),
         ("c_dyn", C.c_int64),
+    ]
+
+
+class MitPGemm(C.Structure):
+    """Descriptor of ``mit_pgemm`` (include/mit_hip.h): a plain GEMM on operands that arrive as three bf16 planes."""
+    _fields_ = [
+        ("a_planes", C.c_void_p), ("a_zs", C.c_int64), ("lda", C.c_int64),
+        ("w_planes", C.c_void_p), ("w_zs", C.c_int64), ("ldw", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("Z", C.c_int32),
+        ("c", C.c_void_p), ("ldc", C.c_int64), ("c_zs", C.c_int64),
+        ("pre", C.c_void_p), ("ld_pre", C.c_int64), ("pre_zs", C.c_int64),
+        ("post", C.c_void_p), ("ld_post", C.c_int64), ("post_zs", C.c_int64),
+        ("c_planes", C.c_void_p), ("ld_cp", C.c_int64), ("cp_zs", C.c_int64),
+        ("scale", C.c_void_p), ("bias", C.c_void_p),
+        ("act", C.c_int32), ("act_alpha", C.c_float), ("nprod", C.c_int32), ("tile", C.c_int32),
     ]
 
 
@@ -227,6 +242,11 @@ SYMBOLS = {
     "mit_ocr_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_dwconv_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p]),
+    "mit_pgemm": (C.c_int, [C.POINTER(MitPGemm), C.c_void_p]),
+    "mit_pgemm_tile_name": (C.c_char_p, [C.c_int]),
+    "mit_pgemm_supported": (C.c_int, [C.POINTER(MitPGemm)]),
+    "mit_split_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mit_join_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "mit_dwconv_nhwc_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mit_dwconv_nhwc_ragged_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -25,8 +25,8 @@ __device__ __forceinline__ float2 *run_fixed12(float2 *a, float2 *b, const float
 """
 core = core.replace("constexpr int LD_UNROLL", fixed + "constexpr int LD_UNROLL", 1)
 # two more hooks inside stage<P>(): how a butterfly input is read from LDS, where a twiddle comes from
-n1 = core.count("x[i] = src[(q + s * (p + m * i)) * CC + c];")
-core = core.replace("x[i] = src[(q + s * (p + m * i)) * CC + c];", "x[i] = MIT_LDS_READ(src, (q + s * (p + m * i)) * CC + c);")
+n1 = core.count("x[i] = lds_pair(src + (q + s * (p + m * i)) * CC + c);")
+core = core.replace("x[i] = lds_pair(src + (q + s * (p + m * i)) * CC + c);", "x[i] = MIT_LDS_READ(src, (q + s * (p + m * i)) * CC + c);")
 n2 = core.count("float2 w = tw[p * k * tws];")
 core = core.replace("float2 w = tw[p * k * tws];", "float2 w = MIT_TW(tw, p * k * tws, N);")
 assert n1 == 1 and n2 == 1, (n1, n2)

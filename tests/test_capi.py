@@ -54,7 +54,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     structs = {"MitTensorMap": lib.MitTensorMap, "MitConvGemm": lib.MitConvGemm, "MitXposTables": lib.MitXposTables,
                "MitLinear": lib.MitLinear, "MitOcrDecoderLayer": lib.MitOcrDecoderLayer, "MitOcr48Decoder": lib.MitOcr48Decoder,
                "MitOcr48DecodeArgs": lib.MitOcr48DecodeArgs, "MitProfStat": lib.MitProfStat, "MitWarpLine": lib.MitWarpLine,
-               "MitDilateJob": lib.MitDilateJob, "MitMaskRun": lib.MitMaskRun}
+               "MitDilateJob": lib.MitDilateJob, "MitMaskRun": lib.MitMaskRun, "MitPGemm": lib.MitPGemm}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
     for name, st in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
