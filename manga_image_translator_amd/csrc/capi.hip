@@ -21,6 +21,24 @@ int mit_set_error(const char *fmt, ...) {
 extern "C" const char *mit_last_error(void) { return g_err; }
 extern "C" int mit_abi_version(void) { return MIT_ABI_VERSION; }
 
+namespace {
+std::atomic<int> g_cotenant_safe{-1};  // -1: not read yet
+}
+bool mit_cotenant_safe() {
+    int v = g_cotenant_safe.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("MIT_COTENANT_SAFE");
+        v = (e && *e && *e != '0') ? 1 : 0;
+        g_cotenant_safe.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int mit_cotenant_safe_set(int on) {
+    const int prev = mit_cotenant_safe() ? 1 : 0;
+    if (on >= 0) g_cotenant_safe.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+
 #ifndef MIT_SOURCE_DIGEST
 #define MIT_SOURCE_DIGEST "unknown"
 #endif

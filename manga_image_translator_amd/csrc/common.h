@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <mutex>
 
 // Records a thread-local error string (returned by mit_last_error) and returns 1.
 int mit_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
@@ -19,6 +21,34 @@ int mit_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
     } while (0)
 
 static inline int mit_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Dynamic LDS beyond 64 KB needs an opt-in per kernel and per device (hipFuncAttributeMaxDynamicSharedMemorySize).  One static
+// instance per kernel; ensure() raises the grant whenever a launch needs more than what was granted before (a layer with more taps
+// needs a larger gather table than the first launch of that kernel did).  Thread-safe and monotonic: the engines launch from several
+// host threads, and a smaller grant must never land between another thread's larger grant and its launch.
+struct DynSmemOptIn {
+    std::atomic<size_t> granted[16];
+    std::mutex mu;
+    DynSmemOptIn() {
+        for (auto &g : granted) g.store(0, std::memory_order_relaxed);
+    }
+    void ensure(const void *kern, size_t smem) {
+        if (smem <= 64 * 1024) return;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t> &g = granted[dev & 15];
+        if (g.load(std::memory_order_acquire) >= smem) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (g.load(std::memory_order_relaxed) >= smem) return;
+        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        g.store(smem, std::memory_order_release);
+    }
+};
+
+// MIT_COTENANT_SAFE (mit_cotenant_safe_set): kernels known to return wrong results while ANOTHER queue's MFMA + LDS kernel shares their CU
+// (the FFT rows kernels) take a whole CU's LDS so that nothing of that kind can be co-resident.  Off by default: one process
+// per GPU on one stream never has two kernels resident at once.
+bool mit_cotenant_safe();
 
 // ---- generic kernel-time probe (mit_prof_kernels_read): while mit_prof_enable(1) is in force, a MitProbeScope around a
 // launch brackets it with HIP events on its stream and files it under `name` with the caller's algorithmic bytes / FLOPs.

@@ -800,21 +800,6 @@ size_t smem_bytes() {
     return staging > rows ? staging : rows;
 }
 
-// Dynamic LDS beyond 64 KB needs an opt-in per kernel (and per device).  The opt-in is raised whenever a launch needs more than what
-// was granted before — a layer with more taps needs a larger gather table than the first launch of that kernel did.
-struct DynSmemOptIn {
-    size_t granted[16] = {0};
-    void ensure(const void *kern, size_t smem) {
-        if (smem <= 64 * 1024) return;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        size_t &g = granted[dev & 15];
-        if (g >= smem) return;
-        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        g = smem;
-    }
-};
-
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 void launch_cfg(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_t s) {
     dim3 grid(MT * NT, p.Z, 1);

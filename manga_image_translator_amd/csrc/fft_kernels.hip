@@ -173,11 +173,8 @@ extern "C" int mit_fft_cols(const float *in_dev, int64_t in_bs, int64_t in_ts, i
 #define MIT_FFT_LAUNCH(ROWS, NT)                                                                                               \
     do {                                                                                                                       \
         auto kern = fft_cols_kernel<ROWS, NT>;                                                                                 \
-        static bool attr_set = false;                                                                                          \
-        if (!attr_set && smem > 64 * 1024) {                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set = true;                                                                                                   \
-        }                                                                                                                      \
+        static DynSmemOptIn optin;                                                                                             \
+        optin.ensure(reinterpret_cast<const void *>(kern), smem);                                                              \
         hipLaunchKernelGGL(kern, grid, dim3(NT), smem, st, in_dev, in_bs, in_ts, in_hs, out_dev, out_bs, out_ts, out_hs, tw2, h, logh, \
                            ncols, inverse, scale);                                                                            \
     } while (0)

@@ -347,6 +347,10 @@ int make_plan(int N, RowPlan *plan) {
 
 bool aligned4(int64_t v) { return (v & 3) == 0; }
 
+// with MIT_COTENANT_SAFE: 140 of a CU's 160 KB — no workgroup of the split-bf16 GEMM tiles (>= 37 KB) fits beside it (round 3: "giving the
+// victim a whole CU removes it"); costs these two kernels their own co-residency (three workgroups per CU otherwise)
+constexpr size_t kCotenantSafeLds = 140 * 1024;
+
 }  // namespace
 
 extern "C" int mit_rfft_rows_supported(int w) {
@@ -372,11 +376,9 @@ extern "C" int mit_rfft_rows(const float *in_dev, int64_t in_bs, int64_t in_hs, 
         int pad = 0;
         if (sscanf(e, "%d,%d", &pad, &dbg_zero) >= 1 && pad > 0) smem += (size_t)pad;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rfft_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if (mit_cotenant_safe() && smem < kCotenantSafeLds) smem = kCotenantSafeLds;
+    static DynSmemOptIn optin;
+    optin.ensure(reinterpret_cast<const void *>(rfft_rows_kernel), smem);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const double rows = (double)B * h * C;
     // algorithmic bytes: the real rows read once, the half spectrum written once; FLOPs: 2.5 w log2 w per real row
@@ -402,12 +404,10 @@ extern "C" int mit_irfft_rows(const float *in_dev, int64_t in_bs, int64_t in_ts,
     if (res_dev && (!aligned4(res_bs) || !aligned4(res_hs) || !aligned4(res_ws) || (reinterpret_cast<uintptr_t>(res_dev) & 15)))
         return mit_set_error("mit_irfft_rows: residual strides and base must be multiples of 4 floats");
     const int N = w / 2;
-    const size_t smem = ((size_t)2 * (N + 1) * CC + 2 * N + 1) * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(irfft_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    size_t smem = ((size_t)2 * (N + 1) * CC + 2 * N + 1) * sizeof(float2);
+    if (mit_cotenant_safe() && smem < kCotenantSafeLds) smem = kCotenantSafeLds;
+    static DynSmemOptIn optin;
+    optin.ensure(reinterpret_cast<const void *>(irfft_rows_kernel), smem);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const double rows = (double)B * h * C;
     MitProbeScope probe("irfft_rows_kernel", st, 4.0 * rows * ((res_dev ? 2.0 : 1.0) * w + 2.0 * (N + 1)), 2.5 * w * log2((double)w) * rows);

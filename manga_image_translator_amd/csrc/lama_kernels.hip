@@ -253,12 +253,8 @@ extern "C" int mit_lama_mpe_index(const uint8_t *mask_dev, int B, int H, int W, 
                        yw, ymax, xs, xc, xw, xmax, hole_dev);
     MIT_CHECK_LAUNCH("mit_lama_mpe_index(downsample)");
     const size_t smem = 2 * MPE_S * MPE_S;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MIT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mpe_rings_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static DynSmemOptIn optin;
+    optin.ensure(reinterpret_cast<const void *>(mpe_rings_kernel), smem);
     hipLaunchKernelGGL(mpe_rings_kernel, dim3(B), dim3(1024), smem, (hipStream_t)stream, hole_dev, relpos_dev, direct_dev);
     MIT_CHECK_LAUNCH("mit_lama_mpe_index(rings)");
     return 0;

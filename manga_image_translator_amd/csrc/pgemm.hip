@@ -78,9 +78,9 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &h,
 #define MIT_PG_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0) only (expcnt 7, lgkmcnt 15: no wait) */
 
 // ---- fp32 row-major epilogue of one wave's TM x TN blocks (OUTP = 0): a per-wave LDS transpose gives a lane four consecutive columns
-// of one row (dwordx4 stores and residual loads), arithmetic per element in the order of mitcg::epilogue_store_vec.  Per 32-column
-// half: the residual operands of the NEXT half are requested before this half's stores are issued (so waiting for them never waits
-// for a store), which keeps at most one half's residuals in registers.  pre / post may alias c element for element (in-place
+// of one row (dwordx4 stores and residual loads), arithmetic per element in the order of mitcg::epilogue_store_vec.  Per chunk (64
+// rows x 32 columns): the residual operands of the NEXT chunk are requested before this chunk's stores are issued (so waiting for them
+// never waits for a store), which keeps at most one chunk's residuals in registers.  pre / post may alias c element for element (in-place
 // residual layers): no __restrict__ on them, the order loads-of-a-column-before-its-store is the program's.
 // Addressing: one buffer descriptor per tensor for the wave's TM*32 x TN*32 window (SGPRs) whose size is the window's VALID rows, and a
 // 32-bit byte offset per access: rows past M fall outside the descriptor (loads return 0, stores are dropped by the hardware range
@@ -121,9 +121,13 @@ __device__ __forceinline__ void pg_store_rows(const MitPGemm &p, f32x16 (&acc)[T
     const unsigned int ldc4 = (unsigned int)p.ldc * 4u, ldpre4 = (unsigned int)p.ld_pre * 4u, ldpost4 = (unsigned int)p.ld_post * 4u;
     const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;
     const int act = p.act & 0xff;
-    f32x4 sc, bi, prv[TM][4], pov[TM][4];
+    // a chunk = one or two 32 x 32 blocks of one 32-column strip: the unit whose residuals are in registers at one time
+    constexpr int CB = (TM < 2 || TM * TN > 4) ? 1 : 2, MCH = TM / CB, NCH = TN * MCH;  // (one block per chunk where the accumulators alone take half the registers)
+    static_assert(TM % CB == 0, "chunks");
+    f32x4 sc, bi, prv[CB][4], pov[CB][4];
     unsigned int colb;  // byte offset of this lane's four columns inside a window row; past N: beyond any window
-    auto load_half = [&](const int ni) __attribute__((always_inline)) {
+    auto load_chunk = [&](const int ch) __attribute__((always_inline)) {
+        const int ni = ch / MCH, m_first = (ch % MCH) * CB;
         const int n = n0w + ni * 32 + vc;
         const int nl = n < p.N ? n : 0;
         colb = n < p.N ? (unsigned int)(ni * 32 + vc) * 4u : 0xF0000000u;
@@ -132,64 +136,66 @@ __device__ __forceinline__ void pg_store_rows(const MitPGemm &p, f32x16 (&acc)[T
         if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + nl);
         if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + nl);
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int b = 0; b < CB; ++b)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned int row = (unsigned int)(mi * 32 + vr + 8 * j);
-                prv[mi][j] = pov[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (has_pre) prv[mi][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpre, (int)(colb + row * ldpre4), 0, 0));
-                if (has_post) pov[mi][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpost, (int)(colb + row * ldpost4), 0, 0));
+                const unsigned int row = (unsigned int)((m_first + b) * 32 + vr + 8 * j);
+                prv[b][j] = pov[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (has_pre) prv[b][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpre, (int)(colb + row * ldpre4), 0, 0));
+                if (has_post) pov[b][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpost, (int)(colb + row * ldpost4), 0, 0));
             }
     };
-    load_half(0);
+    load_chunk(0);
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        f32x4 rv[TM][4];
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int ni = ch / MCH, m_first = (ch % MCH) * CB;
+        f32x4 rv[CB][4];
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
+        for (int b = 0; b < CB; ++b) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_PITCH + li] = acc[mi][ni][r];
+            for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_PITCH + li] = acc[m_first + b][ni][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-synchronous exchange: LDS serves a wave's accesses in order
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rv[mi][j] = *reinterpret_cast<const f32x4 *>(tbuf + (vr + 8 * j) * EPI_PITCH + vc);
+            for (int j = 0; j < 4; ++j) rv[b][j] = *reinterpret_cast<const f32x4 *>(tbuf + (vr + 8 * j) * EPI_PITCH + vc);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next block overwrites the buffer
         }
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int b = 0; b < CB; ++b)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 v = rv[mi][j];
-                if (has_pre) v += prv[mi][j];
+                f32x4 v = rv[b][j];
+                if (has_pre) v += prv[b][j];
                 v = v * sc + bi;
-                if (has_post && post_first) v += pov[mi][j];
-                rv[mi][j] = v;
+                if (has_post && post_first) v += pov[b][j];
+                rv[b][j] = v;
             }
         if (act == MIT_ACT_RELU) {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
+            for (int b = 0; b < CB; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rv[mi][j] = pg_act4<MIT_ACT_RELU>(rv[mi][j], p.act_alpha);
+                for (int j = 0; j < 4; ++j) rv[b][j] = pg_act4<MIT_ACT_RELU>(rv[b][j], p.act_alpha);
         } else if (act == MIT_ACT_GELU) {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
+            for (int b = 0; b < CB; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rv[mi][j] = pg_act4<MIT_ACT_GELU>(rv[mi][j], p.act_alpha);
+                for (int j = 0; j < 4; ++j) rv[b][j] = pg_act4<MIT_ACT_GELU>(rv[b][j], p.act_alpha);
         }
         if (has_post && !post_first) {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
+            for (int b = 0; b < CB; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rv[mi][j] += pov[mi][j];
+                for (int j = 0; j < 4; ++j) rv[b][j] += pov[b][j];
         }
         const unsigned int colb_st = colb;
         __builtin_amdgcn_sched_barrier(0);
-        if (ni + 1 < TN) load_half(ni + 1);  // the next half's residuals are requested ahead of this half's stores
+        if (ch + 1 < NCH) load_chunk(ch + 1);  // the next chunk's residuals are requested ahead of this chunk's stores
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+        for (int b = 0; b < CB; ++b)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv[mi][j]), rc, (int)(colb_st + (unsigned int)(mi * 32 + vr + 8 * j) * ldc4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rv[b][j]), rc,
+                                                       (int)(colb_st + (unsigned int)((m_first + b) * 32 + vr + 8 * j) * ldc4), 0, 0);
     }
 }
 
@@ -273,7 +279,10 @@ __device__ __forceinline__ void pg_epilogue(const MitPGemm &p, f32x16 (&acc)[TM]
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, int NPROD, int OUTP, int MINW>
+// VAR: variants for scripts/pgemm_check.  Timing ablations (WRONG results): 1 = no DMA pieces, 2 = no MFMAs, 4 = no barriers.  Schedules
+// (same results): 16 = all DMA pieces of an iteration right behind the first fragment reads, in the shadow of their latency, instead of
+// spread behind the MFMA groups; 32 = s_setprio 1 around the MFMAs
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, int NPROD, int OUTP, int MINW, int VAR = 0>
 __global__ __launch_bounds__(64 * WAVES_M *WAVES_N, MINW) void pgemm_kernel(const MitPGemm p, const int MT, const int NT, const int KT,
                                                                            const int tiles_total, const int order) {
     constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
@@ -402,10 +411,6 @@ __global__ __launch_bounds__(64 * WAVES_M *WAVES_N, MINW) void pgemm_kernel(cons
         if constexpr (TN >= 3) bf[PB[o]][TN >= 3 ? 2 : 0] = lds_read16<(PB[o] * KH * BN + 64) * 16>(ba);         \
         if constexpr (TN >= 4) bf[PB[o]][TN >= 4 ? 3 : 0] = lds_read16<(PB[o] * KH * BN + 96) * 16>(ba);         \
     }
-        MIT_PG_READ_GROUP(0)
-        MIT_PG_READ_GROUP(1)
-        MIT_PG_READ_GROUP(2)
-#undef MIT_PG_READ_GROUP
         static_assert(TM <= 4 && TN <= 4, "fragment read macro");
         auto tie_group = [&](const int o) __attribute__((always_inline)) {
 #pragma unroll
@@ -418,30 +423,48 @@ __global__ __launch_bounds__(64 * WAVES_M *WAVES_N, MINW) void pgemm_kernel(cons
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) {
-                    if constexpr (OUTP == 0)
+                    if constexpr ((VAR & 2) != 0) {  // timing ablation: no MFMAs (the fragments stay live)
+                        asm volatile("" ::"v"(af[kSplitPA[pr]][mi]), "v"(bf[kSplitPB[pr]][ni]));
+                    } else if constexpr (OUTP == 0)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kSplitPA[pr]][mi], bf[kSplitPB[pr]][ni], acc[mi][ni], 0, 0, 0);
                     else  // transposed result: rows = output columns
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[kSplitPB[pr]][ni], af[kSplitPA[pr]][mi], acc[mi][ni], 0, 0, 0);
                 }
         };
         constexpr int PER = (G + 2) / 3;  // DMA pieces behind each of the first three MFMA groups
+        int dma_calls = 0;  // (compile-time after unrolling: with VAR & 16 the first three calls issue, the later ones are empty)
         auto dma_group = [&](const int g) __attribute__((always_inline)) {
+            if ((VAR & 16) != 0 && dma_calls++ >= 3) return;  // VAR & 16: the first three calls (ahead of the MFMAs) issue, the ones behind the MFMA groups are empty
             __builtin_amdgcn_sched_barrier(0);
             if (do_issue) {  // wave-uniform: a scalar branch around the pieces; ONE instance of the MFMA chain keeps the accumulators in place
+                if constexpr ((VAR & 1) == 0) {
 #pragma unroll
-                for (int i = g * PER; i < (g + 1) * PER && i < G; ++i) issue_piece(dma_slot, i);
+                    for (int i = g * PER; i < (g + 1) * PER && i < G; ++i) issue_piece(dma_slot, i);
+                }
                 if (g == 2) issue_done();
             }
             __builtin_amdgcn_sched_barrier(0);
         };
         if constexpr (NPROD == 6) {  // pairs 3 .. 8 = (A0 W2) (A2 W0) (A1 W1) (A0 W1) (A1 W0) (A0 W0): group o completes pair 3 + o
-            lds_wait<2 * (TM + TN)>();
+            // W plane 2 and A plane 2 serve one pair each: the third group's reads are issued behind the second pair's MFMAs (long before
+            // they are needed) so that their registers can be the ones planes 2 leave — twelve fragments live instead of eighteen
+            MIT_PG_READ_GROUP(0)
+            MIT_PG_READ_GROUP(1)
+            if constexpr ((VAR & 16) != 0) {
+                dma_group(0);
+                dma_group(1);
+                dma_group(2);
+            }
+            lds_wait<TM + TN>();
             tie_group(0);
+            if constexpr ((VAR & 32) != 0) __builtin_amdgcn_s_setprio(1);
             mfma_pair(3);
             dma_group(0);
-            lds_wait<TM + TN>();
+            lds_wait<0>();
             tie_group(1);
             mfma_pair(4);
+            __builtin_amdgcn_sched_barrier(0);
+            MIT_PG_READ_GROUP(2)
             dma_group(1);
             lds_wait<0>();
             tie_group(2);
@@ -450,7 +473,11 @@ __global__ __launch_bounds__(64 * WAVES_M *WAVES_N, MINW) void pgemm_kernel(cons
             mfma_pair(6);
             mfma_pair(7);
             mfma_pair(8);
+            if constexpr ((VAR & 32) != 0) __builtin_amdgcn_s_setprio(0);
         } else {
+            MIT_PG_READ_GROUP(0)
+            MIT_PG_READ_GROUP(1)
+            MIT_PG_READ_GROUP(2)
             lds_wait<0>();
             tie_group(0);
             tie_group(1);
@@ -461,6 +488,7 @@ __global__ __launch_bounds__(64 * WAVES_M *WAVES_N, MINW) void pgemm_kernel(cons
                 if (pr < 3) dma_group(pr);
             }
         }
+#undef MIT_PG_READ_GROUP
         __builtin_amdgcn_sched_barrier(0);
     };
     load_tile_setup();
@@ -473,44 +501,50 @@ __global__ __launch_bounds__(64 * WAVES_M *WAVES_N, MINW) void pgemm_kernel(cons
         }
     zero_acc();
 
-    int kt = 0, ctile = 0, skip = 0;
-    bool pending = false;  // an output tile finished in the previous iteration: its accumulators are still to be stored
-    for (int it = 0;; ++it) {  // one pass more than there are K-tiles: the last one only stores the last output tile
-        // ---- the DMA pieces of K-tile `it` must have landed.  In issue order behind them: the K-tiles it+1 .. issued-1 and, after an
-        // epilogue, its stores.  An epilogue iteration drains everything (all of it was issued at least one K-tile ago) and the
-        // following NS-2 iterations need what that drain already covered; afterwards every store precedes the K-tile waited for, so
-        // "at most (issued - it - 1) G operations outstanding" again implies it has landed, in whatever order stores retire.
-        if (pending) {
+    // ---- the walk over this workgroup's output tiles and their K-tiles (`it` counts K-tiles over all of them; the DMA runs NS-1 of
+    // them ahead, across tile boundaries).  The DMA pieces of K-tile `it` must have landed before its fragments are read.  In issue
+    // order behind them: the K-tiles it+1 .. issued-1 and, after an epilogue, its stores.
+    //   steady iterations (all but a few per output tile): exactly NS-2 K-tiles were issued after `it` -> vmcnt((NS-2) G)
+    //   the first iteration of an output tile stores the previous one first: it drains everything (all of it was issued at least one
+    //   K-tile ago), the NS-2 iterations after it need what that drain covered, and from then on every store precedes the K-tile
+    //   waited for, so "at most (issued - it - 1) G operations outstanding" again implies it has landed, in whatever order stores retire
+    //   the last NS-2 iterations of the run wait with the count of what is still behind them.
+    // The accumulators are written by ONE chain of MFMAs in the inner loop and zeroed in the outer one: any other shape of this loop made
+    // hipcc copy all of them on every iteration.
+    int it = 0, slot = 0, fslot = NS - 1;  // slot: stage of K-tile it; fslot: stage of K-tile it-1 (free once the barrier is passed)
+    for (int ti = 0;; ++ti) {              // one pass more than there are tiles: the last one only stores the last tile
+        if (ti > 0) {
             wait_vmcnt<0>();
-            skip = NS - 2;
-        } else if (skip > 0) {
-            --skip;
-        } else {
-            const int ahead = issued - it - 1;
-            if (ahead <= 0) wait_vmcnt<0>();
-            else if (ahead == 1) wait_vmcnt<G>();
-            else wait_vmcnt<2 * G>();
-        }
-        wg_barrier();
-        const int free_slot = (it + NS - 1) % NS;  // held K-tile it-1: every wave is done with its fragments
-        if (pending) {
-            const int t = tile_lo + (ctile - 1) * tile_step;
+            if constexpr ((VAR & 4) == 0) wg_barrier();
+            const int t = tile_lo + (ti - 1) * tile_step;
             const int z = uni(t / tiles_per_z), tt = t - z * tiles_per_z;
             const int mt = uni(tt / NT), nt = tt - mt * NT;
-            float *tbuf = reinterpret_cast<float *>(ring + free_slot * STAGE) + wave * (32 * EPI_PITCH);
+            float *tbuf = reinterpret_cast<float *>(ring + fslot * STAGE) + wave * (32 * EPI_PITCH);
             pg_epilogue<TM, TN, OUTP>(p, acc, tbuf, z, mt * BM + wm0, nt * BN + wn0, lane);
-            if (it == total) break;
-            zero_acc();
-            pending = false;
+            if (ti == tile_n) break;
             if (OUTP == 0) wg_barrier();  // the transpose buffers are about to be overwritten by the DMA
         }
-        const bool do_issue = issued < total;
-        compute(it % NS, free_slot, do_issue);
-        issued += do_issue ? 1 : 0;
-        if (++kt == KT) {
-            kt = 0;
-            ++ctile;
-            pending = true;
+        zero_acc();
+        const int steady_lo = ti > 0 ? NS - 1 : 0;                                // the first kt that waits with the steady count
+        const int steady_hi = total - (NS - 1) - it + 1 < KT ? total - (NS - 1) - it + 1 : KT;  // iterations it' <= total - (NS-1) have NS-2 K-tiles behind them
+        for (int kt = 0; kt < KT; ++kt, ++it) {
+            if (kt >= steady_lo && kt < steady_hi) {
+                wait_vmcnt<(NS - 2) * G>();
+                if constexpr ((VAR & 4) == 0) wg_barrier();
+            } else if (kt >= steady_lo) {  // the tail of the run
+                const int ahead = issued - it - 1;
+                if (ahead <= 0) wait_vmcnt<0>();
+                else if (ahead == 1) wait_vmcnt<G>();
+                else wait_vmcnt<2 * G>();
+                if constexpr ((VAR & 4) == 0) wg_barrier();
+            } else if (kt > 0) {  // covered by the drain ahead of the epilogue; kt == 0 has passed its barrier there too
+                if constexpr ((VAR & 4) == 0) wg_barrier();
+            }
+            const bool do_issue = issued < total;
+            compute(slot, fslot, do_issue);
+            issued += do_issue ? 1 : 0;
+            fslot = slot;
+            slot = slot + 1 == NS ? 0 : slot + 1;
         }
     }
 }
@@ -571,12 +605,12 @@ struct PgTile {
     PgLaunch launch;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, int NPROD, int OUTP, int MINW>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, int NPROD, int OUTP, int MINW, int VAR = 0>
 void pg_launch(const MitPGemm &p, int MT, int NT, int KT, int tiles, int grid, int order, hipStream_t s) {
     constexpr int NTHR = 64 * WAVES_M * WAVES_N, KH = 2;
     constexpr int GA = (3 * KH * BM + NTHR - 1) / NTHR, GB = (3 * KH * BN + NTHR - 1) / NTHR;
     const size_t smem = (size_t)NS * (GA + GB) * NTHR * 16;
-    auto kern = pgemm_kernel<BM, BN, WAVES_M, WAVES_N, NS, NPROD, OUTP, MINW>;
+    auto kern = pgemm_kernel<BM, BN, WAVES_M, WAVES_N, NS, NPROD, OUTP, MINW, VAR>;
     static DynSmemOptIn optin;
     optin.ensure(reinterpret_cast<const void *>(kern), smem);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), smem, s, p, MT, NT, KT, tiles, order);
@@ -584,6 +618,8 @@ void pg_launch(const MitPGemm &p, int MT, int NT, int KT, int tiles, int grid, i
 
 #define PG_TILE(name, BM, BN, WMV, WNV, NS, NPROD, OUTP, MINW, WGS) \
     {name, "pgemm_kernel<" name ">", BM, BN, NPROD, OUTP, WGS, pg_launch<BM, BN, WMV, WNV, NS, NPROD, OUTP, MINW>}
+#define PG_TILE_V(name, BM, BN, WMV, WNV, NS, NPROD, OUTP, MINW, WGS, VARV) \
+    {name, "pgemm_kernel<" name ">", BM, BN, NPROD, OUTP, WGS, pg_launch<BM, BN, WMV, WNV, NS, NPROD, OUTP, MINW, VARV>}
 const PgTile kPgTiles[] = {
     // the shipped set (pick_tile): 128 x 128 and 128 x 64, fp32 and planar output, 6 and 9 plane pairs; 3 stages, two workgroups per CU
     PG_TILE("pg128x128s3p6", 128, 128, 2, 2, 3, 6, 0, 2, 2),       // 0
@@ -600,6 +636,20 @@ const PgTile kPgTiles[] = {
     PG_TILE("pg256x128s3p6", 256, 128, 4, 2, 3, 6, 0, 2, 1),       // 10: eight waves, wave tile 64 x 64
     PG_TILE("pg256x128s3p6P", 256, 128, 4, 2, 3, 6, 1, 2, 1),      // 11
     PG_TILE("pg128x128s3p6Q", 128, 128, 2, 2, 3, 6, 2, 2, 2),      // 12: 2 with the cell exchange through __shfl_xor instead of v_permlane32_swap
+    PG_TILE("pg256x256s3p6P", 256, 256, 2, 4, 3, 6, 1, 2, 1),      // 13: eight waves, wave tile 128 x 64: 12 KB of DMA per 128 x 128 of output and K-tile (24 for tile 0); the fp32-output form does not fit 256 registers
+    PG_TILE("pg256x128s4p6", 256, 128, 4, 2, 4, 6, 0, 2, 1),       // 14: 10 with four stages
+    PG_TILE_V("pg128x128s3p6d", 128, 128, 2, 2, 3, 6, 0, 2, 2, 16),  // 15: tile 0 with the DMA pieces in the shadow of the fragment reads
+    PG_TILE_V("pg128x128s3p6dp", 128, 128, 2, 2, 3, 6, 0, 2, 2, 48), // 16: ... and s_setprio around the MFMAs
+    PG_TILE_V("pg128x128s3p6p", 128, 128, 2, 2, 3, 6, 0, 2, 2, 32),  // 17: tile 0 with s_setprio around the MFMAs
+#ifdef MIT_CONV_EXPERIMENTS  // timing ablations of tile 0 (WRONG results; scripts/pgemm_check prints their times only)
+    {"xpgNoDma", "pgemm_kernel<xpgNoDma>", 128, 128, 6, 0, 2, pg_launch<128, 128, 2, 2, 3, 6, 0, 2, 1>},
+    {"xpgNoMfma", "pgemm_kernel<xpgNoMfma>", 128, 128, 6, 0, 2, pg_launch<128, 128, 2, 2, 3, 6, 0, 2, 2>},
+    {"xpgNoBar", "pgemm_kernel<xpgNoBar>", 128, 128, 6, 0, 2, pg_launch<128, 128, 2, 2, 3, 6, 0, 2, 4>},
+    {"xpgNoDmaNoBar", "pgemm_kernel<xpgNoDmaNoBar>", 128, 128, 6, 0, 2, pg_launch<128, 128, 2, 2, 3, 6, 0, 2, 5>},
+    {"xpgNoMfmaNoBar", "pgemm_kernel<xpgNoMfmaNoBar>", 128, 128, 6, 0, 2, pg_launch<128, 128, 2, 2, 3, 6, 0, 2, 6>},
+    {"xpg256NoDmaP", "pgemm_kernel<xpg256NoDmaP>", 256, 256, 6, 1, 1, pg_launch<256, 256, 2, 4, 3, 6, 1, 2, 1>},
+    {"xpg256NoMfmaP", "pgemm_kernel<xpg256NoMfmaP>", 256, 256, 6, 1, 1, pg_launch<256, 256, 2, 4, 3, 6, 1, 2, 2>},
+#endif
 };
 constexpr int kNumPgTiles = sizeof(kPgTiles) / sizeof(kPgTiles[0]);
 

@@ -242,6 +242,7 @@ SYMBOLS = {
     "mit_ocr_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_dwconv_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p]),
+    "mit_cotenant_safe_set": (C.c_int, [C.c_int]),
     "mit_pgemm": (C.c_int, [C.POINTER(MitPGemm), C.c_void_p]),
     "mit_pgemm_tile_name": (C.c_char_p, [C.c_int]),
     "mit_pgemm_supported": (C.c_int, [C.POINTER(MitPGemm)]),

@@ -20,7 +20,7 @@ import torch
 
 from . import lib as _lib
 from .lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_POST_FIRST, ACT_RELU, ACT_SIGMOID, ACT_SILU, MIT_MAX_TAPS, PAD_REFLECT,
-                  PAD_ZERO, MitConvGemm, MitTensorMap)
+                  PAD_ZERO, MitConvGemm, MitPGemm, MitTensorMap)
 
 __all__ = [
     "ACT_NONE", "ACT_RELU", "ACT_LEAKY", "ACT_SILU", "ACT_SIGMOID", "ACT_GELU", "ACT_POST_FIRST", "PAD_ZERO", "PAD_REFLECT",
@@ -242,6 +242,87 @@ def _split_for(w: torch.Tensor, ldw: int, Kw: int, w_zs: Tuple[int, int]):
     if e is None or e[0]() is not w or (e[3], e[4]) != (Kw, ldw) or w_zs[0] != 0 or (e[2] > 1 and w_zs[1] != Kw * ldw):
         return None, 0
     return e[1], (3 * Kw * ldw if e[2] > 1 else 0)
+
+
+# ---- planar operands (include/mit_hip.h "planar operands", csrc/pgemm.hip) ---------------------------------------------------------
+def split_planes(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 ``[R, K]`` (row stride free, K % 8 == 0) -> int16 planes ``[3, K / 8, R, 8]`` with x == hi + mid + lo exactly."""
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1 or x.shape[1] % 8:
+        raise ValueError("split_planes: fp32 [R, K] with unit column stride and K % 8 == 0 expected")
+    R, K = x.shape
+    if out is None:
+        out = torch.empty(3, K // 8, R, 8, dtype=torch.int16, device=x.device)
+    elif out.dtype != torch.int16 or tuple(out.shape) != (3, K // 8, R, 8) or not out.is_contiguous():
+        raise ValueError("split_planes: out must be a contiguous int16 [3, K / 8, R, 8]")
+    _lib.check(_lib.load().mit_split_planes(x.data_ptr(), x.stride(0), R, K, out.data_ptr(), R, C.c_void_p(current_stream())), "mit_split_planes")
+    return out
+
+
+def join_planes(planes: torch.Tensor) -> torch.Tensor:
+    """int16 planes ``[3, K / 8, R, 8]`` -> fp32 ``[R, K]`` (the exact sum of the three bf16 planes)."""
+    if planes.dtype != torch.int16 or planes.dim() != 4 or planes.shape[0] != 3 or planes.shape[3] != 8 or not planes.is_contiguous():
+        raise ValueError("join_planes: contiguous int16 [3, K / 8, R, 8] expected")
+    _, K8, R, _ = planes.shape
+    out = torch.empty(R, K8 * 8, dtype=torch.float32, device=planes.device)
+    _lib.check(_lib.load().mit_join_planes(planes.data_ptr(), R, R, K8 * 8, out.data_ptr(), K8 * 8, C.c_void_p(current_stream())), "mit_join_planes")
+    return out
+
+
+def pgemm_tile(name: str) -> int:
+    """Index of a ``mit_pgemm`` tile by name (``mit_pgemm_tile_name``)."""
+    L, i = _lib.load(), 0
+    while True:
+        n = L.mit_pgemm_tile_name(i)
+        if n is None:
+            raise KeyError(name)
+        if n.decode() == name:
+            return i
+        i += 1
+
+
+def pgemm(a_planes: torch.Tensor, w: torch.Tensor, N: int, *, out: Optional[torch.Tensor] = None, out_planes: Optional[torch.Tensor] = None,
+          pre: Optional[torch.Tensor] = None, post: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 0.0, nprod: int = 0, tile: int = -1):
+    """``mit_pgemm``: C = epilogue(A @ W) with A given as planes ``[3, K / 8, M, 8]`` (split_planes, or a planar producer) and W a packed
+    weight carrying split planes (pack_weight_kn / register_split).  Output fp32 ``out [M, N]`` (row stride free) or ``out_planes
+    [3, N / 8, M, 8]``.  Bit-identical to the split-bf16 tiles of mit_conv_gemm on the same operands."""
+    if a_planes.dtype != torch.int16 or a_planes.dim() != 4 or a_planes.shape[0] != 3 or a_planes.shape[3] != 8 or not a_planes.is_contiguous():
+        raise ValueError("pgemm: a_planes must be a contiguous int16 [3, K / 8, M, 8]")
+    _, K8, M, _ = a_planes.shape
+    e = _SPLITS.get(w.data_ptr())
+    if e is None or e[0]() is not w or w.dim() != 2:
+        raise ValueError("pgemm: w must be a 2-D packed weight with registered split planes")
+    Kp, Np = w.shape
+    if Kp != K8 * 8 or N > Np:
+        raise ValueError(f"pgemm: operand shapes do not match (A has K = {K8 * 8}, W is {Kp} x {Np}, N = {N})")
+    d = MitPGemm()
+    d.a_planes, d.a_zs, d.lda = a_planes.data_ptr(), 0, M
+    d.w_planes, d.w_zs, d.ldw = e[1].data_ptr(), 0, Np
+    d.M, d.N, d.K, d.Z = M, N, Kp, 1
+    if (out is None) == (out_planes is None):
+        raise ValueError("pgemm: exactly one of out / out_planes")
+    keep = [a_planes, e[1]]
+    if out is not None:
+        if out.dtype != torch.float32 or tuple(out.shape) != (M, N) or out.stride(1) != 1:
+            raise ValueError("pgemm: out must be fp32 [M, N] with unit column stride")
+        d.c, d.ldc = out.data_ptr(), out.stride(0)
+        for t, nm in ((pre, "pre"), (post, "post")):
+            if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (M, N) or t.stride(1) != 1):
+                raise ValueError(f"pgemm: {nm} must be fp32 [M, N] with unit column stride")
+        if pre is not None:
+            d.pre, d.ld_pre = pre.data_ptr(), pre.stride(0)
+        if post is not None:
+            d.post, d.ld_post = post.data_ptr(), post.stride(0)
+    else:
+        if out_planes.dtype != torch.int16 or tuple(out_planes.shape) != (3, N // 8, M, 8) or N % 8 or not out_planes.is_contiguous():
+            raise ValueError("pgemm: out_planes must be a contiguous int16 [3, N / 8, M, 8] (N % 8 == 0)")
+        if pre is not None or post is not None:
+            raise ValueError("pgemm: pre / post are not available with planar output")
+        d.c_planes, d.ld_cp = out_planes.data_ptr(), M
+    d.scale, d.bias = _ptr(scale), _ptr(bias)
+    d.act, d.act_alpha, d.nprod, d.tile = act, alpha, nprod, tile
+    _lib.check(_lib.load().mit_pgemm(C.byref(d), C.c_void_p(current_stream())), "mit_pgemm")
+    return out if out is not None else out_planes
 
 
 def pack_weight_kn(w_kn: torch.Tensor, device) -> Tuple[torch.Tensor, int, int]:

@@ -230,6 +230,10 @@ int main(int argc, char **argv) {
                 continue;
             }
             int64_t diff = 0, first = -1;
+            if (nm[0] == 'x') {  // timing ablation (MIT_CONV_EXPERIMENTS builds): wrong results by construction
+                printf("  %-20s %9.3f ms %8.1f TFLOP/s-equivalent   x%.2f   (ablation: not compared)\n", tn, ms, flops / ms * 1e-9, ms_ref / ms);
+                continue;
+            }
             if (is9) {  // nine pairs: compare with the nine-pair split tile
                 static std::vector<float> href9;
                 href9.resize(c_el);

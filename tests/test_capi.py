@@ -48,6 +48,38 @@ def test_error_channel_without_gpu():
     assert handle.mit_ocr_warp_lines(None, 1, 1, None, 0, None, 48, 8, None) != 0
 
 
+def test_pgemm_argument_checks_without_gpu():
+    """mit_pgemm validates its descriptor before any HIP call (sizes, alignment, output kind, activation)."""
+    from manga_image_translator_amd import lib
+
+    handle = lib.load()
+    assert handle.mit_pgemm(None, None) != 0 and b"null descriptor" in handle.mit_last_error()
+    d = lib.MitPGemm()
+    assert handle.mit_pgemm(C.byref(d), None) != 0 and b"null operand" in handle.mit_last_error()
+    d.a_planes, d.w_planes = 4096, 8192     # never dereferenced: every case below is refused first
+    d.M, d.N, d.K, d.Z, d.lda, d.ldw = 128, 64, 24, 1, 128, 64
+    assert handle.mit_pgemm(C.byref(d), None) != 0 and b"K % 16" in handle.mit_last_error()
+    d.K = 32
+    assert handle.mit_pgemm(C.byref(d), None) != 0 and b"exactly one of c / c_planes" in handle.mit_last_error()
+    d.c, d.ldc = 16384, 62
+    assert handle.mit_pgemm(C.byref(d), None) != 0 and b"ldc % 4" in handle.mit_last_error()
+    d.ldc, d.act = 64, lib.ACT_SILU
+    assert handle.mit_pgemm(C.byref(d), None) != 0 and b"none / relu / gelu" in handle.mit_last_error()
+    d.act, d.lda = lib.ACT_RELU, 100
+    assert handle.mit_pgemm(C.byref(d), None) != 0 and b"lda / ldw" in handle.mit_last_error()
+    d.lda, d.c, d.c_planes, d.ld_cp, d.N = 128, None, 16384, 128, 60
+    assert handle.mit_pgemm(C.byref(d), None) != 0 and b"N % 8" in handle.mit_last_error()
+    assert handle.mit_pgemm_supported(C.byref(d)) == 0
+    d.N = 64
+    assert handle.mit_pgemm_supported(C.byref(d)) == 1
+    names = []
+    while handle.mit_pgemm_tile_name(len(names)) is not None:
+        names.append(handle.mit_pgemm_tile_name(len(names)).decode())
+    assert names[:4] == ["pg128x128s3p6", "pg128x64s3p6", "pg128x128s3p6P", "pg128x64s3p6P"] and len(set(names)) == len(names)
+    assert handle.mit_split_planes(None, 0, 1, 8, None, 1, None) != 0 and b"null pointer" in handle.mit_last_error()
+    assert handle.mit_split_planes(4096, 12, 4, 12, 8192, 4, None) != 0 and b"K % 8" in handle.mit_last_error()
+
+
 def test_ctypes_structs_match_c_layout(tmp_path):
     from manga_image_translator_amd import lib
 

@@ -1,11 +1,12 @@
 """Multi-GPU path on one GPU box: what can be checked without a second GPU.
 
-* two ranks (gloo rendezvous, both on cuda:0) run the real PageEngine on their contiguous page blocks and rank 0 gathers the
+* two ranks (gloo rendezvous, both on cuda:0, running CONCURRENTLY) run the real PageEngine on their contiguous page blocks and rank 0 gathers the
   per-page records: byte-identical to one process running all pages — a page's result does not depend on the world size, the
   shard it landed in, or its neighbours in a batch (the reference processes pages independently, manga_translator.py:1491-1519);
 * a world-size-1 RCCL group (backend "nccl") runs the collectives dist.py uses — uint8 arena broadcast, gather to rank 0,
   MAX all-reduce, barrier — on device tensors (inside rank 0's process of the same spawn: a fresh interpreter costs minutes of
   imports on a cold box)."""
+import contextlib
 import os
 import socket
 
@@ -40,18 +41,18 @@ def _records(weights, lo, hi):
 
 def _shard_worker(rank, world, port, q, gpu_turn):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      MIT_DIST_BACKEND="gloo")
+                      MIT_DIST_BACKEND="gloo", MIT_COTENANT_SAFE="1")   # two engines on ONE GPU: the co-tenant-safe launches
     try:
         from manga_image_translator_amd import dist as Dm, pipeline
 
         Dm.init()
         weights = Dm.broadcast_weights(pipeline.synthetic_weights(dict_size=D) if rank == 0 else None)
         lo, hi = Dm.shard_range(N_PAGES, rank, world)
-        # Both ranks of this rehearsal sit on ONE GPU (a real job has one GPU per rank).  Their compute phases take turns: two copies of
-        # the engine running kernels on one device AT THE SAME TIME is not a configuration the engine supports — scripts/diag_concurrent2.py,
-        # diag_ffc_load.py and diag_rfft_culprit.py: the 128 x 128 split GEMM tile of one process disturbs kernels of the other that share a
-        # CU with it (rfft / irfft rows most visibly); cause open, DESIGN §7.
-        with gpu_turn:
+        # Both ranks of this rehearsal sit on ONE GPU (a real job has one GPU per rank) and run their engines AT THE SAME TIME: kernels of
+        # the two processes share CUs.  Round 3 had to serialise them (the 128 x 128 split GEMM tile of one process disturbed the FFT rows
+        # kernels of the other); with MIT_COTENANT_SAFE=1 (set above: those kernels take a whole CU's LDS) the concurrent run
+        # is byte-identical to the single process again.  MIT_TEST_SERIALISE_RANKS=1 restores the turn-taking for diagnosis.
+        with (gpu_turn if os.environ.get("MIT_TEST_SERIALISE_RANKS") else contextlib.nullcontext()):
             recs = _records(weights, lo, hi)
             torch.cuda.synchronize()
         out = Dm.gather_pages(recs)
