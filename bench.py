@@ -866,6 +866,13 @@ def main():
 
     roof = per_cfg = cpu = parity = dropin = fp32 = None
     leg_errors = {}
+    gather_info = None
+    if world > 1:   # every block rank 0 received in the timed region against the checksum its source rank computed before sending it
+        try:
+            gather_info = {"verified_blocks": gather.check(), "overlap_with_compute": bool(gather.async_op),
+                           "note": "each rank sends page_checksum(block) beside its block; rank 0 recomputes it on what arrived"}
+        except Exception as ex:  # a corrupted gather must not lose the line, and must not go unnoticed
+            leg_errors["gather_checksum"] = f"{type(ex).__name__}: {ex}"
     from manga_image_translator_amd import ops as _ops
 
     shipped_mode = _ops.split_mode()
@@ -968,6 +975,8 @@ def main():
             out["gemm_mode"] = {"mode": 0, "arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"}
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        if gather_info:
+            out["gather"] = gather_info
         if leg_errors:
             out["leg_errors"] = leg_errors
         print(json.dumps(out))

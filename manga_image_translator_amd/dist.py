@@ -114,18 +114,47 @@ def gather_pages(packed: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
     return None
 
 
-class PageGather:
-    """The per-step result gather with one step of slack: ``submit(packed)`` issues the gather asynchronously (RCCL runs it on its own
-    stream, ordered after the work that produced ``packed``) and returns the PREVIOUS step's gathered tensor; the caller's stream never
-    waits for peer traffic before launching the next step's kernels — rank 0 receives ``world - 1`` result blocks (0.8 GB each at 64
-    pages) over its xGMI links while its next batch is already computing.  ``wait()`` drains the last one (call it before the end of a
-    timed region).  At most one gather is in flight, so at most two result blocks per rank are alive.  Same semantics on gloo."""
+def page_checksum(t: torch.Tensor) -> torch.Tensor:
+    """Two wrapping int64 sums over a uint8 tensor, computed where the tensor lives: the plain sum of its 8-byte words and the sum of
+    its 32 KB chunk sums weighted by the chunk's position (so that chunks landing in the wrong place are seen too).  What a rank
+    sends beside its result block so that rank 0 can verify what arrived."""
+    flat = t.contiguous().reshape(-1)
+    if flat.dtype != torch.uint8:
+        flat = flat.view(torch.uint8)
+    if flat.storage_offset() % 8:   # the word view needs an 8-byte aligned start (the value must not depend on where the bytes sit)
+        flat = flat.clone()
+    n8 = flat.numel() // 8 * 8
+    words = flat[:n8].view(torch.int64)
+    CH = 4096
+    m = words.numel() // CH * CH
+    rows = words[:m].view(-1, CH).sum(dim=1)
+    s0 = rows.sum() + words[m:].sum() + flat[n8:].to(torch.int64).sum()
+    s1 = (rows * torch.arange(1, rows.numel() + 1, dtype=torch.int64, device=flat.device)).sum()
+    return torch.stack([s0, s1])
 
-    def __init__(self, dst: int = 0):
+
+class PageGather:
+    """The per-step result gather to rank ``dst`` (point-to-point over xGMI, no ring), verified end to end.
+
+    ``submit(packed)`` issues the gather of the ranks' result blocks and of their checksums (``page_checksum``, computed on the source
+    rank before the send) and returns the PREVIOUS step's gathered tensor; on ``dst`` every received block is checksummed again and
+    compared — on the device, accumulated into a counter that ``check()`` reads (one host sync, outside the step loop) and turns into an
+    error.  By default the caller's stream is ordered behind the gather before ``submit`` returns: no RCCL kernel runs beside the next
+    step's compute kernels (two queues sharing CUs is the configuration DESIGN §7 restricts).  ``async_op=True`` (or MIT_GATHER_ASYNC=1)
+    gives the gather one step of slack instead — rank 0 receives ``world - 1`` blocks (0.8 GB each at 64 pages) while its next batch is
+    computing; ``wait()`` drains it (call it before the end of a timed region).  At most one gather is in flight, so at most two result
+    blocks per rank are alive.  Same semantics on gloo."""
+
+    def __init__(self, dst: int = 0, async_op: Optional[bool] = None, verify: bool = True):
         self.dst = dst
-        self._work = None
+        self.async_op = (os.environ.get("MIT_GATHER_ASYNC", "0") not in ("", "0")) if async_op is None else bool(async_op)
+        self.verify = verify
+        self._work: List = []
         self._out: Optional[torch.Tensor] = None
+        self._sums: Optional[torch.Tensor] = None
         self._keep = None
+        self._bad: Optional[torch.Tensor] = None   # blocks whose checksum did not match, counted where the blocks live
+        self.verified_blocks = 0
         self.last_bytes = 0
 
     def submit(self, packed: torch.Tensor) -> Optional[torch.Tensor]:
@@ -138,24 +167,52 @@ class PageGather:
         packed = packed.contiguous()
         if dist.get_backend() != "nccl" and packed.is_cuda:  # gloo rehearsal: stage through host memory
             packed = packed.cpu()
+        cs = page_checksum(packed) if self.verify else None
         if rank == self.dst:
-            out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-            self._work = dist.gather(packed, list(out.unbind(0)), dst=self.dst, async_op=True)
+            n = packed.numel()
+            pitch = (n * packed.element_size() + 7) // 8 * 8 // packed.element_size() if (8 % packed.element_size()) == 0 else n
+            slab = torch.empty(world, pitch, dtype=packed.dtype, device=packed.device)   # every rank's block starts 8-byte aligned
+            out = slab[:, :n].unflatten(1, tuple(packed.shape)) if packed.dim() != 1 else slab[:, :n]
+            self._work = [dist.gather(packed, [slab[r, :n].view(packed.shape) for r in range(world)], dst=self.dst, async_op=True)]
+            if self.verify:
+                self._sums = torch.empty(world, 2, dtype=torch.int64, device=packed.device)
+                self._work.append(dist.gather(cs, list(self._sums.unbind(0)), dst=self.dst, async_op=True))
             self._out = out
             self.last_bytes = out.numel() * out.element_size()
         else:
-            self._work = dist.gather(packed, None, dst=self.dst, async_op=True)
+            self._work = [dist.gather(packed, None, dst=self.dst, async_op=True)]
+            if self.verify:
+                self._work.append(dist.gather(cs, None, dst=self.dst, async_op=True))
             self._out = None
-        self._keep = packed  # alive until the gather has been waited for
+        self._keep = (packed, cs)  # alive until the gather has been waited for
+        if not self.async_op:
+            self._finish()
         return prev
+
+    def _finish(self) -> None:
+        for w in self._work:
+            w.wait()  # nccl: the current stream waits for the collective (no host block); gloo: blocks
+        self._work = []
+        if self._out is not None and self._sums is not None:
+            bad = torch.zeros((), dtype=torch.int64, device=self._out.device)
+            for r in range(self._out.shape[0]):
+                bad = bad + (page_checksum(self._out[r]) != self._sums[r]).any().to(torch.int64)
+            self._bad = bad if self._bad is None else self._bad + bad
+            self.verified_blocks += int(self._out.shape[0])
+            self._sums = None
 
     def wait(self) -> Optional[torch.Tensor]:
         """Result of the gather in flight ([world, *shape] on ``dst``, None elsewhere or when nothing was submitted); a failure raises."""
-        if self._work is not None:
-            self._work.wait()  # nccl: the current stream waits for the collective (no host block); gloo: blocks
-            self._work = None
+        self._finish()
         out, self._out, self._keep = self._out, None, None
         return out
+
+    def check(self) -> int:
+        """Blocks verified so far; raises if any block's checksum on ``dst`` differed from the one its source rank computed."""
+        self._finish()
+        if self._bad is not None and int(self._bad.item()) != 0:
+            raise RuntimeError(f"PageGather: {int(self._bad.item())} gathered result block(s) failed their checksum")
+        return self.verified_blocks
 
 
 def max_over_ranks(value: float) -> float:

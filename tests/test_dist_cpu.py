@@ -55,20 +55,23 @@ def _worker(rank, world, port, q):
             assert out.reshape(-1).tolist() == [p for p in range(n_pages) for _ in range(4)]
         else:
             assert out is None
-        # the asynchronous form bench.py uses: submit() returns the previous step's block, wait() drains the last one
-        pg = D.PageGather()
-        seen = []
-        for stepno in range(3):
-            prev = pg.submit(packed + stepno)
-            seen.append(prev)
-        seen.append(pg.wait())
-        assert pg.wait() is None                                    # nothing left in flight
-        if rank == 0:
-            assert seen[0] is None and pg.last_bytes == world * packed.numel()
-            for stepno, blk in enumerate(seen[1:]):
-                assert blk.reshape(-1).tolist() == [p + stepno for p in range(n_pages) for _ in range(4)]
-        else:
-            assert all(x is None for x in seen)
+        # the per-step form bench.py uses: submit() returns the previous step's block, wait() drains the last one; both the stream-ordered
+        # default and the one-step-slack form, each block verified against the checksum its source rank sent
+        for async_op in (False, True):
+            pg = D.PageGather(async_op=async_op)
+            seen = []
+            for stepno in range(3):
+                prev = pg.submit(packed + stepno)
+                seen.append(prev)
+            seen.append(pg.wait())
+            assert pg.wait() is None                                    # nothing left in flight
+            if rank == 0:
+                assert seen[0] is None and pg.last_bytes == world * packed.numel()
+                for stepno, blk in enumerate(seen[1:]):
+                    assert blk.reshape(-1).tolist() == [p + stepno for p in range(n_pages) for _ in range(4)]
+                assert pg.check() == 3 * world                          # every received block was checksummed and matched
+            else:
+                assert all(x is None for x in seen) and pg.check() == 0
         assert D.max_over_ranks(float(rank + 1)) == float(world)
         D.barrier()
         torch.distributed.destroy_process_group()
@@ -102,3 +105,29 @@ def test_single_process_paths():
     pg = D.PageGather()
     assert pg.submit(t) is None and torch.equal(pg.submit(t + 1), t[None]) and torch.equal(pg.wait(), (t + 1)[None]) and pg.wait() is None
     assert D.max_over_ranks(2.5) == 2.5
+
+
+def test_page_checksum_sees_flipped_bytes_and_misplaced_chunks():
+    from manga_image_translator_amd import dist as D
+
+    g = torch.Generator().manual_seed(0)
+    t = torch.randint(0, 256, (3, 100_003), dtype=torch.uint8, generator=g)     # not a multiple of 8 bytes, several 32 KB chunks
+    ref = D.page_checksum(t)
+    assert ref.dtype == torch.int64 and tuple(ref.shape) == (2,) and torch.equal(ref, D.page_checksum(t.clone()))
+    for pos in (0, 12345, t.numel() - 1):
+        u = t.clone().reshape(-1)
+        u[pos] ^= 0x40
+        assert not torch.equal(D.page_checksum(u), ref), pos
+    u = t.clone().reshape(-1)
+    a, b = u[:32768].clone(), u[65536:65536 + 32768].clone()
+    u[:32768], u[65536:65536 + 32768] = b, a                                      # two chunks swapped: the plain sum alone would not see it
+    cs = D.page_checksum(u)
+    assert cs[0] == ref[0] and cs[1] != ref[1]
+    assert torch.equal(D.page_checksum(t.view(torch.int8)), ref)                  # any dtype: the bytes are what counts
+    # a tampered block is reported by the gather object
+    pg = D.PageGather()
+    pg._out, pg._sums = t[None].clone(), ref[None].clone()
+    pg._out[0, 1, 7] ^= 1
+    import pytest
+    with pytest.raises(RuntimeError, match="failed their checksum"):
+        pg.check()
