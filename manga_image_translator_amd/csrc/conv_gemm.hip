@@ -39,7 +39,6 @@ bool fast_eligible(const MitConvGemm &p, int BK) {
     return maxoff + tmax < 0x7fffffffLL;
 }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-constexpr int kCfgSmall = 26, kCfgGemv16 = 27, kCfgGemv4 = 28, kCfgGemv16N1 = 29, kCfgGemv4N1 = 30;
 
 int cfg_by_name(const char *name) {
     for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i)
@@ -91,18 +90,21 @@ int64_t split_min_now() {
     return m;
 }
 
-int env_cfg(const char *name, int dflt) {  // tuning knob for scripts/: replaces a default fast tile by another fast tile
+int env_cfg(const char *name, const char *dflt_name) {  // tuning knob for scripts/: replaces a default fast tile by another fast tile, BY NAME
+    const int dflt = dflt_name ? cfg_by_name(dflt_name) : -1;  // -1: rule off
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
-    const int c = atoi(v);
-    return (c >= 0 && c < kNumCfgs && (kCfgs[c].fast == 1 || kCfgs[c].fast == 2) && kCfgs[c].BK == 16) ? c : dflt;  // dflt may be -1 (rule off)
+    const int c = cfg_by_name(v);
+    return (c >= 0 && (kCfgs[c].fast == 1 || kCfgs[c].fast == 2) && kCfgs[c].BK == 16) ? c : dflt;
 }
 
 int pick_cfg(const MitConvGemm &p, int64_t M) {
     // measured on MI355X (scripts/bench_conv.py)
-    static const int wide = env_cfg("MIT_CONV_TILE_WIDE", 20), narrow = env_cfg("MIT_CONV_TILE_NARROW", 24);
-    static const int m192 = env_cfg("MIT_CONV_TILE_M192", 22), bigk = env_cfg("MIT_CONV_TILE_BIGK", -1);
-    static const int wide_l = env_cfg("MIT_CONV_TILE_WIDE_L", -1), narrow_l = env_cfg("MIT_CONV_TILE_NARROW_L", -1);  // experiments: Cin % 32 == 0
+    static const int wide = env_cfg("MIT_CONV_TILE_WIDE", "fast128x128x16w4c"), narrow = env_cfg("MIT_CONV_TILE_NARROW", "fast128x64x16w5c");
+    static const int m192 = env_cfg("MIT_CONV_TILE_M192", "fast192x64x16w4c"), bigk = env_cfg("MIT_CONV_TILE_BIGK", nullptr);
+    static const int wide_l = env_cfg("MIT_CONV_TILE_WIDE_L", nullptr), narrow_l = env_cfg("MIT_CONV_TILE_NARROW_L", nullptr);  // experiments: Cin % 32 == 0
+    static const int kCfgGemv16 = cfg_by_name("gemv16"), kCfgGemv4 = cfg_by_name("gemv4"), kCfgGemv16N1 = cfg_by_name("gemv16n1"), kCfgGemv4N1 = cfg_by_name("gemv4n1");
+    static const int kCfgSmall = cfg_by_name("fast64x64x16w8c"), kCfgGen128 = cfg_by_name("128x128x16"), kCfgGen64 = cfg_by_name("128x64x16"), kCfgGen32 = cfg_by_name("128x32x16");
     static const int narrow_max = getenv("MIT_CONV_NARROW_MAX") ? atoi(getenv("MIT_CONV_NARROW_MAX")) : 64;
     const bool f16 = fast_eligible(p, 16);
     static const bool gemv_off = getenv("MIT_CONV_NO_GEMV") != nullptr;  // A/B knob for scripts/
@@ -117,7 +119,7 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
             if (c >= 0) return c;
         }
         if (f16 && n32_fast >= 0) return n32_fast;
-        return 2;
+        return kCfgGen32;
     }
     // split-bf16 tiles (GEMM mode 6 | 9, mit_gemm_mode_set): layers whose packer attached split planes of W, large enough to fill the chip
     const int split = gemm_mode_now();
@@ -155,8 +157,8 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
     if (f16 && small >= 0 && p.Z == 1 && p.N > 32 && ((M + 127) / 128) * ((p.N + 63) / 64) < small_max) return small;
     const int rem = p.N % 128;
     const bool lines = f16 && p.Cin % 32 == 0;
-    if (p.N <= 64 || (rem != 0 && rem <= narrow_max)) return f16 ? (lines && narrow_l >= 0 ? narrow_l : narrow) : 1;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
-    return f16 ? (lines && wide_l >= 0 ? wide_l : wide) : 0;  // 4 waves of 128 x 32, <= 128 registers: 4 workgroups per CU (+3-7 % over the 2 x 2 layout)
+    if (p.N <= 64 || (rem != 0 && rem <= narrow_max)) return f16 ? (lines && narrow_l >= 0 ? narrow_l : narrow) : kCfgGen64;  // e.g. N = 192: 3 x 64 beats 2 x 128 with a half-empty tile
+    return f16 ? (lines && wide_l >= 0 ? wide_l : wide) : kCfgGen128;  // 4 waves of 128 x 32, <= 128 registers: 4 workgroups per CU (+3-7 % over the 2 x 2 layout)
 }
 
 // ---- kernel-time probe (mit_prof_*): HIP events around every launch while enabled ----
@@ -317,7 +319,7 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     if (p.dyn && ((p.a_dyn | p.c_dyn) & 3)) return mit_set_error("mit_conv_gemm: a_dyn / c_dyn must be multiples of 4 floats");
     if (c.fast == 2 && (p.Cin % 32)) return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% 32 == 0", c.name);
     if (c.fast == 3) {
-        const int lpr = (cfg == kCfgGemv16 || cfg == kCfgGemv16N1) ? 16 : 4;
+        const int lpr = (!strcmp(c.name, "gemv16") || !strcmp(c.name, "gemv16n1")) ? 16 : 4;
         if (!gemv_eligible(p, lpr) || p.N > c.BN)
             return mit_set_error("mit_conv_gemm: cfg %s needs N <= %d, Z == 1, unsplit maps and Cin %% %d == 0", c.name, c.BN, 4 * lpr);
     }

@@ -69,15 +69,22 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
     return make_float2(__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x));
 }
 
-// A (re, im) pair out of LDS as TWO 4-byte loads.  The butterfly inputs of a stage sit a constant stride apart, which hipcc merges into
-// two-address 8-byte reads (ds_read2_b64 / ds_read2st64_b64); launches of these kernels then returned wrong workgroups whenever ANOTHER
-// queue's kernel that mixes MFMAs with LDS traffic was resident on the same CU (7-15 of 60 launches; scripts/cotenant_check,
-// profiles/r04a_cotenant_check.log), while the same kernel with these reads as 4-byte loads — and every other victim tried, including
-// single-address 8- and 16-byte LDS reads — stayed bit-exact (0 of 60).  The volatile keeps the two loads from being merged again.  The
-// kernels are HBM-bound: the narrower reads cost nothing measurable.
+// A (re, im) pair out of LDS.  SAFE = false: one 8-byte load — the butterfly inputs of a stage sit a constant stride apart and hipcc
+// merges them into two-address reads (ds_read2_b64 / ds_read2st64_b64).  SAFE = true (the kernels of MIT_COTENANT_SAFE launches): TWO
+// 4-byte loads, kept apart by the volatile.  Round 4 (scripts/cotenant_check, profiles/r04b_cotenant_check.log): while ANOTHER queue's
+// kernel that mixes MFMAs with LDS traffic shares the CU, the radix-4 / 3 plan returns wrong workgroups in 7-21 of 100 launches with the
+// merged reads and in 0 of 100 with the narrow ones — every other victim tried, single-address 8- and 16-byte reads included, stays exact.
+// The radix-7 / 13 plan of the BASELINE page is disturbed even then (tests/test_cotenant_gpu.py), which is why safe launches also take
+// a whole CU's LDS; the narrow reads cost the two kernels 30-45 % (385 vs 265 us, 437 vs 335 us per 16-page launch), so the default
+// launches — one queue per GPU — keep the wide ones.
+template <bool SAFE>
 __device__ __forceinline__ float2 lds_pair(const float2 *p) {
-    const volatile float *f = reinterpret_cast<const volatile float *>(p);
-    return make_float2(f[0], f[1]);
+    if constexpr (SAFE) {
+        const volatile float *f = reinterpret_cast<const volatile float *>(p);
+        return make_float2(f[0], f[1]);
+    } else {
+        return *p;
+    }
 }
 
 // y_k = sum_i x_i exp(-/+ 2 pi i ik / P), in place.
@@ -130,7 +137,7 @@ __device__ __forceinline__ void butterfly(float2 (&x)[P]) {
 
 // One Stockham stage of radix P over the N-point sequences of CC channels: current sub-length n, stride s.
 //   dst[q + s (P p + k)] = (sum_i src[q + s (p + m i)] w_P^{ik}) w_n^{pk},   m = n / P, q < s, p < m
-template <int P, bool INV>
+template <int P, bool INV, bool SAFE>
 __device__ __forceinline__ void stage(const float2 *__restrict__ src, float2 *__restrict__ dst, const float2 *__restrict__ tw, int N,
                                       int n, int s, int slot, int c) {
     const int m = n / P, nb = N / P, tws = N / n;
@@ -138,7 +145,7 @@ __device__ __forceinline__ void stage(const float2 *__restrict__ src, float2 *__
         const int q = bf % s, p = bf / s;
         float2 x[P];
 #pragma unroll
-        for (int i = 0; i < P; ++i) x[i] = lds_pair(src + (q + s * (p + m * i)) * CC + c);
+        for (int i = 0; i < P; ++i) x[i] = lds_pair<SAFE>(src + (q + s * (p + m * i)) * CC + c);
         butterfly<P, INV>(x);
         if (m > 1) {
 #pragma unroll
@@ -154,19 +161,19 @@ __device__ __forceinline__ void stage(const float2 *__restrict__ src, float2 *__
 }
 
 // Runs every stage of the plan, ping-ponging between the two LDS buffers; returns the buffer holding the result.
-template <bool INV>
+template <bool INV, bool SAFE>
 __device__ __forceinline__ float2 *run_stages(float2 *a, float2 *b, const float2 *tw, const RowPlan &plan, int N, int slot, int c) {
     int n = N, s = 1;
     for (int st = 0; st < plan.nrad; ++st) {
         const int P = plan.radix[st];
         switch (P) {
-            case 2: stage<2, INV>(a, b, tw, N, n, s, slot, c); break;
-            case 3: stage<3, INV>(a, b, tw, N, n, s, slot, c); break;
-            case 4: stage<4, INV>(a, b, tw, N, n, s, slot, c); break;
-            case 5: stage<5, INV>(a, b, tw, N, n, s, slot, c); break;
-            case 7: stage<7, INV>(a, b, tw, N, n, s, slot, c); break;
-            case 11: stage<11, INV>(a, b, tw, N, n, s, slot, c); break;
-            default: stage<13, INV>(a, b, tw, N, n, s, slot, c); break;
+            case 2: stage<2, INV, SAFE>(a, b, tw, N, n, s, slot, c); break;
+            case 3: stage<3, INV, SAFE>(a, b, tw, N, n, s, slot, c); break;
+            case 4: stage<4, INV, SAFE>(a, b, tw, N, n, s, slot, c); break;
+            case 5: stage<5, INV, SAFE>(a, b, tw, N, n, s, slot, c); break;
+            case 7: stage<7, INV, SAFE>(a, b, tw, N, n, s, slot, c); break;
+            case 11: stage<11, INV, SAFE>(a, b, tw, N, n, s, slot, c); break;
+            default: stage<13, INV, SAFE>(a, b, tw, N, n, s, slot, c); break;
         }
         __syncthreads();
         float2 *t = a;
@@ -181,6 +188,7 @@ __device__ __forceinline__ float2 *run_stages(float2 *a, float2 *b, const float2
 constexpr int LD_UNROLL = 3;  // (row pair) loads in flight per thread: 3 x 32 pairs cover N <= 96 in one round
 
 // Forward: x[b, h, w, C] (real) -> planar spectrum out[b, t, h, k, C], k <= w/2, scaled by `scale` (1/sqrt(w) for 'ortho').
+template <bool SAFE>
 __global__ __launch_bounds__(256) void rfft_rows_kernel(const float *__restrict__ in, int64_t in_bs, int64_t in_hs, int64_t in_ws,
                                                          float *__restrict__ out, int64_t out_bs, int64_t out_ts, int64_t out_hs,
                                                          int64_t out_ks, const float2 *__restrict__ tables, RowPlan plan, int N,
@@ -225,13 +233,13 @@ __global__ __launch_bounds__(256) void rfft_rows_kernel(const float *__restrict_
     for (int j = threadIdx.x; j < 2 * N + 1; j += 256) tw[j] = tables[j];
     __syncthreads();
     const int slot = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const float2 *Z = run_stages<false>(bufA, bufB, tw, plan, N, slot, c);
+    const float2 *Z = run_stages<false, SAFE>(bufA, bufB, tw, plan, N, slot, c);
     // untangle: X[k] = (Z[k] + conj Z[N-k]) / 2 - i e^{-2 pi i k / w} (Z[k] - conj Z[N-k]) / 2,  k = 0 .. N (Z[N] = Z[0])
     const bool sok = c0 + c < Cn;
     const float hs = 0.5f * scale;
     for (int k = slot; k <= N; k += NSLOT) {
-        const float2 zk = lds_pair(Z + (k == N ? 0 : k) * CC + c);
-        const float2 zr = lds_pair(Z + (k == 0 ? 0 : N - k) * CC + c);
+        const float2 zk = lds_pair<SAFE>(Z + (k == N ? 0 : k) * CC + c);
+        const float2 zr = lds_pair<SAFE>(Z + (k == 0 ? 0 : N - k) * CC + c);
         const float2 zn = make_float2(zr.x, -zr.y);
         const float2 e = cadd(zk, zn), d = csub(zk, zn);
         const float2 w = tw2[k];                                  // (cos, sin); e^{-i th} = (cos, -sin)
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(256) void rfft_rows_kernel(const float *__restrict_
 }
 
 // Inverse: planar Hermitian half spectrum in[b, t, h, k, C], k <= w/2 -> real rows out[b, h, w, C] = scale * irfft (+ res).
+template <bool SAFE>
 __global__ __launch_bounds__(256) void irfft_rows_kernel(const float *__restrict__ in, int64_t in_bs, int64_t in_ts, int64_t in_hs,
                                                           int64_t in_ks, float *__restrict__ out, int64_t out_bs, int64_t out_hs,
                                                           int64_t out_ws, const float *__restrict__ res, int64_t res_bs,
@@ -289,15 +298,15 @@ __global__ __launch_bounds__(256) void irfft_rows_kernel(const float *__restrict
     const int slot = threadIdx.x >> 5, c = threadIdx.x & 31;
     // tangle: Z[k] = (X[k] + conj X[N-k]) + i e^{+2 pi i k / w} (X[k] - conj X[N-k]),  k < N
     for (int k = slot; k < N; k += NSLOT) {
-        const float2 xk = lds_pair(bufA + k * CC + c);
-        const float2 xr = lds_pair(bufA + (N - k) * CC + c);
+        const float2 xk = lds_pair<SAFE>(bufA + k * CC + c);
+        const float2 xr = lds_pair<SAFE>(bufA + (N - k) * CC + c);
         const float2 xn = make_float2(xr.x, -xr.y);
         const float2 e = cadd(xk, xn), d = csub(xk, xn);
         const float2 o = cmul(make_float2(-d.y, d.x), tw2[k]);  // i d e^{+i th}
         bufB[k * CC + c] = cadd(e, o);
     }
     __syncthreads();
-    const float2 *Z = run_stages<true>(bufB, bufA, tw, plan, N, slot, c);
+    const float2 *Z = run_stages<true, SAFE>(bufB, bufA, tw, plan, N, slot, c);
     // z[n] = x[2n] + i x[2n+1]; same thread <-> (row pair, 4 channels) mapping as the forward load
     for (int base = 0; base < N; base += 32 * LD_UNROLL) {
         f32x4 r0[LD_UNROLL], r1[LD_UNROLL];
@@ -376,15 +385,17 @@ extern "C" int mit_rfft_rows(const float *in_dev, int64_t in_bs, int64_t in_hs, 
         int pad = 0;
         if (sscanf(e, "%d,%d", &pad, &dbg_zero) >= 1 && pad > 0) smem += (size_t)pad;
     }
-    if (mit_cotenant_safe() && smem < kCotenantSafeLds) smem = kCotenantSafeLds;
-    static DynSmemOptIn optin;
-    optin.ensure(reinterpret_cast<const void *>(rfft_rows_kernel), smem);
+    const bool safe = mit_cotenant_safe();
+    if (safe && smem < kCotenantSafeLds) smem = kCotenantSafeLds;
+    static DynSmemOptIn optin_fast, optin_safe;
+    auto kern = safe ? rfft_rows_kernel<true> : rfft_rows_kernel<false>;
+    (safe ? optin_safe : optin_fast).ensure(reinterpret_cast<const void *>(kern), smem);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const double rows = (double)B * h * C;
     // algorithmic bytes: the real rows read once, the half spectrum written once; FLOPs: 2.5 w log2 w per real row
     MitProbeScope probe("rfft_rows_kernel", st, 4.0 * rows * (w + 2.0 * (N + 1)), 2.5 * w * log2((double)w) * rows);
     dim3 grid(mit_div_up(C, CC), h, B), block(256);
-    hipLaunchKernelGGL(rfft_rows_kernel, grid, block, smem, st, in_dev, in_bs, in_hs, in_ws, out_dev, out_bs, out_ts, out_hs, out_ks,
+    hipLaunchKernelGGL(kern, grid, block, smem, st, in_dev, in_bs, in_hs, in_ws, out_dev, out_bs, out_ts, out_hs, out_ks,
                        reinterpret_cast<const float2 *>(tables_dev), plan, N, C, scale, dbg_zero);
     MIT_CHECK_LAUNCH("mit_rfft_rows");
     return 0;
@@ -405,14 +416,16 @@ extern "C" int mit_irfft_rows(const float *in_dev, int64_t in_bs, int64_t in_ts,
         return mit_set_error("mit_irfft_rows: residual strides and base must be multiples of 4 floats");
     const int N = w / 2;
     size_t smem = ((size_t)2 * (N + 1) * CC + 2 * N + 1) * sizeof(float2);
-    if (mit_cotenant_safe() && smem < kCotenantSafeLds) smem = kCotenantSafeLds;
-    static DynSmemOptIn optin;
-    optin.ensure(reinterpret_cast<const void *>(irfft_rows_kernel), smem);
+    const bool safe = mit_cotenant_safe();
+    if (safe && smem < kCotenantSafeLds) smem = kCotenantSafeLds;
+    static DynSmemOptIn optin_fast, optin_safe;
+    auto kern = safe ? irfft_rows_kernel<true> : irfft_rows_kernel<false>;
+    (safe ? optin_safe : optin_fast).ensure(reinterpret_cast<const void *>(kern), smem);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const double rows = (double)B * h * C;
     MitProbeScope probe("irfft_rows_kernel", st, 4.0 * rows * ((res_dev ? 2.0 : 1.0) * w + 2.0 * (N + 1)), 2.5 * w * log2((double)w) * rows);
     dim3 grid(mit_div_up(C, CC), h, B), block(256);
-    hipLaunchKernelGGL(irfft_rows_kernel, grid, block, smem, st, in_dev, in_bs, in_ts, in_hs, in_ks, out_dev, out_bs, out_hs, out_ws,
+    hipLaunchKernelGGL(kern, grid, block, smem, st, in_dev, in_bs, in_ts, in_hs, in_ks, out_dev, out_bs, out_hs, out_ws,
                        res_dev, res_bs, res_hs, res_ws, reinterpret_cast<const float2 *>(tables_dev), plan, N, C, scale);
     MIT_CHECK_LAUNCH("mit_irfft_rows");
     return 0;

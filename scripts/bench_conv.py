@@ -9,8 +9,17 @@ from manga_image_translator_amd import ops, lib
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", "4"))
-WIDE = [int(c) for c in os.environ.get('WIDE', '16,20,23').split(',')]
-NARROW = [int(c) for c in os.environ.get('NARROW', '9,21').split(',')]
+def _tiles(names):
+    """tile names -> indices (mit_conv_gemm_config_name); names a default build does not carry (MIT_CONV_EXPERIMENTS tiles) are skipped"""
+    L_, by, i = lib.load(), {}, 0
+    while L_.mit_conv_gemm_config_name(i) is not None:
+        by[L_.mit_conv_gemm_config_name(i).decode()] = i
+        i += 1
+    return [by[n] for n in names.split(',') if n in by]
+
+
+WIDE = _tiles(os.environ.get('WIDE', 'fast128x128x16w4b,fast128x128x16w4c,fast256x128x16w2c'))
+NARROW = _tiles(os.environ.get('NARROW', 'fast128x64x16,fast128x64x16c,fast128x64x16w5c'))
 SHAPES = [
     # name, Cin, Cout, H, W, k, s, p, mode, batch, cfgs
     ("lama fused 512->128 3x3", 512, 128, 256, 182, 3, 1, 1, ops.PAD_REFLECT, B, WIDE),
@@ -19,7 +28,7 @@ SHAPES = [
     ("lama st2 192->384 1x1", 192, 384, 256, 182, 1, 1, 0, ops.PAD_ZERO, B, WIDE),
     ("lama down2 128->256 3x3 s2", 128, 256, 1024, 728, 3, 2, 1, ops.PAD_REFLECT, B, WIDE),
     ("lama down1 64->128 3x3 s2", 64, 128, 2048, 1456, 3, 2, 1, ops.PAD_REFLECT, 1, WIDE),
-    ("lama stem 4->64 7x7", 4, 64, 2048, 1456, 7, 1, 3, ops.PAD_REFLECT, 1, [1, 5]),
+    ("lama stem 4->64 7x7", 4, 64, 2048, 1456, 7, 1, 3, ops.PAD_REFLECT, 1, _tiles("128x64x16,256x64x16")),
     ("ocr grp pw1 80->320 (1.2M rows)", 80, 320, 1200, 1024, 1, 1, 0, ops.PAD_ZERO, 1, WIDE),
     ("ocr grp pw2 320->80 (1.2M rows)", 320, 80, 1200, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),
     ("ocr grp pw2 1280->320 (150k rows)", 1280, 320, 150, 1024, 1, 1, 0, ops.PAD_ZERO, 1, NARROW),

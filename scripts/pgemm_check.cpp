@@ -184,6 +184,14 @@ int main(int argc, char **argv) {
         }
         const double flops = 2.0 * M * (double)N * K * Z;
         printf("  %-20s %9.3f ms %8.1f TFLOP/s (fp32-equivalent)\n", mit_conv_gemm_config_name(ref_cfg), ms_ref, flops / ms_ref * 1e-9);
+        {   // the other split tile of mit_conv_gemm on the same problem (which of the two should the automatic choice take?)
+            const int other = narrow ? s_wide : s_narrow;
+            float ms_o = 0.f;
+            d.c.base = dc;
+            if (!time_it([&] { return mit_conv_gemm_cfg(&d, other, nullptr); }, &ms_o))
+                printf("  %-20s %9.3f ms %8.1f TFLOP/s   x%.2f   (the other split tile)\n", mit_conv_gemm_config_name(other), ms_o, flops / ms_o * 1e-9, ms_ref / ms_o);
+            d.c.base = dref;
+        }
         std::vector<float> href(c_el), hc(c_el);
         CK(hipMemcpy(href.data(), dref, c_el * 4, hipMemcpyDeviceToHost));
         std::vector<uint16_t> hrefpl, hcpl;

@@ -44,31 +44,41 @@ def _act(v, act, alpha):
     }[act](v)
 
 
+def _tile(name):
+    from manga_image_translator_amd import lib
+    L, i = lib.load(), 0
+    while L.mit_conv_gemm_config_name(i) is not None:
+        if L.mit_conv_gemm_config_name(i).decode() == name:
+            return i
+        i += 1
+    raise KeyError(name)
+
+
 CASES = [
-    # B, Cin, Cout, H, W, k, s, p, mode, act, bn, cfg
-    (1, 16, 32, 17, 23, 3, 1, 1, "zero", 0, False, -1),
-    (2, 128, 128, 20, 26, 3, 1, 1, "reflect", 1, True, -1),
-    (1, 384, 128, 24, 18, 3, 1, 1, "reflect", 1, True, 0),
-    (1, 128, 384, 24, 18, 3, 1, 1, "reflect", 0, False, 4),
-    (1, 4, 64, 40, 36, 7, 1, 3, "reflect", 1, True, -1),
-    (1, 64, 3, 33, 29, 7, 1, 3, "reflect", 4, False, -1),
-    (2, 64, 128, 32, 28, 3, 2, 1, "reflect", 1, True, -1),
-    (1, 3, 32, 64, 48, 6, 2, 2, "zero", 3, False, -1),
-    (1, 256, 256, 16, 16, 1, 1, 0, "zero", 2, True, 3),
-    (3, 192, 384, 9, 7, 1, 1, 0, "zero", 0, False, 1),
-    (1, 64, 16, 31, 17, 3, 1, 1, "zero", 1, True, 2),
-    (1, 80, 320, 12, 40, 1, 1, 0, "zero", 5, False, 5),
-    (1, 32, 64, 8, 8, 3, 1, 1, "zero", 0, False, 6),
-    (1, 160, 160, 6, 33, (2, 1), (2, 1), 0, "zero", 1, True, -1),
-    (2, 64, 1, 20, 24, 3, 1, 1, "zero", 4, True, -1),      # N = 1: conv_gemv_kernel, 16 lanes per row
-    (1, 16, 1, 19, 21, 1, 1, 0, "zero", 4, False, -1),     # N = 1, Cin = 16: 4 lanes per row
-    (1, 16, 2, 15, 18, 3, 1, 1, "reflect", 1, True, 28),   # N = 2 forced onto gemv4
-    (1, 128, 4, 9, 40, 3, 2, 1, "zero", 2, False, 27),     # N = 4, stride 2, forced onto gemv16
-    (2, 320, 320, 7, 33, 1, 1, 0, "zero", 5, False, 26),   # the 64 x 64 fast tile (decoder-sized GEMM), GELU
-    (1, 64, 96, 12, 10, 3, 1, 1, "reflect", 1, True, 26),  # 64 x 64 fast tile, 3x3 reflect, ragged N
-    (1, 64, 32, 31, 17, 3, 1, 1, "zero", 1, True, 49),     # 128 x 32 fast tile (ESRGAN's growth-32 convolutions)
-    (2, 160, 32, 12, 10, 3, 1, 1, "zero", 2, False, 49),
-    (1, 64, 16, 9, 40, 3, 1, 1, "reflect", 0, False, 49),  # ragged N on it
+    # B, Cin, Cout, H, W, k, s, p, mode, act, bn, tile (name; None = automatic)
+    (1, 16, 32, 17, 23, 3, 1, 1, "zero", 0, False, None),
+    (2, 128, 128, 20, 26, 3, 1, 1, "reflect", 1, True, None),
+    (1, 384, 128, 24, 18, 3, 1, 1, "reflect", 1, True, "128x128x16"),
+    (1, 128, 384, 24, 18, 3, 1, 1, "reflect", 0, False, "128x128x16"),
+    (1, 4, 64, 40, 36, 7, 1, 3, "reflect", 1, True, None),
+    (1, 64, 3, 33, 29, 7, 1, 3, "reflect", 4, False, None),
+    (2, 64, 128, 32, 28, 3, 2, 1, "reflect", 1, True, None),
+    (1, 3, 32, 64, 48, 6, 2, 2, "zero", 3, False, None),
+    (1, 256, 256, 16, 16, 1, 1, 0, "zero", 2, True, "128x128x16"),
+    (3, 192, 384, 9, 7, 1, 1, 0, "zero", 0, False, "128x64x16"),
+    (1, 64, 16, 31, 17, 3, 1, 1, "zero", 1, True, "128x32x16"),
+    (1, 80, 320, 12, 40, 1, 1, 0, "zero", 5, False, "128x64x16"),
+    (1, 32, 64, 8, 8, 3, 1, 1, "zero", 0, False, "128x64x16"),
+    (1, 160, 160, 6, 33, (2, "128x64x16"), (2, 1), 0, "zero", 1, True, -1),
+    (2, 64, 1, 20, 24, 3, 1, 1, "zero", 4, True, None),      # N = 1: conv_gemv_kernel, 16 lanes per row
+    (1, 16, 1, 19, 21, 1, 1, 0, "zero", 4, False, None),     # N = 1, Cin = 16: 4 lanes per row
+    (1, 16, 2, 15, 18, 3, 1, 1, "reflect", 1, True, "gemv4"),   # N = 2 forced onto gemv4
+    (1, 128, 4, 9, 40, 3, 2, 1, "zero", 2, False, "gemv16"),     # N = 4, stride 2, forced onto gemv16
+    (2, 320, 320, 7, 33, 1, 1, 0, "zero", 5, False, "fast64x64x16w8c"),   # the 64 x 64 fast tile (decoder-sized GEMM), GELU
+    (1, 64, 96, 12, 10, 3, 1, 1, "reflect", 1, True, "fast64x64x16w8c"),  # 64 x 64 fast tile, 3x3 reflect, ragged N
+    (1, 64, 32, 31, 17, 3, 1, 1, "zero", 1, True, "fast128x32x16w4c"),     # 128 x 32 fast tile (ESRGAN's growth-32 convolutions)
+    (2, 160, 32, 12, 10, 3, 1, 1, "zero", 2, False, "fast128x32x16w4c"),
+    (1, 64, 16, 9, 40, 3, 1, 1, "reflect", 0, False, "fast128x32x16w4c"),  # ragged N on it
 ]
 
 
@@ -94,7 +104,7 @@ def test_conv2d_parity(cuda, case):
     xg[..., :Cin] = _nhwc(x)
     xg = xg.to(cuda)
     post = torch.randn(B, Cout, *layer.out_hw(H, W), generator=g)
-    out = layer(xg, post=_nhwc(post).to(cuda), cfg=cfg)
+    out = layer(xg, post=_nhwc(post).to(cuda), cfg=-1 if cfg is None else _tile(cfg))
     torch.cuda.synchronize()
 
     xd, wd = x.double(), w.double()
@@ -233,7 +243,7 @@ def test_large_batch_is_split_for_the_fast_kernel(cuda):
     w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
     layer = ops.Conv2d(w, None, stride=2, padding=1, pad_mode=ops.PAD_REFLECT, act=ops.ACT_RELU, device=cuda)
     fast = layer(x)                 # auto: split + fast tile
-    generic = layer(x, cfg=0)       # the generic 128x128 kernel on the whole batch
+    generic = layer(x, cfg=_tile("128x128x16"))       # the generic 128x128 kernel on the whole batch
     torch.cuda.synchronize()
     assert torch.equal(fast, generic)
     assert fast[-1].abs().sum().item() > 0   # the last run of images was written
