@@ -592,6 +592,20 @@ int mit_xpos_rotate(const float *in_dev, int64_t in_rs, int64_t in_ts, float *ou
 int mit_attention(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k_dev, int64_t k_rs, int64_t k_ts,
                   const float *v_dev, int64_t v_rs, int64_t v_ts, float *out_dev, int64_t o_rs, int64_t o_ts,
                   const int *klen_dev, int R, int Tq, int Tk, int kv_div, void *stream);
+/* The encoder's self-attention (XposMultiheadAttention.forward, ocr/model_48px.py:327-394) for ALL lines of a page group in one launch
+ * with the XPOS rotation of q (scale) and k (inverse scale) folded in (xpos_relative_position.py:44-71): line r owns lines[r] = {first row,
+ * L_r} rows of the flat [rows, heads * head_dim] q / k / v / out tensors (row stride in floats), L_r = its chunk's memory length = its
+ * query and key count, positions centred per chunk (p0 = -((L_r + 1) / 2)), klen[r] valid keys.  Bitwise equal to mit_xpos_rotate (q),
+ * mit_xpos_rotate (k, downscale) and mit_attention chunk by chunk.  Lmax = the longest line (LDS sizing). */
+int mit_attention_lines_xpos(const float *q_dev, const float *k_dev, const float *v_dev, float *out_dev, int64_t row_stride,
+                             const int32_t *lines_dev, const int *klen_dev, int n_lines, int Lmax, int heads, int head_dim,
+                             const MitXposTables *tables, void *stream);
+/* Cross-attention memory of one decoder layer for the same lines: mem_k[first_line + r][t][:] = the XPOS-rotated (inverse scale) k rows,
+ * mem_v[...] = the v rows, t < L_r (line_stride floats between lines of the pooled [n, Lmax, heads * head_dim] memory); n_rows = the
+ * rows the lines cover.  Replaces one mit_xpos_rotate and one copy per chunk (OCR.infer_beam_batch_tensor's memory, :678-704). */
+int mit_memory_kv_lines(const float *k_dev, const float *v_dev, int64_t row_stride, float *mem_k_dev, float *mem_v_dev, int64_t line_stride,
+                        const int32_t *lines_dev, int n_lines, int first_line, int64_t n_rows, int Lmax, int head_dim,
+                        const MitXposTables *tables, void *stream);
 /* Same with an explicit head layout (heads x head_dim contiguous in the feature axis): 8 x 40 for the 48px_ctc encoder's
  * nn.MultiheadAttention (model_48px_ctc.py:216-217,259-265; q already scaled by head_dim**-0.5, PE already added to q/k). */
 int mit_attention_heads(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k_dev, int64_t k_rs, int64_t k_ts,

@@ -949,6 +949,157 @@ __global__ __launch_bounds__(ATTR_THREADS) void attention_rows_kernel(const floa
     }
 }
 
+// ---- the encoder's self-attention for ALL lines of a page group in one launch, with the XPOS rotation of q and k folded in:
+// attention_rows_kernel's arithmetic on rows that are rotated while they are staged in LDS instead of by two xpos_rotate_kernel
+// launches per chunk (the rotated value of an element is the same fp32 expression, so the result is bitwise the one of
+// rotate + rotate + attention_rows_kernel chunk by chunk).  Lines are ragged: line r of the group owns L_r consecutive rows of the flat
+// [rows, heads * HD] q / k / v / o tensors starting at row start_r (its chunk's padded memory length L_r is its query AND key count;
+// positions are centred per chunk: p0 = -((L_r + 1) / 2), model_48px.py:327-394, xpos_relative_position.py:44-71).
+struct OcrLine {
+    int start, L;
+};
+__global__ __launch_bounds__(ATTR_THREADS) void attention_lines_xpos_kernel(const float *__restrict__ Q, const float *__restrict__ K,
+                                                                            const float *__restrict__ V, float *__restrict__ O, int64_t ts,
+                                                                            const OcrLine *__restrict__ lines, const int *__restrict__ klen,
+                                                                            int Tmax, int HD, const float *__restrict__ cosT,
+                                                                            const float *__restrict__ sinT, const float *__restrict__ scaleT,
+                                                                            const float *__restrict__ iscaleT, int pmax) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KP = HD + 4;
+    const int HD4 = HD / 4, HP = HD / 2;  // HP: rotation pairs per head (table row length)
+    const int h = blockIdx.x, r = blockIdx.y;
+    const OcrLine ln = lines[r];
+    const int Tk = ln.L, Tq = ln.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qa = ((int)blockIdx.z * (ATTR_THREADS / 64) + wave) * ATTR_GQ;
+    if ((int)blockIdx.z * (ATTR_THREADS / 64) * ATTR_GQ >= Tq) return;  // whole workgroup: this line is shorter than the group's longest
+    float *kv = lds;                                              // [Tmax][KP]: the keys, then (same buffer) the values
+    float *qs_all = kv + (size_t)Tmax * KP;                       // [waves][GQ][HD]
+    float *ws_all = qs_all + (ATTR_THREADS / 64) * ATTR_GQ * HD;  // [waves][GQ][Tmax]
+    const int valid = klen ? min(klen[r], Tk) : Tk;
+    const int p0 = -((ln.L + 1) / 2);
+    const float *kb = K + (int64_t)ln.start * ts + h * HD, *vb = V + (int64_t)ln.start * ts + h * HD, *qb = Q + (int64_t)ln.start * ts + h * HD;
+    auto rot2 = [&](const float2 x, const int t, const int j, const float *sct) {  // xpos_rotate_kernel's expression for pair j at position t
+        const int pp = p0 + t + pmax;
+        const float sc = sct[pp * HP + j];
+        const float c = cosT[t * HP + j] * sc;
+        const float sn = sinT[t * HP + j] * sc;
+        float2 o;
+        o.x = x.x * c + (-x.y) * sn;
+        o.y = x.y * c + x.x * sn;
+        return o;
+    };
+    for (int i = tid; i < valid * HD4; i += ATTR_THREADS) {  // keys, rotated with the inverse scale
+        const int t = i / HD4, d4 = i - t * HD4;
+        const float4 x = *reinterpret_cast<const float4 *>(kb + (int64_t)t * ts + d4 * 4);
+        const float2 a = rot2(make_float2(x.x, x.y), t, 2 * d4, iscaleT), b = rot2(make_float2(x.z, x.w), t, 2 * d4 + 1, iscaleT);
+        *reinterpret_cast<float4 *>(kv + t * KP + d4 * 4) = make_float4(a.x, a.y, b.x, b.y);
+    }
+    float *qs = qs_all + wave * ATTR_GQ * HD;
+    float *ws = ws_all + (size_t)wave * ATTR_GQ * Tmax;
+    const int ng = max(0, min(ATTR_GQ, Tq - qa));
+    for (int i = lane; i < ATTR_GQ * HP; i += 64) {  // this wave's queries, rotated with the scale
+        const int g = i / HP, j = i - g * HP;
+        float2 o = make_float2(0.f, 0.f);
+        if (g < ng) o = rot2(*reinterpret_cast<const float2 *>(qb + (int64_t)(qa + g) * ts + 2 * j), qa + g, j, scaleT);
+        *reinterpret_cast<float2 *>(qs + g * HD + 2 * j) = o;
+    }
+    __syncthreads();  // keys and queries staged
+    float mx[ATTR_GQ];
+#pragma unroll
+    for (int g = 0; g < ATTR_GQ; ++g) mx[g] = -INFINITY;
+    for (int t = lane; t < Tk; t += 64) {
+        float dot[ATTR_GQ];
+#pragma unroll
+        for (int g = 0; g < ATTR_GQ; ++g) dot[g] = t < valid ? 0.f : -INFINITY;
+        if (t < valid) {
+            const float4 *kp = reinterpret_cast<const float4 *>(kv + t * KP);
+            for (int d4 = 0; d4 < HD4; ++d4) {  // d ascending, one rounding per product and per sum, as in attention_kernel
+                const float4 kk = kp[d4];
+#pragma unroll
+                for (int g = 0; g < ATTR_GQ; ++g) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(qs + g * HD + d4 * 4);
+                    dot[g] += qv.x * kk.x;
+                    dot[g] += qv.y * kk.y;
+                    dot[g] += qv.z * kk.z;
+                    dot[g] += qv.w * kk.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < ATTR_GQ; ++g) {
+            ws[(size_t)g * Tmax + t] = dot[g];
+            mx[g] = fmaxf(mx[g], dot[g]);
+        }
+    }
+    __syncthreads();  // every wave is done with the keys
+    for (int i = tid; i < valid * HD4; i += ATTR_THREADS) {  // the values take the keys' place
+        const int t = i / HD4, d4 = i - t * HD4;
+        *reinterpret_cast<float4 *>(kv + t * KP + d4 * 4) = *reinterpret_cast<const float4 *>(vb + (int64_t)t * ts + d4 * 4);
+    }
+#pragma unroll
+    for (int g = 0; g < ATTR_GQ; ++g) {  // softmax: lanes strided over the keys exactly as attention_kernel's single wave
+        float *w = ws + (size_t)g * Tmax;
+        float m = mx[g];
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int t = lane; t < Tk; t += 64) {
+            const float e = expf(w[t] - m);
+            w[t] = e;
+            sum += e;
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        for (int t = lane; t < Tk; t += 64) w[t] *= inv;
+    }
+    __syncthreads();
+    for (int d = lane; d < HD; d += 64) {  // weighted sum of the values, t-ordered per (query, d)
+        float acc[ATTR_GQ];
+#pragma unroll
+        for (int g = 0; g < ATTR_GQ; ++g) acc[g] = 0.f;
+        for (int t = 0; t < valid; ++t) {
+            const float v = kv[t * KP + d];
+#pragma unroll
+            for (int g = 0; g < ATTR_GQ; ++g) acc[g] += ws[(size_t)g * Tmax + t] * v;
+        }
+#pragma unroll
+        for (int g = 0; g < ATTR_GQ; ++g)
+            if (g < ng) O[(int64_t)(ln.start + qa + g) * ts + h * HD + d] = acc[g];
+    }
+}
+
+// ---- cross-attention memory of one decoder layer for all lines of a group: mem_k[line, t, :] = XPOS-rotated (inverse scale, centred per
+// chunk) k rows, mem_v[line, t, :] = v rows, t < L_line; replaces one xpos_rotate_kernel launch and one copy per chunk.  One thread per
+// (row of the flat k / v, rotation pair).
+__global__ void memory_kv_lines_kernel(const float *__restrict__ Kf, const float *__restrict__ Vf, int64_t ts, float *__restrict__ mem_k,
+                                       float *__restrict__ mem_v, int64_t line_stride, const OcrLine *__restrict__ lines, int n_lines,
+                                       int first_line, int HP, int pairs_per_row, const float *__restrict__ cosT,
+                                       const float *__restrict__ sinT, const float *__restrict__ iscaleT, int pmax, int64_t total) {
+    const int row0 = lines[0].start;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pair = (int)(i % pairs_per_row);
+        const int64_t row = i / pairs_per_row;  // row of the flat tensors, relative to the group's first row
+        int lo = 0, hi = n_lines - 1;           // the line owning this row (lines are consecutive row ranges)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (lines[mid].start - row0 <= row) lo = mid; else hi = mid - 1;
+        }
+        const OcrLine ln = lines[lo];
+        const int t = (int)(row - (ln.start - row0));
+        const int j = pair % HP;
+        const int pp = -((ln.L + 1) / 2) + t + pmax;
+        const float sc = iscaleT[pp * HP + j];
+        const float c = cosT[t * HP + j] * sc, sn = sinT[t * HP + j] * sc;
+        const float2 x = *reinterpret_cast<const float2 *>(Kf + (row0 + row) * ts + pair * 2);
+        float2 o;
+        o.x = x.x * c + (-x.y) * sn;
+        o.y = x.y * c + x.x * sn;
+        const int64_t dst = (int64_t)(first_line + lo) * line_stride + (int64_t)t * ts + pair * 2;
+        *reinterpret_cast<float2 *>(mem_k + dst) = o;
+        *reinterpret_cast<float2 *>(mem_v + dst) = *reinterpret_cast<const float2 *>(Vf + (row0 + row) * ts + pair * 2);
+    }
+}
+
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
                     int kv_div, hipStream_t s, int heads, int head_dim, const int *dstep) {
@@ -1205,6 +1356,47 @@ extern "C" int mit_xpos_rotate(const float *in_dev, int64_t in_rs, int64_t in_ts
     if (check_tables(tables, i0 + T, p0, p0 + T - 1, "mit_xpos_rotate")) return 1;
     ocrk_xpos_rotate(in_dev, in_rs, in_ts, out_dev, out_rs, out_ts, R, T, i0, p0, downscale, *tables, (hipStream_t)stream);
     MIT_CHECK_LAUNCH("mit_xpos_rotate");
+    return 0;
+}
+
+extern "C" int mit_attention_lines_xpos(const float *q_dev, const float *k_dev, const float *v_dev, float *out_dev, int64_t row_stride,
+                                        const int32_t *lines_dev, const int *klen_dev, int n_lines, int Lmax, int heads, int head_dim,
+                                        const MitXposTables *tables, void *stream) {
+    if (!q_dev || !k_dev || !v_dev || !out_dev || !lines_dev) return mit_set_error("mit_attention_lines_xpos: null pointer");
+    if (n_lines <= 0) return 0;
+    if (n_lines > 65535 || Lmax <= 0 || Lmax > 4096 || heads <= 0 || heads > 64 || head_dim <= 0 || head_dim > 128 || (head_dim & 7) || (row_stride & 3))
+        return mit_set_error("mit_attention_lines_xpos: bad sizes (n_lines %d, Lmax %d, heads %d, head_dim %d)", n_lines, Lmax, heads, head_dim);
+    if (check_tables(tables, Lmax, -((Lmax + 1) / 2), Lmax, "mit_attention_lines_xpos")) return 1;
+    const size_t sm = ((size_t)Lmax * (head_dim + 4) + (size_t)(ATTR_THREADS / 64) * ATTR_GQ * (head_dim + Lmax)) * sizeof(float);
+    if (sm > 150 * 1024) return mit_set_error("mit_attention_lines_xpos: lines of %d positions do not fit the LDS form", Lmax);
+    static DynSmemOptIn optin;
+    optin.ensure(reinterpret_cast<const void *>(attention_lines_xpos_kernel), sm);
+    hipStream_t s = (hipStream_t)stream;
+    // algorithmic bytes: q, k, v read once and o written once per position (upper bound: every line counted at Lmax)
+    MitProbeScope probe("attention_lines_xpos_kernel", s, 16.0 * (double)n_lines * Lmax * heads * head_dim, 4.0 * (double)n_lines * Lmax * heads * Lmax * head_dim);
+    const int qblocks = (Lmax + (ATTR_THREADS / 64) * ATTR_GQ - 1) / ((ATTR_THREADS / 64) * ATTR_GQ);
+    hipLaunchKernelGGL(attention_lines_xpos_kernel, dim3(heads, n_lines, qblocks), dim3(ATTR_THREADS), sm, s, q_dev, k_dev, v_dev, out_dev, row_stride,
+                       reinterpret_cast<const OcrLine *>(lines_dev), klen_dev, Lmax, head_dim, tables->cos_t, tables->sin_t, tables->scale_t,
+                       tables->iscale_t, tables->pmax);
+    MIT_CHECK_LAUNCH("mit_attention_lines_xpos");
+    return 0;
+}
+
+extern "C" int mit_memory_kv_lines(const float *k_dev, const float *v_dev, int64_t row_stride, float *mem_k_dev, float *mem_v_dev,
+                                   int64_t line_stride, const int32_t *lines_dev, int n_lines, int first_line, int64_t n_rows, int Lmax,
+                                   int head_dim, const MitXposTables *tables, void *stream) {
+    if (!k_dev || !v_dev || !mem_k_dev || !mem_v_dev || !lines_dev) return mit_set_error("mit_memory_kv_lines: null pointer");
+    if (n_lines <= 0 || n_rows <= 0) return 0;
+    if ((row_stride & 1) || (line_stride & 1) || head_dim <= 0 || (head_dim & 1) || (row_stride % head_dim)) return mit_set_error("mit_memory_kv_lines: bad strides");
+    if (check_tables(tables, Lmax, -((Lmax + 1) / 2), Lmax, "mit_memory_kv_lines")) return 1;
+    const int pairs = (int)(row_stride / 2);
+    const int64_t total = n_rows * pairs;
+    hipStream_t s = (hipStream_t)stream;
+    MitProbeScope probe("memory_kv_lines_kernel", s, 16.0 * (double)n_rows * row_stride);
+    hipLaunchKernelGGL(memory_kv_lines_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, k_dev, v_dev, row_stride, mem_k_dev, mem_v_dev, line_stride,
+                       reinterpret_cast<const OcrLine *>(lines_dev), n_lines, first_line, head_dim / 2, pairs, tables->cos_t, tables->sin_t,
+                       tables->iscale_t, tables->pmax, total);
+    MIT_CHECK_LAUNCH("mit_memory_kv_lines");
     return 0;
 }
 

@@ -178,6 +178,7 @@ class Ocr48Engine:
         d.dict_size = dict_size
         self.dec = d
         self._ws: Dict[Tuple, torch.Tensor] = {}
+        self.per_chunk_attention = False   # True: the encoder's attention chunk by chunk (rotate q, rotate k, attention): the reference form for tests
 
     def _buf(self, name, *shape, dtype=torch.float32):
         """Named workspace slab, grown to the largest request (chunk widths vary from call to call; all users are
@@ -314,17 +315,36 @@ class Ocr48Engine:
         if first_lines is None:
             first_lines = np.concatenate([[0], np.cumsum(Ns)])[:-1].tolist()
         line0 = [int(f) for f in first_lines]
+        # one launch per layer for all lines of the group (XPOS rotation folded into the attention kernel) when the group's lines are
+        # consecutive in the pooled memory; else chunk by chunk (rotate q, rotate k, attention) — bitwise the same either way
+        ragged = all(line0[c + 1] == line0[c] + Ns[c] for c in range(nc - 1)) and max(Ls) <= 400 and not self.per_chunk_attention
+        if ragged:
+            tab = np.empty((sum(Ns), 2), dtype=np.int32)
+            i = 0
+            for c in range(nc):
+                tab[i:i + Ns[c], 0] = int(row0[c]) + np.arange(Ns[c], dtype=np.int64) * Ls[c]
+                tab[i:i + Ns[c], 1] = Ls[c]
+                i += Ns[c]
+            tab_pin = torch.from_numpy(tab).pin_memory()
+            lines_dev = tab_pin.to(self.device, non_blocking=True)
+            klen_g = klen_all[line0[0]:line0[0] + sum(Ns)]
+            Lg = int(max(Ls))
         for ly in self.enc:
             self._layernorm(mem, *ly.ln[0], nrm)
             ly.qkv(nrm, qkv[0], nsplit=EMBD, nhi=M * EMBD)
-            for c in range(nc):
-                N, L = Ns[c], Ls[c]
-                a, b = int(row0[c]), int(row0[c + 1])
-                minpos, LE = -((L + 1) // 2), L * EMBD
-                self._rotate(qkv[0][a:b], qr[a:b], N, L, 0, minpos, False, LE, EMBD, LE, EMBD)
-                self._rotate(qkv[1][a:b], kr[a:b], N, L, 0, minpos, True, LE, EMBD, LE, EMBD)
-                self._attention(qr[a:b], kr[a:b], qkv[2][a:b], att[a:b], klen_all[line0[c]:line0[c] + N], N, L, L, 1,
-                                ((LE, EMBD),) * 4)
+            if ragged:
+                _lib.check(lib.mit_attention_lines_xpos(qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), att.data_ptr(), EMBD,
+                                                        lines_dev.data_ptr(), klen_g.data_ptr(), sum(Ns), Lg, HEADS, HEAD_DIM,
+                                                        C.byref(self.xpos), st), "mit_attention_lines_xpos")
+            else:
+                for c in range(nc):
+                    N, L = Ns[c], Ls[c]
+                    a, b = int(row0[c]), int(row0[c + 1])
+                    minpos, LE = -((L + 1) // 2), L * EMBD
+                    self._rotate(qkv[0][a:b], qr[a:b], N, L, 0, minpos, False, LE, EMBD, LE, EMBD)
+                    self._rotate(qkv[1][a:b], kr[a:b], N, L, 0, minpos, True, LE, EMBD, LE, EMBD)
+                    self._attention(qr[a:b], kr[a:b], qkv[2][a:b], att[a:b], klen_all[line0[c]:line0[c] + N], N, L, L, 1,
+                                    ((LE, EMBD),) * 4)
             ly.out(att, mem, post=mem)
             self._layernorm(mem, *ly.ln[1], nrm)
             ly.ff1(nrm, ffh, act=ACT_RELU)
@@ -336,11 +356,18 @@ class Ocr48Engine:
         vtmp = self._buf("g.vtmp", M, EMBD)
         for l in range(5):
             self.mem_kv[l](mem, ktmp, nsplit=EMBD, nhi=(vtmp.data_ptr() - ktmp.data_ptr()) // 4)
+            if ragged:
+                _lib.check(lib.mit_memory_kv_lines(ktmp.data_ptr(), vtmp.data_ptr(), EMBD, mem_k[l].data_ptr(), mem_v[l].data_ptr(),
+                                                   mem_k.shape[2] * EMBD, lines_dev.data_ptr(), sum(Ns), line0[0], M, Lg, HEAD_DIM,
+                                                   C.byref(self.xpos), st), "mit_memory_kv_lines")
+                continue
             for c in range(nc):
                 N, L = Ns[c], Ls[c]
                 a, b, l0 = int(row0[c]), int(row0[c + 1]), int(line0[c])
                 self._rotate(ktmp[a:b], mem_k[l, l0:l0 + N], N, L, 0, -((L + 1) // 2), True, L * EMBD, EMBD, Lmax * EMBD, EMBD)
                 mem_v[l, l0:l0 + N, :L].copy_(vtmp[a:b].view(N, L, EMBD))
+        if ragged:
+            stage = (stage, tab_pin, lines_dev)
         return (mem_k, mem_v, (stage, tab_dev)) if own else (stage, tab_dev)
 
     def _rotate(self, src, dst, R, T, i0, p0, downscale, src_rs, src_ts, dst_rs, dst_ts):

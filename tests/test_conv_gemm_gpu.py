@@ -69,7 +69,7 @@ CASES = [
     (1, 64, 16, 31, 17, 3, 1, 1, "zero", 1, True, "128x32x16"),
     (1, 80, 320, 12, 40, 1, 1, 0, "zero", 5, False, "128x64x16"),
     (1, 32, 64, 8, 8, 3, 1, 1, "zero", 0, False, "128x64x16"),
-    (1, 160, 160, 6, 33, (2, "128x64x16"), (2, 1), 0, "zero", 1, True, -1),
+    (1, 160, 160, 6, 33, (2, 1), (2, 1), 0, "zero", 1, True, None),
     (2, 64, 1, 20, 24, 3, 1, 1, "zero", 4, True, None),      # N = 1: conv_gemv_kernel, 16 lanes per row
     (1, 16, 1, 19, 21, 1, 1, 0, "zero", 4, False, None),     # N = 1, Cin = 16: 4 lanes per row
     (1, 16, 2, 15, 18, 3, 1, 1, "reflect", 1, True, "gemv4"),   # N = 2 forced onto gemv4

@@ -167,6 +167,29 @@ def test_group_encode_equals_per_chunk(cuda, ocr_setup):
         l0 += n
 
 
+def test_ragged_xpos_attention_equals_the_per_chunk_launches(cuda, ocr_setup):
+    """mit_attention_lines_xpos / mit_memory_kv_lines (one launch per encoder layer / decoder layer for all lines of a group, XPOS
+    rotation folded in) against the per-chunk form of the same engine (mit_xpos_rotate x 2 + mit_attention per chunk): bitwise."""
+    sd, D, eng = ocr_setup
+    crops = _crops([30 + 11 * i for i in range(37)], seed=4)  # 3 chunks of 16 + 16 + 5 lines, three memory lengths
+    chunks = list(eng.make_chunks(crops))
+    regions = [torch.from_numpy(r).to(cuda) for _, _, r in chunks]
+    Ls = [eng.memory_len(r.shape[2]) for r in regions]
+    assert len(set(Ls)) == 3
+    klens = torch.tensor([eng.valid_len(w, L) for (_, ws, _), L in zip(chunks, Ls) for w in ws], dtype=torch.int32, device=cuda)
+    assert not eng.per_chunk_attention
+    gk, gv, _ = eng.encode_group(regions, klens, max(Ls))
+    gk, gv = gk.clone(), gv.clone()
+    eng.per_chunk_attention = True
+    try:
+        pk, pv, _ = eng.encode_group(regions, klens, max(Ls))
+    finally:
+        eng.per_chunk_attention = False
+    torch.cuda.synchronize()
+    assert torch.equal(gk, pk) and torch.equal(gv, pv)
+    assert gk.abs().sum() > 0
+
+
 @pytest.mark.parametrize("G,Tk,heads,hd", [(5, 70, 4, 80), (5, 200, 4, 80), (3, 64, 8, 40), (8, 129, 2, 16)])
 def test_shared_kv_attention_bitwise_equals_per_row(cuda, G, Tk, heads, hd):
     """The beams of a line share the K / V block (kv_div = beams): the shared-K/V kernel must give bit for bit what the
