@@ -24,7 +24,7 @@ constexpr int E = 320;
 constexpr int FF = 2048;
 
 struct Ws {
-    float *tgt, *nrm, *qkv, *krot, *qrot, *att, *q2, *ffh, *decoded, *p1, *logits, *vals, *logp, *cfeat, *part;
+    float *tgt, *nrm, *qkv, *att, *q2, *ffh, *decoded, *p1, *logits, *vals, *logp, *cfeat, *part;
     int *idx, *hist, *done, *done_count, *dstep;
 };
 
@@ -50,8 +50,6 @@ int64_t carve(Ws *w, char *base, int N, int T, int D) {
     float *tgt = (float *)take(R * E * 4);
     float *nrm = (float *)take(R * E * 4);
     float *qkv = (float *)take(5 * 3 * R * T * E * 4);
-    float *krot = (float *)take(R * T * E * 4);
-    float *qrot = (float *)take(R * E * 4);
     float *att = (float *)take(R * E * 4);
     float *q2 = (float *)take(R * E * 4);
     float *ffh = (float *)take(R * FF * 4);
@@ -67,7 +65,7 @@ int64_t carve(Ws *w, char *base, int N, int T, int D) {
     int *done = (int *)take((int64_t)N * 4);
     int *done_count = (int *)take(256);
     int *dstep = (int *)take(256);
-    if (w) *w = Ws{tgt, nrm, qkv, krot, qrot, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, part, idx, hist, done, done_count, dstep};
+    if (w) *w = Ws{tgt, nrm, qkv, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, part, idx, hist, done, done_count, dstep};
     return off;
 }
 
@@ -159,7 +157,6 @@ __global__ void copy_hist_kernel(const int *src, int *dst, int64_t n) {
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
-inline int neg_ceil_half(int n) { return -((n + 1) / 2); }  // python: -(n) // 2
 
 // instantiated step graphs whose launches may still be in flight; destroyed once their event has completed
 struct PendingGraph {
@@ -224,7 +221,6 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
         const int64_t so = dyn ? 0 : (int64_t)step * E;  // host-side step offset; the dyn form adds step * E on the device
         if (dyn) ocrk_embed(hist[0], hist_ld, dec->embd, w.tgt, R, E, st, hist[1], dyn);
         else ocrk_embed(hist[cur] + step, hist_ld, dec->embd, w.tgt, R, E, st);
-        const int minpos = neg_ceil_half(step + 1);
         const int Tk = dyn ? T : step + 1;  // dyn: capacity (grid / LDS); the kernels stop at *dyn + 1
         for (int l = 0; l < 5; ++l) {
             const MitOcrDecoderLayer &ly = dec->layers[l];
@@ -234,17 +230,17 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
             // self attention (:565)
             ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, w.nrm, E, R, E, 1e-5f, st);
             if (gemm(ly.qkv, w.nrm, E, qc + so, TE, R, MIT_ACT_NONE, nullptr, 0, st, E, (int64_t)R * TE, nullptr, dyn, 0, E)) return 1;
-            ocrk_xpos_rotate(qc + so, TE, E, w.qrot, E, E, R, 1, step, step + minpos, 0, dec->xpos, st, dyn, 1, E);
-            ocrk_xpos_rotate(kc, TE, E, w.krot, TE, E, R, Tk, 0, minpos, 1, dec->xpos, st, dyn, 2, 0);
-            ocrk_attention(w.qrot, E, E, w.krot, TE, E, vc, TE, E, w.att, E, E, nullptr, R, 1, Tk, 1, st, 4, 80, dyn);
+            // (the XPOS rotation of the step's query and of the key history 0 .. step happens inside the attention kernel)
+            OcrAttXpos xs{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 1, E};
+            ocrk_attention(qc + so, TE, E, kc, TE, E, vc, TE, E, w.att, E, E, nullptr, R, 1, Tk, 1, st, 4, 80, dyn, &xs);
             if (gemm(ly.out, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
             // cross attention (:567)
             ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, w.nrm, E, R, E, 1e-5f, st);
             if (gemm(ly.q2, w.nrm, E, w.q2, E, R, MIT_ACT_NONE, nullptr, 0, st)) return 1;
-            ocrk_xpos_rotate(w.q2, E, E, w.qrot, E, E, R, 1, step, step + minpos, 0, dec->xpos, st, dyn, 1, 0);
             const float *mk = a->mem_k + (int64_t)l * N * L * E;
             const float *mv = a->mem_v + (int64_t)l * N * L * E;
-            ocrk_attention(w.qrot, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, w.att, E, E, a->mem_len, R, 1, L, 5, st);
+            OcrAttXpos xc{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 0, 0};
+            ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, w.att, E, E, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc);
             if (gemm(ly.out2, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
             // feed forward (:568)
             ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, st);

@@ -10,9 +10,19 @@ void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float 
 void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
                       int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s, const int *dstep = nullptr, int dyn_mode = 0,
                       int64_t dyn_in = 0);
+// XPOS rotation folded into the decoder's one-query attention (Tq == 1): the query is the token of position `step` (scaled up), and
+// with rot_k the keys are the raw history 0 .. step, rotated (scaled down) as they are read — positions centred on the history,
+// origin -((step + 2) / 2).  The rotated value of an element is xpos_rotate_kernel's fp32 expression, so the result is bitwise the one
+// of rotate + (rotate +) attention.  dstep != NULL: step = *dstep and the query row starts step * q_dyn floats further.
+struct OcrAttXpos {
+    const float *cos_t, *sin_t, *scale_t, *iscale_t;   // cos_t == NULL: no rotation
+    int pmax, step, rot_k;
+    int64_t q_dyn;
+};
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
-                    int kv_div, hipStream_t s, int heads = 4, int head_dim = 80, const int *dstep = nullptr);
+                    int kv_div, hipStream_t s, int heads = 4, int head_dim = 80, const int *dstep = nullptr,
+                    const OcrAttXpos *xpos = nullptr);
 void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s, const int *tok1 = nullptr,
                 const int *dstep = nullptr);
 void ocrk_beam_dyn(const float *vals, const int *idx, int *hist0, int *hist1, int hist_ld, float *logp0, float *logp1, int *done,

@@ -407,8 +407,11 @@ __global__ void xpos_rotate_kernel(const float *__restrict__ in, int64_t in_rs, 
 __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int64_t q_ts, const float *__restrict__ K,
                                  int64_t k_rs, int64_t k_ts, const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
                                  float *__restrict__ O, int64_t o_rs, int64_t o_ts, const int *__restrict__ klen, int Tk,
-                                 int kv_div, int HD, const int *__restrict__ dstep) {
-    if (dstep) Tk = *dstep + 1;     // the decoder's self-attention over the tokens 0 .. step (LDS is sized for the longest history)
+                                 int kv_div, int HD, const int *__restrict__ dstep, OcrAttXpos xp) {
+    // dstep without folded rotation / with rotated keys: the decoder's self-attention over the tokens 0 .. step (LDS is sized for the longest history)
+    if (dstep && (!xp.cos_t || xp.rot_k)) Tk = *dstep + 1;
+    const int step = dstep ? *dstep : xp.step;
+    const int minpos = -((step + 2) / 2);
     extern __shared__ float lds[];  // [HD] q + [Tk] weights
     float *qs = lds;
     float *ws = lds + HD;
@@ -416,7 +419,20 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
     const int lane = threadIdx.x;
     const int kr = r / kv_div;
     const float *q = Q + (int64_t)r * q_rs + (int64_t)tq * q_ts + h * HD;
-    for (int d = lane; d < HD; d += 64) qs[d] = q[d];
+    const int HP = HD / 2;
+    if (xp.cos_t) {  // the query of position `step`, rotated on the way into LDS (xpos_rotate_kernel's expression, scale up)
+        if (dstep) q += (int64_t)step * xp.q_dyn;
+        const int pp = step + minpos + xp.pmax;
+        for (int j = lane; j < HP; j += 64) {
+            const float sc = xp.scale_t[pp * HP + j];
+            const float c = xp.cos_t[step * HP + j] * sc, sn = xp.sin_t[step * HP + j] * sc;
+            const float2 x = *reinterpret_cast<const float2 *>(q + 2 * j);
+            qs[2 * j] = x.x * c + (-x.y) * sn;
+            qs[2 * j + 1] = x.y * c + x.x * sn;
+        }
+    } else {
+        for (int d = lane; d < HD; d += 64) qs[d] = q[d];
+    }
     __syncthreads();
     const int valid = klen ? min(klen[kr], Tk) : Tk;
     const float *kb = K + (int64_t)kr * k_rs + h * HD;
@@ -426,12 +442,34 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
         if (t < valid) {
             const float4 *kp = reinterpret_cast<const float4 *>(kb + (int64_t)t * k_ts);
             dot = 0.f;
-            for (int d4 = 0; d4 < HD / 4; ++d4) {
-                const float4 kv = kp[d4];
-                dot += qs[d4 * 4 + 0] * kv.x;
-                dot += qs[d4 * 4 + 1] * kv.y;
-                dot += qs[d4 * 4 + 2] * kv.z;
-                dot += qs[d4 * 4 + 3] * kv.w;
+            if (xp.cos_t && xp.rot_k) {  // key t of the raw history, rotated (scale down) as it is read
+                const float4 *cp = reinterpret_cast<const float4 *>(xp.cos_t + t * HP);
+                const float4 *sp = reinterpret_cast<const float4 *>(xp.sin_t + t * HP);
+                const float4 *ip = reinterpret_cast<const float4 *>(xp.iscale_t + (minpos + t + xp.pmax) * HP);
+                for (int d8 = 0; d8 < HD / 8; ++d8) {
+                    const float4 k0 = kp[2 * d8], k1 = kp[2 * d8 + 1], cc = cp[d8], ss = sp[d8], ii = ip[d8];
+                    float c, sn;
+                    c = cc.x * ii.x, sn = ss.x * ii.x;
+                    dot += qs[d8 * 8 + 0] * (k0.x * c + (-k0.y) * sn);
+                    dot += qs[d8 * 8 + 1] * (k0.y * c + k0.x * sn);
+                    c = cc.y * ii.y, sn = ss.y * ii.y;
+                    dot += qs[d8 * 8 + 2] * (k0.z * c + (-k0.w) * sn);
+                    dot += qs[d8 * 8 + 3] * (k0.w * c + k0.z * sn);
+                    c = cc.z * ii.z, sn = ss.z * ii.z;
+                    dot += qs[d8 * 8 + 4] * (k1.x * c + (-k1.y) * sn);
+                    dot += qs[d8 * 8 + 5] * (k1.y * c + k1.x * sn);
+                    c = cc.w * ii.w, sn = ss.w * ii.w;
+                    dot += qs[d8 * 8 + 6] * (k1.z * c + (-k1.w) * sn);
+                    dot += qs[d8 * 8 + 7] * (k1.w * c + k1.z * sn);
+                }
+            } else {
+                for (int d4 = 0; d4 < HD / 4; ++d4) {
+                    const float4 kv = kp[d4];
+                    dot += qs[d4 * 4 + 0] * kv.x;
+                    dot += qs[d4 * 4 + 1] * kv.y;
+                    dot += qs[d4 * 4 + 2] * kv.z;
+                    dot += qs[d4 * 4 + 3] * kv.w;
+                }
             }
         }
         ws[t] = dot;
@@ -503,7 +541,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
                                                                           const float *__restrict__ K, int64_t k_rs, int64_t k_ts,
                                                                           const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
                                                                           float *__restrict__ O, int64_t o_rs,
-                                                                          const int *__restrict__ klen, int Tk, int G, int HD) {
+                                                                          const int *__restrict__ klen, int Tk, int G, int HD,
+                                                                          const int *__restrict__ dstep, OcrAttXpos xp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int KP = HD + 4;                    // 16-byte aligned rows; lane t reads row t as float4s (pitch 84: conflict-free per 16 lanes)
     float *qs = lds;                          // [G][HD]
@@ -512,7 +551,22 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
     const int h = blockIdx.x, kr = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = kr * G;
-    for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = Q[(int64_t)(r0 + i / HD) * q_rs + h * HD + (i % HD)];
+    if (xp.cos_t) {  // the beams' queries of position `step`, rotated on the way into LDS (xpos_rotate_kernel's expression, scale up)
+        const int step = dstep ? *dstep : xp.step;
+        const int HP = HD / 2;
+        const int pp = step + -((step + 2) / 2) + xp.pmax;
+        const int64_t qo = dstep ? (int64_t)step * xp.q_dyn : 0;
+        for (int i = tid; i < G * HP; i += ATT_THREADS) {
+            const int g = i / HP, j = i - g * HP;
+            const float sc = xp.scale_t[pp * HP + j];
+            const float c = xp.cos_t[step * HP + j] * sc, sn = xp.sin_t[step * HP + j] * sc;
+            const float2 x = *reinterpret_cast<const float2 *>(Q + qo + (int64_t)(r0 + g) * q_rs + h * HD + 2 * j);
+            qs[g * HD + 2 * j] = x.x * c + (-x.y) * sn;
+            qs[g * HD + 2 * j + 1] = x.y * c + x.x * sn;
+        }
+    } else {
+        for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = Q[(int64_t)(r0 + i / HD) * q_rs + h * HD + (i % HD)];
+    }
     const int valid = klen ? min(klen[kr], Tk) : Tk;
     const int HD4 = HD / 4;
     float4 stage[ATT_STAGE];
@@ -1102,8 +1156,11 @@ __global__ void memory_kv_lines_kernel(const float *__restrict__ Kf, const float
 
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
-                    int kv_div, hipStream_t s, int heads, int head_dim, const int *dstep) {
-    if (!dstep && Tq == 1 && kv_div > 1 && kv_div <= ATT_G_MAX && R % kv_div == 0 && R / kv_div <= 65535 && 2 * head_dim <= ATT_THREADS &&
+                    int kv_div, hipStream_t s, int heads, int head_dim, const int *dstep, const OcrAttXpos *xpos) {
+    OcrAttXpos xp{};
+    if (xpos) xp = *xpos;
+    // (the shared-K/V form never shortens Tk by the step counter: with a step counter it is only used for the rotated query)
+    if ((!dstep || (xp.cos_t && !xp.rot_k)) && Tq == 1 && kv_div > 1 && kv_div <= ATT_G_MAX && R % kv_div == 0 && R / kv_div <= 65535 && 2 * head_dim <= ATT_THREADS &&
         ATT_KCHUNK * (head_dim / 4) <= ATT_STAGE * ATT_THREADS) {
         const size_t sm = ((size_t)kv_div * head_dim + (size_t)ATT_KCHUNK * (head_dim + 4) + (size_t)kv_div * Tk) * sizeof(float);
         if (sm <= 64 * 1024) {
@@ -1111,12 +1168,12 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
             MitProbeScope probe("attention_shared_kv_kernel", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * R),
                                 4.0 * (double)R * heads * Tk * head_dim);
             hipLaunchKernelGGL(attention_shared_kv_kernel, dim3(heads, R / kv_div), dim3(ATT_THREADS), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts,
-                               O, o_rs, klen, Tk, kv_div, head_dim);
+                               O, o_rs, klen, Tk, kv_div, head_dim, dstep, xp);
             return;
         }
     }
     static const bool no_rows = getenv("MIT_ATT_NO_ROWS") != nullptr;
-    if (!no_rows && !dstep && kv_div == 1 && Tq >= 2 * ATTR_GQ && R <= 65535 && Tq <= 65535 * 32 && head_dim <= 128 && ((q_rs | q_ts | k_rs | k_ts | v_rs | v_ts) & 3) == 0) {
+    if (!no_rows && !dstep && !xp.cos_t && kv_div == 1 && Tq >= 2 * ATTR_GQ && R <= 65535 && Tq <= 65535 * 32 && head_dim <= 128 && ((q_rs | q_ts | k_rs | k_ts | v_rs | v_ts) & 3) == 0) {
         const size_t sm = ((size_t)Tk * (head_dim + 4) + (size_t)(ATTR_THREADS / 64) * ATTR_GQ * (head_dim + Tk)) * sizeof(float);
         if (sm <= 150 * 1024 && head_dim % 8 == 0) {
             // algorithmic bytes: q, k, v read once and o written once per row; FLOPs 4 Tk d per query and head
@@ -1140,7 +1197,7 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
     MitProbeScope probe("attention_kernel", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * (double)R * Tq),
                         4.0 * (double)R * Tq * heads * Tk * head_dim);
     hipLaunchKernelGGL(attention_kernel, dim3(Tq, heads, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
-                       o_ts, klen, Tk, kv_div, head_dim, dstep);   // dstep: Tk = the LDS capacity, the kernel attends to *dstep + 1 keys
+                       o_ts, klen, Tk, kv_div, head_dim, dstep, xp);   // dstep: Tk = the LDS capacity, the kernel attends to *dstep + 1 keys
 }
 
 void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s, const int *tok1,
