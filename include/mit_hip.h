@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 7
+#define MIT_ABI_VERSION 8
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -635,6 +635,12 @@ int mit_logsoftmax_top5(const float *logits_dev, int64_t ld, int R, int D, int s
  * log-softmax/top-5 -> beam bookkeeping, all on `stream`; synchronises the stream every few steps to test for early exit. */
 int64_t mit_ocr48_decode_workspace_bytes(int N, int T, int dict_size);
 int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *args, void *stream);
+/* Largest number of decoder rows (5 N: lines x beams) whose steps run in the few-row form — every Linear of a step as one wave per
+ * 32 x 32 output block on bf16-plane activations (pgemm_rows_kernel), the LayerNorm / attention kernels producing the planes — instead
+ * of the tiled form that pays off on full batches.  Both forms give identical results (tests/test_ocr_gpu.py); the few-row one takes a
+ * third of the time per Linear at one page.  Needs GEMM mode 6 | 9.  rows < 0 only queries; 0 = never.  Initial value: MIT_OCR_ROWS_MAX in
+ * the environment, else 2560 (16 pages of 32 lines).  Returns the previous value.  Nothing in the reference corresponds to it. */
+int mit_ocr48_decode_rows_max_set(int rows);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 // Included at the end of conv_gemm_kernels.h (it shares that header's epilogue, RowOff and launch conventions); instantiated by
 // conv_gemm_inst5 / 6 / 7.hip through conv_gemm_cfgs.inc.
 #pragma once
+#include "bf16_split.h"
 
 namespace mitcg {
 
@@ -20,42 +21,6 @@ namespace mitcg {
 // Range precondition: finite operands with |x| <= the largest bf16 (3.39e38).  hi = bf16(x) of a larger (or infinite) x is Inf and
 // the residual x - Inf is -Inf / NaN, so such an operand yields NaN here where the fp32 MFMA yields Inf or a finite value.  Activations
 // and weights of the networks on this path are many orders of magnitude inside the range.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: a in the low half, round to nearest even
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(unsigned int pk) { return __uint_as_float(pk << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned int pk) { return __uint_as_float(pk & 0xffff0000u); }
-
-template <bool ASM_SUB>
-__device__ __forceinline__ float sub_f32(float a, float b) {
-    if (ASM_SUB) {
-        float r;
-        asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-        return r;
-    }
-    return a - b;
-}
-template <bool ASM_SUB = false>
-__device__ __forceinline__ void split3(const f32x4 x, u32x2 &h, u32x2 &m, u32x2 &l) {
-    h.x = pack_bf16(x.x, x.y);
-    h.y = pack_bf16(x.z, x.w);
-    const float r0 = sub_f32<ASM_SUB>(x.x, bf16_lo(h.x)), r1 = sub_f32<ASM_SUB>(x.y, bf16_hi(h.x));
-    const float r2 = sub_f32<ASM_SUB>(x.z, bf16_lo(h.y)), r3 = sub_f32<ASM_SUB>(x.w, bf16_hi(h.y));
-    m.x = pack_bf16(r0, r1);
-    m.y = pack_bf16(r2, r3);
-    const float s0 = sub_f32<ASM_SUB>(r0, bf16_lo(m.x)), s1 = sub_f32<ASM_SUB>(r1, bf16_hi(m.x));
-    const float s2 = sub_f32<ASM_SUB>(r2, bf16_lo(m.y)), s3 = sub_f32<ASM_SUB>(r3, bf16_hi(m.y));
-    l.x = pack_bf16(s0, s1);
-    l.y = pack_bf16(s2, s3);
-}
-
 // plane pairs, smallest products first; NPROD takes the last NPROD entries
 __device__ constexpr int kSplitPA[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
 __device__ constexpr int kSplitPB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};

@@ -15,8 +15,10 @@
 #include <string.h>
 #include <vector>
 #include "../../include/mit_hip.h"
+#include <atomic>
 #include "common.h"
 #include "ocr_kernels.h"
+#include "pgemm_rows.h"
 
 namespace {
 
@@ -26,6 +28,9 @@ constexpr int FF = 2048;
 struct Ws {
     float *tgt, *nrm, *qkv, *att, *q2, *ffh, *decoded, *p1, *logits, *vals, *logp, *cfeat, *part;
     int *idx, *hist, *done, *done_count, *dstep;
+    // the few-row form (rows_path): activations that only feed a Linear live as bf16 planes [3][K / 8][Rp][8] (pgemm_rows.h)
+    uint16_t *nrm_p, *att_p, *ffh_p, *dec_p, *p1_p;
+    int64_t Rp;
 };
 
 // Few rows, long contraction (the FFN's second Linear, K = 2048, at one page: R = lines x beams = 160 rows): a 64-row tiling is
@@ -65,7 +70,14 @@ int64_t carve(Ws *w, char *base, int N, int T, int D) {
     int *done = (int *)take((int64_t)N * 4);
     int *done_count = (int *)take(256);
     int *dstep = (int *)take(256);
-    if (w) *w = Ws{tgt, nrm, qkv, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, part, idx, hist, done, done_count, dstep};
+    const int64_t Rp = (R + 31) / 32 * 32;
+    uint16_t *nrm_p = (uint16_t *)take(3 * E * Rp * 2);
+    uint16_t *att_p = (uint16_t *)take(3 * E * Rp * 2);
+    uint16_t *ffh_p = (uint16_t *)take(3 * FF * Rp * 2);
+    uint16_t *dec_p = (uint16_t *)take(3 * E * Rp * 2);
+    uint16_t *p1_p = (uint16_t *)take(3 * E * Rp * 2);
+    if (w) *w = Ws{tgt, nrm, qkv, att, q2, ffh, decoded, p1, logits, vals, logp, cfeat, part, idx, hist, done, done_count, dstep,
+                   nrm_p, att_p, ffh_p, dec_p, p1_p, Rp};
     return off;
 }
 
@@ -145,6 +157,28 @@ int gemm(const MitLinear &lin, const float *A, int64_t lda, float *Cp, int64_t l
     return mit_conv_gemm(&d, s);
 }
 
+// The same Linear on planar activations (pgemm_rows.h): C fp32 (optional, with the column split / step offset of gemm()) and / or planes.
+int pgemm(const MitLinear &lin, const uint16_t *a_planes, int64_t lda, int M, float *Cp, int64_t ldc, int act, const float *post,
+          int64_t ldpost, uint16_t *c_planes, int64_t ld_cp, hipStream_t s, int nsplit = 0, int64_t nhi = 0, const int *dyn = nullptr,
+          int64_t c_dyn = 0) {
+    MitPGemm d;
+    memset(&d, 0, sizeof(d));
+    d.a_planes = a_planes; d.lda = lda;
+    d.w_planes = lin.w_split; d.ldw = lin.ldw;
+    d.M = M; d.N = lin.N; d.K = lin.K; d.Z = 1;
+    d.c = Cp; d.ldc = ldc;
+    d.post = post; d.ld_post = ldpost;
+    d.scale = lin.scale; d.bias = lin.bias; d.act = act;
+    d.nprod = 0;  // the GEMM mode of the moment
+    PgRowsExt x;
+    memset(&x, 0, sizeof(x));
+    x.nsplit = nsplit; x.nhi = nhi; x.dyn = dyn; x.c_dyn = c_dyn;
+    if (Cp) x.also_planes = c_planes, x.also_ld = ld_cp;
+    else d.c_planes = c_planes, d.ld_cp = ld_cp;
+    return mit_pgemm_rows(d, x, s);
+}
+inline bool rows_ok(const MitLinear &l) { return l.w_split && l.Kp == l.K && (l.K % 16) == 0 && (l.N % 8) == 0; }
+
 __global__ void fill_int_kernel(int *p, int64_t n, int v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -183,6 +217,26 @@ void reap_graphs() {
 
 }  // namespace
 
+namespace {
+std::atomic<int> g_rows_max{-1};
+int rows_max_now() {
+    int v = g_rows_max.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("MIT_OCR_ROWS_MAX");
+        v = (e && *e) ? atoi(e) : 2560;
+        if (v < 0) v = 0;
+        g_rows_max.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+}  // namespace
+
+extern "C" int mit_ocr48_decode_rows_max_set(int rows) {
+    const int prev = rows_max_now();
+    if (rows >= 0) g_rows_max.store(rows, std::memory_order_relaxed);
+    return prev;
+}
+
 extern "C" int64_t mit_ocr48_decode_workspace_bytes(int N, int T, int dict_size) {
     if (N <= 0 || T <= 0 || dict_size <= 0) return 0;
     return carve(nullptr, nullptr, N, T, dict_size);
@@ -217,42 +271,88 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
     // ``dyn`` != nullptr: every kernel takes them from the device-resident counter w.dstep, so the SAME sequence serves every step and
     // can be replayed from a hipGraph (one graph launch instead of 74 kernel launches per step: at one page — R = 160 rows — the loop
     // was bound by launch cost, not by its kernels).  Both forms run the same kernels on the same operands: identical results.
+    // rows_path: the few-row form of a step (see body).  mit_ocr48_decode_rows_max_set: largest R = 5 N it is used for; measured equal to
+    // the 64 x 64 split tiles at R = 2560 (16 pages) and 2-3.5x faster per Linear at R = 160 .. 640 (profiles/r04u_pgemm_rows.log)
+    const int rows_max = rows_max_now();
+    static const bool splitk_env = getenv("MIT_OCR_SPLITK") != nullptr && atoi(getenv("MIT_OCR_SPLITK")) != 0;
+    const int gmode = mit_gemm_mode_get();
+    bool rows_path = (gmode == 6 || gmode == 9) && R <= rows_max && !splitk_env && rows_ok(dec->pred1) && dec->pred.w_split &&
+                     dec->pred.Kp == dec->pred.K && (dec->pred.K % 16) == 0 && (dec->pred.N % 4) == 0;
+    for (int l = 0; l < 5 && rows_path; ++l) {
+        const MitOcrDecoderLayer &ly = dec->layers[l];
+        rows_path = rows_ok(ly.qkv) && rows_ok(ly.out) && rows_ok(ly.q2) && rows_ok(ly.out2) && rows_ok(ly.ff1) && rows_ok(ly.ff2);
+    }
     auto body = [&](const int step, const int *dyn, hipStream_t st) -> int {
         const int64_t so = dyn ? 0 : (int64_t)step * E;  // host-side step offset; the dyn form adds step * E on the device
         if (dyn) ocrk_embed(hist[0], hist_ld, dec->embd, w.tgt, R, E, st, hist[1], dyn);
         else ocrk_embed(hist[cur] + step, hist_ld, dec->embd, w.tgt, R, E, st);
         const int Tk = dyn ? T : step + 1;  // dyn: capacity (grid / LDS); the kernels stop at *dyn + 1
-        for (int l = 0; l < 5; ++l) {
-            const MitOcrDecoderLayer &ly = dec->layers[l];
-            float *qc = w.qkv + (int64_t)(l * 3 + 0) * R * TE;
-            float *kc = w.qkv + (int64_t)(l * 3 + 1) * R * TE;
-            float *vc = w.qkv + (int64_t)(l * 3 + 2) * R * TE;
-            // self attention (:565)
-            ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, w.nrm, E, R, E, 1e-5f, st);
-            if (gemm(ly.qkv, w.nrm, E, qc + so, TE, R, MIT_ACT_NONE, nullptr, 0, st, E, (int64_t)R * TE, nullptr, dyn, 0, E)) return 1;
-            // (the XPOS rotation of the step's query and of the key history 0 .. step happens inside the attention kernel)
-            OcrAttXpos xs{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 1, E};
-            ocrk_attention(qc + so, TE, E, kc, TE, E, vc, TE, E, w.att, E, E, nullptr, R, 1, Tk, 1, st, 4, 80, dyn, &xs);
-            if (gemm(ly.out, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
-            // cross attention (:567)
-            ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, w.nrm, E, R, E, 1e-5f, st);
-            if (gemm(ly.q2, w.nrm, E, w.q2, E, R, MIT_ACT_NONE, nullptr, 0, st)) return 1;
-            const float *mk = a->mem_k + (int64_t)l * N * L * E;
-            const float *mv = a->mem_v + (int64_t)l * N * L * E;
-            OcrAttXpos xc{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 0, 0};
-            ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, w.att, E, E, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc);
-            if (gemm(ly.out2, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
-            // feed forward (:568)
-            ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, st);
-            if (gemm(ly.ff1, w.nrm, E, w.ffh, FF, R, MIT_ACT_RELU, nullptr, 0, st)) return 1;
-            if (l < 4) {
-                if (gemm(ly.ff2, w.ffh, FF, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st, 0, 0, w.part)) return 1;
-            } else {  // last layer writes the step's output straight into the activation cache (:570)
-                if (gemm(ly.ff2, w.ffh, FF, w.decoded + so, TE, R, MIT_ACT_NONE, w.tgt, E, st, 0, 0, dyn ? nullptr : w.part, dyn, 0, E)) return 1;
+        if (rows_path) {
+            // few rows (one page .. a group of pages): every Linear on the one-wave-per-block planar GEMM (pgemm_rows.h) — the LayerNorms,
+            // the attention kernels and the ReLU / GELU epilogues hand over bf16 planes, the residual stream and the K / V caches stay
+            // fp32.  Same kernels' arithmetic, same plane split, same MFMA order as the tiles of the other form: identical results.
+            const int64_t Rp = w.Rp;
+            const OcrPlanes nrm_pl{w.nrm_p, Rp, E / 8}, att_pl{w.att_p, Rp, E / 8};
+            for (int l = 0; l < 5; ++l) {
+                const MitOcrDecoderLayer &ly = dec->layers[l];
+                float *qc = w.qkv + (int64_t)(l * 3 + 0) * R * TE;
+                float *kc = w.qkv + (int64_t)(l * 3 + 1) * R * TE;
+                float *vc = w.qkv + (int64_t)(l * 3 + 2) * R * TE;
+                ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl);
+                if (pgemm(ly.qkv, w.nrm_p, Rp, R, qc + so, TE, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st, E, (int64_t)R * TE, dyn, E)) return 1;
+                OcrAttXpos xs{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 1, E};
+                ocrk_attention(qc + so, TE, E, kc, TE, E, vc, TE, E, nullptr, 0, 0, nullptr, R, 1, Tk, 1, st, 4, 80, dyn, &xs, &att_pl);
+                if (pgemm(ly.out, w.att_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
+                ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl);
+                if (pgemm(ly.q2, w.nrm_p, Rp, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st)) return 1;
+                const float *mk = a->mem_k + (int64_t)l * N * L * E;
+                const float *mv = a->mem_v + (int64_t)l * N * L * E;
+                OcrAttXpos xc{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 0, 0};
+                ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, nullptr, 0, 0, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc, &att_pl);
+                if (pgemm(ly.out2, w.att_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
+                ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl);
+                if (pgemm(ly.ff1, w.nrm_p, Rp, R, nullptr, 0, MIT_ACT_RELU, nullptr, 0, w.ffh_p, Rp, st)) return 1;
+                if (l < 4) {
+                    if (pgemm(ly.ff2, w.ffh_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
+                } else {  // last layer: the step's output into the activation cache (:570), and as planes for the prediction head
+                    if (pgemm(ly.ff2, w.ffh_p, Rp, R, w.decoded + so, TE, MIT_ACT_NONE, w.tgt, E, w.dec_p, Rp, st, 0, 0, dyn, E)) return 1;
+                }
             }
+            if (pgemm(dec->pred1, w.dec_p, Rp, R, nullptr, 0, MIT_ACT_GELU, nullptr, 0, w.p1_p, Rp, st)) return 1;
+            if (pgemm(dec->pred, w.p1_p, Rp, R, w.logits, Dp, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st)) return 1;
+        } else {
+            for (int l = 0; l < 5; ++l) {
+                const MitOcrDecoderLayer &ly = dec->layers[l];
+                float *qc = w.qkv + (int64_t)(l * 3 + 0) * R * TE;
+                float *kc = w.qkv + (int64_t)(l * 3 + 1) * R * TE;
+                float *vc = w.qkv + (int64_t)(l * 3 + 2) * R * TE;
+                // self attention (:565)
+                ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, w.nrm, E, R, E, 1e-5f, st);
+                if (gemm(ly.qkv, w.nrm, E, qc + so, TE, R, MIT_ACT_NONE, nullptr, 0, st, E, (int64_t)R * TE, nullptr, dyn, 0, E)) return 1;
+                // (the XPOS rotation of the step's query and of the key history 0 .. step happens inside the attention kernel)
+                OcrAttXpos xs{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 1, E};
+                ocrk_attention(qc + so, TE, E, kc, TE, E, vc, TE, E, w.att, E, E, nullptr, R, 1, Tk, 1, st, 4, 80, dyn, &xs);
+                if (gemm(ly.out, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
+                // cross attention (:567)
+                ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, w.nrm, E, R, E, 1e-5f, st);
+                if (gemm(ly.q2, w.nrm, E, w.q2, E, R, MIT_ACT_NONE, nullptr, 0, st)) return 1;
+                const float *mk = a->mem_k + (int64_t)l * N * L * E;
+                const float *mv = a->mem_v + (int64_t)l * N * L * E;
+                OcrAttXpos xc{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 0, 0};
+                ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, w.att, E, E, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc);
+                if (gemm(ly.out2, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
+                // feed forward (:568)
+                ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, st);
+                if (gemm(ly.ff1, w.nrm, E, w.ffh, FF, R, MIT_ACT_RELU, nullptr, 0, st)) return 1;
+                if (l < 4) {
+                    if (gemm(ly.ff2, w.ffh, FF, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st, 0, 0, w.part)) return 1;
+                } else {  // last layer writes the step's output straight into the activation cache (:570)
+                    if (gemm(ly.ff2, w.ffh, FF, w.decoded + so, TE, R, MIT_ACT_NONE, w.tgt, E, st, 0, 0, dyn ? nullptr : w.part, dyn, 0, E)) return 1;
+                }
+            }
+            if (gemm(dec->pred1, w.decoded + so, TE, w.p1, E, R, MIT_ACT_GELU, nullptr, 0, st, 0, 0, nullptr, dyn, E, 0)) return 1;
+            if (gemm(dec->pred, w.p1, E, w.logits, Dp, R, MIT_ACT_NONE, nullptr, 0, st)) return 1;
         }
-        if (gemm(dec->pred1, w.decoded + so, TE, w.p1, E, R, MIT_ACT_GELU, nullptr, 0, st, 0, 0, nullptr, dyn, E, 0)) return 1;
-        if (gemm(dec->pred, w.p1, E, w.logits, Dp, R, MIT_ACT_NONE, nullptr, 0, st)) return 1;
         if (a->trace_logits)
             MIT_CHECK_HIP(hipMemcpy2DAsync(a->trace_logits + (int64_t)step * R * D, (size_t)D * 4, w.logits, (size_t)Dp * 4,
                                            (size_t)D * 4, R, hipMemcpyDeviceToDevice, st));

@@ -4,8 +4,15 @@
 #include <stdint.h>
 #include "../../include/mit_hip.h"
 
+// Planar output of a kernel whose result feeds a few-row planar GEMM (pgemm_rows.h): the fp32 value a kernel would store goes out as its
+// three bf16 planes [3][K8][ld][8] instead (bf16_split.h: the split a GEMM tile would apply to the fp32 value itself).  p == NULL: none.
+struct OcrPlanes {
+    uint16_t *p;
+    int64_t ld;   // rows per (plane, k-cell) slab
+    int K8;       // k-cells per plane (row length / 8)
+};
 void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
-                    int D, float eps, hipStream_t s);
+                    int D, float eps, hipStream_t s, const OcrPlanes *planes = nullptr);   // planes: instead of out (D % 8 == 0)
 // dstep != NULL: step-dependent arguments come from the decoder's device-resident step counter (see the kernels' comments)
 void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
                       int i0, int p0, int downscale, const MitXposTables &tb, hipStream_t s, const int *dstep = nullptr, int dyn_mode = 0,
@@ -22,7 +29,7 @@ struct OcrAttXpos {
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
                     int kv_div, hipStream_t s, int heads = 4, int head_dim = 80, const int *dstep = nullptr,
-                    const OcrAttXpos *xpos = nullptr);
+                    const OcrAttXpos *xpos = nullptr, const OcrPlanes *o_planes = nullptr);   // o_planes: instead of O (Tq == 1, head_dim % 8 == 0)
 void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s, const int *tok1 = nullptr,
                 const int *dstep = nullptr);
 void ocrk_beam_dyn(const float *vals, const int *idx, int *hist0, int *hist1, int hist_ld, float *logp0, float *logp1, int *done,

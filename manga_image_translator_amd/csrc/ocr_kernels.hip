@@ -12,10 +12,28 @@
 #include "../../include/mit_hip.h"
 #include "common.h"
 #include "ocr_kernels.h"
+#include "bf16_split.h"
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// eight consecutive fp32 values (16-byte aligned, LDS) -> the three cells of (k-cell k8, row) of a planar output
+__device__ __forceinline__ void store_cells(const OcrPlanes &o, const int k8, const int64_t row, const float *v8) {
+    mitcg::u32x4 h, m, l;
+    mitcg::split8(*reinterpret_cast<const f32x4 *>(v8), *reinterpret_cast<const f32x4 *>(v8 + 4), h, m, l);
+    mitcg::u32x4 *dst = reinterpret_cast<mitcg::u32x4 *>(o.p) + (int64_t)k8 * o.ld + row;
+    const int64_t plane = (int64_t)o.K8 * o.ld;
+    dst[0] = h;
+    dst[plane] = m;
+    dst[2 * plane] = l;
+}
+__device__ __forceinline__ void wave_lds_fence() {  // a wave's own LDS accesses complete in order: wait for them, keep the compiler from reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 inline int grid_for(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;
@@ -326,7 +344,8 @@ __global__ void gelu_kernel(float *__restrict__ x, int64_t n) {
 // ---- LayerNorm over the last dim (D <= 64*8), one wave per row ----
 __global__ void layernorm_kernel(const float *__restrict__ in, int64_t in_rs, const float *__restrict__ w,
                                  const float *__restrict__ b, float *__restrict__ out, int64_t out_rs, int rows, int D,
-                                 float eps) {
+                                 float eps, OcrPlanes pl) {
+    __shared__ __attribute__((aligned(16))) float ybuf[4][512];  // planar output: a row's values pass through LDS to become cells of 8
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -348,8 +367,18 @@ __global__ void layernorm_kernel(const float *__restrict__ in, int64_t in_rs, co
     }
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = 1.0f / sqrtf(var / (float)D + eps);
-    float *y = out + (int64_t)row * out_rs;
     n = 0;
+    if (pl.p) {
+        float *yb = ybuf[threadIdx.x >> 6];
+        for (int d = lane; d < D; d += 64) {
+            yb[d] = (v[n] - mean) * rstd * w[d] + b[d];
+            ++n;
+        }
+        wave_lds_fence();
+        for (int c = lane; c < (D >> 3); c += 64) store_cells(pl, c, row, yb + c * 8);
+        return;
+    }
+    float *y = out + (int64_t)row * out_rs;
     for (int d = lane; d < D; d += 64) {
         y[d] = (v[n] - mean) * rstd * w[d] + b[d];
         ++n;
@@ -407,12 +436,12 @@ __global__ void xpos_rotate_kernel(const float *__restrict__ in, int64_t in_rs, 
 __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int64_t q_ts, const float *__restrict__ K,
                                  int64_t k_rs, int64_t k_ts, const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
                                  float *__restrict__ O, int64_t o_rs, int64_t o_ts, const int *__restrict__ klen, int Tk,
-                                 int kv_div, int HD, const int *__restrict__ dstep, OcrAttXpos xp) {
+                                 int kv_div, int HD, const int *__restrict__ dstep, OcrAttXpos xp, OcrPlanes opl) {
     // dstep without folded rotation / with rotated keys: the decoder's self-attention over the tokens 0 .. step (LDS is sized for the longest history)
     if (dstep && (!xp.cos_t || xp.rot_k)) Tk = *dstep + 1;
     const int step = dstep ? *dstep : xp.step;
     const int minpos = -((step + 2) / 2);
-    extern __shared__ float lds[];  // [HD] q + [Tk] weights
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [HD] q + [Tk] weights
     float *qs = lds;
     float *ws = lds + HD;
     const int tq = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
@@ -499,7 +528,12 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
             for (int u = 0; u < U; ++u)
                 if (t0 + u < valid) acc += ws[t0 + u] * vv[u];
         }
-        ob[d] = acc;
+        if (opl.p) qs[d] = acc;   // planar output (Tq == 1): the head's HD values become HD / 8 cells of row r (qs is free by now)
+        else ob[d] = acc;
+    }
+    if (opl.p) {
+        wave_lds_fence();
+        for (int c = lane; c < (HD >> 3); c += 64) store_cells(opl, h * (HD >> 3) + c, r, qs + c * 8);
     }
 }
 
@@ -508,14 +542,17 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
 // Per (query, key) dot products, the lane-strided softmax sums and the t-ordered weighted sum are evaluated in exactly the
 // order of attention_kernel, so both give bitwise identical results.
 constexpr int ATT_G_MAX = 8;
-constexpr int ATT_KCHUNK = 64;
 constexpr int ATT_THREADS = 256;
-constexpr int ATT_STAGE = 8;  // float4 loads per thread per chunk: head_dim <= 128
+// keys per LDS chunk / float4 loads per thread per chunk (head_dim 80): the throughput form (many workgroups per CU) and the latency form
+// for launches that leave CUs idle (one page: 4 heads x 32 lines) — a line's keys in ONE chunk, so one load round trip per pass
+constexpr int ATT_KCHUNK = 64, ATT_STAGE = 8;
+constexpr int ATT_KCHUNK_L = 160, ATT_STAGE_L = 13;
 
 // chunk [nk keys x HD] of one head, global -> registers (coalesced: consecutive threads walk a key row)
-__device__ __forceinline__ void att_chunk_load(float4 (&reg)[ATT_STAGE], const float *base, int64_t ts, int t0, int nk, int HD4, int tid) {
+template <int STAGE>
+__device__ __forceinline__ void att_chunk_load(float4 (&reg)[STAGE], const float *base, int64_t ts, int t0, int nk, int HD4, int tid) {
 #pragma unroll
-    for (int j = 0; j < ATT_STAGE; ++j) {
+    for (int j = 0; j < STAGE; ++j) {
         const int i = tid + j * ATT_THREADS;
         float4 v = {0.f, 0.f, 0.f, 0.f};
         if (i < nk * HD4) {
@@ -526,9 +563,10 @@ __device__ __forceinline__ void att_chunk_load(float4 (&reg)[ATT_STAGE], const f
     }
 }
 
-__device__ __forceinline__ void att_chunk_store(const float4 (&reg)[ATT_STAGE], float *ks, int nk, int HD4, int KP, int tid) {
+template <int STAGE>
+__device__ __forceinline__ void att_chunk_store(const float4 (&reg)[STAGE], float *ks, int nk, int HD4, int KP, int tid) {
 #pragma unroll
-    for (int j = 0; j < ATT_STAGE; ++j) {
+    for (int j = 0; j < STAGE; ++j) {
         const int i = tid + j * ATT_THREADS;
         if (i < nk * HD4) {
             const int t = i / HD4, d4 = i - t * HD4;
@@ -537,23 +575,34 @@ __device__ __forceinline__ void att_chunk_store(const float4 (&reg)[ATT_STAGE], 
     }
 }
 
+template <int KCHUNK, int STAGE, int HD, int G>
 __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const float *__restrict__ Q, int64_t q_rs,
                                                                           const float *__restrict__ K, int64_t k_rs, int64_t k_ts,
                                                                           const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
                                                                           float *__restrict__ O, int64_t o_rs,
-                                                                          const int *__restrict__ klen, int Tk, int G, int HD,
-                                                                          const int *__restrict__ dstep, OcrAttXpos xp) {
+                                                                          const int *__restrict__ klen, int Tk,
+                                                                          const int *__restrict__ dstep, OcrAttXpos xp, OcrPlanes opl) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int KP = HD + 4;                    // 16-byte aligned rows; lane t reads row t as float4s (pitch 84: conflict-free per 16 lanes)
+    constexpr int KP = HD + 4;                // 16-byte aligned rows; lane t reads row t as float4s (pitch 84: conflict-free per 16 lanes)
+    constexpr int HD4 = HD / 4;
     float *qs = lds;                          // [G][HD]
-    float *ks = qs + G * HD;                  // [ATT_KCHUNK][KP]   keys, then values
-    float *ws = ks + ATT_KCHUNK * KP;         // [G][Tk]
+    float *ks = qs + G * HD;                  // [KCHUNK][KP]   keys, then values
+    float *ws = ks + KCHUNK * KP;             // [G][Tk]
     const int h = blockIdx.x, kr = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = kr * G;
+    float4 stage[STAGE];
+    const float *kb = K + (int64_t)kr * k_rs + h * HD;
+    const float *vb = V + (int64_t)kr * v_rs + h * HD;
+    // the first keys travel while the queries are prepared; the latency form does not even wait for the line's length (rows past it are
+    // padding inside the line's block: loaded, stored, never used)
+    constexpr bool EAGER = KCHUNK > 64;
+    if (EAGER) att_chunk_load<STAGE>(stage, kb, k_ts, 0, min(KCHUNK, Tk), HD4, tid);
+    const int valid = klen ? min(klen[kr], Tk) : Tk;
+    if (!EAGER) att_chunk_load<STAGE>(stage, kb, k_ts, 0, min(KCHUNK, valid), HD4, tid);
     if (xp.cos_t) {  // the beams' queries of position `step`, rotated on the way into LDS (xpos_rotate_kernel's expression, scale up)
         const int step = dstep ? *dstep : xp.step;
-        const int HP = HD / 2;
+        constexpr int HP = HD / 2;
         const int pp = step + -((step + 2) / 2) + xp.pmax;
         const int64_t qo = dstep ? (int64_t)step * xp.q_dyn : 0;
         for (int i = tid; i < G * HP; i += ATT_THREADS) {
@@ -567,36 +616,56 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
     } else {
         for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = Q[(int64_t)(r0 + i / HD) * q_rs + h * HD + (i % HD)];
     }
-    const int valid = klen ? min(klen[kr], Tk) : Tk;
-    const int HD4 = HD / 4;
-    float4 stage[ATT_STAGE];
 
-    // ---- pass 1: scores.  The next chunk's keys travel to registers while this chunk's dot products run.
-    const float *kb = K + (int64_t)kr * k_rs + h * HD;
-    att_chunk_load(stage, kb, k_ts, 0, min(ATT_KCHUNK, valid), HD4, tid);
-    for (int t0 = 0; t0 < Tk; t0 += ATT_KCHUNK) {
-        const int nk = max(0, min(ATT_KCHUNK, valid - t0));
+    // ---- pass 1: scores.  The next chunk's keys travel to registers while this chunk's dot products run; behind the last chunk of keys
+    // the first chunk of VALUES does (its latency is hidden by the last dot products and the softmax).  A thread owns one key of the
+    // chunk — its row read from LDS once, into registers — and every KT-th ... query of the line.
+    constexpr int KT = KCHUNK > 128 ? 256 : (KCHUNK > 64 ? 128 : 64), NGRP = ATT_THREADS / KT;
+    const int tl = tid % KT, gsub = tid / KT;
+    bool v_ahead = false;
+    for (int t0 = 0; t0 < Tk; t0 += KCHUNK) {
+        const int nk = max(0, min(KCHUNK, valid - t0));
         __syncthreads();  // previous chunk consumed (and qs visible)
-        att_chunk_store(stage, ks, nk, HD4, KP, tid);
+        if (!v_ahead) att_chunk_store<STAGE>(stage, ks, (EAGER && t0 == 0) ? min(KCHUNK, Tk) : nk, HD4, KP, tid);
         __syncthreads();
-        if (t0 + ATT_KCHUNK < valid) att_chunk_load(stage, kb, k_ts, t0 + ATT_KCHUNK, min(ATT_KCHUNK, valid - t0 - ATT_KCHUNK), HD4, tid);
-        const int t = t0 + lane;
-        if (t < Tk) {
-            const float4 *kp = reinterpret_cast<const float4 *>(ks + lane * KP);
-            for (int g = wave; g < G; g += ATT_THREADS / 64) {
-                float dot = -INFINITY;
-                if (t < valid) {
-                    const float4 *qp = reinterpret_cast<const float4 *>(qs + g * HD);  // same address in every lane: broadcast
-                    dot = 0.f;
-                    for (int d4 = 0; d4 < HD4; ++d4) {  // d ascending, one rounding per product and per sum, as in attention_kernel
-                        const float4 kv = kp[d4], qv = qp[d4];
-                        dot += qv.x * kv.x;
-                        dot += qv.y * kv.y;
-                        dot += qv.z * kv.z;
-                        dot += qv.w * kv.w;
+        if (t0 + KCHUNK < valid) {
+            att_chunk_load<STAGE>(stage, kb, k_ts, t0 + KCHUNK, min(KCHUNK, valid - t0 - KCHUNK), HD4, tid);
+        } else if (!v_ahead) {
+            att_chunk_load<STAGE>(stage, vb, v_ts, 0, min(KCHUNK, valid), HD4, tid);
+            v_ahead = true;
+        }
+        const int t = t0 + tl;
+        if (tl < KCHUNK && t < Tk) {
+            if (t < valid) {
+                float4 kv[HD4];
+#pragma unroll
+                for (int d4 = 0; d4 < HD4; ++d4) kv[d4] = *reinterpret_cast<const float4 *>(ks + tl * KP + d4 * 4);
+                // the thread's queries side by side: their (d-ordered, dependent) sums are independent of each other and interleave
+                constexpr int NQ = (G + NGRP - 1) / NGRP;
+                float dot[NQ];
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) dot[qi] = 0.f;
+#pragma unroll
+                for (int d4 = 0; d4 < HD4; ++d4) {  // d ascending, one rounding per product and per sum, as in attention_kernel
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) {
+                        const int g = gsub + qi * NGRP;
+                        if (g < G) {
+                            const float4 qv = *reinterpret_cast<const float4 *>(qs + g * HD + d4 * 4);  // same address in every lane: broadcast
+                            dot[qi] += qv.x * kv[d4].x;
+                            dot[qi] += qv.y * kv[d4].y;
+                            dot[qi] += qv.z * kv[d4].z;
+                            dot[qi] += qv.w * kv[d4].w;
+                        }
                     }
                 }
-                ws[(int64_t)g * Tk + t] = dot;
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    const int g = gsub + qi * NGRP;
+                    if (g < G) ws[(int64_t)g * Tk + t] = dot[qi];
+                }
+            } else {
+                for (int g = gsub; g < G; g += NGRP) ws[(int64_t)g * Tk + t] = -INFINITY;
             }
         }
     }
@@ -618,33 +687,69 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
     }
 
     // ---- pass 2: weighted sum of the values, t-ordered per (query, d); thread (d, half) owns the queries g = half, half + 2, ...
-    const float *vb = V + (int64_t)kr * v_rs + h * HD;
-    const int d = tid % HD, half = tid / HD;
-    const bool owner = half < 2;
-    float acc[ATT_G_MAX / 2];
+    // Waves 0 / 1: half = wave, d = lane; wave 2: d = 64 .. 79 of both halves (a wave's weight reads are then one address: a broadcast).
+    // Branch-free inner loop: a (d, half) whose last query index falls past G sums a duplicate of query G - 1 that is never stored.
+    static_assert(HD == 80, "thread mapping of the weighted sum");
+    constexpr int J = (G + 1) / 2;
+    const int half = wave < 2 ? wave : ((lane >> 4) & 1);
+    const int d = wave < 2 ? lane : 64 + (lane & 15);
+    const bool owner = wave < 2 || (wave == 2 && lane < 32);
+    float acc[J];
+    const float *wrow[J];
 #pragma unroll
-    for (int j = 0; j < ATT_G_MAX / 2; ++j) acc[j] = 0.f;
-    att_chunk_load(stage, vb, v_ts, 0, min(ATT_KCHUNK, valid), HD4, tid);
-    for (int t0 = 0; t0 < valid; t0 += ATT_KCHUNK) {
-        const int nk = min(ATT_KCHUNK, valid - t0);
+    for (int j = 0; j < J; ++j) {
+        acc[j] = 0.f;
+        wrow[j] = ws + (int64_t)min(half + 2 * j, G - 1) * Tk;
+    }
+    for (int t0 = 0; t0 < valid; t0 += KCHUNK) {
+        const int nk = min(KCHUNK, valid - t0);
         __syncthreads();  // previous chunk consumed (and the softmax weights visible)
-        att_chunk_store(stage, ks, nk, HD4, KP, tid);
+        att_chunk_store<STAGE>(stage, ks, nk, HD4, KP, tid);
         __syncthreads();
-        if (t0 + ATT_KCHUNK < valid) att_chunk_load(stage, vb, v_ts, t0 + ATT_KCHUNK, min(ATT_KCHUNK, valid - t0 - ATT_KCHUNK), HD4, tid);
+        if (t0 + KCHUNK < valid) att_chunk_load<STAGE>(stage, vb, v_ts, t0 + KCHUNK, min(KCHUNK, valid - t0 - KCHUNK), HD4, tid);
         if (owner) {
-            for (int t = 0; t < nk; ++t) {
-                const float v = ks[t * KP + d];
+            constexpr int U = 8;  // values and weights of U keys read ahead of their (t-ordered) multiply-adds
+            const float *vcol = ks + d;
+            int tb = 0;
+            for (; tb + U <= nk; tb += U) {
+                float vv[U], wv[J][U];
 #pragma unroll
-                for (int j = 0; j < ATT_G_MAX / 2; ++j) {
-                    const int g = half + 2 * j;
-                    if (g < G) acc[j] += ws[(int64_t)g * Tk + t0 + t] * v;
+                for (int u = 0; u < U; ++u) {
+                    vv[u] = vcol[(tb + u) * KP];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) wv[j][u] = wrow[j][t0 + tb + u];
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) acc[j] += wv[j][u] * vv[u];
+            }
+            for (; tb < nk; ++tb) {
+                const float v = vcol[tb * KP];
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc[j] += wrow[j][t0 + tb] * v;
             }
         }
     }
+    if (opl.p) {  // planar output: the G x HD block passes through LDS (qs: last read in pass 1) to become cells of 8
+        if (owner) {
+#pragma unroll
+            for (int j = 0; j < (G + 1) / 2; ++j) {
+                const int g = half + 2 * j;
+                if (g < G) qs[g * HD + d] = acc[j];
+            }
+        }
+        __syncthreads();
+        const int HC = HD >> 3;
+        for (int i = tid; i < G * HC; i += ATT_THREADS) {
+            const int g = i / HC, c = i - g * HC;
+            store_cells(opl, h * HC + c, r0 + g, qs + g * HD + c * 8);
+        }
+        return;
+    }
     if (owner) {
 #pragma unroll
-        for (int j = 0; j < ATT_G_MAX / 2; ++j) {
+        for (int j = 0; j < (G + 1) / 2; ++j) {
             const int g = half + 2 * j;
             if (g < G) O[(int64_t)(r0 + g) * o_rs + h * HD + d] = acc[j];
         }
@@ -887,11 +992,11 @@ __global__ void beam_finalize_kernel(const int *__restrict__ hist, int hist_ld, 
 // ---------------------------------------------------------------------------------------------
 
 void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
-                    int D, float eps, hipStream_t s) {
+                    int D, float eps, hipStream_t s, const OcrPlanes *planes) {
     const int waves = 4;
-    MitProbeScope probe("layernorm_kernel", s, 8.0 * (double)rows * D);
+    MitProbeScope probe("layernorm_kernel", s, (planes ? 10.0 : 8.0) * (double)rows * D);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + waves - 1) / waves), dim3(64 * waves), 0, s, in, in_rs, w, b, out, out_rs,
-                       rows, D, eps);
+                       rows, D, eps, planes ? *planes : OcrPlanes{nullptr, 0, 0});
 }
 
 void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
@@ -1156,24 +1261,32 @@ __global__ void memory_kv_lines_kernel(const float *__restrict__ Kf, const float
 
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
-                    int kv_div, hipStream_t s, int heads, int head_dim, const int *dstep, const OcrAttXpos *xpos) {
+                    int kv_div, hipStream_t s, int heads, int head_dim, const int *dstep, const OcrAttXpos *xpos, const OcrPlanes *o_planes) {
     OcrAttXpos xp{};
     if (xpos) xp = *xpos;
+    const OcrPlanes opl = (o_planes && Tq == 1) ? *o_planes : OcrPlanes{nullptr, 0, 0};
     // (the shared-K/V form never shortens Tk by the step counter: with a step counter it is only used for the rotated query)
-    if ((!dstep || (xp.cos_t && !xp.rot_k)) && Tq == 1 && kv_div > 1 && kv_div <= ATT_G_MAX && R % kv_div == 0 && R / kv_div <= 65535 && 2 * head_dim <= ATT_THREADS &&
-        ATT_KCHUNK * (head_dim / 4) <= ATT_STAGE * ATT_THREADS) {
-        const size_t sm = ((size_t)kv_div * head_dim + (size_t)ATT_KCHUNK * (head_dim + 4) + (size_t)kv_div * Tk) * sizeof(float);
-        if (sm <= 64 * 1024) {
-            // algorithmic bytes: K and V of each line read once for its kv_div beams (+ q in, o out); FLOPs 4 Tk d per query row and head
-            MitProbeScope probe("attention_shared_kv_kernel", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * R),
-                                4.0 * (double)R * heads * Tk * head_dim);
-            hipLaunchKernelGGL(attention_shared_kv_kernel, dim3(heads, R / kv_div), dim3(ATT_THREADS), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts,
-                               O, o_rs, klen, Tk, kv_div, head_dim, dstep, xp);
+    if ((!dstep || (xp.cos_t && !xp.rot_k)) && Tq == 1 && kv_div == 5 && R % kv_div == 0 && R / kv_div <= 65535 && head_dim == 80) {  // the 48px decoder's cross-attention: 5 beams, 4 x 80
+        // algorithmic bytes: K and V of each line read once for its kv_div beams (+ q in, o out); FLOPs 4 Tk d per query row and head
+        const double bytes = 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * R), flops = 4.0 * (double)R * heads * Tk * head_dim;
+        auto lds_bytes = [&](const int kchunk) { return ((size_t)kv_div * head_dim + (size_t)kchunk * (head_dim + 4) + (size_t)kv_div * Tk) * sizeof(float); };
+        // few workgroups (one page .. a few): the latency form, a line's keys in one chunk; else the throughput form.  Same arithmetic.
+        static const int64_t lat_max = getenv("MIT_ATT_LATENCY_MAX_WGS") ? atoll(getenv("MIT_ATT_LATENCY_MAX_WGS")) : 512;
+        if ((int64_t)heads * (R / kv_div) <= lat_max && ATT_KCHUNK_L * (head_dim / 4) <= ATT_STAGE_L * ATT_THREADS && lds_bytes(ATT_KCHUNK_L) <= 64 * 1024) {
+            MitProbeScope probe("attention_shared_kv_kernel", s, bytes, flops);
+            hipLaunchKernelGGL((attention_shared_kv_kernel<ATT_KCHUNK_L, ATT_STAGE_L, 80, 5>), dim3(heads, R / kv_div), dim3(ATT_THREADS), lds_bytes(ATT_KCHUNK_L), s, Q, q_rs,
+                               K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs, klen, Tk, dstep, xp, opl);
+            return;
+        }
+        if (ATT_KCHUNK * (head_dim / 4) <= ATT_STAGE * ATT_THREADS && lds_bytes(ATT_KCHUNK) <= 64 * 1024) {
+            MitProbeScope probe("attention_shared_kv_kernel", s, bytes, flops);
+            hipLaunchKernelGGL((attention_shared_kv_kernel<ATT_KCHUNK, ATT_STAGE, 80, 5>), dim3(heads, R / kv_div), dim3(ATT_THREADS), lds_bytes(ATT_KCHUNK), s, Q, q_rs, K,
+                               k_rs, k_ts, V, v_rs, v_ts, O, o_rs, klen, Tk, dstep, xp, opl);
             return;
         }
     }
     static const bool no_rows = getenv("MIT_ATT_NO_ROWS") != nullptr;
-    if (!no_rows && !dstep && !xp.cos_t && kv_div == 1 && Tq >= 2 * ATTR_GQ && R <= 65535 && Tq <= 65535 * 32 && head_dim <= 128 && ((q_rs | q_ts | k_rs | k_ts | v_rs | v_ts) & 3) == 0) {
+    if (!no_rows && !dstep && !xp.cos_t && !opl.p && kv_div == 1 && Tq >= 2 * ATTR_GQ && R <= 65535 && Tq <= 65535 * 32 && head_dim <= 128 && ((q_rs | q_ts | k_rs | k_ts | v_rs | v_ts) & 3) == 0) {
         const size_t sm = ((size_t)Tk * (head_dim + 4) + (size_t)(ATTR_THREADS / 64) * ATTR_GQ * (head_dim + Tk)) * sizeof(float);
         if (sm <= 150 * 1024 && head_dim % 8 == 0) {
             // algorithmic bytes: q, k, v read once and o written once per row; FLOPs 4 Tk d per query and head
@@ -1197,7 +1310,7 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
     MitProbeScope probe("attention_kernel", s, 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * (double)R * Tq),
                         4.0 * (double)R * Tq * heads * Tk * head_dim);
     hipLaunchKernelGGL(attention_kernel, dim3(Tq, heads, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
-                       o_ts, klen, Tk, kv_div, head_dim, dstep, xp);   // dstep: Tk = the LDS capacity, the kernel attends to *dstep + 1 keys
+                       o_ts, klen, Tk, kv_div, head_dim, dstep, xp, opl);   // dstep: Tk = the LDS capacity, the kernel attends to *dstep + 1 keys
 }
 
 void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s, const int *tok1,

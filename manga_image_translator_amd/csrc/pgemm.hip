@@ -26,6 +26,7 @@
 // are swapped so that a lane holds 4 consecutive columns of ONE row, v_permlane32_swap completes them to 8 — a whole cell — and the
 // lane splits and stores its cells itself, 512 contiguous bytes per half-wave and no LDS.
 #include "conv_gemm_kernels.h"
+#include "pgemm_rows.h"
 #include <atomic>
 #include <string.h>
 
@@ -62,15 +63,6 @@ __device__ __forceinline__ void lds_wait() {  // at most N of this wave's LDS op
 __device__ __forceinline__ void lds_tie(bf16x8 &v) { asm volatile("" : "+v"(v)); }  // no consumer of v is scheduled above this point
 __device__ __forceinline__ unsigned int lds_addr(const void *p) {
     return (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-}
-
-__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &h, u32x4 &m, u32x4 &l) {
-    u32x2 h0, m0, l0, h1, m1, l1;
-    split3<false>(lo, h0, m0, l0);
-    split3<false>(hi, h1, m1, l1);
-    h = u32x4{h0.x, h0.y, h1.x, h1.y};
-    m = u32x4{m0.x, m0.y, m1.x, m1.y};
-    l = u32x4{l0.x, l0.y, l1.x, l1.y};
 }
 
 // An epilogue must leave no load behind that hipcc still counts as pending at the loop header (it would guard the first register the K
@@ -597,6 +589,156 @@ __global__ __launch_bounds__(256) void join_planes_kernel(const u32x4 *__restric
     }
 }
 
+// ---- few-row GEMMs (the decoder's Linears at one page: M = lines x beams = 160 rows) ---------------------------------------------------
+// A 64 x 64 split tile takes 12-17 us for such a launch whatever its size: every K-tile is a dependent chain global load -> split ->
+// ds_write -> barrier -> ds_read -> MFMA.  With planar operands nothing of that chain is needed: a cell IS a lane's MFMA operand, so one
+// wave per 32 x 32 block of the output streams its 3 + 3 cells per 16-deep k step straight from global memory (L2) into registers, D k
+// steps ahead (buffer loads: a wave-uniform offset per step, no address arithmetic in the loop), and runs the NPROD MFMAs of the step
+// back to back — no LDS, no barrier, no VALU work in the loop; the launch is as long as its one accumulator chain (K / 16 x NPROD MFMAs
+// of 32 cycles) plus one load latency.  The MFMA operands are swapped as for the planar output above, so after v_permlane32_swap a lane
+// holds whole cells (eight consecutive columns of one row): 16-byte fp32 stores and / or a split into planes.  Per element the pair
+// order, the k order and the epilogue arithmetic of the other tiles: bit-identical results.
+// Decoder extras (PgRowsExt; zero-initialised = none): the three-way column split of the q | k | v projection (MitTensorMap::nsplit),
+// the device-resident step counter (the output row of the step), both output kinds at once.
+
+// KTS: K / 16 as a compile-time constant (the decoder's K = 320 and 2048): the k loop fully unrolled, so that hipcc counts the loads in
+// flight exactly — at the header of a run-time loop it waits for vmcnt(0), which empties the prefetch ring once per D steps (KTS = 0).
+template <int NPROD, int D, int KTS>
+__global__ __launch_bounds__(64) void pgemm_rows_kernel(const MitPGemm p, const PgRowsExt x, const int MT, const int NT, const int KT) {
+    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+    // block -> (column block, row block): the row blocks of a column block (same W cells) on one XCD, blocks dealt round-robin to the XCDs
+    const int total = MT * NT, per = (total + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total || (int)(blockIdx.x >> 3) >= per) return;
+    const int nt = t / MT, mt = t - nt * MT;
+    const int m0 = mt * 32, n0 = nt * 32;
+    const int K8 = p.K >> 3;
+    const unsigned int a_step = (unsigned int)p.lda * 32u, w_step = (unsigned int)p.ldw * 32u;     // bytes per k step (two k cells)
+    const unsigned int a_plane = (unsigned int)K8 * (unsigned int)p.lda * 16u, w_plane = (unsigned int)K8 * (unsigned int)p.ldw * 16u;
+    const int z = blockIdx.y;
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.a_planes + (int64_t)z * p.a_zs), 0, 3 * a_plane, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w_planes + (int64_t)z * p.w_zs), 0, 3 * w_plane, 0x00020000);
+    const unsigned int a_off = ((unsigned int)lh * (unsigned int)p.lda + (unsigned int)(m0 + li)) * 16u;
+    const unsigned int w_off = ((unsigned int)lh * (unsigned int)p.ldw + (unsigned int)(n0 + li)) * 16u;
+
+    u32x4 fa[D][3], fw[D][3];
+    auto issue = [&](const int d, const int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            fa[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off, pl * a_plane + (unsigned int)ks * a_step, 0);
+            fw[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off, pl * w_plane + (unsigned int)ks * w_step, 0);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto consume = [&](const int d) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pr = 9 - NPROD; pr < 9; ++pr)   // transposed result (rows = output columns), as the planar tiles
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[d][kSplitPB[pr]]), __builtin_bit_cast(bf16x8, fa[d][kSplitPA[pr]]), acc, 0, 0, 0);
+    };
+    if constexpr (KTS > 0) {
+#pragma unroll
+        for (int d = 0; d < D && d < KTS; ++d) issue(d, d);
+        __builtin_amdgcn_sched_barrier(0);   // (the fences keep the loads D steps ahead: left alone the scheduler sinks each load to its use)
+#pragma unroll
+        for (int ks = 0; ks < KTS; ++ks) {
+            consume(ks % D);
+            if (ks + D < KTS) issue(ks % D, ks + D);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < KT) issue(d, d);
+        int k0 = 0;
+        for (; k0 + 2 * D <= KT; k0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                consume(d);
+                issue(d, k0 + d + D);
+            }
+        }
+        for (; k0 < KT; k0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (k0 + d < KT) {
+                    consume(d);
+                    if (k0 + d + D < KT) issue(d, k0 + d + D);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane (li, lh) holds row m0 + li, columns n0 + (r & 3) + 4 lh + 8 (r >> 2); after the swap the cells 2 pp + lh
+    const int m = m0 + li;
+    const int act = p.act & 0xff;
+    const bool post_first = (p.act & MIT_ACT_POST_FIRST) != 0;
+    float *cbase = p.c ? p.c + (int64_t)z * p.c_zs + (x.dyn ? (int64_t)(*x.dyn) * x.c_dyn : 0) : nullptr;
+    u32x4 *pl_out = p.c_planes ? reinterpret_cast<u32x4 *>(p.c_planes + (int64_t)z * p.cp_zs) : reinterpret_cast<u32x4 *>(x.also_planes);
+    const int64_t pl_ld = p.c_planes ? p.ld_cp : x.also_ld;
+    const int64_t pl_plane = (int64_t)(p.N >> 3) * pl_ld;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int n = n0 + 8 * (2 * pp + lh);
+        f32x4 v0, v1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * pp + q]), __float_as_uint(acc[8 * pp + 4 + q]), false, false);
+            v0[q] = __uint_as_float(sw[0]);
+            v1[q] = __uint_as_float(sw[1]);
+        }
+        if (n >= p.N || m >= p.M) continue;
+        const bool ok1 = n + 4 < p.N;   // N % 4 == 0: the cell's second half may lie past N (fp32 output only; planar output has N % 8 == 0)
+        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, bi0 = {0.f, 0.f, 0.f, 0.f}, bi1 = bi0;
+        if (p.scale) sc0 = *reinterpret_cast<const f32x4 *>(p.scale + n);
+        if (p.scale && ok1) sc1 = *reinterpret_cast<const f32x4 *>(p.scale + n + 4);
+        if (p.bias) bi0 = *reinterpret_cast<const f32x4 *>(p.bias + n);
+        if (p.bias && ok1) bi1 = *reinterpret_cast<const f32x4 *>(p.bias + n + 4);
+        if (p.pre) {
+            const float *q = p.pre + (int64_t)z * p.pre_zs + (int64_t)m * p.ld_pre + n;
+            v0 += *reinterpret_cast<const f32x4 *>(q);
+            if (ok1) v1 += *reinterpret_cast<const f32x4 *>(q + 4);
+        }
+        v0 = v0 * sc0 + bi0;
+        v1 = v1 * sc1 + bi1;
+        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+        if (p.post) {
+            const float *q = p.post + (int64_t)z * p.post_zs + (int64_t)m * p.ld_post + n;
+            r0 = *reinterpret_cast<const f32x4 *>(q);
+            if (ok1) r1 = *reinterpret_cast<const f32x4 *>(q + 4);
+        }
+        if (p.post && post_first) v0 += r0, v1 += r1;
+        if (act == MIT_ACT_RELU) v0 = pg_act4<MIT_ACT_RELU>(v0, p.act_alpha), v1 = pg_act4<MIT_ACT_RELU>(v1, p.act_alpha);
+        else if (act == MIT_ACT_GELU) v0 = pg_act4<MIT_ACT_GELU>(v0, p.act_alpha), v1 = pg_act4<MIT_ACT_GELU>(v1, p.act_alpha);
+        if (p.post && !post_first) v0 += r0, v1 += r1;
+        if (cbase) {
+            const int64_t col = x.nsplit ? (int64_t)(n / x.nsplit) * x.nhi + (n % x.nsplit) : n;
+            float *o = cbase + (int64_t)m * p.ldc + col;
+            *reinterpret_cast<f32x4 *>(o) = v0;
+            if (ok1) *reinterpret_cast<f32x4 *>(o + 4) = v1;
+        }
+        if (pl_out) {
+            u32x4 h, md, l;
+            split8(v0, v1, h, md, l);
+            u32x4 *o = pl_out + (int64_t)(n >> 3) * pl_ld + m;
+            o[0] = h;
+            o[pl_plane] = md;
+            o[2 * pl_plane] = l;
+        }
+    }
+}
+
+template <int NPROD, int D>
+void pg_rows_launch_ext(const MitPGemm &p, const PgRowsExt &x, hipStream_t s) {
+    const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32, KT = p.K / 16;
+    const int total = MT * NT, per = (total + 7) / 8;
+    const dim3 grid(per * 8, p.Z > 0 ? p.Z : 1);
+    if (KT == 20) hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 20>), grid, dim3(64), 0, s, p, x, MT, NT, KT);
+    else if (KT == 128) hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 128>), grid, dim3(64), 0, s, p, x, MT, NT, KT);
+    else hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 0>), grid, dim3(64), 0, s, p, x, MT, NT, KT);
+}
+
 // ---- tiles and launch -------------------------------------------------------------------------------------------------------------
 typedef void (*PgLaunch)(const MitPGemm &, int MT, int NT, int KT, int tiles, int grid, int order, hipStream_t);
 struct PgTile {
@@ -615,6 +757,12 @@ void pg_launch(const MitPGemm &p, int MT, int NT, int KT, int tiles, int grid, i
     optin.ensure(reinterpret_cast<const void *>(kern), smem);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), smem, s, p, MT, NT, KT, tiles, order);
 }
+
+template <int NPROD, int D>
+void pg_rows_launch(const MitPGemm &p, int, int, int, int, int, int, hipStream_t s) {
+    pg_rows_launch_ext<NPROD, D>(p, PgRowsExt{}, s);
+}
+#define PG_ROWS_TILE(name, NPROD, D, OUTP) {name, "pgemm_rows_kernel<" name ">", 32, 32, NPROD, OUTP, 0, pg_rows_launch<NPROD, D>}
 
 #define PG_TILE(name, BM, BN, WMV, WNV, NS, NPROD, OUTP, MINW, WGS) \
     {name, "pgemm_kernel<" name ">", BM, BN, NPROD, OUTP, WGS, pg_launch<BM, BN, WMV, WNV, NS, NPROD, OUTP, MINW>}
@@ -641,6 +789,13 @@ const PgTile kPgTiles[] = {
     PG_TILE_V("pg128x128s3p6d", 128, 128, 2, 2, 3, 6, 0, 2, 2, 16),  // 15: tile 0 with the DMA pieces in the shadow of the fragment reads
     PG_TILE_V("pg128x128s3p6dp", 128, 128, 2, 2, 3, 6, 0, 2, 2, 48), // 16: ... and s_setprio around the MFMAs
     PG_TILE_V("pg128x128s3p6p", 128, 128, 2, 2, 3, 6, 0, 2, 2, 32),  // 17: tile 0 with s_setprio around the MFMAs
+    // few-row launches (the decoder's Linears at one page): one wave per 32 x 32 block, operands streamed through registers
+    PG_ROWS_TILE("pgrows32d6p6", 6, 6, 0),    // 18: six k steps ahead (mit_pgemm_rows: the native decoder loop)
+    PG_ROWS_TILE("pgrows32d6p6P", 6, 6, 1),   // 19
+    PG_ROWS_TILE("pgrows32d6p9", 9, 6, 0),    // 20
+    PG_ROWS_TILE("pgrows32d6p9P", 9, 6, 1),   // 21
+    PG_ROWS_TILE("pgrows32d4p6", 6, 4, 0),    // 22: prefetch depth 4 (scripts/pgemm_check: 4 / 6 / 8 within 10 % of each other, 10 slower)
+    PG_ROWS_TILE("pgrows32d8p6", 6, 8, 0),    // 23: ... 8
 #ifdef MIT_CONV_EXPERIMENTS  // timing ablations of tile 0 (WRONG results; scripts/pgemm_check prints their times only)
     {"xpgNoDma", "pgemm_kernel<xpgNoDma>", 128, 128, 6, 0, 2, pg_launch<128, 128, 2, 2, 3, 6, 0, 2, 1>},
     {"xpgNoMfma", "pgemm_kernel<xpgNoMfma>", 128, 128, 6, 0, 2, pg_launch<128, 128, 2, 2, 3, 6, 0, 2, 2>},
@@ -699,6 +854,28 @@ int num_cus() {
 }
 
 }  // namespace
+
+int mit_pgemm_rows(const MitPGemm &d, const PgRowsExt &x, hipStream_t s) {
+    MitPGemm p = d;
+    p.Z = 1;
+    if (!p.a_planes || !p.w_planes || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % 16) || p.lda < p.M || p.ldw < p.N)
+        return mit_set_error("mit_pgemm_rows: bad operands (M=%d N=%d K=%d)", p.M, p.N, p.K);
+    uint16_t *planes = p.c_planes ? p.c_planes : x.also_planes;
+    if (!p.c && !planes) return mit_set_error("mit_pgemm_rows: no output");
+    if (p.c_planes && x.also_planes) return mit_set_error("mit_pgemm_rows: two planar outputs");
+    if ((p.N & 3) || (planes && (p.N & 7)) || (p.c && (p.ldc & 3)) || (x.nsplit & 7) || (x.nhi & 3) || (x.c_dyn & 3) || (p.post && (p.ld_post & 3)) || (p.pre && (p.ld_pre & 3)))
+        return mit_set_error("mit_pgemm_rows: N / strides must keep 16-byte cells whole");
+    const int a = p.act & 0xff;
+    if (a != MIT_ACT_NONE && a != MIT_ACT_RELU && a != MIT_ACT_GELU) return mit_set_error("mit_pgemm_rows: activation %d", p.act);
+    if (p.nprod == 0) p.nprod = mit_gemm_mode_get();
+    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    const double bytes = (double)p.M * p.K * 6.0 + (double)p.K * p.N * 6.0 + (double)p.M * p.N * ((p.c ? 4.0 : 0.0) + (planes ? 6.0 : 0.0));
+    MitProbeScope probe("pgemm_rows_kernel", s, bytes, flops);
+    if (p.nprod == 6) pg_rows_launch_ext<6, 6>(p, x, s);
+    else if (p.nprod == 9) pg_rows_launch_ext<9, 6>(p, x, s);
+    else return mit_set_error("mit_pgemm_rows: nprod must be 6 or 9 (got %d)", p.nprod);
+    return 0;
+}
 
 extern "C" const char *mit_pgemm_tile_name(int tile) { return tile >= 0 && tile < kNumPgTiles ? kPgTiles[tile].name : nullptr; }
 

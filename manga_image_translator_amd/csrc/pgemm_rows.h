@@ -1,0 +1,18 @@
+// pgemm_rows.h — the few-row planar GEMM of pgemm.hip (pgemm_rows_kernel) as the native decoder loop launches it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mit_hip.h"
+
+// Decoder extras beside a MitPGemm (zero-initialised = none)
+struct PgRowsExt {
+    int nsplit;             // != 0 (multiple of 8): output column n lives at (n / nsplit) * nhi + n % nsplit (the q | k | v projection)
+    int64_t nhi;
+    const int *dyn;         // device step counter: the fp32 output starts *dyn * c_dyn floats further
+    int64_t c_dyn;
+    uint16_t *also_planes;  // planar copy of the result beside the fp32 output (N % 8 == 0)
+    int64_t also_ld;
+};
+// C = epilogue(A @ W) for planar A, one wave per 32 x 32 block (Z == 1).  d.c and / or d.c_planes | x.also_planes; d.tile is ignored,
+// d.nprod 6 | 9.  Returns 0, or 1 with mit_last_error() set.
+int mit_pgemm_rows(const MitPGemm &d, const PgRowsExt &x, hipStream_t s);

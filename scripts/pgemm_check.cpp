@@ -74,6 +74,16 @@ int main(int argc, char **argv) {
         {"long K: 2304->512, M=46592", 46592, 2304, 512, 1, MIT_ACT_RELU, false, false, false, 1},
         {"encoder FFN 320->2048 relu, M=10240", 10240, 320, 2048, 1, MIT_ACT_RELU, false, false, false, 1},
         {"logits 320->6004, M=10240 (N % 8 != 0)", 10240, 320, 6004, 1, MIT_ACT_NONE, false, false, false, 1},
+        // one page's decoder (32 lines x 5 beams): launches bound by the latency of their K loop, not by throughput
+        {"decoder qkv 320->960, M=160", 160, 320, 960, 1, MIT_ACT_NONE, false, false, false, 1},
+        {"decoder out 320->320 + residual, M=160", 160, 320, 320, 1, MIT_ACT_NONE, false, true, false, 1},
+        {"decoder ff1 320->2048 relu, M=160", 160, 320, 2048, 1, MIT_ACT_RELU, false, false, false, 1},
+        {"decoder ff2 2048->320 + residual, M=160", 160, 2048, 320, 1, MIT_ACT_NONE, false, true, false, 1},
+        {"decoder logits 320->6004, M=160", 160, 320, 6004, 1, MIT_ACT_NONE, false, false, false, 1},
+        {"decoder qkv 320->960, M=2560 (16 pages)", 2560, 320, 960, 1, MIT_ACT_NONE, false, false, false, 1},
+        {"decoder ff2 2048->320 + residual, M=2560 (16 pages)", 2560, 2048, 320, 1, MIT_ACT_NONE, false, true, false, 1},
+        {"decoder qkv 320->960, M=640 (4 pages)", 640, 320, 960, 1, MIT_ACT_NONE, false, false, false, 1},
+        {"decoder ff2 2048->320 + residual, M=640 (4 pages)", 640, 2048, 320, 1, MIT_ACT_NONE, false, true, false, 1},
     };
     if (quick) cases.resize(4);
     const char *only_case = getenv("PG_CASE"), *only_tile = getenv("PG_TILE");  // substrings: run only matching cases / pgemm tiles
@@ -190,6 +200,12 @@ int main(int argc, char **argv) {
             d.c.base = dc;
             if (!time_it([&] { return mit_conv_gemm_cfg(&d, other, nullptr); }, &ms_o))
                 printf("  %-20s %9.3f ms %8.1f TFLOP/s   x%.2f   (the other split tile)\n", mit_conv_gemm_config_name(other), ms_o, flops / ms_o * 1e-9, ms_ref / ms_o);
+            if (M <= 4096)   // under-filled launches: the small split tiles the automatic choice gives them
+                for (const char *nm : {"split64x64x16p6o", "split64x64x32p6o"}) {
+                    const int c = find_cfg(nm);
+                    if (c >= 0 && !time_it([&] { return mit_conv_gemm_cfg(&d, c, nullptr); }, &ms_o))
+                        printf("  %-20s %9.3f ms %8.1f TFLOP/s   x%.2f\n", nm, ms_o, flops / ms_o * 1e-9, ms_ref / ms_o);
+                }
             d.c.base = dref;
         }
         std::vector<float> href(c_el), hc(c_el);

@@ -319,3 +319,38 @@ def test_graph_replayed_decode_is_bit_identical(cuda, ocr_setup, widths, T, supp
         assert o["steps_run"] == outs[0]["steps_run"]
         for k in ("tokens", "length", "prob", "colors"):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("widths,T,suppress", [([50, 77, 120, 121, 64, 200], 14, True), ([90, 33], 9, False), ([40 + 5 * i for i in range(40)], 6, True)])
+def test_few_row_decode_equals_the_tiled_form(cuda, ocr_setup, widths, T, suppress):
+    """The few-row form of a decode step (mit_ocr48_decode_rows_max_set: every Linear one wave per 32 x 32 block on bf16-plane
+    activations, LayerNorm / attention kernels producing the planes) against the tiled form the full batches take: the plane split,
+    the MFMA pair order and the epilogue arithmetic are the same, so tokens, lengths, probabilities and colours must be identical —
+    launch by launch and replayed from a graph."""
+    from manga_image_translator_amd import lib as L
+
+    sd, D, eng = ocr_setup
+    crops = _crops(widths, seed=5)
+    mks, mvs, lens = [], [], []
+    for indices, ws, region in eng.make_chunks(crops):
+        mk, mv, kl, _ = eng.encode(torch.from_numpy(region).to(cuda), ws)
+        mks.append(mk.clone()); mvs.append(mv.clone()); lens.append(kl.clone())
+    Lmax = max(m.shape[2] for m in mks)
+    pad = lambda m: m if m.shape[2] == Lmax else torch.cat([m, m.new_zeros(5, m.shape[1], Lmax - m.shape[2], 320)], 2)
+    mem_k, mem_v, klen = torch.cat([pad(m) for m in mks], 1).contiguous(), torch.cat([pad(m) for m in mvs], 1).contiguous(), torch.cat(lens)
+    lib = L.load()
+    prev = lib.mit_ocr48_decode_rows_max_set(-1)
+    assert prev >= 5 * len(widths), "the few-row form must be the default at these sizes"
+    outs = []
+    try:
+        for rows_max, graph in ((0, False), (prev, False), (prev, True)):
+            lib.mit_ocr48_decode_rows_max_set(rows_max)
+            o = eng.decode(mem_k, mem_v, klen, max_seq_length=T, suppress_eos=suppress, graph=graph)
+            torch.cuda.synchronize()
+            outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    finally:
+        lib.mit_ocr48_decode_rows_max_set(prev)
+    for o in outs[1:]:
+        assert o["steps_run"] == outs[0]["steps_run"]
+        for k in ("tokens", "length", "prob", "colors"):
+            assert torch.equal(o[k], outs[0][k]), k

@@ -60,6 +60,9 @@ CASES = [
     (9000, 192, 384, 1, True, True, False),     # spectral conv2: pre + relu + post
     (3000, 256, 256, 1, False, True, True),     # residual joins before the activation
     (2048, 320, 6004, 0, False, False, False),  # N % 8 != 0 (logits)
+    (160, 320, 960, 0, False, False, False),    # one page's decoder: q | k | v projection (20 k steps: the unrolled few-row kernel)
+    (160, 2048, 320, 0, False, True, False),    # ... ff2 + residual (128 k steps)
+    (150, 320, 2048, 1, False, False, False),   # ... ff1 (relu), rows not a multiple of 32
 ]
 
 
@@ -119,6 +122,9 @@ def test_pgemm_equals_the_split_tiles_bit_for_bit(cuda, case):
         ops.launch_conv_gemm(d, _cfg("split128x128x16p9m"))
         ref9 = ref.clone()
         ops.pgemm(apl, lin.w, N, out=got, pre=pre, post=post, scale=lin.scale, bias=lin.bias, act=flags, alpha=0.1, nprod=9)
+        assert torch.equal(got, ref9)
+        got.fill_(float("nan"))
+        ops.pgemm(apl, lin.w, N, out=got, pre=pre, post=post, scale=lin.scale, bias=lin.bias, act=flags, alpha=0.1, nprod=9, tile=ops.pgemm_tile("pgrows32d6p9"))
         assert torch.equal(got, ref9)
 
 
