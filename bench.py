@@ -560,7 +560,7 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4, group=1
         kw = dict(max_seq_length=DECODE_STEPS, suppress_eos=True, prob_threshold=0.0, inject=inj, group=group or None)
         res = eng.run(pages_dev, **kw)   # warm-up
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         phases = {}
         for _ in range(steps):
             res = eng.run(pages_dev, **kw)
@@ -568,15 +568,43 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4, group=1
                 phases[k] = phases.get(k, 0.0) + v
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        cpu = (time.process_time() - c0) / steps   # CPU seconds of ALL host threads of the process (interpreter + native pools)
         n = pages_dev.shape[0]
         found = [len(t) for t in res.textlines]
         out["batch"] = dict(value=round(n / dt, 3), unit="pages/s", pages=n, steps=steps, ms_per_page=round(dt / n * 1e3, 2),
                             host_ms_per_page_by_phase={k: round(v / steps / n * 1e3, 2) for k, v in phases.items()},
+                            host_cpu_ms_per_page=round(cpu / n * 1e3, 2),
                             lines_per_page_after_ocr={"min": min(found), "mean": round(float(np.mean(found)), 1), "max": max(found)},
                             text_regions_per_page=round(float(np.mean([len(r) for r in res.regions])), 1),
                             refined_mask_coverage=round(float((res.mask > 0).float().mean()), 4),
                             pipeline=dict(pages_per_slot=group or n, stage_threads=3 if group and n > group else 1, mask_workers=mask_workers),
-                            note="host wall time per stage thread; the stages work on different page groups at the same time and share one stream")
+                            note="host wall time per stage thread; the stages work on different page groups at the same time")
+        # the same batch with the mask stage's side stream off (everything in the caller's stream): must give the same bytes and texts
+        if eng.side_stream:
+            eng.side_stream = False
+            ref = eng.run(pages_dev, **kw)
+            torch.cuda.synchronize()
+            if os.environ.get("MIT_BENCH_COUPLED_TWICE"):   # diagnostics: is the one-stream run itself reproducible?
+                ref2 = eng.run(pages_dev, **kw)
+                torch.cuda.synchronize()
+                out["batch"]["pipeline"]["one_stream_twice_mask_bytes"] = int((ref2.mask != ref.mask).sum())
+                res2 = None
+                eng.side_stream = True
+                res2 = eng.run(pages_dev, **kw)
+                torch.cuda.synchronize()
+                out["batch"]["pipeline"]["side_stream_twice_mask_bytes"] = int((res2.mask != res.mask).sum())
+                del ref2, res2
+            eng.side_stream = True
+            dm = (ref.mask != res.mask).reshape(n, -1).sum(1)
+            di = (ref.inpainted != res.inpainted).reshape(n, -1).sum(1)
+            same_text = [[(l.text, l.prob) for l in t] for t in ref.textlines] == [[(l.text, l.prob) for l in t] for t in res.textlines]
+            same = bool(dm.sum() == 0 and di.sum() == 0 and same_text)
+            out["batch"]["pipeline"]["streams"] = "caller's + a high-priority side stream for the mask-refinement stage"
+            out["batch"]["pipeline"]["side_stream_results_equal_one_stream"] = same
+            if not same:
+                out["batch"]["pipeline"]["side_stream_diff"] = dict(pages_with_mask_diff=int((dm > 0).sum()), mask_bytes=int(dm.sum()),
+                                                                    pages_with_inpainted_diff=int((di > 0).sum()), inpainted_bytes=int(di.sum()), texts_equal=same_text)
+            del ref
         eng.close()
         del eng, res
         torch.cuda.empty_cache()

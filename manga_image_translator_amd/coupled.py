@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import concurrent.futures as cf
 import math
+import os
 import threading
 import time
 from dataclasses import dataclass, field
@@ -77,7 +78,7 @@ class CoupledPageEngine:
     """Owns the stage engines of one GPU and a host thread pool."""
 
     def __init__(self, weights: Dict[str, Dict[str, torch.Tensor]], dictionary: Sequence[str], device="cuda", lama_blocks: int = 9,
-                 ctd_mb: int = 16, lama_mb: int = 16, host_workers: int = 16, mask_workers: int = 4):
+                 ctd_mb: int = 16, lama_mb: int = 16, host_workers: int = 16, mask_workers: int = 4, side_stream: Optional[bool] = None):
         self.device = torch.device(device)
         self.dictionary = list(dictionary)
         self.ctd = ctd.CtdEngine(weights["ctd.yolo"], weights["ctd.seg"], weights["ctd.det"], device=self.device)
@@ -90,6 +91,10 @@ class CoupledPageEngine:
         # run while another page's kernels execute
         self.mask_pool = cf.ThreadPoolExecutor(max_workers=mask_workers, thread_name_prefix="mit-mask")
         self._tls = threading.local()
+        self.side_stream = bool(int(os.environ.get("MIT_COUPLED_SIDE_STREAM", "0"))) if side_stream is None else bool(side_stream)
+        self._side = None
+        self.ocr_slots = int(os.environ.get("MIT_COUPLED_OCR_SLOTS", "1"))   # pipeline slots recognised together (the OCR stage's own granularity)
+        self._ready: Dict[int, torch.cuda.Event] = {}   # raw-mask tensor (data_ptr) -> event recorded behind its last writer
 
     def _mask_backend(self):
         be = getattr(self._tls, "backend", None)
@@ -134,6 +139,7 @@ class CoupledPageEngine:
 
         for b, m in enumerate(self.mask_pool.map(refine, range(B))):
             refined[b] = m
+        self._ready[refined.data_ptr()] = torch.cuda.current_stream().record_event()   # (merge_and_refine's side stream waits for THIS, not for the queue)
         return textlines, refined
 
     @staticmethod
@@ -163,13 +169,13 @@ class CoupledPageEngine:
             return out
         toks, lens = r["tokens"].cpu().numpy(), r["length"].cpu().numpy()
         probs, cols = r["prob"].cpu().numpy(), r["colors"].cpu().numpy()
+        decoded = P.decode_lines(toks, lens, cols, self.dictionary, rows=[row for row in range(len(r["order"])) if probs[row] >= prob_threshold])
         for row, (p, i) in enumerate(r["order"]):
             q, prob = quads[p][i], float(probs[row])
             q.assigned_direction = dirs[p][i]
             if prob < prob_threshold:
                 continue
-            n = int(lens[row]) - 1
-            q.text, (q.fg_r, q.fg_g, q.fg_b), (q.bg_r, q.bg_g, q.bg_b) = P.decode_line(toks[row, 1:1 + n], cols[row, :n], self.dictionary)
+            q.text, (q.fg_r, q.fg_g, q.fg_b), (q.bg_r, q.bg_g, q.bg_b) = decoded[row]
             q.prob = prob
             if q.text.strip():                   # manga_translator.py:762-770: lines without text are dropped after OCR
                 out[p].append(q)
@@ -178,22 +184,45 @@ class CoupledPageEngine:
     # ---- stages 3 + 4: text-line merge, mask refinement -------------------------------------------------------------------
     def merge_and_refine(self, pages_u8: torch.Tensor, textlines: List[List[Quadrilateral]], mask_raw: torch.Tensor):
         B, H, W, _ = pages_u8.shape
+        main = torch.cuda.current_stream()
+        # Mask refinement alternates short kernels with host arithmetic (labelling -> assignment -> CRF -> dilation): on the caller's
+        # stream each of its read-backs waits for whatever the other stages queued ahead (a LaMa group: a quarter of a second), and the
+        # GPU idles through its host phases once that has drained.  With ``side_stream`` (opt-in: MIT_COUPLED_SIDE_STREAM=1) the page
+        # workers launch into a high-priority stream of their own instead, beside the queued work: it waits for the event the detector
+        # stage recorded behind the raw masks (not for the queue), and the inpainter's launches (caller's stream) wait for its end.
+        # Measured 23.4 -> 26.2 pages/s — and NOT the default: with kernels of two streams resident at once 3-7 of 64 pages come back
+        # with 30-480 of their 3 M mask bytes different from run to run (texts equal; the one-stream path is reproducible to the byte;
+        # each mask kernel alone is stable beside a LaMa forward, scripts/dev/mask_cotenant.py) — the co-tenancy effect of DESIGN.md §7.
+        ready = self._ready.pop(mask_raw.data_ptr(), None)
+        side = self._side_stream() if self.side_stream and ready is not None else main
+        with torch.cuda.stream(side):
+            if side is not main:
+                side.wait_event(ready)
+                mask_raw.record_stream(side)
+            final = torch.zeros(B, H, W, dtype=torch.uint8, device=self.device)   # (from the side stream's own pool of blocks)
         regions = list(self.pool.map(lambda ls: TM.dispatch_sync(ls, W, H) if ls else [], textlines))
-        final = torch.zeros(B, H, W, dtype=torch.uint8, device=self.device)
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
         def refine(b):
             if not regions[b]:
                 return None      # no text: the orchestrator returns the page as it is (manga_translator.py:500-504)
             torch.cuda.set_device(dev_index)
-            with torch.no_grad():
-                return MR.dispatch_device(regions[b], pages_u8[b], mask_raw[b], dilation_offset=MASK_DILATION_OFFSET, kernel_size=KERNEL_SIZE,
-                                          backend=self._mask_backend())
-
-        for b, m in enumerate(self.mask_pool.map(refine, range(B))):
-            if m is not None:
+            with torch.no_grad(), torch.cuda.stream(side):
+                m = MR.dispatch_device(regions[b], pages_u8[b], mask_raw[b], dilation_offset=MASK_DILATION_OFFSET, kernel_size=KERNEL_SIZE,
+                                       backend=self._mask_backend())
                 final[b] = m
+                return True
+
+        list(self.mask_pool.map(refine, range(B)))
+        if side is not main:
+            main.wait_stream(side)
+            final.record_stream(main)
         return regions, final
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._side
 
     # ---- the whole path -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -252,12 +281,18 @@ class CoupledPageEngine:
             inj = None if inject is None else {k: v[a:b] for k, v in inject.items()}
             return timed("detect+boxes+refine_mask", self.detect, pages_u8[a:b], inj)
 
-        def st_ocr(a, b, f_det):
-            tl, mraw = f_det.result()
-            return timed("ocr", self.recognize, pages_u8[a:b], tl, max_seq_length, suppress_eos, prob_threshold), mraw
+        def st_ocr(first, futs):   # ``ocr_slots`` consecutive slots in one recognition: its beam search sees that many more rows per launch
+            dets = [f.result() for f in futs]
+            a, b = spans[first][0], spans[first + len(futs) - 1][1]
+            tl = timed("ocr", self.recognize, pages_u8[a:b], [t for d in dets for t in d[0]], max_seq_length, suppress_eos, prob_threshold)
+            out, k = [], 0
+            for (sa, sb), d in zip(spans[first:first + len(futs)], dets):
+                out.append((tl[k:k + sb - sa], d[1]))
+                k += sb - sa
+            return out
 
-        def st_tail(a, b, f_ocr):
-            tl, mraw = f_ocr.result()
+        def st_tail(a, b, f_ocr, k):
+            tl, mraw = f_ocr.result()[k]
             regions, m = timed("textline_merge+mask_refinement", self.merge_and_refine, pages_u8[a:b], tl, mraw)
             mask[a:b] = m
             timed("inpaint (enqueue)", self._inpaint, pages_u8[a:b], mask[a:b], inpainted[a:b])
@@ -265,8 +300,9 @@ class CoupledPageEngine:
 
         with cf.ThreadPoolExecutor(1, "mit-st-det") as e1, cf.ThreadPoolExecutor(1, "mit-st-ocr") as e2, cf.ThreadPoolExecutor(1, "mit-st-tail") as e3:
             f1 = [e1.submit(st_detect, a, b) for a, b in spans]
-            f2 = [e2.submit(st_ocr, a, b, f) for (a, b), f in zip(spans, f1)]
-            f3 = [e3.submit(st_tail, a, b, f) for (a, b), f in zip(spans, f2)]
+            ns = max(1, int(self.ocr_slots))
+            f2 = [e2.submit(st_ocr, i, f1[i:i + ns]) for i in range(0, len(spans), ns)]
+            f3 = [e3.submit(st_tail, a, b, f2[i // ns], i % ns) for i, (a, b) in enumerate(spans)]
             done = [f.result() for f in f3]
         textlines = [t for tl, _ in done for t in tl]
         regions = [r for _, rg in done for r in rg]

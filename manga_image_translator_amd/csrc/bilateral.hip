@@ -14,6 +14,7 @@
 // (consecutive lanes read consecutive words: conflict-free), the 768-entry colour table sits beside it.  VALU/LDS-bound:
 // 197 taps x ~20 instructions per pixel against 6 bytes of HBM traffic per pixel.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/mit_hip.h"
 #include "common.h"

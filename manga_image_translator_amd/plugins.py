@@ -347,13 +347,13 @@ class HipModel48pxOCR(_OcrBase):
         toks, lens = r["tokens"].cpu().numpy(), r["length"].cpu().numpy()
         probs, cols = r["prob"].cpu().numpy(), r["colors"].cpu().numpy()
         out = []
+        decoded = decode_lines(toks, lens, cols, self.dictionary, rows=[row for row in range(len(r["order"])) if probs[row] >= threshold])
         for row, (_, i) in enumerate(r["order"]):
             q, prob = quads[i], float(probs[row])
             q.assigned_direction = dirs[0][i]
             if prob < threshold:
                 continue
-            n = int(lens[row]) - 1                  # tokens after the start symbol
-            txt, fgc, bgc = decode_line(toks[row, 1:1 + n], cols[row, :n], self.dictionary)
+            txt, fgc, bgc = decoded[row]            # (decode_line of the tokens after the start symbol)
             q.text, q.prob = txt, prob
             q.fg_r, q.fg_g, q.fg_b = fgc
             q.bg_r, q.bg_g, q.bg_b = bgc
@@ -493,6 +493,44 @@ def decode_line(token_ids: np.ndarray, colors: np.ndarray, dictionary: Sequence[
             add(3 + k, src[k])
     mean = [min(max(int(s / c) if c else 0, 0), 255) for s, c in acc]
     return "".join(seq), tuple(mean[:3]), tuple(mean[3:])
+
+
+def decode_lines(tokens: np.ndarray, lengths: np.ndarray, colors: np.ndarray, dictionary: Sequence[str], rows=None
+                 ) -> List[Tuple[str, Tuple[int, int, int], Tuple[int, int, int]]]:
+    """``decode_line`` for all result rows of a decode at once (tokens [n, T + 1] with the start symbol in column 0, lengths [n],
+    colours [n, T, 10]): the same integer arithmetic, vectorised over lines and positions — a page group's 512 lines cost one pass of
+    numpy instead of half a millisecond of interpreter each.  ``rows``: only these rows (others give None)."""
+    tokens, lengths, colors = np.asarray(tokens), np.asarray(lengths), np.asarray(colors, dtype=np.float32)
+    n, T = tokens.shape[0], colors.shape[1]
+    if n == 0:
+        return []
+    ids = tokens[:, 1:1 + T].astype(np.int64)
+    pos = np.arange(ids.shape[1])[None, :]
+    inside = pos < (lengths.astype(np.int64)[:, None] - 1)
+    s_id, e_id = dictionary.index("<S>"), dictionary.index("</S>")
+    is_end = inside & (ids == e_id)
+    cut = np.where(is_end.any(1), is_end.argmax(1), ids.shape[1])          # the first </S> ends the line
+    keep = inside & (pos < cut[:, None]) & (ids != s_id)                   # <S> is skipped, not counted
+    c = colors[:, :ids.shape[1]]
+    q = (c[..., :6] * np.float32(255)).astype(np.int64)                    # int(v * 255) on float32 values: truncation
+    has_fg = keep & (c[..., 7] > c[..., 6])
+    has_bg = c[..., 9] > c[..., 8]
+    fg_sum = (q[..., 0:3] * has_fg[..., None]).sum(1)
+    fg_cnt = has_fg.sum(1)
+    bsrc = np.where(has_bg[..., None], q[..., 3:6], q[..., 0:3])
+    bg_sum = (bsrc * keep[..., None]).sum(1)
+    bg_cnt = keep.sum(1)
+
+    def mean(sm, cnt):   # int(sum / count) clamped to a byte; 0 without samples
+        m = np.where(cnt[:, None] > 0, np.trunc(sm / np.maximum(cnt, 1)[:, None]), 0).astype(np.int64)
+        return np.clip(m, 0, 255)
+
+    fg, bg = mean(fg_sum, fg_cnt), mean(bg_sum, bg_cnt)
+    chars = np.asarray([" " if ch == "<SP>" else ch for ch in dictionary], dtype=object)
+    out: List = [None] * n
+    for r in (range(n) if rows is None else rows):
+        out[r] = ("".join(chars[ids[r, keep[r]]]), tuple(int(v) for v in fg[r]), tuple(int(v) for v in bg[r]))
+    return out
 
 
 class HipLamaMPEInpainter(_InpBase):

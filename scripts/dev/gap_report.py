@@ -1,12 +1,15 @@
 """GPU idle time of a rocprofv3 --kernel-trace run, attributed to the kernel that ended each gap (= whose launch came late).
 
-usage: python scripts/dev/gap_report.py <kernel_trace.csv> [min_gap_us [after_last_kernel_substring]]"""
+usage: python scripts/dev/gap_report.py <kernel_trace.csv> [min_gap_us [after_last_kernel_substring | last=<ms>]]"""
 import csv, sys, collections
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-if len(sys.argv) > 3:   # only the part of the trace after the last launch of this kernel (engine construction: the weight packers)
+if len(sys.argv) > 3 and sys.argv[3].startswith("last="):   # only the last N ms of the trace (the timed steps)
+    t_end = max(r[1] for r in rows)
+    rows = [r for r in rows if r[0] >= t_end - float(sys.argv[3][5:]) * 1e6]
+elif len(sys.argv) > 3:   # only the part of the trace after the last launch of this kernel (engine construction: the weight packers)
     last = max(i for i, r in enumerate(rows) if sys.argv[3] in r[2])
     rows = rows[last + 1:]
 min_gap = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 20e3
@@ -20,13 +23,13 @@ for s, e, n in rows[1:]:
         g = s - busy_end
         tot_gap += g
         if g >= min_gap:
-            k = n.split("(")[0][-60:]
+            k = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
             gaps[k][0] += 1
             gaps[k][1] += g
-            pk = (prev_name.split("(")[0][-40:], k[-40:])
+            pk = (prev_name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-40:], k[-40:])
             pairs[pk][0] += 1
             pairs[pk][1] += g
-            big.append((g, (busy_end - t0) / 1e6, prev_name.split("(")[0][-40:], k[-40:]))
+            big.append((g, (busy_end - t0) / 1e6, pk[0], k[-40:]))
     if e > busy_end:
         busy_end, prev_name = e, n
 span = busy_end - t0

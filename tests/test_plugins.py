@@ -102,6 +102,30 @@ def test_decode_line_matches_reference_logic():
         assert got == ref
 
 
+def test_decode_lines_equals_decode_line_row_by_row():
+    """The vectorised decoder of a whole result tensor against the per-line definition: every row, including </S> in the middle, <S>
+    inside a line, lengths shorter than the tensor and rows with no foreground sample."""
+    rng = np.random.default_rng(1)
+    dictionary = ["<PAD>", "<S>", "</S>", "<SP>"] + [chr(0x3041 + i) for i in range(60)]
+    n, T = 200, 14
+    toks = rng.integers(3, len(dictionary), size=(n, T + 1))
+    toks[:, 0] = 1
+    lens = rng.integers(1, T + 2, size=n)            # the start symbol counts
+    for r in range(0, n, 3):
+        toks[r, rng.integers(1, T + 1)] = 2
+    for r in range(0, n, 7):
+        toks[r, rng.integers(1, T + 1)] = 1
+    cols = rng.normal(0.5, 0.6, size=(n, T, 10)).astype(np.float32)
+    cols[5:9, :, 7] = -5.0                            # never a foreground colour: mean of nothing = 0
+    got = P.decode_lines(toks, lens, cols, dictionary)
+    for r in range(n):
+        k = int(lens[r]) - 1
+        assert got[r] == P.decode_line(toks[r, 1:1 + k], cols[r, :k], dictionary), r
+    some = P.decode_lines(toks, lens, cols, dictionary, rows=[3, 8])
+    assert some[3] == got[3] and some[8] == got[8] and some[0] is None
+    assert P.decode_lines(toks[:0], lens[:0], cols[:0], dictionary) == []
+
+
 def test_decode_ctc_line_matches_reference_logic():
     """model_48px_ctc.py:105-134: mean log-prob -> prob, colours averaged over non-space characters only."""
     dictionary = ["<PAD>", "<S>", "</S>", "<SP>", "a", "b", "c"]
