@@ -132,9 +132,11 @@ class CoupledPageEngine:
         refined = torch.empty_like(mask_full)
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
+        caller = torch.cuda.current_stream()
+
         def refine(b):  # refine_mask(img, mask, textlines) (ctd.py:177): batched over the page's lines on the device; its three phases
             torch.cuda.set_device(dev_index)   # alternate with host arithmetic (histograms -> candidates), so a few pages run interleaved
-            with torch.no_grad():
+            with torch.no_grad(), torch.cuda.stream(caller):   # a pool thread's own current stream is the default one: launch into the caller's
                 return hostglue.refine_mask_gpu(pages_u8[b], mask_full[b], textlines[b], None)
 
         for b, m in enumerate(self.mask_pool.map(refine, range(B))):

@@ -401,7 +401,8 @@ def _complete_mask_tail(be, img, mask, textlines, rects, _line_crop, _line_crops
             continue
         jobs.append((i, (x1, y1, w1, h1), dilate_size))
     crops = _line_crops([(i, x, y, w, h) for i, (x, y, w, h), _ in jobs])
-    if getattr(be, "gpu_tail", False) and kernel_size % 2 == 1:
+    # (the device dilation takes ellipse sizes up to 255 — a text size of ~830 px at the scaled page; anything larger stays on the host form)
+    if getattr(be, "gpu_tail", False) and kernel_size % 2 == 1 and kernel_size <= 255 and all(k <= 255 for _, _, k in jobs):
         # device tail: the windows are the host form's own rectangles; inside a window every non-zero pixel of the line's component
         # image lies in its crop rectangle (the crop is the components' bounding box, extended), so the refined crop is all the
         # dilation has to read
