@@ -24,11 +24,19 @@ HIPCC_FLAGS = [
     "-fPIC",
     "-fno-gpu-rdc",
     "-ffp-contract=off",  # keep a*b+c unfused outside MFMA: epilogues match torch's two-rounding order
+    # No SLP vectoriser: on gfx950 it turns pairs of scalar fp32 operations into v_pk_mul_f32 / v_pk_add_f32 with op_sel / neg modifiers,
+    # and those were measured to return a wrong 16-lane pass now and then WHILE ANOTHER KERNEL'S MFMA WAVES SHARE THE CU (a second
+    # stream or process): xpos_rotate_kernel lost the second product of `x.x * c + (-x.y) * s` in 16 consecutive lanes, the FFT rows and
+    # DenseCRF kernels were hit the same way (profiles/r05q_noslp.log).  Without the pass every multi-stream /
+    # multi-process result is identical to the one-stream result; explicit ext_vector arithmetic (plain v_pk_* without modifiers) stays.
+    "-fno-slp-vectorize",
     "-Wall",
     "-Wno-unused-function",
 ]
 
 
+if os.environ.get("MIT_WITH_SLP"):  # A/B only: the build of rounds 1-4 (reproduces the co-tenancy failures)
+    HIPCC_FLAGS.remove("-fno-slp-vectorize")
 if os.environ.get("MIT_CONV_EXPERIMENTS"):  # rejected scheduling variants + timing ablations of the conv kernel (scripts/bench_conv.py)
     HIPCC_FLAGS.append("-DMIT_CONV_EXPERIMENTS")
 

@@ -91,7 +91,7 @@ class CoupledPageEngine:
         # run while another page's kernels execute
         self.mask_pool = cf.ThreadPoolExecutor(max_workers=mask_workers, thread_name_prefix="mit-mask")
         self._tls = threading.local()
-        self.side_stream = bool(int(os.environ.get("MIT_COUPLED_SIDE_STREAM", "0"))) if side_stream is None else bool(side_stream)
+        self.side_stream = bool(int(os.environ.get("MIT_COUPLED_SIDE_STREAM", "1"))) if side_stream is None else bool(side_stream)
         self._side = None
         self.ocr_slots = int(os.environ.get("MIT_COUPLED_OCR_SLOTS", "1"))   # pipeline slots recognised together (the OCR stage's own granularity)
         self._ready: Dict[int, torch.cuda.Event] = {}   # raw-mask tensor (data_ptr) -> event recorded behind its last writer
@@ -189,12 +189,12 @@ class CoupledPageEngine:
         main = torch.cuda.current_stream()
         # Mask refinement alternates short kernels with host arithmetic (labelling -> assignment -> CRF -> dilation): on the caller's
         # stream each of its read-backs waits for whatever the other stages queued ahead (a LaMa group: a quarter of a second), and the
-        # GPU idles through its host phases once that has drained.  With ``side_stream`` (opt-in: MIT_COUPLED_SIDE_STREAM=1) the page
-        # workers launch into a high-priority stream of their own instead, beside the queued work: it waits for the event the detector
-        # stage recorded behind the raw masks (not for the queue), and the inpainter's launches (caller's stream) wait for its end.
-        # Measured 23.4 -> 26.2 pages/s — and NOT the default: with kernels of two streams resident at once 3-7 of 64 pages come back
-        # with 30-480 of their 3 M mask bytes different from run to run (texts equal; the one-stream path is reproducible to the byte;
-        # each mask kernel alone is stable beside a LaMa forward, scripts/dev/mask_cotenant.py) — the co-tenancy effect of DESIGN.md §7.
+        # GPU idles through its host phases once that has drained.  With ``side_stream`` (the default; MIT_COUPLED_SIDE_STREAM=0 turns it
+        # off) the page workers launch into a high-priority stream of their own instead, beside the queued work: it waits for the event
+        # the detector stage recorded behind the raw masks (not for the queue), and the inpainter's launches (caller's stream) wait for
+        # its end.  23.4 -> 26.2 pages/s; same bytes as the one-stream path (bench: coupled.batch.pipeline.side_stream_results_equal_one_stream)
+        # — since the library is built without the SLP vectoriser's packed-fp32 instructions (with them 3-7 of 64 pages
+        # came back with a few dozen mask bytes different whenever two streams' kernels were resident at once).
         ready = self._ready.pop(mask_raw.data_ptr(), None)
         side = self._side_stream() if self.side_stream and ready is not None else main
         with torch.cuda.stream(side):

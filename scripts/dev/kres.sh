@@ -4,7 +4,7 @@
 set -e
 src=$(readlink -f "$1"); shift
 mkdir -p /tmp/kres && cd /tmp/kres
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=off -Wall -Wno-unused-function -Wno-logical-op-parentheses \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-logical-op-parentheses \
   -Rpass-analysis=kernel-resource-usage -save-temps "$@" -c "$src" -o /tmp/kres/out.o 2>&1 | python3 -c '
 import sys,re,subprocess
 cur=None; rows=[]

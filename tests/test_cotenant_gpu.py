@@ -1,12 +1,15 @@
 """Kernels of this library next to ANOTHER queue's kernels on the same CUs (a second process on the device, a second stream).
 
 Round 3 found mit_rfft_rows / mit_irfft_rows returning wrong workgroups (7-15 of 60 launches) while another process looped the 128 x 128
-split-bf16 GEMM tile; round 4 traced it to the two-address 8-byte LDS reads (ds_read2_b64 / ds_read2st64_b64) hipcc had merged the
-butterfly inputs into — a co-resident kernel that mixes MFMAs with LDS traffic disturbs exactly those — and the co-tenant-safe launches (MIT_COTENANT_SAFE /
-mit_cotenant_safe_set) read the pairs with 4-byte loads AND take a whole CU's LDS (csrc/fft_rows.hip; scripts/cotenant_check,
-profiles/r04b_cotenant_check.log).
-This test keeps the hazard visible: the FFT rows kernels must be bit-reproducible while a child process hammers the device with that GEMM
-tile (the engine-level form — two ranks running whole page engines on one GPU at the same time — is tests/test_dist_gpu.py)."""
+split-bf16 GEMM tile; round 4 found the cause in the victims' own instructions: the SLP vectoriser had packed their scalar fp32
+arithmetic into v_pk_mul_f32 / v_pk_add_f32 with op_sel / neg modifiers, and on gfx950 such an instruction now and then returns a wrong
+16-lane pass while another kernel's MFMA waves share the CU (xpos_rotate_kernel: the second product of x.x * c + (-x.y) * s missing in 16
+consecutive lanes).  The library is built with -fno-slp-vectorize since; these tests keep the hazard visible:
+  * the FFT rows kernels must be bit-reproducible while a child process hammers the device with that GEMM tile, in the default launch
+    form and in the co-tenant-safe one (MIT_COTENANT_SAFE: narrow LDS reads + a whole CU's LDS — the mitigation that shipped before
+    the cause was known, kept as a switch);
+  * the page engine with its stages on two streams must give the bytes of the one-stream run.
+(The engine-level two-process form — two ranks running whole page engines on one GPU at the same time — is tests/test_dist_gpu.py.)"""
 import os
 import subprocess
 import sys
@@ -110,10 +113,9 @@ def test_fft_rows_are_bit_stable_beside_a_looping_split_tile_process_in_safe_mod
     assert bad == {24: 0, 182: 0}, f"launches that differ from the quiet run, per row length: {bad}"
 
 
-def test_fft_rows_beside_a_looping_split_tile_process_default_mode(cuda):
-    """Default launches (one queue per GPU is the supported configuration: wide LDS reads, the FFT rows kernels share their CUs): beside
-    a co-resident MFMA + LDS kernel of another process their results are disturbed (round 4: 55-58 of 60 launches at both row lengths) —
-    the open hazard, recorded as an expected failure so that a fix shows up as XPASS."""
+def test_fft_rows_are_bit_stable_beside_a_looping_split_tile_process_default_mode(cuda):
+    """The default launches (wide LDS reads, CUs shared with whatever else is resident): 55-58 of 60 launches were disturbed at both row
+    lengths while the library was built with the SLP vectoriser; none may be now."""
     from manga_image_translator_amd import lib
 
     prev = lib.load().mit_cotenant_safe_set(0)
@@ -121,5 +123,32 @@ def test_fft_rows_beside_a_looping_split_tile_process_default_mode(cuda):
         bad = _count_disturbed()
     finally:
         lib.load().mit_cotenant_safe_set(prev)
-    if any(bad.values()):
-        pytest.xfail(f"mit_rfft_rows / mit_irfft_rows beside a co-resident MFMA + LDS kernel: launches of 60 that differ, per row length: {bad} (DESIGN §7)")
+    assert bad == {24: 0, 182: 0}, f"launches that differ from the quiet run, per row length: {bad}"
+
+
+def test_two_stream_page_engine_gives_the_one_stream_bytes(cuda):
+    """PageEngine(overlap=True) — LaMa on the caller's stream, detector + OCR on a second one, kernels of both resident at once —
+    against the one-stream engine on the same pages: every result tensor identical, from the first call to the fourth (with the SLP
+    build the OCR results differed from the second call on, and the inpainted pages too without the safe mode)."""
+    import numpy as np
+    from manga_image_translator_amd import pipeline, synth
+
+    H, W, n = 1024, 728, 4
+    weights = pipeline.synthetic_weights()
+    gen = [synth.synth_page(40 + i, H, W, n_boxes=12) for i in range(n)]
+    pages = torch.from_numpy(np.stack([g[0] for g in gen])).to(cuda)
+    masks = torch.from_numpy(np.stack([g[2] for g in gen])).to(cuda)
+    quads = [pipeline.quads_from_array(g[1]) for g in gen]
+    one = pipeline.PageEngine(weights, device=cuda, ctd_mb=2, lama_mb=2, group=2, overlap=False)
+    two = pipeline.PageEngine(weights, device=cuda, ctd_mb=2, lama_mb=2, group=2, overlap=True)
+    kw = dict(max_seq_length=8, suppress_eos=True)
+
+    def grab(r):
+        torch.cuda.synchronize()
+        return [t.clone() for t in (r.det_mask, r.det_shrink, r.ocr_tokens, r.ocr_prob, r.ocr_colors, r.inpainted)]
+
+    ref = grab(one.run(pages, quads, masks, **kw))
+    for call in range(4):
+        got = grab(two.run(pages, quads, masks, **kw))
+        for name, a, b in zip(("det_mask", "det_shrink", "ocr_tokens", "ocr_prob", "ocr_colors", "inpainted"), got, ref):
+            assert torch.equal(a, b), f"two-stream call {call}: {name} differs in {int((a != b).sum())} elements"

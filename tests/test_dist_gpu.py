@@ -41,7 +41,7 @@ def _records(weights, lo, hi):
 
 def _shard_worker(rank, world, port, q, gpu_turn):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      MIT_DIST_BACKEND="gloo", MIT_COTENANT_SAFE="1")   # two engines on ONE GPU: the co-tenant-safe launches
+                      MIT_DIST_BACKEND="gloo")
     try:
         from manga_image_translator_amd import dist as Dm, pipeline
 
@@ -50,8 +50,8 @@ def _shard_worker(rank, world, port, q, gpu_turn):
         lo, hi = Dm.shard_range(N_PAGES, rank, world)
         # Both ranks of this rehearsal sit on ONE GPU (a real job has one GPU per rank) and run their engines AT THE SAME TIME: kernels of
         # the two processes share CUs.  Round 3 had to serialise them (the 128 x 128 split GEMM tile of one process disturbed the FFT rows
-        # kernels of the other); with MIT_COTENANT_SAFE=1 (set above: those kernels take a whole CU's LDS) the concurrent run
-        # is byte-identical to the single process again.  MIT_TEST_SERIALISE_RANKS=1 restores the turn-taking for diagnosis.
+        # kernels of the other: packed-fp32 instructions of the SLP vectoriser); built without them the concurrent run — default
+        # launches, no safe mode — is byte-identical to the single process.  MIT_TEST_SERIALISE_RANKS=1 restores the turn-taking for diagnosis.
         with (gpu_turn if os.environ.get("MIT_TEST_SERIALISE_RANKS") else contextlib.nullcontext()):
             recs = _records(weights, lo, hi)
             torch.cuda.synchronize()
