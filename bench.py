@@ -580,8 +580,9 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4, group=1
                             pipeline=dict(pages_per_slot=group or n, stage_threads=3 if group and n > group else 1, mask_workers=mask_workers),
                             note="host wall time per stage thread; the stages work on different page groups at the same time")
         # the same batch with the mask stage's side stream off (everything in the caller's stream): must give the same bytes and texts
-        if eng.side_stream:
-            eng.side_stream = False
+        if eng.side_stream or eng.stage_streams:
+            keep = (eng.side_stream, eng.stage_streams)
+            eng.side_stream = eng.stage_streams = False
             ref = eng.run(pages_dev, **kw)
             torch.cuda.synchronize()
             if os.environ.get("MIT_BENCH_COUPLED_TWICE"):   # diagnostics: is the one-stream run itself reproducible?
@@ -589,17 +590,17 @@ def coupled_leg(weights, n_pages, distinct, device, steps=2, b1_pages=4, group=1
                 torch.cuda.synchronize()
                 out["batch"]["pipeline"]["one_stream_twice_mask_bytes"] = int((ref2.mask != ref.mask).sum())
                 res2 = None
-                eng.side_stream = True
+                eng.side_stream, eng.stage_streams = keep
                 res2 = eng.run(pages_dev, **kw)
                 torch.cuda.synchronize()
                 out["batch"]["pipeline"]["side_stream_twice_mask_bytes"] = int((res2.mask != res.mask).sum())
                 del ref2, res2
-            eng.side_stream = True
+            eng.side_stream, eng.stage_streams = keep
             dm = (ref.mask != res.mask).reshape(n, -1).sum(1)
             di = (ref.inpainted != res.inpainted).reshape(n, -1).sum(1)
             same_text = [[(l.text, l.prob) for l in t] for t in ref.textlines] == [[(l.text, l.prob) for l in t] for t in res.textlines]
             same = bool(dm.sum() == 0 and di.sum() == 0 and same_text)
-            out["batch"]["pipeline"]["streams"] = "caller's + a high-priority side stream for the mask-refinement stage"
+            out["batch"]["pipeline"]["streams"] = ("one per stage thread" if keep[1] else "caller's") + (" + a high-priority side stream for the mask-refinement stage" if keep[0] else "")
             out["batch"]["pipeline"]["side_stream_results_equal_one_stream"] = same
             if not same:
                 out["batch"]["pipeline"]["side_stream_diff"] = dict(pages_with_mask_diff=int((dm > 0).sum()), mask_bytes=int(dm.sum()),
