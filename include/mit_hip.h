@@ -119,11 +119,13 @@ int mit_abi_version(void);
  * binding refuses (or rebuilds) a library whose digest differs from the tree's, so stale kernels are never measured. */
 const char *mit_source_digest(void);
 
-/* Kernels of this library that are known to return wrong results while ANOTHER queue's kernel (a second process on the GPU, a second
- * stream) that mixes MFMAs with LDS traffic is resident on the same CU — mit_rfft_rows / mit_irfft_rows at row lengths with radix-7 / 13
- * stages, DESIGN.md §7 — are launched with a whole CU's LDS when this is on, so nothing of that kind fits beside them (about 3 % of a LaMa
- * forward).  Off by default (one process per GPU on one stream never has two kernels resident at once); the initial value comes from
- * MIT_COTENANT_SAFE in the environment.  on < 0 only queries.  Returns the previous value.  Nothing in the reference corresponds to it. */
+/* The mitigation that shipped before the co-tenancy failure was understood: mit_rfft_rows / mit_irfft_rows were
+ * seen returning wrong workgroups while ANOTHER queue's kernel (a second process on the GPU, a second stream) that issues MFMAs was
+ * resident on the same CU; with this on they read LDS with 4-byte loads and take a whole CU's LDS, so nothing fits beside them (about 3 %
+ * of a LaMa forward).  The cause was the SLP vectoriser's packed-fp32 instructions; the library is built without them now and gives
+ * the one-stream bytes beside any co-tenant in its DEFAULT launch form (tests/test_cotenant_gpu.py), so this switch is no longer needed —
+ * it stays for A/B runs.  Off by default; initial value from MIT_COTENANT_SAFE in the environment.  on < 0 only queries.  Returns the
+ * previous value.  Nothing in the reference corresponds to it. */
 int mit_cotenant_safe_set(int on);
 
 /* device / runtime ------------------------------------------------------------------- */

@@ -71,12 +71,12 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 w) {
 
 // A (re, im) pair out of LDS.  SAFE = false: one 8-byte load — the butterfly inputs of a stage sit a constant stride apart and hipcc
 // merges them into two-address reads (ds_read2_b64 / ds_read2st64_b64).  SAFE = true (the kernels of MIT_COTENANT_SAFE launches): TWO
-// 4-byte loads, kept apart by the volatile.  Round 4 (scripts/cotenant_check, profiles/r04b_cotenant_check.log): while ANOTHER queue's
-// kernel that mixes MFMAs with LDS traffic shares the CU, the radix-4 / 3 plan returns wrong workgroups in 7-21 of 100 launches with the
-// merged reads and in 0 of 100 with the narrow ones — every other victim tried, single-address 8- and 16-byte reads included, stays exact.
-// The radix-7 / 13 plan of the BASELINE page is disturbed even then (tests/test_cotenant_gpu.py), which is why safe launches also take
-// a whole CU's LDS; the narrow reads cost the two kernels 30-45 % (385 vs 265 us, 437 vs 335 us per 16-page launch), so the default
-// launches — one queue per GPU — keep the wide ones.
+// 4-byte loads, kept apart by the volatile — the mitigation of round 4 for the co-tenancy failure (wrong workgroups while another
+// queue's MFMA kernel shares the CU), together with a whole CU's LDS per launch; 30-45 % slower (385 vs 265 us, 437 vs 335 us per
+// 16-page launch).  The failure turned out to sit in the butterflies' ARITHMETIC, not in the reads: the SLP vectoriser had packed it
+// into v_pk_*_f32 with op_sel / neg modifiers (1317 of them in this file), which go wrong beside MFMA co-tenants on gfx950; the narrow
+// reads only changed the instruction mix enough to hide it for the radix-4 / 3 plan.  Built with -fno-slp-vectorize the default form is
+// exact (tests/test_cotenant_gpu.py); the SAFE form stays as a switch.
 template <bool SAFE>
 __device__ __forceinline__ float2 lds_pair(const float2 *p) {
     if constexpr (SAFE) {
