@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 8
+#define MIT_ABI_VERSION 9
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -455,6 +455,12 @@ int mit_axpy(float *out_dev, float a, const float *x_dev, const float *y_dev, in
 int mit_boxes_from_bitmap(const float *pred, const uint8_t *bitmap, int H, int W, int dest_w, int dest_h, int max_candidates,
                           float unclip_ratio, float min_sside, float box_thresh, float min_sside_out, int roll_start,
                           int64_t *boxes_out, float *scores_out, int *n_out);
+/* Minimum distance between the quadrilaterals of index pairs (host code, no GPU): quads [n][4][2] doubles (vertex rings), pairs [m][2]
+ * -> out [m]; 0 when the two rings touch, cross or contain one another, else the smallest vertex-to-edge distance.  What shapely's
+ * Polygon(a.pts).distance(Polygon(b.pts)) returns in Quadrilateral.can_merge / quadrilateral_can_merge_region (utils/generic.py:660-662),
+ * which the OCR direction vote (ocr/common.py:12-39) and the text-line merge graph (textline_merge/__init__.py:112-141) evaluate for
+ * every pair of neighbouring lines of a page.  The arithmetic is textline.polygon_distance's, operation for operation (doubles). */
+int mit_quad_pair_distances(const double *quads, int n, const int32_t *pairs, int m, double *out);
 /* Number of contours / border points cv2.findContours(RETR_LIST) would trace in a 0/1 bitmap (diagnostics, tests). */
 int mit_find_contours_count(const uint8_t *bitmap, int H, int W, int *n_contours, int64_t *n_points);
 

@@ -404,6 +404,61 @@ extern "C" int mit_boxes_from_bitmap(const float *pred, const uint8_t *bitmap, i
     return 0;
 }
 
+// ---- distance between two quadrilaterals (textline.polygon_distance, operation for operation) -------------------------------------
+namespace {
+struct P2 {
+    double x, y;
+};
+inline double pd_orient(const P2 &p, const P2 &q, const P2 &r) { return (q.x - p.x) * (r.y - p.y) - (q.y - p.y) * (r.x - p.x); }
+inline bool pd_on(const P2 &p, const P2 &q, const P2 &r) {
+    return std::min(p.x, q.x) <= r.x && r.x <= std::max(p.x, q.x) && std::min(p.y, q.y) <= r.y && r.y <= std::max(p.y, q.y);
+}
+inline bool pd_segs_intersect(const P2 &a, const P2 &b, const P2 &c, const P2 &d) {
+    const double o1 = pd_orient(a, b, c), o2 = pd_orient(a, b, d), o3 = pd_orient(c, d, a), o4 = pd_orient(c, d, b);
+    if (((o1 > 0) != (o2 > 0)) && ((o3 > 0) != (o4 > 0)) && o1 * o2 != 0 && o3 * o4 != 0) return true;
+    return (o1 == 0 && pd_on(a, b, c)) || (o2 == 0 && pd_on(a, b, d)) || (o3 == 0 && pd_on(c, d, a)) || (o4 == 0 && pd_on(c, d, b));
+}
+inline bool pd_point_in_quad(const P2 &p, const P2 *poly) {
+    bool inside = false;
+    for (int i = 0; i < 4; ++i) {
+        const P2 &a = poly[i], &b = poly[(i + 1) & 3];
+        if ((a.y > p.y) != (b.y > p.y) && p.x < (b.x - a.x) * (p.y - a.y) / (b.y - a.y) + a.x) inside = !inside;
+    }
+    return inside;
+}
+inline double pd_seg_point(const P2 &p, const P2 &a, const P2 &b) {
+    const double abx = b.x - a.x, aby = b.y - a.y, apx = p.x - a.x, apy = p.y - a.y;
+    const double den = abx * abx + aby * aby;
+    const double t = den == 0 ? 0.0 : std::min(1.0, std::max(0.0, (apx * abx + apy * aby) / den));
+    const double dx = apx - t * abx, dy = apy - t * aby;
+    return std::sqrt(dx * dx + dy * dy);
+}
+double quad_distance(const P2 *pa, const P2 *pb) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (pd_segs_intersect(pa[i], pa[(i + 1) & 3], pb[j], pb[(j + 1) & 3])) return 0.0;
+    if (pd_point_in_quad(pb[0], pa) || pd_point_in_quad(pa[0], pb)) return 0.0;
+    double d = 1e300;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            d = std::min(d, pd_seg_point(pa[i], pb[j], pb[(j + 1) & 3]));
+            d = std::min(d, pd_seg_point(pb[j], pa[i], pa[(i + 1) & 3]));
+        }
+    return d;
+}
+}  // namespace
+
+extern "C" int mit_quad_pair_distances(const double *quads, int n, const int32_t *pairs, int m, double *out) {
+    if (m < 0 || n < 0 || (m > 0 && (!quads || !pairs || !out))) return mit_set_error("mit_quad_pair_distances: null pointer");
+    const P2 *q = reinterpret_cast<const P2 *>(quads);
+    for (int k = 0; k < m; ++k) {
+        const int u = pairs[2 * k], v = pairs[2 * k + 1];
+        if (u < 0 || v < 0 || u >= n || v >= n) return mit_set_error("mit_quad_pair_distances: pair %d = (%d, %d) outside [0, %d)", k, u, v, n);
+        out[k] = quad_distance(q + 4 * (int64_t)u, q + 4 * (int64_t)v);
+    }
+    return 0;
+}
+
 extern "C" int mit_find_contours_count(const uint8_t *bitmap, int H, int W, int *n_contours, int64_t *n_points) {
     if (!bitmap || !n_contours || !n_points) return mit_set_error("mit_find_contours_count: null pointer");
     std::vector<std::vector<Pt>> contours;

@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 8
+MIT_ABI_VERSION = 9
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -243,6 +243,7 @@ SYMBOLS = {
     "mit_dwconv_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p]),
     "mit_cotenant_safe_set": (C.c_int, [C.c_int]),
+    "mit_quad_pair_distances": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mit_ocr48_decode_rows_max_set": (C.c_int, [C.c_int]),
     "mit_pgemm": (C.c_int, [C.POINTER(MitPGemm), C.c_void_p]),
     "mit_pgemm_tile_name": (C.c_char_p, [C.c_int]),

@@ -15,7 +15,7 @@ from __future__ import annotations
 import functools
 import math
 from dataclasses import dataclass
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -213,9 +213,29 @@ def polygon_distance(pa: np.ndarray, pb: np.ndarray) -> float:
     return d
 
 
+def quad_pair_distances(quads: Sequence["Quadrilateral"], pairs: Sequence[Tuple[int, int]]) -> List[float]:
+    """``polygon_distance(quads[u].pts, quads[v].pts)`` for every pair at once, in native host code (``mit_quad_pair_distances``: the
+    same double arithmetic, operation for operation — tests/test_textline.py compares them bit for bit): a page's direction vote and
+    merge graph ask for ~60 such distances, 75 us each in the interpreter."""
+    if not pairs:
+        return []
+    import ctypes as C
+
+    from . import lib as _lib
+
+    pts = np.ascontiguousarray([q.pts for q in quads], dtype=np.float64)
+    if pts.ndim != 3 or pts.shape[1:] != (4, 2):
+        return [polygon_distance(quads[u].pts, quads[v].pts) for u, v in pairs]
+    pr = np.ascontiguousarray(pairs, dtype=np.int32)
+    out = np.empty(len(pr), dtype=np.float64)
+    _lib.check(_lib.load().mit_quad_pair_distances(pts.ctypes.data, len(pts), pr.ctypes.data, len(pr), out.ctypes.data), "mit_quad_pair_distances")
+    return out.tolist()
+
+
 def quadrilateral_can_merge_region(a: Quadrilateral, b: Quadrilateral, ratio=1.9, discard_connection_gap=2, char_gap_tolerance=0.6,
-                                   char_gap_tolerance2=1.5, font_size_ratio_tol=1.5, aspect_ratio_tol=2) -> bool:
-    """utils/generic.py:653-698, line for line (shapely's polygon distance replaced by ``polygon_distance``)."""
+                                   char_gap_tolerance2=1.5, font_size_ratio_tol=1.5, aspect_ratio_tol=2, dist: Optional[float] = None) -> bool:
+    """utils/generic.py:653-698, line for line (shapely's polygon distance replaced by ``polygon_distance``).  ``dist``: that distance
+    when the caller already has it (``quad_pair_distances`` over all near pairs of a page)."""
     b1, b2 = a.aabb, b.aabb
     char_size = min(a.font_size, b.font_size)
     x1, y1, w1, h1 = b1.x, b1.y, b1.w, b1.h
@@ -229,7 +249,8 @@ def quadrilateral_can_merge_region(a: Quadrilateral, b: Quadrilateral, ratio=1.9
     gy = max(0.0, max(ea[1], eb[1]) - min(ea[3], eb[3]))
     if gx * gx + gy * gy > (discard_connection_gap * char_size) ** 2:
         return False
-    dist = polygon_distance(a.pts, b.pts)  # Polygon(a.pts).distance(Polygon(b.pts))
+    if dist is None:
+        dist = polygon_distance(a.pts, b.pts)  # Polygon(a.pts).distance(Polygon(b.pts))
     if dist > discard_connection_gap * char_size:
         return False
     if max(a.font_size, b.font_size) / char_size > font_size_ratio_tol:
@@ -292,8 +313,9 @@ def generate_text_direction(quads: Sequence[Quadrilateral]):
             i = parent[i]
         return i
 
-    for u, v in near_pairs(quads):
-        if quadrilateral_can_merge_region(quads[u], quads[v], aspect_ratio_tol=1):
+    pairs = near_pairs(quads)
+    for (u, v), d in zip(pairs, quad_pair_distances(quads, pairs)):
+        if quadrilateral_can_merge_region(quads[u], quads[v], aspect_ratio_tol=1, dist=d):
             ru, rv = find(u), find(v)
             if ru != rv:
                 parent[max(ru, rv)] = min(ru, rv)

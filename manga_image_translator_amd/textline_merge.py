@@ -146,16 +146,19 @@ def split_text_region(bboxes: Sequence[Quadrilateral], indices: Iterable[int], w
 def merge_bboxes_text_region(bboxes: Sequence[Quadrilateral], width, height):
     """textline_merge/__init__.py:112-184: yields (lines in reading order, fg colour, bg colour) per text region."""
     n = len(bboxes)
-    edges = [(u, v) for u, v in TL.near_pairs(bboxes)   # the pairs of itertools.combinations(range(n), 2) that can pass the predicate's first test
+    pairs = TL.near_pairs(bboxes)   # the pairs of itertools.combinations(range(n), 2) that can pass the predicate's first test
+    edges = [(u, v) for (u, v), d in zip(pairs, TL.quad_pair_distances(bboxes, pairs))
              if TL.quadrilateral_can_merge_region(bboxes[u], bboxes[v], aspect_ratio_tol=1.3, font_size_ratio_tol=2,
-                                                  char_gap_tolerance=1, char_gap_tolerance2=3)]
+                                                  char_gap_tolerance=1, char_gap_tolerance2=3, dist=d)]
     regions: List[Set[int]] = []
     for comp in _components(list(range(n)), edges):
         regions.extend(split_text_region(bboxes, comp, width, height))
     for node_set in regions:
         nodes = list(node_set)
         lines = [bboxes[i] for i in nodes]
-        mean = lambda attr: round(float(np.mean([getattr(b, attr) for b in lines])))
+        # round(np.mean(...)) of the integer colour components: the integer sum is exact in float64, so the true division below is the
+        # same double (six numpy reductions per region cost a millisecond per page)
+        mean = lambda attr: round(sum(int(getattr(b, attr)) for b in lines) / len(lines))
         fg = (mean("fg_r"), mean("fg_g"), mean("fg_b"))
         bg = (mean("bg_r"), mean("bg_g"), mean("bg_b"))
         dirs = [b.direction for b in lines]

@@ -151,3 +151,38 @@ def test_is_ignore_matches_the_reference_function():
     got = np.array([[TL.is_ignore(c, int(lv)) for lv in g["levels"]] for c in crops])
     assert np.array_equal(got, g["want"])
     assert not got[:, 0].any() and not got[:, -1].any() and got[:, 3].any() and not got[:, 3].all()   # 0 and 51 switch it off
+
+
+def test_native_quad_pair_distances_equal_polygon_distance_bit_for_bit():
+    """mit_quad_pair_distances (host C++ behind the direction vote and the merge graph) against textline.polygon_distance on random
+    quadrilaterals — apart, touching at a vertex, sharing an edge, crossing, one inside the other, degenerate (repeated vertices): the
+    same double arithmetic in the same order, so every distance is the same double."""
+    rng = np.random.default_rng(7)
+    quads = []
+    for k in range(120):
+        c = rng.uniform(0, 300, size=2)
+        w, h, a = rng.uniform(5, 120), rng.uniform(5, 60), rng.uniform(0, np.pi)
+        R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        pts = (np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) / 2) @ R.T + c
+        if k % 3 == 0:
+            pts = np.rint(pts)                      # integer corners: exact ties / touching configurations occur
+        quads.append(pts)
+    quads.append(np.array([[0, 0], [10, 0], [10, 10], [0, 10]], dtype=np.float64))
+    quads.append(np.array([[10, 10], [20, 10], [20, 20], [10, 20]], dtype=np.float64))      # touches the previous one in a corner
+    quads.append(np.array([[10, 0], [20, 0], [20, 10], [10, 10]], dtype=np.float64))         # shares an edge with the first
+    quads.append(np.array([[2, 2], [4, 2], [4, 4], [2, 4]], dtype=np.float64))               # inside the first
+    quads.append(np.array([[5, 5], [5, 5], [5, 5], [5, 5]], dtype=np.float64))               # a point
+    quads.append(np.array([[30, 0], [40, 0], [40, 0], [30, 0]], dtype=np.float64))           # a segment
+    objs = [TL.Quadrilateral(q) for q in quads]
+    for o, q in zip(objs, quads):
+        o.pts = q                                   # (the constructor sorts / rounds: compare on the raw rings)
+    pairs = [(u, v) for u in range(len(quads)) for v in range(u + 1, len(quads))]
+    got = TL.quad_pair_distances(objs, pairs)
+    assert len(got) == len(pairs)
+    zero = 0
+    for (u, v), d in zip(pairs, got):
+        ref = TL.polygon_distance(quads[u], quads[v])
+        assert d == ref and np.signbit(d) == np.signbit(ref), (u, v, d, ref)
+        zero += d == 0.0
+    assert zero > 50 and zero < len(pairs) - 1000       # both regimes are exercised
+    assert TL.quad_pair_distances(objs, []) == []
