@@ -107,6 +107,12 @@ except Exception:  # stand-alone: mirror the ModelWrapper lifecycle
 _RELEASE = "https://github.com/zyddnys/manga-image-translator/releases/download/beta-0.3/"
 
 
+def _own_quad(q) -> Quadrilateral:
+    """A text line in this package's geometry type: the object itself when it already is one (the detector plugins of this package return
+    them; building it again would re-sort its corners with five numpy calls, 65 us a line), else built from the reference object's points."""
+    return q if type(q) is Quadrilateral else Quadrilateral(np.asarray(q.pts))
+
+
 def _weights_handed_over(plugin, *given) -> None:
     """State dicts injected through the constructor stand for the checkpoint files: nothing is left to download, so
     ModelWrapper.load() (utils/inference.py:330-338) must not try to fetch ``_MODEL_MAPPING`` (there is no network offline)."""
@@ -326,7 +332,7 @@ class HipModel48pxOCR(_OcrBase):
             return list(self._generate_text_direction(textlines))
         from . import textline as TL
 
-        own = [TL.Quadrilateral(np.asarray(q.pts)) for q in textlines]
+        own = [_own_quad(q) for q in textlines]
         back = {id(o): q for o, q in zip(own, textlines)}
         return [(back[id(o)], d) for o, d in TL.generate_text_direction(own)]
 
@@ -342,7 +348,7 @@ class HipModel48pxOCR(_OcrBase):
         quads = [q for q, _ in pairs]
         dirs = [[d for _, d in pairs]]
         page = torch.from_numpy(np.ascontiguousarray(image)).to(self.engine.device)[None]
-        own = [Quadrilateral(np.asarray(q.pts)) for q in quads]  # geometry in this package's type
+        own = [_own_quad(q) for q in quads]  # geometry in this package's type
         r = self.engine.recognize_pages(page, [own], max_seq_length=max_seq_length, suppress_eos=suppress_eos, directions=dirs)
         toks, lens = r["tokens"].cpu().numpy(), r["length"].cpu().numpy()
         probs, cols = r["prob"].cpu().numpy(), r["colors"].cpu().numpy()
@@ -418,7 +424,7 @@ class HipModel48pxCTCOCR(HipModel48pxOCR):
         H, W = image.shape[:2]
         dev = self.engine.device
         page = torch.from_numpy(np.ascontiguousarray(image)).to(dev)[None]
-        own = [Quadrilateral(np.asarray(q.pts)) for q in quads]
+        own = [_own_quad(q) for q in quads]
         rec = TL.warp_plans(own, dirs, H, W, 48)
         widths = np.where(rec["vertical"] != 0, rec["dh"], rec["dw"]).tolist()
         out = []
