@@ -236,15 +236,18 @@ double polygon_mean(const float *pred, int H, int W, const std::vector<Pt> &poly
             }
         }
     }
-    // interior: even-odd rule sampled at pixel centres
-    std::vector<double> xs;
+    // interior: even-odd rule sampled at pixel centres.  An edge (a, b) crosses the scan line y when min(a.y, b.y) <= y < max(a.y, b.y)
+    // (integer coordinates): every edge is filed under the rows it crosses once — a traced contour's edges are unit steps, so that is
+    // O(edges) instead of O(rows x edges) — and a row's crossings are sorted as before (their order of discovery never mattered).
+    std::vector<std::vector<double>> rows((size_t)mh);
+    for (int i = 0; i < n; ++i) {
+        const Pt a = poly[i], b = poly[(i + 1) % n];
+        if (a.y == b.y) continue;
+        const int y0 = std::max(std::min(a.y, b.y), ymin), y1 = std::min(std::max(a.y, b.y), ymax + 1);   // rows [y0, y1)
+        for (int y = y0; y < y1; ++y) rows[(size_t)(y - ymin)].push_back(a.x + ((double)y - a.y) * (double)(b.x - a.x) / (double)(b.y - a.y));
+    }
     for (int y = ymin; y <= ymax; ++y) {
-        xs.clear();
-        const double yc = y;
-        for (int i = 0; i < n; ++i) {
-            const Pt a = poly[i], b = poly[(i + 1) % n];
-            if ((a.y <= yc && b.y > yc) || (b.y <= yc && a.y > yc)) xs.push_back(a.x + (yc - a.y) * (double)(b.x - a.x) / (double)(b.y - a.y));
-        }
+        std::vector<double> &xs = rows[(size_t)(y - ymin)];
         std::sort(xs.begin(), xs.end());
         for (size_t k = 0; k + 1 < xs.size(); k += 2)
             for (int x = (int)ceil(xs[k]); x <= (int)floor(xs[k + 1]); ++x) set(x, y);
