@@ -186,3 +186,25 @@ def test_native_quad_pair_distances_equal_polygon_distance_bit_for_bit():
         zero += d == 0.0
     assert zero > 50 and zero < len(pairs) - 1000       # both regimes are exercised
     assert TL.quad_pair_distances(objs, []) == []
+
+
+def test_native_quad_pair_distances_property():
+    """Property form of the comparison above (hypothesis): arbitrary finite corner coordinates, integer-valued ones included (exact ties,
+    collinear and repeated corners) — the native distance is the Python routine's double, and it is symmetric in its arguments."""
+    hyp = pytest.importorskip("hypothesis")
+    st = hyp.strategies
+    coord = st.one_of(st.integers(-50, 50).map(float), st.floats(-1e3, 1e3, allow_nan=False, allow_infinity=False, width=64))
+    quad = st.lists(st.tuples(coord, coord), min_size=4, max_size=4)
+
+    @hyp.settings(max_examples=300, deadline=None)
+    @hyp.given(quad, quad)
+    def check(a, b):
+        qa, qb = np.array(a, dtype=np.float64), np.array(b, dtype=np.float64)
+        oa, ob = TL.Quadrilateral(np.array([[0, 0], [4, 0], [4, 2], [0, 2]])), TL.Quadrilateral(np.array([[0, 0], [4, 0], [4, 2], [0, 2]]))
+        oa.pts, ob.pts = qa, qb
+        d_ab, d_ba = TL.quad_pair_distances([oa, ob], [(0, 1), (1, 0)])
+        ref = TL.polygon_distance(qa, qb)
+        assert d_ab == ref, (a, b, d_ab, ref)
+        assert d_ba == TL.polygon_distance(qb, qa)
+
+    check()
