@@ -993,6 +993,10 @@ __global__ void beam_finalize_kernel(const int *__restrict__ hist, int hist_ld, 
 
 void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
                     int D, float eps, hipStream_t s, const OcrPlanes *planes) {
+    if (planes && (D > 512 || (D & 7))) {  // the planar form stages a row in 512 floats of LDS and writes cells of 8
+        mit_set_error("ocrk_layernorm: planar output needs D %% 8 == 0 and D <= 512 (got %d)", D);
+        return;
+    }
     const int waves = 4;
     MitProbeScope probe("layernorm_kernel", s, (planes ? 10.0 : 8.0) * (double)rows * D);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + waves - 1) / waves), dim3(64 * waves), 0, s, in, in_rs, w, b, out, out_rs,
