@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: pages/sec end-to-end (detect + OCR + inpaint) on 2048x1456 pages (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W        (N > 1: one rank per GPU; started outside torch.distributed.run it launches
+                                                        its own N ranks through it on 127.0.0.1 — the driver's command shape works as is)
+  python bench.py --gpus 2 --launch-rehearsal          the launch / rendezvous / weight broadcast / verified gather / max-over-ranks
+                                                        plumbing alone on gloo, no GPU work (a rehearsal line, not a measurement)
   python bench.py --config4 ...                        BASELINE config 4 preset: 128 pages per GPU
   python bench.py --mode dropin                        the drop-in path instead: B = 1, page at a time through the plugins
 
@@ -80,7 +83,12 @@ def parse(argv=None):
     ap.add_argument("--config4", action="store_true", help="BASELINE config 4 preset: 128 pages per GPU (1024 pages over 8 GPUs)")
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 on one GPU: ESRGAN 4x + lama_large (its own line)")
     ap.add_argument("--config1", action="store_true", help="BASELINE config 1 on one GPU: default detector + 48px + lama_mpe at 1024^2, B = 1 (its own line)")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pages (global page g shows page g %% distinct)")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct synthetic pages (global page g shows page g %% distinct); 0 = every global page is its own page "
+                         "(synth_page(g), SURVEY.md §8d), the default")
+    ap.add_argument("--launch-rehearsal", action="store_true",
+                    help="run only the N-rank plumbing (self-launch, rendezvous, weight-arena broadcast, checksummed result gather, max-over-ranks "
+                         "timing) on the gloo backend with CPU tensors and print a line marked rehearsal; needs no GPU")
     ap.add_argument("--stages", default="detect,ocr,inpaint")
     ap.add_argument("--lama-mb", type=int, default=16)
     ap.add_argument("--ctd-mb", type=int, default=16)
@@ -99,6 +107,8 @@ def parse(argv=None):
     ap.add_argument("--coupled-group", type=int, default=16, help="pages per pipeline slot of the coupled batch path (0: one unpipelined pass)")
     ap.add_argument("--coupled-mask-workers", type=int, default=4, help="host threads of the coupled path's per-page mask stages")
     ap.add_argument("--coupled-only", action="store_true", help="only the coupled batch measurement (A/B runs of its knobs)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short sub-measurements of BASELINE configs 1, 2 and 5 (other_configs) the default one-GPU run appends")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the two-stream sub-measurement (two_streams)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-MFMA sub-measurement (fp32_mfma) taken beside a split-mode headline")
     ap.add_argument("--fp32-steps", type=int, default=3, help="timed steps of the fp32_mfma sub-measurement (after 1 warm-up step)")
@@ -112,18 +122,25 @@ def parse(argv=None):
 
 
 def make_inputs(n_pages, distinct, rank, device):
-    """Rank r owns the contiguous global pages [r * n_pages, (r + 1) * n_pages); global page g shows synthetic page g % distinct,
-    so a page's content — and therefore its result record — does not depend on the world size."""
+    """Rank r owns the contiguous global pages [r * n_pages, (r + 1) * n_pages); global page g shows synthetic page g (``distinct`` = 0,
+    the default: every page of the job is its own page) or page g % distinct, so a page's content — and therefore its result record —
+    does not depend on the world size.  Returns the device batch, and the host copies of the rank's distinct pages with the batch's
+    index into them (the CPU baseline / parity legs read those)."""
     from manga_image_translator_amd import pipeline, synth
 
-    distinct = max(1, min(distinct, n_pages))
+    if distinct <= 0:
+        ids = [rank * n_pages + i for i in range(n_pages)]
+    else:
+        ids = [(rank * n_pages + i) % distinct for i in range(n_pages)]
+    uniq = sorted(set(ids))
+    slot = {g: k for k, g in enumerate(uniq)}
     pages, quads, masks = [], [], []
-    for i in range(distinct):
-        p, q, m = synth.synth_page(i, H, W, n_boxes=N_BOXES)
+    for g in uniq:
+        p, q, m = synth.synth_page(g, H, W, n_boxes=N_BOXES)
         pages.append(p)
         quads.append(q)
         masks.append(m)
-    idx = [(rank * n_pages + i) % distinct for i in range(n_pages)]
+    idx = [slot[g] for g in ids]
     pages_t = torch.from_numpy(np.stack([pages[i] for i in idx])).to(device)
     masks_t = torch.from_numpy(np.stack([masks[i] for i in idx])).to(device)
     quad_objs = [pipeline.quads_from_array(quads[i]) for i in idx]
@@ -145,9 +162,10 @@ def _pmc_traffic():
         return None, {}
 
 
-def _mfma_busy():
-    """Newest committed MFMA-busy summary (scripts/pmc_mfma.sh): stage -> fraction of matrix-pipe cycles used (PMC)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy.json")))
+def _mfma_busy(fp32=False):
+    """Newest committed MFMA-busy summary (scripts/pmc_mfma.sh) OF THE GEMM MODE THE LEG RUNS IN (``…_mfma_busy.json`` = the shipped split
+    mode, ``…_mfma_busy_fp32.json`` = mode 0): stage -> fraction of matrix-pipe cycles used (PMC)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy_fp32.json" if fp32 else "r*_mfma_busy.json")))
     if not files:
         return None, {}
     try:
@@ -170,7 +188,7 @@ def stage_legs(engine, pages, quads, masks, stages, dump=""):
 
     lib = L.load()
     ncfg_max = 64
-    per_stage, conv_tot, kern_tot = {}, {}, {}
+    per_stage, conv_tot, kern_tot, alg_bytes = {}, {}, {}, {}
     n = pages.shape[0]
     for s in stages:
         torch.cuda.synchronize()
@@ -187,6 +205,18 @@ def stage_legs(engine, pages, quads, masks, stages, dump=""):
         kst = (L.MitProfKernelStat * 64)()
         nk = C.c_int(0)
         L.check(lib.mit_prof_kernels_read(kst, 64, C.byref(nk)), "mit_prof_kernels_read")
+        import tempfile
+
+        with tempfile.NamedTemporaryFile(suffix=".csv") as tf:   # per-launch records (tile, M, N, K, taps, Z): the algorithmic bytes per tile
+            L.check(lib.mit_prof_dump(tf.name.encode()), "mit_prof_dump")
+            for ln in open(tf.name).read().splitlines()[1:]:
+                f = ln.split(",")
+                m_, n_, k_, taps_, z_ = (float(v) for v in f[1:6])
+                ab = alg_bytes.setdefault(f[0], [0, 0.0, 0.0, 0.0])
+                ab[0] += 1
+                ab[1] += 4.0 * z_ * m_ * k_ / max(taps_, 1.0)   # A: every input element of a stride-1 layer once (M x Cin per slice)
+                ab[2] += 4.0 * z_ * k_ * n_                     # W as fp32
+                ab[3] += 4.0 * z_ * m_ * n_                     # C written once
         if dump:
             L.check(lib.mit_prof_dump(f"{dump}.{s}".encode()), "mit_prof_dump")
         L.check(lib.mit_prof_enable(0), "mit_prof_enable")
@@ -226,6 +256,7 @@ def stage_legs(engine, pages, quads, masks, stages, dump=""):
             mfma_ms_at_peak_per_page=round(peak_ms / n, 3), frac_of_mfma_roofline=round(peak_ms / wall_ms, 4),
             executed_bf16_tflops=round(bf16_exec / (wall_ms * 1e-3) / 1e12, 1) if bf16_exec else 0.0)
         per_stage[STAGE_NAMES.get(s, s)]["_peak_ms"] = peak_ms
+    stage_legs.alg_bytes = alg_bytes
     return per_stage, conv_tot, kern_tot, n
 
 
@@ -251,8 +282,15 @@ def roofline_leg(engine, pages, quads, masks, stages, dump=""):
     cname, kname = lib.mit_conv_gemm_config_name(dom).decode(), lib.mit_conv_gemm_config_kernel(dom).decode()
     achieved = alg / (ms * 1e-3) / 1e12
     tr = _traffic_entry(pmc, kname)
+    ab = getattr(stage_legs, "alg_bytes", {}).get(cname)
     if tr is not None:
         tr["source"] = src
+        tr["joined_from_committed_pmc_pass"] = True    # counters need their own profiler passes: not re-measured by this run
+        if ab and ab[0]:
+            alg = dict(A_GB=round(ab[1] / ab[0] / 1e9, 4), W_GB=round(ab[2] / ab[0] / 1e9, 4), C_GB=round(ab[3] / ab[0] / 1e9, 4))
+            alg["total_GB"] = round(sum(alg.values()), 4)
+            tr["algorithmic_per_launch"] = alg      # measured in THIS run's launch mix (every input element once, W once, C once)
+            tr["ratio_to_algorithmic"] = round((tr["read_GB"] + tr["write_GB"]) / max(alg["total_GB"], 1e-9), 3)
     hbm = {}
     for name, (kl, kms, kb, kf) in sorted(kern_tot.items(), key=lambda kv: -kv[1][1]):
         e = dict(launches=int(kl), avg_us=round(kms * 1e3 / kl, 2), ms_per_page=round(kms / n, 4))
@@ -265,10 +303,13 @@ def roofline_leg(engine, pages, quads, masks, stages, dump=""):
         if t is not None:
             e["pmc_traffic"] = t
         hbm[name] = e
-    busy_src, busy = _mfma_busy()
+    from manga_image_translator_amd import ops as _ops_mode
+
+    busy_src, busy = _mfma_busy(fp32=not _ops_mode.split_mode())
     for sname, key in (("ctd", "detect"), ("ocr48", "ocr"), ("lama_mpe", "inpaint")):
-        if sname in per_stage and key in busy:   # PMC view of the same stage (counters-only pass of scripts/pmc_mfma.sh, committed under profiles/)
-            per_stage[sname]["mfma_busy"] = dict(frac=busy[key].get("mfma_busy"), effective_clock_GHz=busy[key].get("effective_clock_GHz"), source=busy_src)
+        if sname in per_stage and key in busy:   # PMC view of the same stage (counters-only pass of scripts/pmc_mfma.sh, committed under profiles/);
+            # (the summaries' derived effective_clock_GHz is not carried over: for stages made of short kernels it came out above the chip clock)
+            per_stage[sname]["mfma_busy"] = dict(frac=busy[key].get("mfma_busy"), source=busy_src, joined_from_committed_pmc_pass=True)
     total_exec = sum(v[2] for v in conv_tot.values())
     total_wall = sum(s["ms_per_page"] for s in per_stage.values()) * n
     total_peak_ms = sum(s.pop("_peak_ms") for s in per_stage.values())
@@ -512,7 +553,7 @@ def _coupled_inputs(n_pages, distinct, device):
     separate the overlapping boxes of the headline pages, which are fed to the stages as ground-truth quads instead."""
     from manga_image_translator_amd import synth
 
-    distinct = max(1, min(distinct, n_pages))
+    distinct = n_pages if distinct <= 0 else max(1, min(distinct, n_pages))
     gen = [synth.synth_page(i, H, W, n_boxes=N_BOXES, disjoint=True) for i in range(distinct)]
     idx = [i % distinct for i in range(n_pages)]
     pages_dev = torch.from_numpy(np.stack([gen[i][0] for i in idx])).to(device)
@@ -843,14 +884,85 @@ def config1_line(args, device):
             "gemm_mode": {"mode": _ops.split_mode()}, "stages_ms_per_page": stages}
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` started OUTSIDE torch.distributed.run (no WORLD_SIZE in the environment): start the N ranks ourselves,
+    exactly the way the contract's launcher does — ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <same arguments>`` — and pass their exit code on.  Rank 0 of that job prints the one JSON line on the stdout
+    we share with it."""
+    import subprocess
+
+    if not args.launch_rehearsal and os.environ.get("MIT_DIST_BACKEND") != "gloo":
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus:   # one rank per GPU over RCCL: refuse early, with the reason, instead of a rendezvous that hangs
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node shows {n} "
+                  "(MIT_DIST_BACKEND=gloo rehearses the N-rank path on fewer GPUs)", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_rehearsal(args) -> None:
+    """The N-rank plumbing of the headline run and nothing else, on gloo with CPU tensors: rendezvous, the weight arena broadcast from
+    rank 0, ``--steps`` verified gathers of a synthetic per-rank result block, barrier + max-over-ranks timing, one line on rank 0.
+    No kernel runs and the line says so (``rehearsal: true``, ``value`` null): it exists so that the launch path the driver's 8-GPU
+    command takes can be exercised where there is no GPU (tests/test_bench_launch.py)."""
+    from manga_image_translator_amd import dist as D
+
+    os.environ["MIT_DIST_BACKEND"] = "gloo"
+    rank, world, _ = D.init(backend="gloo")
+    g = torch.Generator().manual_seed(7)
+    weights = {"demo": {"w": torch.randn(257, 33, generator=g), "b": torch.arange(5, dtype=torch.int64)}} if rank == 0 else None
+    weights = D.broadcast_weights(weights)
+    wsum = float(weights["demo"]["w"].double().sum()) + float(weights["demo"]["b"].sum())
+    gather = D.PageGather()
+    D.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        block = ((torch.arange(args.pages * 1001, dtype=torch.int64) * (rank + 3) + k) % 251).to(torch.uint8)
+        gather.submit(block)
+    got = gather.wait()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    sums = [None] * world
+    torch.distributed.all_gather_object(sums, wsum) if world > 1 else sums.__setitem__(0, wsum)
+    if rank == 0:
+        k = args.steps - 1
+        blocks_ok = all(torch.equal(got[r], ((torch.arange(args.pages * 1001, dtype=torch.int64) * (r + 3) + k) % 251).to(torch.uint8))
+                        for r in range(world))
+        print(json.dumps({"metric": "pages/sec end-to-end (detect+OCR+inpaint), 2048x1456", "rehearsal": True, "value": None, "unit": "pages/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
+                          "backend": "gloo", "weights_equal_on_all_ranks": len(set(sums)) == 1, "last_blocks_equal_what_ranks_sent": bool(blocks_ok),
+                          "gather": {"verified_blocks": gather.check(), "bytes_per_step": gather.last_bytes, "wait_ms_rank0": round(gather.wait_ms, 3)},
+                          "note": "launch / rendezvous / broadcast / gather plumbing only; no kernel ran, nothing here is a measurement"}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.launch_rehearsal:
+        launch_rehearsal(args)
+        return
     from manga_image_translator_amd import dist as D
 
     rank, world, local = D.init()
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
@@ -926,6 +1038,10 @@ def main():
     if world > 1:   # every block rank 0 received in the timed region against the checksum its source rank computed before sending it
         try:
             gather_info = {"verified_blocks": gather.check(), "overlap_with_compute": bool(gather.async_op),
+                           "bytes_per_step": gathered["bytes"], "wait_ms_rank0_per_step": round(gather.wait_ms / max(gather.submits, 1), 3),
+                           "wait_note": "rank 0's time inside the gather (receive of world - 1 blocks + their checksums) per submit over the whole "
+                                        "run, from events on the compute stream (nccl) or the host clock (gloo): what max-over-ranks timing "
+                                        "charges to the step because of the gather",
                            "note": "each rank sends page_checksum(block) beside its block; rank 0 recomputes it on what arrived"}
         except Exception as ex:  # a corrupted gather must not lose the line, and must not go unnoticed
             leg_errors["gather_checksum"] = f"{type(ex).__name__}: {ex}"
@@ -980,6 +1096,21 @@ def main():
                    note="PageEngine(overlap=True): LaMa on the caller's stream, detector + OCR on a second stream that joins at the end of the step")
         del r2
 
+    cfg2 = None
+    if world == 1 and not args.no_other_configs and "detect" in stages:
+        # BASELINE config 2 (the same 64-page batch, detector = ctd only) on the headline's engine: 1 warm-up + 2 timed steps
+        def run_ctd():
+            return engine.run(pages, quads, masks, max_seq_length=DECODE_STEPS, suppress_eos=True, stages=("detect",))
+        run_ctd()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(2):
+            run_ctd()
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - tc) / 2
+        cfg2 = dict(metric="pages/sec, detector=ctd only (BASELINE config 2), 2048x1456", value=round(args.pages / dtc, 2), unit="pages/s",
+                    pages=args.pages, steps=2, warmup=1, ms_per_step=round(dtc * 1e3, 2))
+
     def leg(name, fn):
         """The legs run after the timed region; a failing leg is reported in the line (``leg_errors``), it does not lose the headline."""
         try:
@@ -1020,6 +1151,22 @@ def main():
             torch.cuda.empty_cache()
             coupled = leg("coupled", lambda: coupled_leg(weights, args.pages, args.distinct, device, group=args.coupled_group,
                                                          mask_workers=args.coupled_mask_workers))
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        # The other one-GPU BASELINE configurations, each a SHORT run of its own preset (python bench.py --config1 / --config5 print the
+        # full lines): so that the driver's default command leaves a number for every configuration that fits one GPU.
+        import copy
+
+        other = {"config2_ctd_only": cfg2}
+        for key, fn, npg in (("config1_default_48px_lama_1024", config1_line, 4), ("config5_esrgan4x_lama_large", config5_line, 1)):
+            a2 = copy.copy(args)
+            a2.pages, a2.steps, a2.warmup = npg, 1, 1
+            engine = pages = masks = None   # noqa: F841 - the headline's buffers are not needed any more
+            torch.cuda.empty_cache()
+            r = leg(key, lambda fn=fn, a2=a2: fn(a2, device))
+            if r is not None:
+                other[key] = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "stages_ms_per_page") if k in r}
+                other[key]["pages_per_step"] = npg
     D.barrier()
 
     if rank == 0:
@@ -1033,13 +1180,13 @@ def main():
             "config": {"workload": f"{cfg_name}: {args.pages} synthetic {H}x{W} pages per GPU, detector=ctd + ocr=48px "
                                    f"({N_BOXES} lines/page, {DECODE_STEPS} decode steps, EOS suppressed) + inpainter=lama_mpe; "
                                    "random-init weights of the reference architectures",
-                       "pages_per_gpu": args.pages, "distinct_pages": min(args.distinct, args.pages), "stages": list(stages),
+                       "pages_per_gpu": args.pages, "distinct_pages": len(host_inputs[0]), "stages": list(stages),
                        "microbatch": {"ctd": args.ctd_mb, "lama": args.lama_mb, "ocr_group": args.group},
                        "streams": 2 if args.overlap else 1,
                        "parallelism": f"pages sharded one contiguous block per GPU x{world}; RCCL weight broadcast"
                                       + (f" + per-step gather of {gathered['bytes']} result bytes to rank 0" if world > 1 else "")},
             "roofline": roof, "fp32_mfma": fp32, "two_streams": two, "cpu_baseline": cpu, "parity_checked": parity, "dropin": dropin, "coupled": coupled,
-            "conv_gemm_by_tile": per_cfg,
+            "other_configs": other, "conv_gemm_by_tile": per_cfg,
         }
         if shipped_mode:  # say so wherever the number travels
             n = shipped_mode

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 9
+#define MIT_ABI_VERSION 10
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -608,6 +608,9 @@ int mit_attention(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k
 int mit_attention_lines_xpos(const float *q_dev, const float *k_dev, const float *v_dev, float *out_dev, int64_t row_stride,
                              const int32_t *lines_dev, const int *klen_dev, int n_lines, int Lmax, int heads, int head_dim,
                              const MitXposTables *tables, void *stream);
+/* Longest line (Lmax) whose keys + per-wave score rows fit mit_attention_lines_xpos's LDS form for this head_dim (308 at head_dim 80);
+ * longer lines take the chunk-by-chunk path (mit_xpos_rotate + mit_attention), which has no such limit.  0 for an unsupported head_dim. */
+int mit_attention_lines_xpos_max_len(int head_dim);
 /* Cross-attention memory of one decoder layer for the same lines: mem_k[first_line + r][t][:] = the XPOS-rotated (inverse scale) k rows,
  * mem_v[...] = the v rows, t < L_r (line_stride floats between lines of the pooled [n, Lmax, heads * head_dim] memory); n_rows = the
  * rows the lines cover.  Replaces one mit_xpos_rotate and one copy per chunk (OCR.infer_beam_batch_tensor's memory, :678-704). */

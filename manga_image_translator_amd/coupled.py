@@ -99,7 +99,6 @@ class CoupledPageEngine:
         self.stage_streams = bool(int(os.environ.get("MIT_COUPLED_STAGE_STREAMS", "0")))
         self._stage = None
         self.ocr_slots = int(os.environ.get("MIT_COUPLED_OCR_SLOTS", "1"))   # pipeline slots recognised together (the OCR stage's own granularity)
-        self._ready: Dict[int, torch.cuda.Event] = {}   # raw-mask tensor (data_ptr) -> event recorded behind its last writer
 
     def _mask_backend(self):
         be = getattr(self._tls, "backend", None)
@@ -146,7 +145,9 @@ class CoupledPageEngine:
 
         for b, m in enumerate(self.mask_pool.map(refine, range(B))):
             refined[b] = m
-        self._ready[refined.data_ptr()] = torch.cuda.current_stream().record_event()   # (merge_and_refine's side stream waits for THIS, not for the queue)
+        # the event recorded behind the raw masks' last writer TRAVELS WITH THE TENSOR (merge_and_refine's side stream waits for this, not
+        # for the whole queue): no table keyed by address that a failed stage could leave behind for an unrelated tensor to inherit
+        refined.mit_ready_event = torch.cuda.current_stream().record_event()
         return textlines, refined
 
     @staticmethod
@@ -200,7 +201,7 @@ class CoupledPageEngine:
         # its end.  23.4 -> 26.2 pages/s; same bytes as the one-stream path (bench: coupled.batch.pipeline.side_stream_results_equal_one_stream)
         # — since the library is built without the SLP vectoriser's packed-fp32 instructions (with them 3-7 of 64 pages
         # came back with a few dozen mask bytes different whenever two streams' kernels were resident at once).
-        ready = self._ready.pop(mask_raw.data_ptr(), None)
+        ready = getattr(mask_raw, "mit_ready_event", None)   # set by detect(); a mask from anywhere else has none: one-stream path
         side = self._side_stream() if self.side_stream and ready is not None else main
         with torch.cuda.stream(side):
             if side is not main:

@@ -298,19 +298,19 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
                 float *qc = w.qkv + (int64_t)(l * 3 + 0) * R * TE;
                 float *kc = w.qkv + (int64_t)(l * 3 + 1) * R * TE;
                 float *vc = w.qkv + (int64_t)(l * 3 + 2) * R * TE;
-                ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl);
+                if (ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
                 if (pgemm(ly.qkv, w.nrm_p, Rp, R, qc + so, TE, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st, E, (int64_t)R * TE, dyn, E)) return 1;
                 OcrAttXpos xs{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 1, E};
                 ocrk_attention(qc + so, TE, E, kc, TE, E, vc, TE, E, nullptr, 0, 0, nullptr, R, 1, Tk, 1, st, 4, 80, dyn, &xs, &att_pl);
                 if (pgemm(ly.out, w.att_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
-                ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl);
+                if (ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
                 if (pgemm(ly.q2, w.nrm_p, Rp, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st)) return 1;
                 const float *mk = a->mem_k + (int64_t)l * N * L * E;
                 const float *mv = a->mem_v + (int64_t)l * N * L * E;
                 OcrAttXpos xc{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 0, 0};
                 ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, nullptr, 0, 0, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc, &att_pl);
                 if (pgemm(ly.out2, w.att_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
-                ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl);
+                if (ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
                 if (pgemm(ly.ff1, w.nrm_p, Rp, R, nullptr, 0, MIT_ACT_RELU, nullptr, 0, w.ffh_p, Rp, st)) return 1;
                 if (l < 4) {
                     if (pgemm(ly.ff2, w.ffh_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
@@ -327,14 +327,14 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
                 float *kc = w.qkv + (int64_t)(l * 3 + 1) * R * TE;
                 float *vc = w.qkv + (int64_t)(l * 3 + 2) * R * TE;
                 // self attention (:565)
-                ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, w.nrm, E, R, E, 1e-5f, st);
+                if (ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, w.nrm, E, R, E, 1e-5f, st)) return 1;
                 if (gemm(ly.qkv, w.nrm, E, qc + so, TE, R, MIT_ACT_NONE, nullptr, 0, st, E, (int64_t)R * TE, nullptr, dyn, 0, E)) return 1;
                 // (the XPOS rotation of the step's query and of the key history 0 .. step happens inside the attention kernel)
                 OcrAttXpos xs{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 1, E};
                 ocrk_attention(qc + so, TE, E, kc, TE, E, vc, TE, E, w.att, E, E, nullptr, R, 1, Tk, 1, st, 4, 80, dyn, &xs);
                 if (gemm(ly.out, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
                 // cross attention (:567)
-                ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, w.nrm, E, R, E, 1e-5f, st);
+                if (ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, w.nrm, E, R, E, 1e-5f, st)) return 1;
                 if (gemm(ly.q2, w.nrm, E, w.q2, E, R, MIT_ACT_NONE, nullptr, 0, st)) return 1;
                 const float *mk = a->mem_k + (int64_t)l * N * L * E;
                 const float *mv = a->mem_v + (int64_t)l * N * L * E;
@@ -342,7 +342,7 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
                 ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, w.att, E, E, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc);
                 if (gemm(ly.out2, w.att, E, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st)) return 1;
                 // feed forward (:568)
-                ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, st);
+                if (ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, w.nrm, E, R, E, 1e-5f, st)) return 1;
                 if (gemm(ly.ff1, w.nrm, E, w.ffh, FF, R, MIT_ACT_RELU, nullptr, 0, st)) return 1;
                 if (l < 4) {
                     if (gemm(ly.ff2, w.ffh, FF, w.tgt, E, R, MIT_ACT_NONE, w.tgt, E, st, 0, 0, w.part)) return 1;

@@ -11,7 +11,7 @@ struct OcrPlanes {
     int64_t ld;   // rows per (plane, k-cell) slab
     int K8;       // k-cells per plane (row length / 8)
 };
-void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
+int ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
                     int D, float eps, hipStream_t s, const OcrPlanes *planes = nullptr);   // planes: instead of out (D % 8 == 0)
 // dstep != NULL: step-dependent arguments come from the decoder's device-resident step counter (see the kernels' comments)
 void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,

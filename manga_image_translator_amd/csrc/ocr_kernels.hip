@@ -342,10 +342,12 @@ __global__ void gelu_kernel(float *__restrict__ x, int64_t n) {
 }
 
 // ---- LayerNorm over the last dim (D <= 64*8), one wave per row ----
+// PLANAR: the output goes out as bf16 planes (cells of 8 values): a row passes through 512 floats of LDS per wave.  Only that
+// instantiation declares the LDS buffer — the row-major form (encoder, mit_layernorm) keeps its occupancy.
+template <bool PLANAR>
 __global__ void layernorm_kernel(const float *__restrict__ in, int64_t in_rs, const float *__restrict__ w,
                                  const float *__restrict__ b, float *__restrict__ out, int64_t out_rs, int rows, int D,
                                  float eps, OcrPlanes pl) {
-    __shared__ __attribute__((aligned(16))) float ybuf[4][512];  // planar output: a row's values pass through LDS to become cells of 8
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -368,7 +370,8 @@ __global__ void layernorm_kernel(const float *__restrict__ in, int64_t in_rs, co
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = 1.0f / sqrtf(var / (float)D + eps);
     n = 0;
-    if (pl.p) {
+    if constexpr (PLANAR) {
+        __shared__ __attribute__((aligned(16))) float ybuf[4][512];
         float *yb = ybuf[threadIdx.x >> 6];
         for (int d = lane; d < D; d += 64) {
             yb[d] = (v[n] - mean) * rstd * w[d] + b[d];
@@ -991,16 +994,20 @@ __global__ void beam_finalize_kernel(const int *__restrict__ hist, int hist_ld, 
 // internal launch helpers (shared with ocr_decoder.hip) + C-ABI wrappers
 // ---------------------------------------------------------------------------------------------
 
-void ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
-                    int D, float eps, hipStream_t s, const OcrPlanes *planes) {
-    if (planes && (D > 512 || (D & 7))) {  // the planar form stages a row in 512 floats of LDS and writes cells of 8
-        mit_set_error("ocrk_layernorm: planar output needs D %% 8 == 0 and D <= 512 (got %d)", D);
-        return;
-    }
+int ocrk_layernorm(const float *in, int64_t in_rs, const float *w, const float *b, float *out, int64_t out_rs, int rows,
+                   int D, float eps, hipStream_t s, const OcrPlanes *planes) {
+    if (D <= 0 || D > 512) return mit_set_error("ocrk_layernorm: D out of range (got %d; a lane holds 8 values)", D);
+    if (planes && (!planes->p || (D & 7)))  // the planar form stages a row in 512 floats of LDS and writes cells of 8
+        return mit_set_error("ocrk_layernorm: planar output needs a plane buffer and D %% 8 == 0 (got %d)", D);
     const int waves = 4;
     MitProbeScope probe("layernorm_kernel", s, (planes ? 10.0 : 8.0) * (double)rows * D);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + waves - 1) / waves), dim3(64 * waves), 0, s, in, in_rs, w, b, out, out_rs,
-                       rows, D, eps, planes ? *planes : OcrPlanes{nullptr, 0, 0});
+    if (planes)
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + waves - 1) / waves), dim3(64 * waves), 0, s, in, in_rs, w, b, out, out_rs,
+                           rows, D, eps, *planes);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + waves - 1) / waves), dim3(64 * waves), 0, s, in, in_rs, w, b, out, out_rs,
+                           rows, D, eps, OcrPlanes{nullptr, 0, 0});
+    return 0;
 }
 
 void ocrk_xpos_rotate(const float *in, int64_t in_rs, int64_t in_ts, float *out, int64_t out_rs, int64_t out_ts, int R, int T,
@@ -1510,7 +1517,7 @@ extern "C" int mit_layernorm(const float *in_dev, int64_t in_rowstride, const fl
     if (!in_dev || !w_dev || !b_dev || !out_dev) return mit_set_error("mit_layernorm: null pointer");
     if (D <= 0 || D > 512) return mit_set_error("mit_layernorm: D out of range");
     if (rows <= 0) return 0;
-    ocrk_layernorm(in_dev, in_rowstride, w_dev, b_dev, out_dev, out_rowstride, rows, D, eps, (hipStream_t)stream);
+    if (ocrk_layernorm(in_dev, in_rowstride, w_dev, b_dev, out_dev, out_rowstride, rows, D, eps, (hipStream_t)stream)) return 1;
     MIT_CHECK_LAUNCH("mit_layernorm");
     return 0;
 }
@@ -1533,6 +1540,21 @@ extern "C" int mit_xpos_rotate(const float *in_dev, int64_t in_rs, int64_t in_ts
     return 0;
 }
 
+static size_t attention_lines_lds_bytes(int Lmax, int head_dim) {
+    return ((size_t)Lmax * (head_dim + 4) + (size_t)(ATTR_THREADS / 64) * ATTR_GQ * (head_dim + Lmax)) * sizeof(float);
+}
+static constexpr size_t ATTENTION_LINES_LDS_MAX = 150 * 1024;
+
+extern "C" int mit_attention_lines_xpos_max_len(int head_dim) {
+    if (head_dim <= 0 || head_dim > 128 || (head_dim & 7)) return 0;
+    int L = 0;  // the LDS need is linear in Lmax: solve, then step down past any rounding
+    const size_t per_l = ((size_t)(head_dim + 4) + (size_t)(ATTR_THREADS / 64) * ATTR_GQ) * sizeof(float);
+    const size_t fixed = (size_t)(ATTR_THREADS / 64) * ATTR_GQ * head_dim * sizeof(float);
+    if (ATTENTION_LINES_LDS_MAX > fixed) L = (int)((ATTENTION_LINES_LDS_MAX - fixed) / per_l);
+    while (L > 0 && attention_lines_lds_bytes(L, head_dim) > ATTENTION_LINES_LDS_MAX) --L;
+    return L > 4096 ? 4096 : L;
+}
+
 extern "C" int mit_attention_lines_xpos(const float *q_dev, const float *k_dev, const float *v_dev, float *out_dev, int64_t row_stride,
                                         const int32_t *lines_dev, const int *klen_dev, int n_lines, int Lmax, int heads, int head_dim,
                                         const MitXposTables *tables, void *stream) {
@@ -1541,8 +1563,10 @@ extern "C" int mit_attention_lines_xpos(const float *q_dev, const float *k_dev, 
     if (n_lines > 65535 || Lmax <= 0 || Lmax > 4096 || heads <= 0 || heads > 64 || head_dim <= 0 || head_dim > 128 || (head_dim & 7) || (row_stride & 3))
         return mit_set_error("mit_attention_lines_xpos: bad sizes (n_lines %d, Lmax %d, heads %d, head_dim %d)", n_lines, Lmax, heads, head_dim);
     if (check_tables(tables, Lmax, -((Lmax + 1) / 2), Lmax, "mit_attention_lines_xpos")) return 1;
-    const size_t sm = ((size_t)Lmax * (head_dim + 4) + (size_t)(ATTR_THREADS / 64) * ATTR_GQ * (head_dim + Lmax)) * sizeof(float);
-    if (sm > 150 * 1024) return mit_set_error("mit_attention_lines_xpos: lines of %d positions do not fit the LDS form", Lmax);
+    const size_t sm = attention_lines_lds_bytes(Lmax, head_dim);
+    if (sm > ATTENTION_LINES_LDS_MAX)
+        return mit_set_error("mit_attention_lines_xpos: lines of %d positions do not fit the LDS form (at most %d at head_dim %d: "
+                             "mit_attention_lines_xpos_max_len)", Lmax, mit_attention_lines_xpos_max_len(head_dim), head_dim);
     static DynSmemOptIn optin;
     optin.ensure(reinterpret_cast<const void *>(attention_lines_xpos_kernel), sm);
     hipStream_t s = (hipStream_t)stream;

@@ -865,6 +865,13 @@ int mit_pgemm_rows(const MitPGemm &d, const PgRowsExt &x, hipStream_t s) {
     if (p.c_planes && x.also_planes) return mit_set_error("mit_pgemm_rows: two planar outputs");
     if ((p.N & 3) || (planes && (p.N & 7)) || (p.c && (p.ldc & 3)) || (x.nsplit & 7) || (x.nhi & 3) || (x.c_dyn & 3) || (p.post && (p.ld_post & 3)) || (p.pre && (p.ld_pre & 3)))
         return mit_set_error("mit_pgemm_rows: N / strides must keep 16-byte cells whole");
+    // the operand part of pg_check: the kernel addresses the three planes through 32-bit buffer offsets and moves 16-byte pieces
+    if ((int64_t)3 * (p.K >> 3) * p.lda * 16 > 0xffffffffLL || (int64_t)3 * (p.K >> 3) * p.ldw * 16 > 0xffffffffLL)
+        return mit_set_error("mit_pgemm_rows: an operand's three planes exceed 4 GB (32-bit piece offsets)");
+    auto unaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
+    if (unaligned(p.a_planes) || unaligned(p.w_planes) || unaligned(p.c) || unaligned(planes) || unaligned(p.scale) || unaligned(p.bias) ||
+        unaligned(p.pre) || unaligned(p.post))
+        return mit_set_error("mit_pgemm_rows: operands, outputs, scale / bias and pre / post must be 16-byte aligned");
     const int a = p.act & 0xff;
     if (a != MIT_ACT_NONE && a != MIT_ACT_RELU && a != MIT_ACT_GELU) return mit_set_error("mit_pgemm_rows: activation %d", p.act);
     if (p.nprod == 0) p.nprod = mit_gemm_mode_get();
@@ -874,6 +881,7 @@ int mit_pgemm_rows(const MitPGemm &d, const PgRowsExt &x, hipStream_t s) {
     if (p.nprod == 6) pg_rows_launch_ext<6, 6>(p, x, s);
     else if (p.nprod == 9) pg_rows_launch_ext<9, 6>(p, x, s);
     else return mit_set_error("mit_pgemm_rows: nprod must be 6 or 9 (got %d)", p.nprod);
+    MIT_CHECK_LAUNCH("mit_pgemm_rows");
     return 0;
 }
 

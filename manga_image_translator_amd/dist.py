@@ -143,7 +143,11 @@ class PageGather:
     step's compute kernels (two queues sharing CUs is the configuration DESIGN §7 restricts).  ``async_op=True`` (or MIT_GATHER_ASYNC=1)
     gives the gather one step of slack instead — rank 0 receives ``world - 1`` blocks (0.8 GB each at 64 pages) while its next batch is
     computing; ``wait()`` drains it (call it before the end of a timed region).  At most one gather is in flight, so at most two result
-    blocks per rank are alive.  Same semantics on gloo."""
+    blocks per rank are alive.  Same semantics on gloo.
+
+    Layout of the result on ``dst``: ``[world, *shape]`` as a VIEW into a slab whose rows are padded to 8 bytes (every rank's block starts
+    word-aligned for the checksum), so when a block's byte size is not a multiple of 8 the result is not contiguous across dim 0: index
+    it per rank (``out[r]`` is dense) or call ``.contiguous()`` before ``.view(-1)`` / handing ``data_ptr()`` to native code."""
 
     def __init__(self, dst: int = 0, async_op: Optional[bool] = None, verify: bool = True):
         self.dst = dst
@@ -156,6 +160,20 @@ class PageGather:
         self._bad: Optional[torch.Tensor] = None   # blocks whose checksum did not match, counted where the blocks live
         self.verified_blocks = 0
         self.last_bytes = 0
+        self.submits = 0
+        self._host_wait_s = 0.0
+        self._events: List = []      # (start, stop) device events bracketing a gather on the caller's stream (nccl)
+        self._t_issue: Optional[float] = None
+
+    @property
+    def wait_ms(self) -> float:
+        """Time this rank spent inside its gathers so far (issue -> received and checksummed): device events on the caller's stream when
+        the tensors live on the GPU (the stream is what waits for RCCL), the host clock otherwise.  Reading it synchronises the events."""
+        ms = self._host_wait_s * 1e3
+        for e0, e1 in self._events:
+            e1.synchronize()
+            ms += e0.elapsed_time(e1)
+        return ms
 
     def submit(self, packed: torch.Tensor) -> Optional[torch.Tensor]:
         prev = self.wait()
@@ -167,6 +185,13 @@ class PageGather:
         packed = packed.contiguous()
         if dist.get_backend() != "nccl" and packed.is_cuda:  # gloo rehearsal: stage through host memory
             packed = packed.cpu()
+        self.submits += 1
+        if packed.is_cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._events.append([e0, None])
+        else:
+            self._t_issue = _now()
         cs = page_checksum(packed) if self.verify else None
         if rank == self.dst:
             n = packed.numel()
@@ -200,6 +225,13 @@ class PageGather:
             self._bad = bad if self._bad is None else self._bad + bad
             self.verified_blocks += int(self._out.shape[0])
             self._sums = None
+        if self._events and self._events[-1][1] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._events[-1][1] = e1
+        if self._t_issue is not None:
+            self._host_wait_s += _now() - self._t_issue
+            self._t_issue = None
 
     def wait(self) -> Optional[torch.Tensor]:
         """Result of the gather in flight ([world, *shape] on ``dst``, None elsewhere or when nothing was submitted); a failure raises."""
@@ -213,6 +245,12 @@ class PageGather:
         if self._bad is not None and int(self._bad.item()) != 0:
             raise RuntimeError(f"PageGather: {int(self._bad.item())} gathered result block(s) failed their checksum")
         return self.verified_blocks
+
+
+def _now() -> float:
+    import time
+
+    return time.perf_counter()
 
 
 def max_over_ranks(value: float) -> float:

@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 9
+MIT_ABI_VERSION = 10
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -261,6 +261,7 @@ SYMBOLS = {
     "mit_attention": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                 C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p]),
+    "mit_attention_lines_xpos_max_len": (C.c_int, [C.c_int]),
     "mit_attention_lines_xpos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.POINTER(MitXposTables), C.c_void_p]),
     "mit_memory_kv_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,

@@ -178,6 +178,7 @@ class Ocr48Engine:
         d.dict_size = dict_size
         self.dec = d
         self._ws: Dict[Tuple, torch.Tensor] = {}
+        self.lines_attention_max_len = int(_lib.load().mit_attention_lines_xpos_max_len(HEAD_DIM))   # longest line of the one-launch form
         self.per_chunk_attention = False   # True: the encoder's attention chunk by chunk (rotate q, rotate k, attention): the reference form for tests
 
     def _buf(self, name, *shape, dtype=torch.float32):
@@ -317,7 +318,10 @@ class Ocr48Engine:
         line0 = [int(f) for f in first_lines]
         # one launch per layer for all lines of the group (XPOS rotation folded into the attention kernel) when the group's lines are
         # consecutive in the pooled memory; else chunk by chunk (rotate q, rotate k, attention) — bitwise the same either way
-        ragged = all(line0[c + 1] == line0[c] + Ns[c] for c in range(nc - 1)) and max(Ls) <= 400 and not self.per_chunk_attention
+        # (lines longer than the kernel's LDS form holds — mit_attention_lines_xpos_max_len, 308 positions = crops wider than ~1230 px —
+        # take the chunk-by-chunk path, which has no length limit)
+        ragged = (all(line0[c + 1] == line0[c] + Ns[c] for c in range(nc - 1)) and max(Ls) <= self.lines_attention_max_len
+                  and not self.per_chunk_attention)
         if ragged:
             tab = np.empty((sum(Ns), 2), dtype=np.int32)
             i = 0

@@ -118,3 +118,26 @@ def _rccl_smoke(port):
         return "ok" if torch.equal(arena, ref) and torch.equal(out[0], packed) and float(t.item()) == 3.5 else "wrong results"
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_gpus_2_self_launch_two_ranks_share_the_gpu(cuda):
+    """The driver's command shape, `python bench.py --gpus 2 …` with no launcher around it: bench.py starts its own two ranks
+    (torch.distributed.run on 127.0.0.1), here on the gloo backend because both ranks sit on the box's one GPU.  The REAL engine runs on
+    each rank's page block; the line must carry n_gpus = 2 and a gather whose blocks all passed their checksums."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MIT_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pages", "2",
+                          "--no-cpu-baseline", "--no-roofline", "--no-dropin", "--no-fp32-leg", "--no-two-streams"],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 2 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]       # pages of ALL ranks over the max-over-ranks time
+    assert d["gather"]["verified_blocks"] == 2 * 3 and d["gather"]["bytes_per_step"] > 0 and "leg_errors" not in d

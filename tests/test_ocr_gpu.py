@@ -190,6 +190,42 @@ def test_ragged_xpos_attention_equals_the_per_chunk_launches(cuda, ocr_setup):
     assert gk.abs().sum() > 0
 
 
+def test_lines_longer_than_the_lds_form_take_the_per_chunk_path(cuda, ocr_setup):
+    """Crops around 1230-1600 px wide (aspect ratio 26-33: long vertical lines) give memory lengths past what mit_attention_lines_xpos
+    holds in LDS (mit_attention_lines_xpos_max_len, 308 at head_dim 80).  The engine must derive its guard from the library's limit and
+    encode such a group chunk by chunk — same result as forcing that path — instead of failing the page group (ADVICE r04, ocr48.py:320);
+    a group right at the limit still takes the one-launch form; the C entry itself refuses the oversize line with an error, no launch."""
+    from manga_image_translator_amd import lib as L_
+
+    sd, D, eng = ocr_setup
+    lib = L_.load()
+    lim = lib.mit_attention_lines_xpos_max_len(80)
+    assert lim == eng.lines_attention_max_len == 308 and lib.mit_attention_lines_xpos_max_len(81) == 0
+    for widths, over in (([1300, 90, 1500], True), ([1216, 64], False)):
+        crops = _crops(widths, seed=11)
+        chunks = list(eng.make_chunks(crops))
+        regions = [torch.from_numpy(r).to(cuda) for _, _, r in chunks]
+        Ls = [eng.memory_len(r.shape[2]) for r in regions]
+        assert (max(Ls) > lim) == over, (Ls, lim)
+        klens = torch.tensor([eng.valid_len(w, Lc) for (_, ws, _), Lc in zip(chunks, Ls) for w in ws], dtype=torch.int32, device=cuda)
+        gk, gv, _ = eng.encode_group(regions, klens, max(Ls))       # raised "do not fit the LDS form" for the first group before the fix
+        gk, gv = gk.clone(), gv.clone()
+        eng.per_chunk_attention = True
+        try:
+            pk, pv, _ = eng.encode_group(regions, klens, max(Ls))
+        finally:
+            eng.per_chunk_attention = False
+        torch.cuda.synchronize()
+        assert torch.equal(gk, pk) and torch.equal(gv, pv) and torch.isfinite(gk).all() and gk.abs().sum() > 0
+    q = torch.zeros(lim + 1, 320, device=cuda)
+    tab = torch.tensor([[0, lim + 1]], dtype=torch.int32, device=cuda)
+    kl = torch.tensor([lim + 1], dtype=torch.int32, device=cuda)
+    import ctypes as C
+    rc = lib.mit_attention_lines_xpos(q.data_ptr(), q.data_ptr(), q.data_ptr(), q.data_ptr(), 320, tab.data_ptr(), kl.data_ptr(), 1, lim + 1, 4, 80,
+                                      C.byref(eng.xpos), None)
+    assert rc != 0 and b"mit_attention_lines_xpos_max_len" in lib.mit_last_error()
+
+
 @pytest.mark.parametrize("G,Tk,heads,hd", [(5, 70, 4, 80), (5, 200, 4, 80), (3, 64, 8, 40), (8, 129, 2, 16)])
 def test_shared_kv_attention_bitwise_equals_per_row(cuda, G, Tk, heads, hd):
     """The beams of a line share the K / V block (kv_div = beams): the shared-K/V kernel must give bit for bit what the
