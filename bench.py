@@ -462,8 +462,27 @@ def parity_leg(res, idx, oracle_outputs, stages):
             near_n += int(near.sum())
             md = np.abs(res.det_mask[b].cpu().numpy().astype(np.int32) - rmask.astype(np.int32))  # rmask: postprocess_mask bytes
             mask_max, mask_bad, mask_tot = max(mask_max, int(md.max())), mask_bad + int((md != 0).sum()), mask_tot + md.size
+        # what the margin means for the boxes: every in-margin pixel of the oracle map forced above / below the threshold, box extraction
+        # (mit_ctd_boxes = SegDetectorRepresenter, db_utils.py:127-216) on each variant (tests/test_margin_flips.py does the same on
+        # trained-head-like maps, where boxes exist)
+        from manga_image_translator_amd import hostglue as _hg
+
+        n_base = n_up = n_dn = changed = 0
+        for o in oracle_outputs:
+            rl = np.ascontiguousarray(o["detect"][1], dtype=np.float32)
+            near = np.abs(rl[0, 0] - 0.3) < 1e-4
+            b0, _ = _hg.ctd_boxes(rl, H, W)
+            var = []
+            for sign in (1.0, -1.0):
+                q = rl.copy()
+                q[0, 0][near] = np.float32(0.3 + sign * 2e-4)
+                var.append(_hg.ctd_boxes(q, H, W)[0])
+            n_base, n_up, n_dn = n_base + len(b0), n_up + len(var[0]), n_dn + len(var[1])
+            changed += sum(int(len(v) != len(b0) or (len(v) and not np.array_equal(v, b0))) for v in var)
         out["detect"] = dict(bitmap_flips_outside_margin=flips, px_inside_margin=near_n, mask_u8_max_abs_diff=mask_max,
-                             mask_u8_frac_different=float(f"{mask_bad / max(mask_tot, 1):.3e}"))
+                             mask_u8_frac_different=float(f"{mask_bad / max(mask_tot, 1):.3e}"),
+                             boxes_with_margin_pixels_forced=dict(as_is=n_base, all_above=n_up, all_below=n_dn, variants_with_any_box_changed=changed,
+                                                                  note="random-init weights: the map crosses 0.3 only in noise, so few or no boxes exist to move"))
         ok &= flips == 0 and mask_max <= 1 and mask_bad / max(mask_tot, 1) < 1e-3
     if "ocr" in stages and res.ocr_tokens is not None:
         toks, lens, probs = res.ocr_tokens.cpu().numpy(), res.ocr_length.cpu().numpy(), res.ocr_prob.cpu().numpy()

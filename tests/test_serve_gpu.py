@@ -1,0 +1,49 @@
+"""Worker-pool serving on a GPU box: two shared-mode workers (manga_translator/mode/share.py:47-174 protocol), each a
+process pinned with HIP_VISIBLE_DEVICES, each loading the three HIP plugins, answer the same request with byte-identical results — alone
+and while the other worker is busy on the same GPU — and equal to the plugin chain run in this process."""
+import asyncio
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H, W, LINES, D = 512, 384, 5, 128
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_workers_on_one_box_return_identical_pages(cuda):
+    from manga_image_translator_amd import serve, synth
+
+    page, quads, _ = synth.synth_page(3, H, W, n_boxes=LINES, disjoint=True)
+    page2 = synth.synth_page(4, H, W, n_boxes=LINES, disjoint=True)[0]
+    cfg = {"textlines": np.asarray(quads).tolist(), "ocr": {"max_seq_length": 8, "suppress_eos": True, "prob": 0.0},
+           "inpainter": {"inpainting_size": 512}}
+    base = _port()
+    pool = serve.WorkerPool(gpus=["0", "0"], base_port=base, worker_args=["--dict-size", str(D)])   # one GPU on the box: both pinned to it
+    with pool:
+        a, b = pool.executors.list
+        ia, ib = asyncio.run(a.sent(None, None, method="device_info")), asyncio.run(b.sent(None, None, method="device_info"))
+        assert ia["visible_devices"] == ib["visible_devices"] == "0" and ia["n_visible"] == ib["n_visible"] == 1 and ia["pid"] != ib["pid"]
+        ra, rb = asyncio.run(a.sent(page, cfg)), asyncio.run(b.sent(page, cfg))
+
+        async def both():   # the two workers busy at the same time, on different pages, then swapped
+            return await asyncio.gather(a.sent(page, cfg), b.sent(page2, cfg), )
+        ca, cb2 = asyncio.run(both())
+        rb2 = asyncio.run(a.sent(page2, cfg))
+        outs = asyncio.run(pool.map([page, page2, page, page2], cfg))
+    for x, y in ((ra, rb), (ra, ca), (cb2, rb2), (outs[0], ra), (outs[1], rb2), (outs[2], ra), (outs[3], rb2)):
+        assert np.array_equal(x["inpainted"], y["inpainted"]) and np.array_equal(x["mask"], y["mask"]) and np.array_equal(x["mask_raw"], y["mask_raw"])
+        assert x["textlines"] == y["textlines"]
+    assert ra["inpainted"].shape == (H, W, 3) and ra["inpainted"].dtype == np.uint8 and len(ra["textlines"]) >= 1
+    assert not np.array_equal(ra["inpainted"], page)            # something was inpainted
+    # the same chain in this process (the plugins called directly): what a worker returns is what the plugins compute
+    eng = serve.DenseStages({"dict_size": D})
+    here = asyncio.new_event_loop().run_until_complete(eng.translate(page, cfg))
+    assert np.array_equal(here["inpainted"], ra["inpainted"]) and np.array_equal(here["mask"], ra["mask"]) and here["textlines"] == ra["textlines"]
