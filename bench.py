@@ -287,10 +287,10 @@ def roofline_leg(engine, pages, quads, masks, stages, dump=""):
         tr["source"] = src
         tr["joined_from_committed_pmc_pass"] = True    # counters need their own profiler passes: not re-measured by this run
         if ab and ab[0]:
-            alg = dict(A_GB=round(ab[1] / ab[0] / 1e9, 4), W_GB=round(ab[2] / ab[0] / 1e9, 4), C_GB=round(ab[3] / ab[0] / 1e9, 4))
-            alg["total_GB"] = round(sum(alg.values()), 4)
-            tr["algorithmic_per_launch"] = alg      # measured in THIS run's launch mix (every input element once, W once, C once)
-            tr["ratio_to_algorithmic"] = round((tr["read_GB"] + tr["write_GB"]) / max(alg["total_GB"], 1e-9), 3)
+            algb = dict(A_GB=round(ab[1] / ab[0] / 1e9, 4), W_GB=round(ab[2] / ab[0] / 1e9, 4), C_GB=round(ab[3] / ab[0] / 1e9, 4))
+            algb["total_GB"] = round(sum(algb.values()), 4)
+            tr["algorithmic_per_launch"] = algb     # measured in THIS run's launch mix (every input element once, W once, C once)
+            tr["ratio_to_algorithmic"] = round((tr["read_GB"] + tr["write_GB"]) / max(algb["total_GB"], 1e-9), 3)
     hbm = {}
     for name, (kl, kms, kb, kf) in sorted(kern_tot.items(), key=lambda kv: -kv[1][1]):
         e = dict(launches=int(kl), avg_us=round(kms * 1e3 / kl, 2), ms_per_page=round(kms / n, 4))
@@ -1184,7 +1184,8 @@ def main():
             torch.cuda.empty_cache()
             r = leg(key, lambda fn=fn, a2=a2: fn(a2, device))
             if r is not None:
-                other[key] = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "stages_ms_per_page") if k in r}
+                other[key] = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step") if k in r}
+                other[key]["stage_ms_per_page"] = {k: v.get("ms") for k, v in r.get("stages_ms_per_page", {}).items()}
                 other[key]["pages_per_step"] = npg
     D.barrier()
 

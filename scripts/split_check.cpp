@@ -51,6 +51,7 @@ int main(int argc, char **argv) {
     const int s6o = find_cfg("split128x128x16p6o"), n6o = find_cfg("split128x64x16p6o");
     if (s6o < 0 || n6o < 0) return 2;  // (tiles of MIT_CONV_EXPERIMENTS builds come back as -1 from a default build and are skipped below)
     const int s64 = find_cfg("split64x64x16p6o"), s32 = find_cfg("split128x32x16p6o"), f32t = find_cfg("fast128x32x16w4c");  // small / narrow tiles (-1: skipped)
+    const int w6o = find_cfg("split64x256x16p6o");  // wide-N tile (-1 in builds without it: skipped)
     const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c"), s64k = find_cfg("split64x64x32p6o");
     if (f_wide < 0 || f_narrow < 0 || s6 < 0 || s9 < 0 || s3 < 0 || n6 < 0 || n9 < 0 || s9m < 0) {
         fprintf(stderr, "tile names not found\n");
@@ -58,11 +59,14 @@ int main(int argc, char **argv) {
     }
     std::vector<Case> cases = {
         {"probe: A[m][k] = (k == m % 16), W[k][n] = 1000 k + n", 1, 1, 256, 16, 128, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, s3, n6, s6s, n6s, s6m, n6m, s6o, n6o, s64}},
-        {"1x1 320->1280 (ConvNeXt pw1), M=65536, gelu", 1, 256, 256, 320, 1280, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6, s9, s3, s6s, s6m, s9m, s6k32m, s6o, s6m, s6o, s6m, s6o}},
+        {"1x1 320->1280 (ConvNeXt pw1), M=65536, gelu", 1, 256, 256, 320, 1280, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6, s9, s3, s6s, s6m, s9m, s6k32m, s6o, w6o, s6o, w6o, s6o}},
         {"3x3 reflect 128->128, 2x96x160, relu", 2, 96, 160, 128, 128, 3, 1, MIT_PAD_REFLECT, 1, MIT_ACT_RELU, f_wide, {s6, s9, s6s, s6m, s9m, s6k32m, s6o, s6m, s6o, s6m, s6o}},
-        {"winograd-like Z=36, T=8192, 128->384", 1, 1, 8192, 128, 384, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6, s9, s6m, s9m, s6o, n6o, s6o, n6o}},
-        {"1x1 192->384 (spectral conv2), M=131072, relu", 1, 256, 512, 192, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, n6o, s6o, n6o}},
-        {"1x1 160->640 (ConvNeXt stage 2 pw1), M=131072, gelu", 1, 256, 512, 160, 640, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, n6o, s6o, n6o}},
+        {"winograd-like Z=36, T=8192, 128->384", 1, 1, 8192, 128, 384, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6, s9, s6m, s9m, s6o, n6o, w6o, s6o, n6o, w6o}},
+        {"1x1 192->384 (spectral conv2), M=131072, relu", 1, 256, 512, 192, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, n6o, w6o, s6o, n6o, w6o}},
+        {"1x1 160->640 (ConvNeXt stage 2 pw1), M=131072, gelu", 1, 256, 512, 160, 640, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, n6o, w6o, s6o, n6o, w6o}},
+        {"1x1 80->320 (ConvNeXt stage 1 pw1), M=262144, gelu", 1, 512, 512, 80, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, n6o, w6o, s6o, n6o, w6o}},
+        {"3x3 s2 zero 128->256 (LaMa down), 2x128x96", 2, 256, 192, 128, 256, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, w6o, s6o, w6o}},
+        {"1x1 384x2taps-like: 768->384, M=65536", 1, 256, 256, 768, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, w6o, s6o, w6o}},
         {"3x3 s2 zero 64->64, 4x128x128", 4, 128, 128, 64, 64, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_narrow, {n6, n9, n6s, n6m, n6o, n6m, n6o}},
         {"1x1 1280->320 (pw2), M=65536", 1, 256, 256, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6, s9, n6, s6m, n6m, s6k32m, s6o, n6o, s6m, s6o}},
         {"3x3 zero 128->32 (ESRGAN dense conv3), 2x256x256, leaky", 2, 256, 256, 128, 32, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, gen32, {f32t, s32, n6o}},
