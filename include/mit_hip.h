@@ -111,6 +111,14 @@ typedef struct MitConvGemm {
      * c_dyn * (*dyn) floats further than the descriptor says.  NULL everywhere else. */
     const int32_t *dyn;
     int64_t a_dyn, c_dyn;
+    /* optional: a two-table row lookup joined AFTER the activation and the post residual — y += lut1[r1][n]; y += lut2[r2][n], in that
+     * order — where output row m (= its pixel index, batch-major) carries lut_rows[m] = r1 | r2 << 16 and both tables have lut_ld floats
+     * per row.  LaMa's masked position encoding rides on it: the 7x7 stem writes relu(bn(conv)) + alpha5 * emb[rel] + alpha6 * dir in
+     * one pass instead of a separate read-modify-write of the 64-channel stem output (inpainting_lama_mpe.py:609-613).  NULL = off.
+     * Not available on the N <= 4 (gemv) kernel. */
+    const int32_t *lut_rows;
+    const float *lut1, *lut2;
+    int64_t lut_ld;
 } MitConvGemm;
 
 const char *mit_last_error(void);
@@ -405,6 +413,13 @@ int mit_lama_mpe_index(const uint8_t *mask_dev, int B, int H, int W, const int *
 int mit_lama_mpe_add(float *x_dev, const uint8_t *mask_dev, const uint8_t *relpos_dev, const uint8_t *direct_dev,
                      const int *ymap_dev, const int *xmap_dev, const float *emb_dev, const float *dirw_dev, float alpha5,
                      float alpha6, int B, int H, int W, void *stream);
+/* The same lookup as per-pixel TABLE ROWS for the stem convolution's epilogue (MitConvGemm.lut_rows): rows[b][y][x] = rel | bits << 16
+ * inside the mask, 0 outside, with rel / bits read from the 256-grid maps through ymap / xmap exactly as mit_lama_mpe_add reads them.
+ * With lut1[rel] = alpha5 * rel_pos_emb[rel] (128 rows) and lut2[bits] = alpha6 * sum of the set directions' rows of direct_emb (16 rows,
+ * summed in bit order), the stem launch performs the two adds of FFCResNetGenerator.forward :611-612 itself — bit-identical to
+ * mit_lama_mpe_add after the stem, without the extra read-modify-write of [B,H,W,64]. */
+int mit_lama_mpe_rows(const uint8_t *mask_dev, const uint8_t *relpos_dev, const uint8_t *direct_dev, const int *ymap_dev,
+                      const int *xmap_dev, int32_t *rows_dev, int B, int H, int W, void *stream);
 
 /* predicted fp32 (pixel stride pred_pixstride floats, 3 used) + page + mask -> inpainted u8 [B,H,W,3]:
  * pred*m + (1-m)*img (:726), *255 truncated to u8 (:111), composited with the original through mask >= 127 (:59-60,117).

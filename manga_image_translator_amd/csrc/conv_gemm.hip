@@ -58,7 +58,7 @@ bool split_eligible(const MitConvGemm &p, int BK) {
 bool gemv_eligible(const MitConvGemm &p, int lpr) {
     if (p.N > 4 || p.Z != 1 || p.Cin % (4 * lpr) || (int64_t)p.NB * p.Ho > 65535) return false;  // one output row per blockIdx.y
     if ((int64_t)p.ntaps * p.Cin * (p.N == 1 ? 1 : 4) * 4 > 60 * 1024) return false;            // the transposed weight panel must fit the default dynamic-LDS limit
-    if (p.c.nsplit || p.pre.nsplit || p.post.nsplit) return false;
+    if (p.c.nsplit || p.pre.nsplit || p.post.nsplit || p.lut_rows) return false;
     return true;
 }
 
@@ -254,6 +254,7 @@ bool vec_epilogue_ok(const MitConvGemm &p) {
     if (off || (p.N & 3) || !map_vec_ok(p.c)) return false;
     if (p.pre.base && !map_vec_ok(p.pre)) return false;
     if (p.post.base && !map_vec_ok(p.post)) return false;
+    if (p.lut_rows && ((p.lut_ld & 3) || (reinterpret_cast<uintptr_t>(p.lut1) & 15) || (reinterpret_cast<uintptr_t>(p.lut2) & 15))) return false;
     return !(reinterpret_cast<uintptr_t>(p.scale) & 15) && !(reinterpret_cast<uintptr_t>(p.bias) & 15);
 }
 }  // namespace
@@ -285,6 +286,11 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     }
     const int64_t M64 = (int64_t)p.NB * p.Ho * p.Wo;
     if (M64 > 0x7fffffffLL) return mit_set_error("mit_conv_gemm: M too large");
+    if (p.lut_rows) {  // the row-lookup epilogue: both tables, rows long enough, one slice (lut_rows is indexed by the output row)
+        if (!p.lut1 || !p.lut2 || p.lut_ld < p.N) return mit_set_error("mit_conv_gemm: lut_rows needs lut1, lut2 and lut_ld >= N");
+        if (p.Z != 1) return mit_set_error("mit_conv_gemm: the row-lookup epilogue is for Z == 1 launches");
+        if (p.lut_ld > 0x7fff) return mit_set_error("mit_conv_gemm: lut_ld too large (row offsets are 16-bit row x lut_ld in 32 bits)");
+    }
     if (p.Z > 65535) return mit_set_error("mit_conv_gemm: Z too large");
     if (cfg < 0 && p.Z == 1 && p.NB > 1 && p.Cin % 16 == 0 && p.ntaps <= FAST_MAX_TAPS && p.a_bs > 0 && !fast_eligible(p, 16)) {
         // The fast kernels index A with 32-bit element offsets.  A batch whose activations exceed 2^31 elements (16 pages of
@@ -305,6 +311,7 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
                 sub.c.base = d->c.base + (int64_t)b0 * d->c.bs;
                 if (d->pre.base) sub.pre.base = d->pre.base + (int64_t)b0 * d->pre.bs;
                 if (d->post.base) sub.post.base = d->post.base + (int64_t)b0 * d->post.bs;
+                if (d->lut_rows) sub.lut_rows = d->lut_rows + (int64_t)b0 * p.Ho * p.Wo;
                 if (g_next_alg_flops >= 0.0) g_next_alg_flops = -1.0;  // a tagged cost does not survive the split
                 const int rc = mit_conv_gemm_cfg(&sub, -1, stream);
                 if (rc) return rc;
@@ -315,6 +322,7 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     if (cfg < 0) cfg = pick_cfg(p, M64);
     if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
     const CfgEntry &c = kCfgs[cfg];
+    if (p.lut_rows && c.fast == 3) return mit_set_error("mit_conv_gemm: the row-lookup epilogue (lut_rows) is not implemented by the N <= 4 kernel");
     if (p.dyn && c.fast == 3) return mit_set_error("mit_conv_gemm: the device-side step offset (dyn) is not implemented by the N <= 4 kernel");
     if (p.dyn && ((p.a_dyn | p.c_dyn) & 3)) return mit_set_error("mit_conv_gemm: a_dyn / c_dyn must be multiples of 4 floats");
     if (c.fast == 2 && (p.Cin % 32)) return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% 32 == 0", c.name);

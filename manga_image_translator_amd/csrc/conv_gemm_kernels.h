@@ -39,6 +39,7 @@ namespace mitcg {
 
 struct RowOff {
     int64_t c, pre, post;
+    int32_t lut1, lut2;  // float offsets of the row's two lookup-table rows (MitConvGemm.lut_rows), 0 without tables
 };
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in exact arithmetic, <= 6e-7 in f32 near 0 where GELU multiplies it by x/2):
@@ -103,6 +104,10 @@ __device__ __forceinline__ void epilogue_store(const MitConvGemm &p, f32x16 (&ac
                 if (HAS_POST && post_first) v += p.post.base[ro.post + ncol_post];
                 if (!(XE & 2)) v = apply_act<ACT>(v, p.act_alpha);
                 if (HAS_POST && !post_first) v += p.post.base[ro.post + ncol_post];
+                if (p.lut_rows) {  // wave-uniform
+                    v += p.lut1[ro.lut1 + n];
+                    v += p.lut2[ro.lut2 + n];
+                }
                 if (XE & 1) {  // timing ablation: results computed but (practically) never stored
                     if (v == 12345.678f) p.c.base[ro.c + ncol_c] = v;
                 } else {
@@ -159,6 +164,10 @@ __device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 
                     v.w = apply_act<ACT>(v.w, p.act_alpha);
                 }
                 if (HAS_POST && !post_first) v += pv;
+                if (p.lut_rows) {  // wave-uniform: two table rows joined after everything else, in this order
+                    v += *reinterpret_cast<const f32x4 *>(p.lut1 + ro.lut1 + n);
+                    v += *reinterpret_cast<const f32x4 *>(p.lut2 + ro.lut2 + n);
+                }
                 *reinterpret_cast<f32x4 *>(p.c.base + ro.c + n) = v;
             }
             asm volatile("" ::: "memory");
@@ -176,7 +185,7 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
     const int64_t c_dyn = p.dyn ? (int64_t)(*p.dyn) * p.c_dyn : 0;  // device-side step offset (hipGraph-replayed sequences), else 0
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
-        RowOff ro = {-1, 0, 0};
+        RowOff ro = {-1, 0, 0, 0, 0};
         if (m < M) {
             const int nb = m / HoWo;
             const int rem = m - nb * HoWo;
@@ -187,6 +196,11 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
                      (int64_t)ox * p.pre.xs;
             ro.post = z1 * p.post.zs1 + z0 * p.post.zs0 + (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys +
                       (int64_t)ox * p.post.xs;
+            if (p.lut_rows) {
+                const unsigned int packed = (unsigned int)p.lut_rows[m];
+                ro.lut1 = (int32_t)((packed & 0xffffu) * (unsigned int)p.lut_ld);
+                ro.lut2 = (int32_t)((packed >> 16) * (unsigned int)p.lut_ld);
+            }
         }
         rowoff[r] = ro;
     }

@@ -190,6 +190,26 @@ __global__ void mpe_add_kernel(float *__restrict__ x, const uint8_t *__restrict_
     }
 }
 
+// ---- (2d) the same lookup as packed table rows for the stem's epilogue: rows[pix] = rel | direction bits << 16 (0 outside the mask) ----
+__global__ void mpe_rows_kernel(const uint8_t *__restrict__ mask, const uint8_t *__restrict__ relpos, const uint8_t *__restrict__ direct,
+                                const int *__restrict__ ymap, const int *__restrict__ xmap, int32_t *__restrict__ rows, int B, int H, int W) {
+    const int64_t total = (int64_t)B * H * W;
+    int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; pix < total; pix += stride) {
+        const int xw = (int)(pix % W);
+        const int64_t r = pix / W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        int32_t v = 0;
+        if ((float)mask[pix] / 255.0f >= 0.5f) {  // ori_mask != 0 :811,813 (the test of mpe_add_kernel)
+            const int64_t cell = ((int64_t)b * MPE_S + ymap[y]) * MPE_S + xmap[xw];
+            v = (int32_t)relpos[cell] | ((int32_t)direct[cell] << 16);
+        }
+        rows[pix] = v;
+    }
+}
+
 // ---- (3) composite: sigmoid output [B,H,W,3] f32 + page + mask -> inpainted page u8 ----
 __global__ void lama_post_kernel(const float *__restrict__ pred, int64_t pred_pixstride, const uint8_t *__restrict__ img,
                                  const uint8_t *__restrict__ mask, uint8_t *__restrict__ out, int64_t npix, int composite) {
@@ -272,6 +292,18 @@ extern "C" int mit_lama_mpe_add(float *x_dev, const uint8_t *mask_dev, const uin
     hipLaunchKernelGGL(mpe_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x_dev, mask_dev,
                        relpos_dev, direct_dev, ymap_dev, xmap_dev, emb_dev, dirw_dev, alpha5, alpha6, B, H, W);
     MIT_CHECK_LAUNCH("mit_lama_mpe_add");
+    return 0;
+}
+
+extern "C" int mit_lama_mpe_rows(const uint8_t *mask_dev, const uint8_t *relpos_dev, const uint8_t *direct_dev, const int *ymap_dev,
+                                 const int *xmap_dev, int32_t *rows_dev, int B, int H, int W, void *stream) {
+    if (!mask_dev || !relpos_dev || !direct_dev || !ymap_dev || !xmap_dev || !rows_dev) return mit_set_error("mit_lama_mpe_rows: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0) return mit_set_error("mit_lama_mpe_rows: bad size");
+    const int64_t total = (int64_t)B * H * W;
+    MitProbeScope probe("mpe_rows_kernel", (hipStream_t)stream, (double)total * 5.0);   // one mask byte read, one row word written
+    hipLaunchKernelGGL(mpe_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, mask_dev, relpos_dev, direct_dev,
+                       ymap_dev, xmap_dev, rows_dev, B, H, W);
+    MIT_CHECK_LAUNCH("mit_lama_mpe_rows");
     return 0;
 }
 

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -162,13 +163,21 @@ class _RowPackedStem:
     def padded_shape(self, B, H, W):
         return (B, H + 2 * self.PAD, W + self.WIN, 4)
 
-    def __call__(self, xp: torch.Tensor, out: torch.Tensor):
+    def __call__(self, xp: torch.Tensor, out: torch.Tensor, lut: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
+        """``lut`` = (rows int32 [B*H*W], table1 [r1, Cout], table2 [r2, Cout]): the epilogue's two-table row lookup
+        (MitConvGemm.lut_rows) — out = act(bn(conv)) + table1[rows & 0xffff] + table2[rows >> 16], added in that order."""
         B, Hp, Wp, _ = xp.shape
         H, W = Hp - 2 * self.PAD, Wp - self.WIN
-        launch_conv_gemm(conv_gemm_desc(
+        d = conv_gemm_desc(
             a=xp, NB=B, Hi=Hp, Wi=W, Cin=self.WIN * 4, a_strides=(Hp * Wp * 4, Wp * 4, 4), Ho=H, Wo=W, sy=1, sx=1,
             taps=[(ky, 0, 0) for ky in range(self.K)], pad_mode=PAD_ZERO, w=self.w, ldw=self.Np, Kw=self.Kp, Nw=self.Np,
-            N=self.Cout, c=tensor_map(out), scale=self.scale, bias=self.bias, act=self.act))
+            N=self.Cout, c=tensor_map(out), scale=self.scale, bias=self.bias, act=self.act)
+        if lut is not None:
+            rows, t1, t2 = lut
+            if rows.dtype != torch.int32 or rows.numel() != B * H * W or t1.shape[1] != self.Cout or t2.shape[1] != self.Cout:
+                raise ValueError("row-packed stem: bad lookup tables")
+            d.lut_rows, d.lut1, d.lut2, d.lut_ld = rows.data_ptr(), t1.data_ptr(), t2.data_ptr(), self.Cout
+        launch_conv_gemm(d)
 
 
 class _FFC:
@@ -236,6 +245,19 @@ class LamaEngine:
             self.mpe = dict(emb=mpe_sd["rel_pos_emb.weight"].to(torch.float32).to(dev).contiguous(),
                             dirw=mpe_sd["direct_emb.weight"].to(torch.float32).to(dev).contiguous(),
                             alpha5=float(mpe_sd["alpha5"]), alpha6=float(mpe_sd["alpha6"]))
+            # The two adds of FFCResNetGenerator.forward (:611-612) as lookup tables for the stem's epilogue, built with the arithmetic of
+            # mpe_add_kernel (fp32, same order): t1[rel] = emb[rel] * alpha5; t2[bits] = (0 + w[k0] + w[k1] + …, set bits ascending) * alpha6
+            emb, dirw = self.mpe["emb"].cpu(), self.mpe["dirw"].cpu()
+            a5, a6 = torch.tensor(self.mpe["alpha5"], dtype=torch.float32), torch.tensor(self.mpe["alpha6"], dtype=torch.float32)
+            t2 = torch.zeros(16, dirw.shape[1], dtype=torch.float32)
+            for bits in range(16):
+                acc = torch.zeros(dirw.shape[1], dtype=torch.float32)
+                for k in range(4):
+                    if bits & (1 << k):
+                        acc = acc + dirw[k]
+                t2[bits] = acc * a6
+            self.mpe["lut1"], self.mpe["lut2"] = (emb * a5).contiguous().to(dev), t2.contiguous().to(dev)
+        self.mpe_in_stem = os.environ.get("MIT_LAMA_MPE_SEPARATE", "") in ("", "0")   # False: the separate mit_lama_mpe_add pass (A/B, tests)
         self._ws = ops.Workspace(self.device)
         self._tw: Dict[int, torch.Tensor] = {}
         self._tw_rows: Dict[int, torch.Tensor] = {}
@@ -423,16 +445,9 @@ class LamaEngine:
         lib = _lib.load()
         st = C.c_void_p(ops.current_stream())
         s64 = self._buf("full64", B, H, W, 64)
-        if self.stem_packed is not None and H > 3 and W > 3:
-            xp = self._buf("in4p", *self.stem_packed.padded_shape(B, H, W))
-            _lib.check(lib.mit_lama_prep_padded(img_u8.data_ptr(), mask_u8.data_ptr(), xp.data_ptr(), B, H, W, 3, xp.shape[2], st),
-                       "mit_lama_prep_padded")
-            self.stem_packed(xp, s64)
-        else:  # row_packed_stem=False: the plain reflect-padded Conv2d on the generic kernel (A/B comparison)
-            x4 = self._buf("in4", B, H, W, 4)
-            _lib.check(lib.mit_lama_prep(img_u8.data_ptr(), mask_u8.data_ptr(), x4.data_ptr(), B, H, W, st), "mit_lama_prep")
-            self.stem(x4, out=s64)
-        if self.mpe is not None:
+        packed = self.stem_packed is not None and H > 3 and W > 3
+        lut = None
+        if self.mpe is not None:   # the masked position encoding's index maps first: the stem's epilogue consumes them
             tb = self._mpe_tables(H, W)
             hole = self._buf("mpe_hole", B, MPE_S, MPE_S, dtype=torch.uint8)
             rel = self._buf("mpe_rel", B, MPE_S, MPE_S, dtype=torch.uint8)
@@ -441,10 +456,26 @@ class LamaEngine:
                                               tb["yw"].data_ptr(), tb["ymax"], tb["xs"].data_ptr(), tb["xc"].data_ptr(),
                                               tb["xw"].data_ptr(), tb["xmax"], hole.data_ptr(), rel.data_ptr(),
                                               dr.data_ptr(), st), "mit_lama_mpe_index")
-            _lib.check(lib.mit_lama_mpe_add(s64.data_ptr(), mask_u8.data_ptr(), rel.data_ptr(), dr.data_ptr(),
-                                            tb["ymap"].data_ptr(), tb["xmap"].data_ptr(), self.mpe["emb"].data_ptr(),
-                                            self.mpe["dirw"].data_ptr(), self.mpe["alpha5"], self.mpe["alpha6"], B, H, W,
-                                            st), "mit_lama_mpe_add")
+            if packed and self.mpe_in_stem:
+                rows = self._buf("mpe_rows", B * H * W, dtype=torch.int32)
+                _lib.check(lib.mit_lama_mpe_rows(mask_u8.data_ptr(), rel.data_ptr(), dr.data_ptr(), tb["ymap"].data_ptr(),
+                                                 tb["xmap"].data_ptr(), rows.data_ptr(), B, H, W, st), "mit_lama_mpe_rows")
+                lut = (rows, self.mpe["lut1"], self.mpe["lut2"])
+        if packed:
+            xp = self._buf("in4p", *self.stem_packed.padded_shape(B, H, W))
+            _lib.check(lib.mit_lama_prep_padded(img_u8.data_ptr(), mask_u8.data_ptr(), xp.data_ptr(), B, H, W, 3, xp.shape[2], st),
+                       "mit_lama_prep_padded")
+            self.stem_packed(xp, s64, lut=lut)   # x_l += rel_pos; x_l += direct (:611-612) inside the stem's epilogue
+        else:  # row_packed_stem=False: the plain reflect-padded Conv2d on the generic kernel (A/B comparison)
+            x4 = self._buf("in4", B, H, W, 4)
+            _lib.check(lib.mit_lama_prep(img_u8.data_ptr(), mask_u8.data_ptr(), x4.data_ptr(), B, H, W, st), "mit_lama_prep")
+            self.stem(x4, out=s64)
+        if self.mpe is not None:
+            if lut is None:   # the separate pass (MIT_LAMA_MPE_SEPARATE=1, or the unpacked stem): bit-identical to the epilogue form
+                _lib.check(lib.mit_lama_mpe_add(s64.data_ptr(), mask_u8.data_ptr(), rel.data_ptr(), dr.data_ptr(),
+                                                tb["ymap"].data_ptr(), tb["xmap"].data_ptr(), self.mpe["emb"].data_ptr(),
+                                                self.mpe["dirw"].data_ptr(), self.mpe["alpha5"], self.mpe["alpha6"], B, H, W,
+                                                st), "mit_lama_mpe_add")
             if taps is not None:
                 taps["mpe_rel"], taps["mpe_dir"], taps["mpe_hole"] = rel.clone(), dr.clone(), hole.clone()
         if taps is not None:

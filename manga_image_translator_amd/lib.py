@@ -72,6 +72,10 @@ class MitConvGemm(C.Structure):
         ("dyn", C.c_void_p),
         ("a_dyn", C.c_int64),
         ("c_dyn", C.c_int64),
+        ("lut_rows", C.c_void_p),
+        ("lut1", C.c_void_p),
+        ("lut2", C.c_void_p),
+        ("lut_ld", C.c_int64),
     ]
 
 
@@ -220,6 +224,7 @@ SYMBOLS = {
     "mit_lama_mpe_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]),
+    "mit_lama_mpe_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_ctd_prep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mit_maxpool_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -243,3 +243,49 @@ def _row_packed_stem_check(cuda, H, W, B):
         taps.append(t)
     assert torch.equal(taps[0]["stem"], taps[1]["stem"])
     assert torch.equal(taps[0]["pred"], taps[1]["pred"])
+
+
+@pytest.mark.parametrize("H,W,B", [(264, 272, 2), (512, 384, 3)])
+def test_mpe_in_the_stem_epilogue_is_bit_identical_to_the_separate_pass(cuda, gemm_mode, H, W, B):
+    """The masked position encoding's two adds (FFCResNetGenerator.forward, inpainting_lama_mpe.py:611-612) as the stem launch's two-table
+    row lookup (MitConvGemm.lut_rows; mit_lama_mpe_rows) against the separate read-modify-write pass (mit_lama_mpe_add) they replace:
+    the stem output and the final page must be the same bytes, in both GEMM modes (fp32 tiles and split tiles share the epilogue)."""
+    from manga_image_translator_amd import synth
+
+    _, _, eng = _setup(9, True, cuda)
+    gen = [synth.synth_page(i, H, W, n_boxes=5) for i in range(B)]
+    img = torch.from_numpy(np.stack([g[0] for g in gen])).to(cuda)
+    msk = torch.from_numpy(np.stack([g[2] for g in gen])).to(cuda)
+    assert eng.mpe_in_stem and msk.any()
+    t1, t2 = {}, {}
+    out1 = eng.forward(img, msk, taps=t1).clone()
+    eng.mpe_in_stem = False
+    try:
+        out2 = eng.forward(img, msk, taps=t2).clone()
+    finally:
+        eng.mpe_in_stem = True
+    torch.cuda.synchronize()
+    assert torch.equal(t1["mpe_rel"], t2["mpe_rel"]) and torch.equal(t1["mpe_dir"], t2["mpe_dir"]) and t1["mpe_rel"].any() and t1["mpe_dir"].any()
+    assert torch.equal(t1["stem"], t2["stem"]), f"{(t1['stem'] != t2['stem']).sum().item()} stem values differ"
+    assert torch.equal(out1, out2)
+
+
+def test_row_lookup_epilogue_is_validated(cuda):
+    """mit_conv_gemm refuses a lookup without its tables, with rows shorter than N, or on a batched (Z > 1) launch."""
+    from manga_image_translator_amd import ops
+
+    x = torch.randn(1, 8, 8, 16, device=cuda)
+    conv = ops.Conv2d(torch.randn(32, 16, 1, 1), None, device=cuda)
+    out = torch.empty(1, 8, 8, 32, device=cuda)
+    rows = torch.zeros(64, dtype=torch.int32, device=cuda)
+    t = torch.zeros(4, 32, device=cuda)
+    d = conv.desc(x, out)
+    d.lut_rows, d.lut1, d.lut2, d.lut_ld = rows.data_ptr(), t.data_ptr(), 0, 32
+    with pytest.raises(RuntimeError, match="lut_rows needs"):
+        ops.launch_conv_gemm(d)
+    d.lut2, d.lut_ld = t.data_ptr(), 16
+    with pytest.raises(RuntimeError, match="lut_rows needs"):
+        ops.launch_conv_gemm(d)
+    d.lut_ld = 32
+    ops.launch_conv_gemm(d)   # valid: all rows 0 of zero tables
+    torch.cuda.synchronize()
