@@ -35,6 +35,20 @@ HIPCC_FLAGS = [
 ]
 
 
+# Packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) is switched off in the code generator for every translation unit that does
+# not ask for it: -fno-slp-vectorize alone still left the loop vectoriser and the vector combiner forming such instructions WITH op_sel /
+# neg modifiers from scalar source (winograd.hip: 30, map_to_u8_kernel: 2, …) — the very form that misbehaved beside MFMA co-tenants.
+# The two units below use packed math on purpose (explicit two-lane vectors whose operands are whole register pairs) and are checked by
+# tests/test_build_flags.py to contain no packed-fp32 instruction with a modifier; every other unit must contain none at all.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+PACKED_FP32_BY_DESIGN = {"conv_small_cout.hip", "pgemm.hip"}
+
+
+def flags_for(src_name: str) -> list:
+    """Compiler flags of one translation unit."""
+    return HIPCC_FLAGS + ([] if src_name in PACKED_FP32_BY_DESIGN else NO_PACKED_FP32)
+
+
 if os.environ.get("MIT_WITH_SLP"):  # A/B only: the build of rounds 1-4 (reproduces the co-tenancy failures)
     HIPCC_FLAGS.remove("-fno-slp-vectorize")
 if os.environ.get("MIT_CONV_EXPERIMENTS"):  # rejected scheduling variants + timing ablations of the conv kernel (scripts/bench_conv.py)
@@ -62,7 +76,7 @@ def _digest() -> str:
     for p in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [PKG_DIR.parent / "include" / "mit_hip.h"]):
         h.update(p.name.encode())
         h.update(p.read_bytes())
-    h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(" ".join(HIPCC_FLAGS + NO_PACKED_FP32 + sorted(PACKED_FP32_BY_DESIGN)).encode())
     return h.hexdigest()
 
 
@@ -72,7 +86,7 @@ def _obj_digest(src: Path) -> str:
     for p in [src] + sorted(list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc"))) + [PKG_DIR.parent / "include" / "mit_hip.h"]:
         h.update(p.name.encode())
         h.update(p.read_bytes())
-    h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(" ".join(flags_for(src.name)).encode())
     return h.hexdigest()
 
 
@@ -95,7 +109,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         od = _obj_digest(src) + (digest if src.name == "capi.hip" else "")
         if obj.exists() and stamp.exists() and stamp.read_text() == od:
             continue
-        cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *flags_for(src.name), "-c", str(src), "-o", str(obj)]
         if src.name == "capi.hip":  # mit_source_digest(): lets lib.load() detect a stale binary
             cmd.insert(1, f'-DMIT_SOURCE_DIGEST="{digest}"')
         if verbose:
@@ -109,8 +123,12 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             sys.stderr.write(f"--- hipcc failed for {src.name} ---\n{out}\n")
         else:
             stamp.write_text(od)
-            if verbose and out.strip():
-                sys.stderr.write(out)
+            # (the host half of each compile says "'-packed-fp32-ops' is not a recognized feature for this target": expected, the feature
+            # belongs to the device half)
+            noise = "is not a recognized feature for this target"
+            rest = "\n".join(l for l in out.splitlines() if noise not in l)
+            if verbose and rest.strip():
+                sys.stderr.write(rest + "\n")
     if failed:
         raise RuntimeError("hipcc compilation failed")
     tmp = LIB_PATH.with_name(f"{LIB_PATH.name}.tmp{os.getpid()}")  # a concurrent dlopen never sees a half-written library

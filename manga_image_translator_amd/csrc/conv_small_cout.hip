@@ -7,7 +7,9 @@
 // are wave-uniform, i.e. scalar loads feeding v_fma_f32 from SGPRs.  Accumulation order: channel slice, tap (ky, kx),
 // channel — a single fmaf chain per output, like the MFMA kernel's (k order differs: slice-major instead of tap-major).
 //
-// Cout <= 3 (the LaMa layer) takes conv_small_cout3_kernel: packed fp32 math (v_pk_fma_f32, two FMAs per lane per issue — the
+// Cout <= 3 (the LaMa layer) takes conv_small_cout3_kernel: packed fp32 math (v_pk_fma_f32, two FMAs per lane per issue; every operand a
+// whole register pair — the weights come as ready-made (w, w) pairs from a duplicated table, so no instruction carries an op_sel / neg
+// modifier: tests/test_build_flags.py, DESIGN.md section 7 — the
 // plain kernel sat at 85 % of the unpacked VALU peak) on 2 x 2 output pixels per thread.  The two rows (y, y + 8) of a thread are
 // the two halves of every packed operand: the LDS tile stores, per pixel and channel pair, (row y c0, row y+8 c0, row y c1,
 // row y+8 c1), so one ds_read_b128 yields two ready-made packed operands; the two columns (x, x + 1) share a sliding window of
@@ -104,7 +106,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int TW3 = 64, TH3 = 16;
 
 template <int K>
-__global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__restrict__ in, int64_t in_pix, const f32x4 *__restrict__ w4,
+__global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__restrict__ in, int64_t in_pix, const f32x2 *__restrict__ wp /* [taps][Cin][4] pairs (w0,w0) (w1,w1) (w2,w2) (0,0) */,
                                                                 const float *__restrict__ bias, float *__restrict__ out,
                                                                 int64_t out_pix, int H, int W, int Cin, int Cout, int reflect,
                                                                 int act, float alpha) {
@@ -172,18 +174,19 @@ __global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__re
                     for (int i = 0; i <= K; ++i) win[i] = tile[cp][ty + ky][tx + (i >> 1) + (i & 1) * HALF];
 #pragma unroll
                     for (int kx = 0; kx < K; ++kx) {
-                        const f32x4 *wt = w4 + (int64_t)(ky * K + kx) * Cin + c0 + cp * 2;  // wave-uniform -> scalar loads
-                        const f32x4 wa = wt[0], wb = wt[1];
+                        // wave-uniform -> scalar loads; each weight arrives twice, as the aligned SGPR pair a packed FMA takes as is
+                        const f32x2 *wt = wp + ((int64_t)(ky * K + kx) * Cin + c0 + cp * 2) * 4;
+                        const f32x2 a0 = wt[0], a1 = wt[1], a2 = wt[2], b0 = wt[4], b1 = wt[5], b2 = wt[6];
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const f32x4 v = win[kx + j];
                             const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-                            acc[j][0] = __builtin_elementwise_fma(lo, f32x2{wa.x, wa.x}, acc[j][0]);
-                            acc[j][1] = __builtin_elementwise_fma(lo, f32x2{wa.y, wa.y}, acc[j][1]);
-                            acc[j][2] = __builtin_elementwise_fma(lo, f32x2{wa.z, wa.z}, acc[j][2]);
-                            acc[j][0] = __builtin_elementwise_fma(hi, f32x2{wb.x, wb.x}, acc[j][0]);
-                            acc[j][1] = __builtin_elementwise_fma(hi, f32x2{wb.y, wb.y}, acc[j][1]);
-                            acc[j][2] = __builtin_elementwise_fma(hi, f32x2{wb.z, wb.z}, acc[j][2]);
+                            acc[j][0] = __builtin_elementwise_fma(lo, a0, acc[j][0]);
+                            acc[j][1] = __builtin_elementwise_fma(lo, a1, acc[j][1]);
+                            acc[j][2] = __builtin_elementwise_fma(lo, a2, acc[j][2]);
+                            acc[j][0] = __builtin_elementwise_fma(hi, b0, acc[j][0]);
+                            acc[j][1] = __builtin_elementwise_fma(hi, b1, acc[j][1]);
+                            acc[j][2] = __builtin_elementwise_fma(hi, b2, acc[j][2]);
                         }
                     }
                 }
@@ -206,14 +209,14 @@ __global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__re
 
 }  // namespace
 
-extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *w4_dev, const float *bias_dev,
+extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *w4_dev, const float *w_pairs_dev, const float *bias_dev,
                                    float *out_dev, int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k,
                                    int pad_mode, int act, float act_alpha, void *stream) {
     if (!in_dev || !w4_dev || !out_dev) return mit_set_error("mit_conv_small_cout: null pointer");
     if (Cout < 1 || Cout > 4) return mit_set_error("mit_conv_small_cout: 1 <= Cout <= 4 required (got %d)", Cout);
     if (Cin <= 0 || (Cin % CCH)) return mit_set_error("mit_conv_small_cout: Cin must be a multiple of %d (got %d)", CCH, Cin);
     if (B <= 0 || H <= 0 || W <= 0 || B > 65535) return mit_set_error("mit_conv_small_cout: bad size");
-    if ((in_pixstride & 3) || (reinterpret_cast<uintptr_t>(in_dev) & 15) || (reinterpret_cast<uintptr_t>(w4_dev) & 15))
+    if ((in_pixstride & 3) || (reinterpret_cast<uintptr_t>(in_dev) & 15) || (reinterpret_cast<uintptr_t>(w4_dev) & 15) || (reinterpret_cast<uintptr_t>(w_pairs_dev) & 31))
         return mit_set_error("mit_conv_small_cout: input pixels and weights must be 16-byte aligned");
     if (pad_mode == MIT_PAD_REFLECT && (k / 2 >= H || k / 2 >= W)) return mit_set_error("mit_conv_small_cout: reflect pad larger than input");
     dim3 grid(mit_div_up(W, TW), mit_div_up(H, TH), B), block(256);
@@ -221,18 +224,19 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w4_dev);
     const int refl = pad_mode == MIT_PAD_REFLECT;
     // VALU-bound: algorithmic FLOPs 2 k^2 Cin Cout per pixel; bytes: input read once + Cout outputs written
-    MitProbeScope probe(Cout <= 3 && !getenv("MIT_SMALL_COUT_PLAIN") ? (k == 7 ? "conv_small_cout3_kernel<7>" : k == 5 ? "conv_small_cout3_kernel<5>" : "conv_small_cout3_kernel<3>")
+    MitProbeScope probe(Cout <= 3 && w_pairs_dev && !getenv("MIT_SMALL_COUT_PLAIN") ? (k == 7 ? "conv_small_cout3_kernel<7>" : k == 5 ? "conv_small_cout3_kernel<5>" : "conv_small_cout3_kernel<3>")
                                                                     : (k == 7 ? "conv_small_cout_kernel<7>" : k == 5 ? "conv_small_cout_kernel<5>" : "conv_small_cout_kernel<3>"), s, 4.0 * (double)B * H * W * (Cin + Cout), 2.0 * k * k * (double)Cin * Cout * (double)B * H * W);
     // Cout <= 3: the packed-FMA kernel (2.7x fewer VALU instructions).  With 4-channel slices loaded straight from HBM it fetched
     // every 128-byte input line 8 times and was slower than the plain kernel (25 vs 17.7 ms per 16 pages); staging 16-channel groups
     // in registers brought it to 15.9 ms (same-box A/B).  MIT_SMALL_COUT_PLAIN=1 selects the plain kernel for comparison.
     static const bool use_pk = getenv("MIT_SMALL_COUT_PLAIN") == nullptr;
-    if (Cout <= 3 && use_pk) {
+    if (Cout <= 3 && use_pk && w_pairs_dev) {
         dim3 grid3(mit_div_up(W, TW3), mit_div_up(H, TH3), B);
+        const f32x2 *wp = reinterpret_cast<const f32x2 *>(w_pairs_dev);
         switch (k) {
-            case 3: hipLaunchKernelGGL(conv_small_cout3_kernel<3>, grid3, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
-            case 5: hipLaunchKernelGGL(conv_small_cout3_kernel<5>, grid3, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
-            case 7: hipLaunchKernelGGL(conv_small_cout3_kernel<7>, grid3, block, 0, s, in_dev, in_pixstride, w4, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            case 3: hipLaunchKernelGGL(conv_small_cout3_kernel<3>, grid3, block, 0, s, in_dev, in_pixstride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            case 5: hipLaunchKernelGGL(conv_small_cout3_kernel<5>, grid3, block, 0, s, in_dev, in_pixstride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            case 7: hipLaunchKernelGGL(conv_small_cout3_kernel<7>, grid3, block, 0, s, in_dev, in_pixstride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
             default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
         }
         MIT_CHECK_LAUNCH("mit_conv_small_cout");

@@ -512,6 +512,8 @@ class ConvSmallCout:
         w4 = torch.zeros(kh * kw, Cin, 4, dtype=torch.float32)
         w4[:, :, :Cout] = weight.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(kh * kw, Cin, Cout)
         self.w4 = w4.to(device).contiguous()
+        # Cout <= 3: every weight twice — the ready-made (w, w) operand pairs of the packed-FMA kernel (no op_sel broadcast in the ISA)
+        self.w_pairs = w4.repeat_interleave(2, dim=2).to(device).contiguous() if Cout <= 3 else None    # [taps, Cin, 8]
         self.bias = None if bias is None else bias.detach().to(torch.float32).to(device).contiguous()
 
     def __call__(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -524,7 +526,7 @@ class ConvSmallCout:
                 and out.stride(1) * H == out.stride(0)):
             raise ValueError("ConvSmallCout: pixel-dense tensors required")
         lib = _lib.load()
-        _lib.check(lib.mit_conv_small_cout(x.data_ptr(), x.stride(2), self.w4.data_ptr(), _ptr(self.bias), out.data_ptr(),
+        _lib.check(lib.mit_conv_small_cout(x.data_ptr(), x.stride(2), self.w4.data_ptr(), _ptr(self.w_pairs), _ptr(self.bias), out.data_ptr(),
                                            out.stride(2), B, H, W, self.Cin, self.Cout, self.k, self.pad_mode, self.act,
                                            self.alpha, C.c_void_p(current_stream())), "mit_conv_small_cout")
         return out
