@@ -230,9 +230,10 @@ int mit_join_planes(const uint16_t *planes_dev, int64_t ld, int R, int K, float 
 /* k x k (3, 5, 7) stride-1 "same" convolution with 1..4 output channels on the fp32 VALU (an MFMA tile would idle 29 of
  * its 32 columns): out[b,y,x,n] = act(sum in[b,y+dy,x+dx,c] * w4[(ky*k+kx)*Cin + c][n] + bias[n]).  in: NHWC with pixel
  * stride in_pixstride floats (Cin % 16 == 0 channels used); w4: [k*k][Cin][4] (output channel padded to 4, zeros beyond
- * Cout); out: pixel stride out_pixstride, Cout floats written.  w_pairs (optional, Cout <= 3, 32-byte aligned): the same weights as
- * [k*k][Cin][8] = (w0, w0, w1, w1, w2, w2, 0, 0) — every weight twice, the operand pair of the packed-FMA kernel that Cout <= 3 takes
- * when it is given (2.7x fewer VALU instructions; no packed instruction with an op_sel / neg modifier); NULL = the plain kernel.
+ * Cout); out: pixel stride out_pixstride, Cout floats written.  w_pairs (optional, Cout <= 3, 32-byte aligned): the same weights
+ * channel-fastest, [k*k][Cin / 4][4 outputs (zeros beyond Cout)][4 channels] — the operand pairs (channels c, c + 1 of one output) of
+ * the packed-FMA kernel that Cout <= 3 takes when it is given (2.7x fewer VALU instructions; accumulators hold even / odd channel
+ * sums, no packed instruction carries an op_sel / neg modifier); NULL = the plain kernel.
  * Replaces ReflectionPad2d(3) + Conv2d(64, 3, 7) + sigmoid at the end of FFCResNetGenerator (inpainting_lama_mpe.py:597-600). */
 int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *w4_dev, const float *w_pairs_dev, const float *bias_dev, float *out_dev,
                         int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k, int pad_mode, int act,

@@ -7,16 +7,17 @@
 // are wave-uniform, i.e. scalar loads feeding v_fma_f32 from SGPRs.  Accumulation order: channel slice, tap (ky, kx),
 // channel — a single fmaf chain per output, like the MFMA kernel's (k order differs: slice-major instead of tap-major).
 //
-// Cout <= 3 (the LaMa layer) takes conv_small_cout3_kernel: packed fp32 math (v_pk_fma_f32, two FMAs per lane per issue; every operand a
-// whole register pair — the weights come as ready-made (w, w) pairs from a duplicated table, so no instruction carries an op_sel / neg
-// modifier: tests/test_build_flags.py, DESIGN.md section 7 — the
-// plain kernel sat at 85 % of the unpacked VALU peak) on 2 x 2 output pixels per thread.  The two rows (y, y + 8) of a thread are
-// the two halves of every packed operand: the LDS tile stores, per pixel and channel pair, (row y c0, row y+8 c0, row y c1,
-// row y+8 c1), so one ds_read_b128 yields two ready-made packed operands; the two columns (x, x + 1) share a sliding window of
-// K + 1 such reads per kernel row.  Even / odd pixels of a tile row sit in separate halves of the LDS row so that the 64 lanes of
-// a wave (stride 2 pixels) read consecutive 16-byte slots.  No 4th accumulator.  Each thread stages a 16-channel group (whole
-// 64-byte pieces of its tile cells) in registers and feeds four 4-channel LDS slices from it, so a 128-byte input line is touched
-// by 4 groups, not by 16 slices.  Accumulation order: 4-channel slice, channel pair, tap (ky, kx), channel.
+// Cout <= 3 (the LaMa layer) takes conv_small_cout3_kernel: packed fp32 math (v_pk_fma_f32, two FMAs per lane per issue — the plain
+// kernel sat at 85 % of the unpacked VALU peak) on 2 x 2 output pixels per thread (columns x, x + 1; rows y, y + 8).  The two halves of
+// every packed operand are two ADJACENT INPUT CHANNELS: an accumulator pair is (even-channel sum, odd-channel sum) of one output, a
+// ds_read_b128 of a pixel's 4-channel slice yields two ready-made input pairs, the matching weight pairs come from one scalar load of
+// the channel-fastest table w_pairs — every operand is a naturally aligned register pair, so no v_pk_fma_f32 carries an op_sel / neg
+// modifier (the earlier row-pair form broadcast each weight with op_sel: 1440 such instructions, the form that misbehaves beside
+// MFMA co-tenants; tests/test_build_flags.py).  The columns share a sliding window of K + 1 reads per kernel row and
+// tile row.  Even / odd pixels of a tile row sit in separate halves of the LDS row so that the 64 lanes of a wave (stride 2 pixels)
+// read consecutive 16-byte slots.  Each thread stages a 16-channel group (whole 64-byte pieces of its tile cells) in registers and
+// feeds four 4-channel LDS slices from it, so a 128-byte input line is touched by 4 groups, not by 16 slices.
+// Accumulation order per half: 4-channel slice, tap (ky, kx), channel pair; out = (even half + odd half) + bias.
 //
 // Reference op: FFCResNetGenerator.model[-2:] = ReflectionPad2d(3) + Conv2d(64, 3, 7) + sigmoid
 // (manga_translator/inpainting/inpainting_lama_mpe.py:597-600).
@@ -106,89 +107,89 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int TW3 = 64, TH3 = 16;
 
 template <int K>
-__global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__restrict__ in, int64_t in_pix, const f32x2 *__restrict__ wp /* [taps][Cin][4] pairs (w0,w0) (w1,w1) (w2,w2) (0,0) */,
+__global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__restrict__ in, int64_t in_pix,
+                                                                const f32x2 *__restrict__ wq /* [taps][Cin / 4][4 out (3 used)][2 channel pairs] */,
                                                                 const float *__restrict__ bias, float *__restrict__ out,
                                                                 int64_t out_pix, int H, int W, int Cin, int Cout, int reflect,
                                                                 int act, float alpha) {
+    // Packed operands are CHANNEL pairs: an accumulator pair holds (sum over even channels, sum over odd channels) of one output, a
+    // pixel's channels (c, c + 1) are adjacent in the NHWC input and so are a kernel tap's weights for them in wq — every operand of
+    // every v_pk_fma_f32 is a naturally aligned register pair (VGPR pair from one ds_read_b128, SGPR pair from one scalar load), no
+    // broadcast, no modifier.  The two halves are added once at the end.
     constexpr int R = K / 2;
-    constexpr int PR = TH3 / 2 + 2 * R;  // row pairs (y, y + 8) held per tile
+    constexpr int TR = TH3 + 2 * R;      // tile rows incl. halo
     constexpr int HW_ = TW3 + 2 * R;     // even for odd K
     constexpr int HALF = HW_ / 2;
-    __shared__ f32x4 tile[2][PR][HW_];   // [channel pair][pair row][even pixels | odd pixels] = (A c0, B c0, A c1, B c1)
+    __shared__ f32x4 tile[TR][HW_];      // [row][even pixels | odd pixels] = the 4 channels of the current slice
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int x0 = blockIdx.x * TW3, y0 = blockIdx.y * TH3, b = blockIdx.z;
     const float *ib = in + (int64_t)b * H * W * in_pix;
-    f32x2 acc[2][3];
+    f32x2 acc[2][2][3];                  // [row r: y, y + 8][column j: x, x + 1][output channel]
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) acc[j][n] = f32x2{0.f, 0.f};
-    constexpr int ITEMS = (PR * HW_ + 255) / 256;  // (pair row, pixel) cells of the tile per thread
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[r][j][n] = f32x2{0.f, 0.f};
+    constexpr int ITEMS = (TR * HW_ + 255) / 256;  // pixel cells of the tile per thread
     for (int g0 = 0; g0 < Cin; g0 += 16) {
-        // stage a 16-channel group of every cell in registers: whole 64-byte pieces per pixel (two rows), so each 128-byte line of
-        // the NHWC input is touched by 4 such groups instead of by 16 four-channel slices
-        f32x4 ra[ITEMS][4], rb[ITEMS][4];
+        // stage a 16-channel group of every cell in registers: whole 64-byte pieces per pixel, so each 128-byte line of the NHWC input
+        // is touched by 4 such groups instead of by 16 four-channel slices
+        f32x4 rg[ITEMS][4];
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const int i = threadIdx.x + it * 256;
             const int ly = i / HW_, lx = i - ly * HW_;
-            int ya = y0 + ly - R, yb = ya + TH3 / 2, xx = x0 + lx - R;
+            int yy = y0 + ly - R, xx = x0 + lx - R;
             if (reflect) {
-                ya = ya < 0 ? -ya : (ya >= H ? 2 * H - 2 - ya : ya);
-                yb = yb < 0 ? -yb : (yb >= H ? 2 * H - 2 - yb : yb);
+                yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
                 xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
             }
-            const bool cell = i < PR * HW_ && xx >= 0 && xx < W;  // still outside after one reflection: tile overhang, never used
-            const bool oka = cell && ya >= 0 && ya < H, okb = cell && yb >= 0 && yb < H;
-            const float *pa = ib + ((int64_t)ya * W + xx) * in_pix + g0, *pb = ib + ((int64_t)yb * W + xx) * in_pix + g0;
+            const bool ok = i < TR * HW_ && xx >= 0 && xx < W && yy >= 0 && yy < H;  // still outside after one reflection: tile overhang, never used
+            const float *pa = ib + ((int64_t)yy * W + xx) * in_pix + g0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                ra[it][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rb[it][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (oka) ra[it][q] = *reinterpret_cast<const f32x4 *>(pa + q * 4);
-                if (okb) rb[it][q] = *reinterpret_cast<const f32x4 *>(pb + q * 4);
+                rg[it][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) rg[it][q] = *reinterpret_cast<const f32x4 *>(pa + q * 4);
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c0 = g0 + q * 4;
+            const int s4 = (g0 >> 2) + q;  // 4-channel slice index
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const int i = threadIdx.x + it * 256;
-                if (i < PR * HW_) {
+                if (i < TR * HW_) {
                     const int ly = i / HW_, lx = i - ly * HW_;
-                    const int slot = (lx >> 1) + (lx & 1) * HALF;
-                    const f32x4 a = ra[it][q], bq = rb[it][q];
-                    tile[0][ly][slot] = f32x4{a.x, bq.x, a.y, bq.y};
-                    tile[1][ly][slot] = f32x4{a.z, bq.z, a.w, bq.w};
+                    tile[ly][(lx >> 1) + (lx & 1) * HALF] = rg[it][q];
                 }
             }
             __syncthreads();
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
 #pragma unroll 1
-                for (int ky = 0; ky < K; ++ky) {
-                    f32x4 win[K + 1];
+            for (int ky = 0; ky < K; ++ky) {
+                f32x4 win[2][K + 1];
 #pragma unroll
-                    for (int i = 0; i <= K; ++i) win[i] = tile[cp][ty + ky][tx + (i >> 1) + (i & 1) * HALF];
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int kx = 0; kx < K; ++kx) {
-                        // wave-uniform -> scalar loads; each weight arrives twice, as the aligned SGPR pair a packed FMA takes as is
-                        const f32x2 *wt = wp + ((int64_t)(ky * K + kx) * Cin + c0 + cp * 2) * 4;
-                        const f32x2 a0 = wt[0], a1 = wt[1], a2 = wt[2], b0 = wt[4], b1 = wt[5], b2 = wt[6];
+                    for (int i = 0; i <= K; ++i) win[r][i] = tile[ty + r * (TH3 / 2) + ky][tx + (i >> 1) + (i & 1) * HALF];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const f32x2 *wt = wq + ((int64_t)(ky * K + kx) * (Cin >> 2) + s4) * 8;  // wave-uniform -> one scalar load of 16 floats
+                    const f32x2 w00 = wt[0], w01 = wt[1], w10 = wt[2], w11 = wt[3], w20 = wt[4], w21 = wt[5];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const f32x4 v = win[kx + j];
+                            const f32x4 v = win[r][kx + j];
                             const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-                            acc[j][0] = __builtin_elementwise_fma(lo, a0, acc[j][0]);
-                            acc[j][1] = __builtin_elementwise_fma(lo, a1, acc[j][1]);
-                            acc[j][2] = __builtin_elementwise_fma(lo, a2, acc[j][2]);
-                            acc[j][0] = __builtin_elementwise_fma(hi, b0, acc[j][0]);
-                            acc[j][1] = __builtin_elementwise_fma(hi, b1, acc[j][1]);
-                            acc[j][2] = __builtin_elementwise_fma(hi, b2, acc[j][2]);
+                            acc[r][j][0] = __builtin_elementwise_fma(lo, w00, acc[r][j][0]);
+                            acc[r][j][1] = __builtin_elementwise_fma(lo, w10, acc[r][j][1]);
+                            acc[r][j][2] = __builtin_elementwise_fma(lo, w20, acc[r][j][2]);
+                            acc[r][j][0] = __builtin_elementwise_fma(hi, w01, acc[r][j][0]);
+                            acc[r][j][1] = __builtin_elementwise_fma(hi, w11, acc[r][j][1]);
+                            acc[r][j][2] = __builtin_elementwise_fma(hi, w21, acc[r][j][2]);
                         }
-                    }
                 }
             }
         }
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__re
             const int y = y0 + ty + r * (TH3 / 2);
             if (x < W && y < H) {
                 float *o = out + (((int64_t)b * H + y) * W + x) * out_pix;
-                for (int n = 0; n < Cout; ++n) o[n] = act_fn(acc[j][n][r] + (bias ? bias[n] : 0.f), act, alpha);
+                for (int n = 0; n < Cout; ++n) o[n] = act_fn((acc[r][j][n].x + acc[r][j][n].y) + (bias ? bias[n] : 0.f), act, alpha);
             }
         }
     }
@@ -233,6 +234,7 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     if (Cout <= 3 && use_pk && w_pairs_dev) {
         dim3 grid3(mit_div_up(W, TW3), mit_div_up(H, TH3), B);
         const f32x2 *wp = reinterpret_cast<const f32x2 *>(w_pairs_dev);
+        if (Cin & 3) return mit_set_error("mit_conv_small_cout: Cin %% 4");
         switch (k) {
             case 3: hipLaunchKernelGGL(conv_small_cout3_kernel<3>, grid3, block, 0, s, in_dev, in_pixstride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
             case 5: hipLaunchKernelGGL(conv_small_cout3_kernel<5>, grid3, block, 0, s, in_dev, in_pixstride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;

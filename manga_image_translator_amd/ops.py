@@ -512,8 +512,9 @@ class ConvSmallCout:
         w4 = torch.zeros(kh * kw, Cin, 4, dtype=torch.float32)
         w4[:, :, :Cout] = weight.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(kh * kw, Cin, Cout)
         self.w4 = w4.to(device).contiguous()
-        # Cout <= 3: every weight twice — the ready-made (w, w) operand pairs of the packed-FMA kernel (no op_sel broadcast in the ISA)
-        self.w_pairs = w4.repeat_interleave(2, dim=2).to(device).contiguous() if Cout <= 3 else None    # [taps, Cin, 8]
+        # Cout <= 3: the same weights channel-fastest, [taps][Cin / 4][4 outputs][4 channels] — operand pairs (channels c, c + 1) of the
+        # packed-FMA kernel, naturally aligned (no op_sel broadcast in the ISA)
+        self.w_pairs = (w4.reshape(kh * kw, Cin // 4, 4, 4).permute(0, 1, 3, 2).to(device).contiguous() if Cout <= 3 else None)
         self.bias = None if bias is None else bias.detach().to(torch.float32).to(device).contiguous()
 
     def __call__(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

@@ -134,7 +134,13 @@ class DenseStages:
         lines = await self.ocr.infer(page, tls, _Cfg(), False, int(ocr.get("ignore_bubble", 0)), steps, bool(ocr.get("suppress_eos", False))) if tls else []
         lines = [l for l in lines if l.text.strip()]
         inp = cfg.get("inpainter", {})
-        if lines:
+        mask_in = cfg.get("mask")          # a request may bring the mask to inpaint ([H, W] uint8) instead of the refined detector mask
+        if mask_in is not None:
+            mask = np.ascontiguousarray(np.asarray(mask_in, dtype=np.uint8))
+            if mask.shape != (H, W):
+                raise ValueError(f"mask must be {H}x{W} (got {mask.shape})")
+            out = await self.inp.infer(page, mask, None, int(inp.get("inpainting_size", 2048)))
+        elif lines:
             regions = TM.dispatch_sync(lines, W, H)
             mask = MR.dispatch_sync(regions, page, mask_raw, "fit_text", int(cfg.get("mask_dilation_offset", 20)), 0, False, int(cfg.get("kernel_size", 3)))
             out = await self.inp.infer(page, mask, None, int(inp.get("inpainting_size", 2048)))

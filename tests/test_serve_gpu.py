@@ -21,9 +21,11 @@ def _port():
 def test_two_workers_on_one_box_return_identical_pages(cuda):
     from manga_image_translator_amd import serve, synth
 
-    page, quads, _ = synth.synth_page(3, H, W, n_boxes=LINES, disjoint=True)
+    page, quads, gmask = synth.synth_page(3, H, W, n_boxes=LINES, disjoint=True)
     page2 = synth.synth_page(4, H, W, n_boxes=LINES, disjoint=True)[0]
-    cfg = {"textlines": np.asarray(quads).tolist(), "ocr": {"max_seq_length": 8, "suppress_eos": True, "prob": 0.0},
+    # (synthetic weights: the detector fires on nothing and the refined mask would be empty — the request brings the generator's text
+    # lines and mask, as the benchmark does, so that every stage has work)
+    cfg = {"textlines": np.asarray(quads).tolist(), "mask": gmask, "ocr": {"max_seq_length": 8, "suppress_eos": True, "prob": 0.0},
            "inpainter": {"inpainting_size": 512}}
     base = _port()
     pool = serve.WorkerPool(gpus=["0", "0"], base_port=base, worker_args=["--dict-size", str(D)])   # one GPU on the box: both pinned to it
