@@ -133,6 +133,20 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
         static const int64_t ssmall_max = getenv("MIT_CONV_SPLIT_SMALL_MAX") ? atoll(getenv("MIT_CONV_SPLIT_SMALL_MAX")) : 768;  // one wave of 128-row split tiles (3 workgroups per CU)
         const int r = p.N % 128;
         int c = (p.N <= 64 || (r != 0 && r <= 64)) ? (split == 6 ? narrow6 : narrow9) : (split == 6 ? wide6 : wide9);
+        // Exact-N tiles (round 5; wave tile 32 x BN, the A tile split once for all BN columns) where the 64-column tile would otherwise
+        // run 3 or 5 times over the same rows, or the 128-column tile would compute 48 padded columns — measured per shape
+        // (profiles/r07f_split_check_exact_n_tiles.log, r07g_split_check_tile192.log; same bits as every other p6 tile):
+        //   N = 160, K = 640 (ConvNeXt stage-2 pw2): 1.36x of 3 x 64;   N = 320, K = 1280 (stage-3 pw2): 1.13x of 5 x 64;
+        //   N = 80, K = 320 (stage-1 pw2): 1.08x of the 128-column tile;   N = 192, K = 384 (LaMa spectral conv1): 1.09x of 3 x 64.
+        // The short-K expansions (pw1: K = 80 / 160 / 320 into N = 4K) are 5-10 % SLOWER on them and keep the tiles above.
+        static const bool exact_n_off = getenv("MIT_CONV_NO_EXACT_N") != nullptr;  // A/B knob
+        if (split == 6 && p.Z == 1 && !exact_n_off) {
+            static const int t160 = cfg_by_name("split128x160x16p6o"), t96 = cfg_by_name("split128x96x16p6o"), t192 = cfg_by_name("split128x192x16p6o");
+            const int K = p.ntaps * p.Cin;
+            if (t160 >= 0 && (p.N == 160 || p.N == 320) && K >= 512) c = t160;
+            else if (t96 >= 0 && p.N > 64 && p.N <= 96 && K >= 256) c = t96;
+            else if (t192 >= 0 && p.N == 192 && K >= 256) c = t192;
+        }
         // under-filled launches (one page through the plugins, the decoder's Linears): 64 x 64 tiles quadruple the workgroup count;
         // the arithmetic per output element is that of the large tiles, so a result does not depend on the choice
         const int sm = split == 6 ? small6 : small9;

@@ -51,7 +51,9 @@ int main(int argc, char **argv) {
     const int s6o = find_cfg("split128x128x16p6o"), n6o = find_cfg("split128x64x16p6o");
     if (s6o < 0 || n6o < 0) return 2;  // (tiles of MIT_CONV_EXPERIMENTS builds come back as -1 from a default build and are skipped below)
     const int s64 = find_cfg("split64x64x16p6o"), s32 = find_cfg("split128x32x16p6o"), f32t = find_cfg("fast128x32x16w4c");  // small / narrow tiles (-1: skipped)
-    const int w6o = find_cfg("split64x256x16p6o");  // wide-N tile (-1 in builds without it: skipped)
+    const int w6o = find_cfg("split64x256x16p6o");
+    const int t192 = find_cfg("split128x192x16p6o");
+    const int t160 = find_cfg("split128x160x16p6o"), t96 = find_cfg("split128x96x16p6o");  // exact-N tiles for N = 160 k / N = 80  // wide-N tile (-1 in builds without it: skipped)
     const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c"), s64k = find_cfg("split64x64x32p6o");
     if (f_wide < 0 || f_narrow < 0 || s6 < 0 || s9 < 0 || s3 < 0 || n6 < 0 || n9 < 0 || s9m < 0) {
         fprintf(stderr, "tile names not found\n");
@@ -65,6 +67,16 @@ int main(int argc, char **argv) {
         {"1x1 192->384 (spectral conv2), M=131072, relu", 1, 256, 512, 192, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, n6o, w6o, s6o, n6o, w6o}},
         {"1x1 160->640 (ConvNeXt stage 2 pw1), M=131072, gelu", 1, 256, 512, 160, 640, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, n6o, w6o, s6o, n6o, w6o}},
         {"1x1 80->320 (ConvNeXt stage 1 pw1), M=262144, gelu", 1, 512, 512, 80, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, n6o, w6o, s6o, n6o, w6o}},
+        {"1x1 640->160 (ConvNeXt stage 2 pw2), M=131072", 1, 256, 512, 640, 160, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6o, n6o, t160, s6o, n6o, t160}},
+        {"1x1 320->80 (ConvNeXt stage 1 pw2), M=262144", 1, 512, 512, 320, 80, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6o, n6o, t96, s6o, n6o, t96}},
+        {"1x1 1280->320 (pw2), M=131072", 1, 256, 512, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6o, n6o, t160, n6o, t160}},
+        {"1x1 320->1280 (pw1), M=131072, gelu", 1, 256, 512, 320, 1280, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, t160, s6o, t160}},
+        {"1x1 160->640 (pw1), M=262144, gelu", 1, 512, 512, 160, 640, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, t160, s6o, t160}},
+        {"1x1 80->320 (pw1), M=524288, gelu", 1, 1024, 512, 80, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, n6o, t160, n6o, t160}},
+        {"1x1 384->192 (spectral conv1), M=262144, relu", 1, 512, 512, 384, 192, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, n6o, t192, n6o, t192}},
+        {"1x1 192->384 (spectral conv2), M=262144, relu", 1, 512, 512, 192, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, t192, s6o, t192}},
+        {"winograd-like Z=36, T=16384, 128->384", 1, 1, 16384, 128, 384, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6o, t192, s6o, t192}},
+        {"1x1 2 taps-like: 768->384, M=131072", 1, 256, 512, 768, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, t192, s6o, t192}},
         {"3x3 s2 zero 128->256 (LaMa down), 2x128x96", 2, 256, 192, 128, 256, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, w6o, s6o, w6o}},
         {"1x1 384x2taps-like: 768->384, M=65536", 1, 256, 256, 768, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, w6o, s6o, w6o}},
         {"3x3 s2 zero 64->64, 4x128x128", 4, 128, 128, 64, 64, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_narrow, {n6, n9, n6s, n6m, n6o, n6m, n6o}},

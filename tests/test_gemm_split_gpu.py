@@ -41,6 +41,12 @@ CASES = [
     (1, 16, 40, 9, 11, 1, 1, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p6o", "split128x128x16p6", "split128x128x16p6o", "split64x64x16p6o")),   # one K-tile, tiny problem
     (1, 32, 96, 20, 24, 1, 1, "zero", 1, "fast128x64x16w5c", ("split128x64x16p6", "split128x128x16p9m", "split128x128x16p6o", "split128x64x16p6o", "split64x64x32p6o")),  # 2 K-tiles (1 of 32)
     (1, 48, 128, 20, 24, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9m", "split128x128x16p6o", "split128x64x16p6o", "split64x64x16p6o", "split64x64x16p9m")),  # 3 K-tiles: every peeled iteration kind
+    # the exact-N tiles (round 5): wave tile 32 x BN; whole and ragged column counts, ragged M
+    (1, 640, 160, 30, 37, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x64x16p6o", "split128x160x16p6o", "split128x128x16p6o")),      # ConvNeXt stage-2 pw2
+    (1, 1280, 320, 12, 50, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x64x16p6o", "split128x160x16p6o")),                           # stage-3 pw2: two column tiles
+    (1, 320, 80, 24, 41, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x128x16p6o", "split128x96x16p6o", "split128x64x16p6o")),        # stage-1 pw2: 80 of 96 columns
+    (2, 384, 192, 16, 23, 1, 1, "zero", 1, "fast128x128x16w4c", ("split128x64x16p6o", "split128x192x16p6o", "split128x128x16p6o")),      # LaMa spectral conv1
+    (1, 64, 200, 9, 13, 3, 1, "reflect", 2, "fast128x128x16w4c", ("split128x128x16p6o", "split128x160x16p6o", "split128x192x16p6o", "split128x96x16p6o")),  # ragged last column tile of each
 ]
 
 
