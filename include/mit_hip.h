@@ -115,7 +115,9 @@ typedef struct MitConvGemm {
      * order — where output row m (= its pixel index, batch-major) carries lut_rows[m] = r1 | r2 << 16 and both tables have lut_ld floats
      * per row.  LaMa's masked position encoding rides on it: the 7x7 stem writes relu(bn(conv)) + alpha5 * emb[rel] + alpha6 * dir in
      * one pass instead of a separate read-modify-write of the 64-channel stem output (inpainting_lama_mpe.py:609-613).  NULL = off.
-     * Not available on the N <= 4 (gemv) kernel. */
+     * Implemented as its own instantiation of the float4 epilogue of the fast / split tiles (every other launch compiles to the code it
+     * had without it): needs Cin % 16 == 0 and <= 16 taps, N % 4 == 0, lut_ld % 4 == 0, 16-byte aligned maps and tables, Z == 1, no
+     * post residual, act none or relu — anything else is refused with an error. */
     const int32_t *lut_rows;
     const float *lut1, *lut2;
     int64_t lut_ld;

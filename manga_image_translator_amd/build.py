@@ -38,10 +38,12 @@ HIPCC_FLAGS = [
 # Packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) is switched off in the code generator for every translation unit that does
 # not ask for it: -fno-slp-vectorize alone still left the loop vectoriser and the vector combiner forming such instructions WITH op_sel /
 # neg modifiers from scalar source (winograd.hip: 30, map_to_u8_kernel: 2, …) — the very form that misbehaved beside MFMA co-tenants.
-# The two units below use packed math on purpose (explicit two-lane vectors whose operands are whole register pairs) and are checked by
-# tests/test_build_flags.py to contain no packed-fp32 instruction with a modifier; every other unit must contain none at all.
+# The units below use packed math on purpose (explicit ext_vector arithmetic whose operands are whole register pairs: the channel-pair
+# FMAs of the 7x7 64->3 convolution, the float4 epilogues of the conv_gemm tiles — the generic tile runs 2.1x slower without them
+# (profiles/r07h) —, the planar GEMM) and are checked by tests/test_build_flags.py to contain no packed-fp32 instruction with a
+# modifier; every other unit must contain none at all.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-PACKED_FP32_BY_DESIGN = {"conv_small_cout.hip", "pgemm.hip"}
+PACKED_FP32_BY_DESIGN = {"conv_small_cout.hip", "pgemm.hip"} | {f"conv_gemm_inst{i}.hip" for i in range(8)}
 
 
 def flags_for(src_name: str) -> list:

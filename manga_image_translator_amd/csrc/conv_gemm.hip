@@ -336,7 +336,13 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
     if (cfg < 0) cfg = pick_cfg(p, M64);
     if (cfg >= kNumCfgs) return mit_set_error("mit_conv_gemm: bad cfg %d", cfg);
     const CfgEntry &c = kCfgs[cfg];
-    if (p.lut_rows && c.fast == 3) return mit_set_error("mit_conv_gemm: the row-lookup epilogue (lut_rows) is not implemented by the N <= 4 kernel");
+    if (p.lut_rows) {  // the row-lookup epilogue exists as an instantiation of the vector store path of the fast / split tiles only
+        if (c.fast != 1 && c.fast != 2 && c.fast != 4)
+            return mit_set_error("mit_conv_gemm: the row-lookup epilogue (lut_rows) needs a fast or split tile (Cin %% 16 == 0, <= %d taps); this launch takes %s", FAST_MAX_TAPS, c.name);
+        if (!(p.act & MIT_ACT_VEC_OK)) return mit_set_error("mit_conv_gemm: lut_rows needs the float4 epilogue (N %% 4 == 0, 16-byte aligned maps, tables and lut_ld %% 4 == 0)");
+        if (p.post.base) return mit_set_error("mit_conv_gemm: lut_rows together with a post residual is not implemented");
+        if ((p.act & 0xff) != MIT_ACT_NONE && (p.act & 0xff) != MIT_ACT_RELU) return mit_set_error("mit_conv_gemm: lut_rows is implemented for act none / relu");
+    }
     if (p.dyn && c.fast == 3) return mit_set_error("mit_conv_gemm: the device-side step offset (dyn) is not implemented by the N <= 4 kernel");
     if (p.dyn && ((p.a_dyn | p.c_dyn) & 3)) return mit_set_error("mit_conv_gemm: a_dyn / c_dyn must be multiples of 4 floats");
     if (c.fast == 2 && (p.Cin % 32)) return mit_set_error("mit_conv_gemm: cfg %s needs Cin %% 32 == 0", c.name);

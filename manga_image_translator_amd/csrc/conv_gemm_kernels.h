@@ -39,7 +39,9 @@ namespace mitcg {
 
 struct RowOff {
     int64_t c, pre, post;
-    int32_t lut1, lut2;  // float offsets of the row's two lookup-table rows (MitConvGemm.lut_rows), 0 without tables
+};
+struct LutOff {
+    int32_t t1, t2;  // float offsets of a row's two lookup-table rows (MitConvGemm.lut_rows); kept in their own LDS array, only by launches that use them
 };
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in exact arithmetic, <= 6e-7 in f32 near 0 where GELU multiplies it by x/2):
@@ -104,10 +106,6 @@ __device__ __forceinline__ void epilogue_store(const MitConvGemm &p, f32x16 (&ac
                 if (HAS_POST && post_first) v += p.post.base[ro.post + ncol_post];
                 if (!(XE & 2)) v = apply_act<ACT>(v, p.act_alpha);
                 if (HAS_POST && !post_first) v += p.post.base[ro.post + ncol_post];
-                if (p.lut_rows) {  // wave-uniform
-                    v += p.lut1[ro.lut1 + n];
-                    v += p.lut2[ro.lut2 + n];
-                }
                 if (XE & 1) {  // timing ablation: results computed but (practically) never stored
                     if (v == 12345.678f) p.c.base[ro.c + ncol_c] = v;
                 } else {
@@ -125,9 +123,9 @@ __device__ __forceinline__ void epilogue_store(const MitConvGemm &p, f32x16 (&ac
 constexpr int EPI_PITCH = 36;
 #define MIT_ACT_VEC_OK 0x200
 
-template <int TM, int TN, int ACT, bool HAS_POST, int XE>
+template <int TM, int TN, int ACT, bool HAS_POST, int XE, bool HAS_LUT = false>
 __device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 (&acc)[TM][TN], const RowOff *rowoff, float *tbuf,
-                                                   const int n0, const int wm0, const int wn0, const int tid) {
+                                                   const int n0, const int wm0, const int wn0, const int tid, const LutOff *lutoff = nullptr) {
     const int lane = tid & 63;
     const int li = lane & 31;
     const int lh = lane >> 5;
@@ -164,9 +162,10 @@ __device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 
                     v.w = apply_act<ACT>(v.w, p.act_alpha);
                 }
                 if (HAS_POST && !post_first) v += pv;
-                if (p.lut_rows) {  // wave-uniform: two table rows joined after everything else, in this order
-                    v += *reinterpret_cast<const f32x4 *>(p.lut1 + ro.lut1 + n);
-                    v += *reinterpret_cast<const f32x4 *>(p.lut2 + ro.lut2 + n);
+                if (HAS_LUT) {  // the row-lookup form (its own instantiation): two table rows joined after everything else, in this order
+                    const LutOff lo = lutoff[wm0 + mi * 32 + rl];
+                    v += *reinterpret_cast<const f32x4 *>(p.lut1 + lo.t1 + n);
+                    v += *reinterpret_cast<const f32x4 *>(p.lut2 + lo.t2 + n);
                 }
                 *reinterpret_cast<f32x4 *>(p.c.base + ro.c + n) = v;
             }
@@ -185,7 +184,7 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
     const int64_t c_dyn = p.dyn ? (int64_t)(*p.dyn) * p.c_dyn : 0;  // device-side step offset (hipGraph-replayed sequences), else 0
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
-        RowOff ro = {-1, 0, 0, 0, 0};
+        RowOff ro = {-1, 0, 0};
         if (m < M) {
             const int nb = m / HoWo;
             const int rem = m - nb * HoWo;
@@ -196,21 +195,31 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
                      (int64_t)ox * p.pre.xs;
             ro.post = z1 * p.post.zs1 + z0 * p.post.zs0 + (int64_t)nb * p.post.bs + (int64_t)oy * p.post.ys +
                       (int64_t)ox * p.post.xs;
-            if (p.lut_rows) {
-                const unsigned int packed = (unsigned int)p.lut_rows[m];
-                ro.lut1 = (int32_t)((packed & 0xffffu) * (unsigned int)p.lut_ld);
-                ro.lut2 = (int32_t)((packed >> 16) * (unsigned int)p.lut_ld);
-            }
         }
         rowoff[r] = ro;
+    }
+    constexpr int ROWOFF_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4;
+    constexpr int LUT_FLOATS = BM * (int)sizeof(LutOff) / 4;   // the row-lookup offsets sit behind the transpose buffers
+    constexpr bool VEC_FITS = SMEM_FLOATS >= ROWOFF_FLOATS + 4 * 32 * EPI_PITCH + LUT_FLOATS && !(XE & 1);
+    LutOff *lutoff = reinterpret_cast<LutOff *>(smem + ROWOFF_FLOATS + 4 * 32 * EPI_PITCH);
+    const bool lut = VEC_FITS && p.lut_rows != nullptr;   // (the launcher admits lut_rows only on kernels and operands that take the vector path)
+    if (VEC_FITS && lut) {
+        for (int r = tid; r < BM; r += 256) {
+            const int m = m0 + r;
+            const unsigned int packed = m < M ? (unsigned int)p.lut_rows[m] : 0u;
+            lutoff[r] = LutOff{(int32_t)((packed & 0xffffu) * (unsigned int)p.lut_ld), (int32_t)((packed >> 16) * (unsigned int)p.lut_ld)};
+        }
     }
     __syncthreads();
 
     const bool has_post = p.post.base != nullptr;
-    constexpr int ROWOFF_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4;
-    constexpr bool VEC_FITS = SMEM_FLOATS >= ROWOFF_FLOATS + 4 * 32 * EPI_PITCH && !(XE & 1);
     float *tbuf = smem + ROWOFF_FLOATS + (tid >> 6) * (32 * EPI_PITCH);
     const bool vec = VEC_FITS && (p.act & MIT_ACT_VEC_OK);
+    if (VEC_FITS && vec && lut) {  // act in {none, relu}, no post residual (mit_conv_gemm_cfg checks)
+        if ((p.act & 0xff) == MIT_ACT_RELU) epilogue_store_vec<TM, TN, MIT_ACT_RELU, false, XE, true>(p, acc, rowoff, tbuf, n0, wm0, wn0, tid, lutoff);
+        else epilogue_store_vec<TM, TN, MIT_ACT_NONE, false, XE, true>(p, acc, rowoff, tbuf, n0, wm0, wn0, tid, lutoff);
+        return;
+    }
 #define MIT_EPI(A)                                                                                   \
     if (VEC_FITS && vec) {                                                                           \
         if (has_post) epilogue_store_vec<TM, TN, A, true, XE>(p, acc, rowoff, tbuf, n0, wm0, wn0, tid); \
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_fast_kernel(const MitConv
 
     // the launcher sizes the dynamic LDS for the larger of the staging area and the epilogue's row table + per-wave transpose
     // buffers, so small tiles (64 x 64) get the dwordx4 store path too
-    constexpr int EPI_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4 + 4 * 32 * EPI_PITCH;
+    constexpr int EPI_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4 + 4 * 32 * EPI_PITCH + BM * (int)sizeof(LutOff) / 4;
     constexpr int SMEM_F = (2 * A_TILE + 2 * B_TILE) > EPI_FLOATS ? (2 * A_TILE + 2 * B_TILE) : EPI_FLOATS;
     epilogue<BM, TM, TN, (VAR >> 12) & 3, SMEM_F>(p, acc, smem, M, m0, n0, wm0, wn0, z1, z0, HoWo, (int)threadIdx.x);
 }
@@ -829,7 +838,7 @@ void launch_fast(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
     constexpr int LDA = BM + (BK == 16 ? 2 : 1);
     constexpr int LDB = BN + 4;
     size_t staging = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + (size_t)p.ntaps * BM * sizeof(int);
-    size_t rows = ((size_t)BM * sizeof(RowOff) + 15) / 16 * 16 + (size_t)4 * 32 * EPI_PITCH * sizeof(float);  // row table + transpose buffers
+    size_t rows = ((size_t)BM * sizeof(RowOff) + 15) / 16 * 16 + (size_t)4 * 32 * EPI_PITCH * sizeof(float) + (size_t)BM * sizeof(LutOff);  // row table + transpose buffers + lookup offsets
     size_t smem = staging > rows ? staging : rows;
     auto kern = conv_gemm_fast_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, VAR>;
     static DynSmemOptIn optin;

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const std::integral_constant<bool, true> yes;
     const std::integral_constant<bool, false> no;
 
-    constexpr int EPI_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4 + 4 * 32 * EPI_PITCH;
+    constexpr int EPI_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4 + 4 * 32 * EPI_PITCH + BM * (int)sizeof(LutOff) / 4;
     constexpr int STAGE_FLOATS = (2 * A_TILE + 2 * B_TILE) * 4;
     constexpr int SMEM_F = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
 
@@ -390,7 +390,7 @@ void launch_split(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream
     constexpr int KH = BK / 8;
     constexpr int SA = BM, SB = BN;
     size_t staging = (size_t)(2 * 3 * KH * SA + 2 * 3 * KH * SB) * 16 + (size_t)p.ntaps * BM * sizeof(int);
-    size_t rows = ((size_t)BM * sizeof(RowOff) + 15) / 16 * 16 + (size_t)4 * 32 * EPI_PITCH * sizeof(float);
+    size_t rows = ((size_t)BM * sizeof(RowOff) + 15) / 16 * 16 + (size_t)4 * 32 * EPI_PITCH * sizeof(float) + (size_t)BM * sizeof(LutOff);
     size_t smem = staging > rows ? staging : rows;
     auto kern = conv_gemm_split_kernel<BM, BN, BK, WAVES_M, WAVES_N, MINW, NPROD, VAR>;
     static DynSmemOptIn optin;

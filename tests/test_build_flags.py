@@ -6,8 +6,8 @@ the built objects are disassembled; hipcc cross-compiles without a GPU):
 * the SLP vectoriser is off and fp contraction is off in the build flags;
 * packed fp32 is switched off in the code generator for every unit that does not use it on purpose — those contain NO v_pk_*_f32 at all
   (the loop vectoriser and the vector combiner formed 30 modifier forms in winograd.hip and 2 in ctd_kernels.hip from scalar source);
-* the units that use packed math on purpose (build.PACKED_FP32_BY_DESIGN: the 7x7 64->3 output convolution, the planar GEMM) contain
-  packed instructions, none of them with a modifier."""
+* the units that use packed math on purpose (build.PACKED_FP32_BY_DESIGN: the 7x7 64->3 output convolution, the conv_gemm tiles' float4
+  epilogues, the planar GEMM) contain packed instructions, none of them with a modifier."""
 import re
 import shutil
 import subprocess
@@ -34,6 +34,44 @@ def _device_isa(obj, tmp_path):
     subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}",
                     "--unbundle"], check=True, capture_output=True, timeout=120)
     return subprocess.run([f"{LLVM}/llvm-objdump", "-d", str(co)], check=True, capture_output=True, text=True, timeout=300).stdout
+
+
+def _code_object(obj, tmp_path):
+    sections = subprocess.run([f"{LLVM}/llvm-readelf", "-S", str(obj)], check=True, capture_output=True, text=True, timeout=120).stdout
+    if ".hip_fatbin" not in sections:
+        return None
+    fat, co = tmp_path / (obj.stem + ".fatbin"), tmp_path / (obj.stem + ".co")
+    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", str(obj)], check=True, capture_output=True, timeout=120)
+    subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}",
+                    "--unbundle"], check=True, capture_output=True, timeout=120)
+    return co
+
+
+def test_no_shipped_kernel_uses_scratch_memory(tmp_path):
+    """no kernel of this library may spill to scratch memory (a spilled K loop costs 2x — the generic conv tile did
+    exactly that for one build of round 5, 824 bytes, when the shared epilogue grew — and scratch traffic was one of the suspects of the
+    co-tenancy failures).  Every kernel descriptor of every shipped code object must say private_segment_fixed_size = 0."""
+    if not (shutil.which("hipcc") or shutil.which("/opt/rocm/bin/hipcc")) or not shutil.which(f"{LLVM}/llvm-readelf"):
+        pytest.skip("ROCm toolchain not available")
+    B.build()
+    n_kernels, bad = 0, []
+    for src in sorted(B.CSRC.glob("*.hip")):
+        co = _code_object(B.CSRC / "build" / (src.stem + ".o"), tmp_path)
+        if co is None:
+            continue
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True, timeout=300).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.search(r"\.name:\s+(\S+)", line)
+            if m and ".symbol" not in line:
+                name = m.group(1)
+            m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
+            if m:
+                n_kernels += 1
+                if int(m.group(1)) != 0:
+                    bad.append((src.name, name, int(m.group(1))))
+    assert n_kernels > 150, n_kernels          # the notes were really parsed
+    assert not bad, f"kernels with scratch memory: {bad[:6]}"
 
 
 def test_no_translation_unit_ships_a_packed_fp32_instruction_with_a_modifier(tmp_path):

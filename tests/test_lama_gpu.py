@@ -289,3 +289,13 @@ def test_row_lookup_epilogue_is_validated(cuda):
     d.lut_ld = 32
     ops.launch_conv_gemm(d)   # valid: all rows 0 of zero tables
     torch.cuda.synchronize()
+    d.post = ops.tensor_map(out)
+    with pytest.raises(RuntimeError, match="post residual"):
+        ops.launch_conv_gemm(d)
+    # a layer that takes the generic kernel (Cin = 4): the lookup exists only as an instantiation of the fast / split tiles' epilogue
+    x4 = torch.randn(1, 8, 8, 4, device=cuda)
+    conv4 = ops.Conv2d(torch.randn(32, 4, 1, 1), None, device=cuda)
+    d4 = conv4.desc(x4, out)
+    d4.lut_rows, d4.lut1, d4.lut2, d4.lut_ld = rows.data_ptr(), t.data_ptr(), t.data_ptr(), 32
+    with pytest.raises(RuntimeError, match="fast or split tile"):
+        ops.launch_conv_gemm(d4)
