@@ -10,7 +10,7 @@ if [ "${2:-}" != "skip-tests" ]; then
 fi
 timeout 900 python bench.py --prof-dump $OUT/layers.csv > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python bench.py --no-cpu-baseline --no-dropin --no-fp32-leg --no-two-streams > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python bench.py --no-cpu-baseline --no-dropin --no-fp32-leg --no-two-streams --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof rc=$?"
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/prof
 bash scripts/pmc_stage.sh detect,ocr,inpaint 64 $OUT/pmc_traffic.json > $OUT/pmc.log 2>&1; echo "pmc rc=$?"

@@ -8,7 +8,7 @@ PAGES=${1:-16}; OUT=${2:-gpurun_out/mfma_busy.json}
 D=/tmp/pmc_mfma; rm -rf $D; mkdir -p $D $(dirname $OUT)
 for s in detect ocr inpaint; do
   timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $D/$s -o $s -- \
-    python bench.py --steps 1 --warmup 0 --pages $PAGES --stages $s --no-overlap --no-cpu-baseline --no-roofline --no-dropin --no-fp32-leg > $D/$s.log 2>&1
+    python bench.py --steps 1 --warmup 0 --pages $PAGES --stages $s --no-overlap --no-cpu-baseline --no-roofline --no-dropin --no-fp32-leg --no-two-streams --no-other-configs > $D/$s.log 2>&1
 done
 python scripts/pmc_mfma.py $OUT $PAGES detect=$(find $D/detect -name "*counter_collection.csv" | head -1) ocr=$(find $D/ocr -name "*counter_collection.csv" | head -1) \
   inpaint=$(find $D/inpaint -name "*counter_collection.csv" | head -1)

@@ -7,6 +7,6 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 STAGES=${1:-detect,ocr,inpaint}; PAGES=${2:-64}; OUT=${3:-gpurun_out/pmc_traffic.json}
 D=/tmp/pmc_stage; rm -rf $D; mkdir -p $D $(dirname $OUT)
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --output-format csv -d $D -o $c -- python bench.py --steps 1 --warmup 0 --pages $PAGES --stages $STAGES --no-cpu-baseline --no-roofline --no-dropin --no-fp32-leg > $D/$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $D -o $c -- python bench.py --steps 1 --warmup 0 --pages $PAGES --stages $STAGES --no-cpu-baseline --no-roofline --no-dropin --no-fp32-leg --no-two-streams --no-other-configs > $D/$c.log 2>&1
 done
 python scripts/pmc_traffic.py $OUT $PAGES $(find $D -name "*counter_collection.csv")
