@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
     if (s6o < 0 || n6o < 0) return 2;  // (tiles of MIT_CONV_EXPERIMENTS builds come back as -1 from a default build and are skipped below)
     const int s64 = find_cfg("split64x64x16p6o"), s32 = find_cfg("split128x32x16p6o"), f32t = find_cfg("fast128x32x16w4c");  // small / narrow tiles (-1: skipped)
     const int w6o = find_cfg("split64x256x16p6o");
-    const int t192 = find_cfg("split128x192x16p6o");
+    const int t192 = find_cfg("split128x192x16p6o"), t256 = find_cfg("split256x64x16p6o");
     const int t160 = find_cfg("split128x160x16p6o"), t96 = find_cfg("split128x96x16p6o");  // exact-N tiles for N = 160 k / N = 80  // wide-N tile (-1 in builds without it: skipped)
     const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c"), s64k = find_cfg("split64x64x32p6o");
     if (f_wide < 0 || f_narrow < 0 || s6 < 0 || s9 < 0 || s3 < 0 || n6 < 0 || n9 < 0 || s9m < 0) {
@@ -77,6 +77,13 @@ int main(int argc, char **argv) {
         {"1x1 192->384 (spectral conv2), M=262144, relu", 1, 512, 512, 192, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, t192, s6o, t192}},
         {"winograd-like Z=36, T=16384, 128->384", 1, 1, 16384, 128, 384, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6o, t192, s6o, t192}},
         {"1x1 2 taps-like: 768->384, M=131072", 1, 256, 512, 768, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, t192, s6o, t192}},
+        {"1x1 224->64 (stem-like K), M=1048576, relu", 1, 1024, 1024, 224, 64, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_narrow, {n6o, t256, n6o, t256}},
+        {"1x1 256->64 (convT parity-like), M=1048576, relu", 1, 1024, 1024, 256, 64, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_narrow, {n6o, t256, n6o, t256}},
+        {"1x1 512->64, M=1048576, relu", 1, 1024, 1024, 512, 64, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_narrow, {n6o, t256, n6o, t256}},
+        {"3x3 zero 64->64, 2x512x512, leaky", 2, 512, 512, 64, 64, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_narrow, {n6o, t256, n6o, t256}},
+        {"1x1 80->320 (pw1) again, M=524288, gelu", 1, 1024, 512, 80, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {n6o, t256, n6o, t256}},
+        {"decoder-like M=10240: 320->960 exact-N", 1, 1, 10240, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {n6o, t160, n6o, t160}},
+        {"encoder-like M=60208: 320->960 exact-N", 1, 1, 60208, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {n6o, t160, n6o, t160}},
         {"3x3 s2 zero 128->256 (LaMa down), 2x128x96", 2, 256, 192, 128, 256, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, w6o, s6o, w6o}},
         {"1x1 384x2taps-like: 768->384, M=65536", 1, 256, 256, 768, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, w6o, s6o, w6o}},
         {"3x3 s2 zero 64->64, 4x128x128", 4, 128, 128, 64, 64, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_narrow, {n6, n9, n6s, n6m, n6o, n6m, n6o}},
