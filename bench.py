@@ -482,7 +482,8 @@ def parity_leg(res, idx, oracle_outputs, stages):
         out["detect"] = dict(bitmap_flips_outside_margin=flips, px_inside_margin=near_n, mask_u8_max_abs_diff=mask_max,
                              mask_u8_frac_different=float(f"{mask_bad / max(mask_tot, 1):.3e}"),
                              boxes_with_margin_pixels_forced=dict(as_is=n_base, all_above=n_up, all_below=n_dn, variants_with_any_box_changed=changed,
-                                                                  note="random-init weights: the map crosses 0.3 only in noise, so few or no boxes exist to move"))
+                                                                  note="random-init weights: the map is noise around the threshold and the representer's 1000-candidate cap is hit either way (none "
+                                                                       "passes the 0.6 score filter); trained-head-like maps: tests/test_margin_flips.py"))
         ok &= flips == 0 and mask_max <= 1 and mask_bad / max(mask_tot, 1) < 1e-3
     if "ocr" in stages and res.ocr_tokens is not None:
         toks, lens, probs = res.ocr_tokens.cpu().numpy(), res.ocr_length.cpu().numpy(), res.ocr_prob.cpu().numpy()
