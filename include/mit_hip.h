@@ -235,9 +235,12 @@ int mit_join_planes(const uint16_t *planes_dev, int64_t ld, int R, int K, float 
  * Cout); out: pixel stride out_pixstride, Cout floats written.  w_pairs (optional, Cout <= 3, 32-byte aligned): the same weights
  * channel-fastest, [k*k][Cin / 4][4 outputs (zeros beyond Cout)][4 channels] — the operand pairs (channels c, c + 1 of one output) of
  * the packed-FMA kernel that Cout <= 3 takes when it is given (2.7x fewer VALU instructions; accumulators hold even / odd channel
- * sums, no packed instruction carries an op_sel / neg modifier); NULL = the plain kernel.
+ * sums, no packed instruction carries an op_sel / neg modifier); NULL = the plain kernel.  in_planestride != 0 (packed kernel only): the
+ * input arrives as Cin / 16 planes of [B,H,W,16] (in_pixstride = 16), in_planestride floats apart — what the producing convolution
+ * writes through a column-split output map (MitTensorMap.nsplit = 16): a 16-channel group of a tile is then a run of whole 128-byte
+ * lines instead of a quarter of every pixel's 256 bytes.
  * Replaces ReflectionPad2d(3) + Conv2d(64, 3, 7) + sigmoid at the end of FFCResNetGenerator (inpainting_lama_mpe.py:597-600). */
-int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *w4_dev, const float *w_pairs_dev, const float *bias_dev, float *out_dev,
+int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, int64_t in_planestride, const float *w4_dev, const float *w_pairs_dev, const float *bias_dev, float *out_dev,
                         int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k, int pad_mode, int act,
                         float act_alpha, void *stream);
 

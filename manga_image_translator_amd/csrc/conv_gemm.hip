@@ -259,13 +259,14 @@ extern "C" const char *mit_conv_gemm_config_kernel(int cfg) {
 }
 
 namespace {
-bool map_vec_ok(const MitTensorMap &m) {
-    return m.nsplit == 0 && !(reinterpret_cast<uintptr_t>(m.base) & 15) && !((m.zs1 | m.zs0 | m.bs | m.ys | m.xs) & 3);
+bool map_vec_ok(const MitTensorMap &m, bool split_ok = false) {
+    if (m.nsplit != 0 && !(split_ok && !(m.nsplit & 3) && !(m.nhi & 3))) return false;  // (only the C map's float4 store handles a column split)
+    return !(reinterpret_cast<uintptr_t>(m.base) & 15) && !((m.zs1 | m.zs0 | m.bs | m.ys | m.xs) & 3);
 }
 // dwordx4 epilogue (epilogue_store_vec): whole float4 column groups, contiguous and 16-byte aligned in every tensor it touches
 bool vec_epilogue_ok(const MitConvGemm &p) {
     static const bool off = getenv("MIT_CONV_SCALAR_EPILOGUE") != nullptr;  // A/B knob for scripts/
-    if (off || (p.N & 3) || !map_vec_ok(p.c)) return false;
+    if (off || (p.N & 3) || !map_vec_ok(p.c, true)) return false;
     if (p.pre.base && !map_vec_ok(p.pre)) return false;
     if (p.post.base && !map_vec_ok(p.post)) return false;
     if (p.lut_rows && ((p.lut_ld & 3) || (reinterpret_cast<uintptr_t>(p.lut1) & 15) || (reinterpret_cast<uintptr_t>(p.lut2) & 15))) return false;

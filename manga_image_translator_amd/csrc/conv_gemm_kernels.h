@@ -136,6 +136,9 @@ __device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 
     for (int ni = 0; ni < TN; ++ni) {
         const int n = n0 + wn0 + ni * 32 + vc;
         const bool n_ok = n < p.N;
+        // column-split output map (planar spectra, q | k | v slabs): a float4 group never straddles a split (nsplit % 4 == 0, checked by
+        // the launcher), so only its first column is mapped
+        const int64_t nc = p.c.nsplit ? (int64_t)(n / p.c.nsplit) * p.c.nhi + (n % p.c.nsplit) : (int64_t)n;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
         if (n_ok && p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + n);
         if (n_ok && p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
@@ -167,7 +170,7 @@ __device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 
                     v += *reinterpret_cast<const f32x4 *>(p.lut1 + lo.t1 + n);
                     v += *reinterpret_cast<const f32x4 *>(p.lut2 + lo.t2 + n);
                 }
-                *reinterpret_cast<f32x4 *>(p.c.base + ro.c + n) = v;
+                *reinterpret_cast<f32x4 *>(p.c.base + ro.c + nc) = v;
             }
             asm volatile("" ::: "memory");
         }

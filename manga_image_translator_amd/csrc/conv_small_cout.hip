@@ -107,7 +107,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int TW3 = 64, TH3 = 16;
 
 template <int K>
-__global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__restrict__ in, int64_t in_pix,
+__global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__restrict__ in, int64_t in_pix, int64_t in_plane /* floats between 16-channel planes; 0: channels interleaved per pixel */,
                                                                 const f32x2 *__restrict__ wq /* [taps][Cin / 4][4 out (3 used)][2 channel pairs] */,
                                                                 const float *__restrict__ bias, float *__restrict__ out,
                                                                 int64_t out_pix, int H, int W, int Cin, int Cout, int reflect,
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__re
                 xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
             }
             const bool ok = i < TR * HW_ && xx >= 0 && xx < W && yy >= 0 && yy < H;  // still outside after one reflection: tile overhang, never used
-            const float *pa = ib + ((int64_t)yy * W + xx) * in_pix + g0;
+            // planar input: the 16-channel group g0 / 16 is a plane of its own whose pixels are 64 contiguous bytes each — the group's
+            // loads are whole 128-byte lines shared by two neighbouring pixels; interleaved input: 64 bytes of every 256-byte pixel
+            const float *pa = ib + ((int64_t)yy * W + xx) * in_pix + (in_plane ? (int64_t)(g0 >> 4) * in_plane : (int64_t)g0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 rg[it][q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__re
 
 }  // namespace
 
-extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, const float *w4_dev, const float *w_pairs_dev, const float *bias_dev,
+extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, int64_t in_planestride, const float *w4_dev, const float *w_pairs_dev, const float *bias_dev,
                                    float *out_dev, int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k,
                                    int pad_mode, int act, float act_alpha, void *stream) {
     if (!in_dev || !w4_dev || !out_dev) return mit_set_error("mit_conv_small_cout: null pointer");
@@ -220,6 +222,8 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     if ((in_pixstride & 3) || (reinterpret_cast<uintptr_t>(in_dev) & 15) || (reinterpret_cast<uintptr_t>(w4_dev) & 15) || (reinterpret_cast<uintptr_t>(w_pairs_dev) & 31))
         return mit_set_error("mit_conv_small_cout: input pixels and weights must be 16-byte aligned");
     if (pad_mode == MIT_PAD_REFLECT && (k / 2 >= H || k / 2 >= W)) return mit_set_error("mit_conv_small_cout: reflect pad larger than input");
+    if (in_planestride && ((in_planestride & 3) || in_pixstride < 16 || !(Cout <= 3 && w_pairs_dev)))
+        return mit_set_error("mit_conv_small_cout: planar input (16-channel planes) needs the packed kernel (Cout <= 3 with w_pairs), pixel stride >= 16 and a plane stride %% 4 == 0");
     dim3 grid(mit_div_up(W, TW), mit_div_up(H, TH), B), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w4_dev);
@@ -231,14 +235,15 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, co
     // every 128-byte input line 8 times and was slower than the plain kernel (25 vs 17.7 ms per 16 pages); staging 16-channel groups
     // in registers brought it to 15.9 ms (same-box A/B).  MIT_SMALL_COUT_PLAIN=1 selects the plain kernel for comparison.
     static const bool use_pk = getenv("MIT_SMALL_COUT_PLAIN") == nullptr;
+    if (in_planestride && !use_pk) return mit_set_error("mit_conv_small_cout: MIT_SMALL_COUT_PLAIN cannot read planar input");
     if (Cout <= 3 && use_pk && w_pairs_dev) {
         dim3 grid3(mit_div_up(W, TW3), mit_div_up(H, TH3), B);
         const f32x2 *wp = reinterpret_cast<const f32x2 *>(w_pairs_dev);
         if (Cin & 3) return mit_set_error("mit_conv_small_cout: Cin %% 4");
         switch (k) {
-            case 3: hipLaunchKernelGGL(conv_small_cout3_kernel<3>, grid3, block, 0, s, in_dev, in_pixstride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
-            case 5: hipLaunchKernelGGL(conv_small_cout3_kernel<5>, grid3, block, 0, s, in_dev, in_pixstride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
-            case 7: hipLaunchKernelGGL(conv_small_cout3_kernel<7>, grid3, block, 0, s, in_dev, in_pixstride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            case 3: hipLaunchKernelGGL(conv_small_cout3_kernel<3>, grid3, block, 0, s, in_dev, in_pixstride, in_planestride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            case 5: hipLaunchKernelGGL(conv_small_cout3_kernel<5>, grid3, block, 0, s, in_dev, in_pixstride, in_planestride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
+            case 7: hipLaunchKernelGGL(conv_small_cout3_kernel<7>, grid3, block, 0, s, in_dev, in_pixstride, in_planestride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
             default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
         }
         MIT_CHECK_LAUNCH("mit_conv_small_cout");

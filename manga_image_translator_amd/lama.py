@@ -257,6 +257,7 @@ class LamaEngine:
                         acc = acc + dirw[k]
                 t2[bits] = acc * a6
             self.mpe["lut1"], self.mpe["lut2"] = (emb * a5).contiguous().to(dev), t2.contiguous().to(dev)
+        self.planar_tail = os.environ.get("MIT_LAMA_PLANAR_TAIL", "1") not in ("", "0")
         self.mpe_in_stem = os.environ.get("MIT_LAMA_MPE_SEPARATE", "") in ("", "0")   # False: the separate mit_lama_mpe_add pass (A/B, tests)
         self._ws = ops.Workspace(self.device)
         self._tw: Dict[int, torch.Tensor] = {}
@@ -499,9 +500,13 @@ class LamaEngine:
         self.ups[0](X, out=u1)
         u2 = self._buf("d1", B, H // 2, W // 2, 128)
         self.ups[1](u1, out=u2)
-        u3 = self._buf("full64", B, H, W, 64)
-        self.ups[2](u2, out=u3)
         pred = self._buf("pred", B, H, W, 3)
+        if self.planar_tail:   # the last up-convolution writes four 16-channel planes, the 7x7 output convolution reads them group by group
+            u3 = self._buf("full64", 4, B, H, W, 16)
+            self.ups[2](u2, out=u3, planes=4)
+        else:                  # MIT_LAMA_PLANAR_TAIL=0: NHWC between the two (A/B, tests) — same values, other addresses
+            u3 = self._buf("full64", B, H, W, 64)
+            self.ups[2](u2, out=u3)
         self.out_conv(u3, out=pred)
         if taps is not None:
             taps["pred"] = pred.clone()

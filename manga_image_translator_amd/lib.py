@@ -181,7 +181,7 @@ SYMBOLS = {
     "mit_gemm_mode_set": (C.c_int, [C.c_int]),
     "mit_gemm_mode_get": (C.c_int, []),
     "mit_gemm_split_min_tiles": (C.c_int64, [C.c_int64]),
-    "mit_conv_small_cout": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+    "mit_conv_small_cout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "mit_prof_enable": (C.c_int, [C.c_int]),
     "mit_prof_tag_next": (C.c_int, [C.c_double]),

@@ -518,6 +518,15 @@ class ConvSmallCout:
         self.bias = None if bias is None else bias.detach().to(torch.float32).to(device).contiguous()
 
     def __call__(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """``x``: [B,H,W,C] NHWC, or the same activations as 16-channel planes [C / 16, B, H, W, 16] (contiguous; what
+        ``ConvTranspose2d(..., planes=)`` writes) — the packed kernel then loads whole lines per channel group."""
+        plane = 0
+        if x.dim() == 5:
+            if self.w_pairs is None or x.shape[4] != 16 or x.shape[0] * 16 < self.Cin or not x.is_contiguous():
+                raise ValueError(f"ConvSmallCout: planar input must be contiguous [Cin / 16, B, H, W, 16] for Cout <= 3 (got {tuple(x.shape)})")
+            plane = x.stride(0)
+            # (an NHWC-shaped handle on plane 0 for the shape checks below; the kernel addresses the planes itself)
+            x = x[0].as_strided((x.shape[1], x.shape[2], x.shape[3], self.Cin), (x.stride(1), x.stride(2), x.stride(3), 1))
         _check_nhwc(x, "ConvSmallCout input")
         _check_nhwc(out, "ConvSmallCout output")
         B, H, W, Cx = x.shape
@@ -527,7 +536,7 @@ class ConvSmallCout:
                 and out.stride(1) * H == out.stride(0)):
             raise ValueError("ConvSmallCout: pixel-dense tensors required")
         lib = _lib.load()
-        _lib.check(lib.mit_conv_small_cout(x.data_ptr(), x.stride(2), self.w4.data_ptr(), _ptr(self.w_pairs), _ptr(self.bias), out.data_ptr(),
+        _lib.check(lib.mit_conv_small_cout(x.data_ptr(), x.stride(2), plane, self.w4.data_ptr(), _ptr(self.w_pairs), _ptr(self.bias), out.data_ptr(),
                                            out.stride(2), B, H, W, self.Cin, self.Cout, self.k, self.pad_mode, self.act,
                                            self.alpha, C.c_void_p(current_stream())), "mit_conv_small_cout")
         return out
@@ -629,7 +638,16 @@ class ConvTranspose2d:
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         return ((H - 1) * self.s - 2 * self.p + self.k[0] + self.op, (W - 1) * self.s - 2 * self.p + self.k[1] + self.op)
 
-    def descs(self, x: torch.Tensor, out: torch.Tensor) -> List[MitConvGemm]:
+    def descs(self, x: torch.Tensor, out: torch.Tensor, planes: int = 0) -> List[MitConvGemm]:
+        """``planes`` = P > 0: ``out`` is [P, B, Ho, Wo, Cout / P] (contiguous) and every launch writes through a column-split map
+        (MitTensorMap.nsplit = Cout / P): channel group g of a pixel goes to plane g.  The consumer that reads channel groups (the 7x7
+        output convolution) then finds each group in whole lines."""
+        split = nhi = 0
+        if planes:
+            if out.dim() != 5 or out.shape[0] != planes or out.shape[4] * planes != self.Cout or not out.is_contiguous():
+                raise ValueError(f"ConvTranspose2d: planar output must be contiguous [{planes}, B, Ho, Wo, {self.Cout // planes}]")
+            split, nhi = out.shape[4], out.stride(0)
+            out = out[0].as_strided((out.shape[1], out.shape[2], out.shape[3], self.Cout), (out.stride(1), out.stride(2), out.stride(3), 1))
         _check_nhwc(x, "ConvTranspose2d input")
         _check_nhwc(out, "ConvTranspose2d output")
         B, H, W, Cx = x.shape
@@ -646,14 +664,15 @@ class ConvTranspose2d:
             ds.append(conv_gemm_desc(
                 a=x, NB=B, Hi=H, Wi=W, Cin=self.Cin, a_strides=(x.stride(0), x.stride(1), x.stride(2)),
                 Ho=ov.shape[1], Wo=ov.shape[2], sy=1, sx=1, taps=pk.taps, pad_mode=PAD_ZERO, w=pk.w, ldw=pk.Np,
-                Kw=pk.Kp, Nw=pk.Np, N=self.Cout, c=tensor_map(ov), scale=self.scale, bias=self.bias, act=self.act,
+                Kw=pk.Kp, Nw=pk.Np, N=self.Cout, c=tensor_map(ov, nsplit=split, nhi=nhi), scale=self.scale, bias=self.bias, act=self.act,
                 alpha=self.alpha))
         return ds
 
-    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, cfg: int = -1) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, cfg: int = -1, planes: int = 0) -> torch.Tensor:
         if out is None:
             Ho, Wo = self.out_hw(x.shape[1], x.shape[2])
-            out = torch.empty(x.shape[0], Ho, Wo, self.Cout, dtype=torch.float32, device=x.device)
-        for d in self.descs(x, out):
+            out = (torch.empty(planes, x.shape[0], Ho, Wo, self.Cout // planes, dtype=torch.float32, device=x.device) if planes else
+                   torch.empty(x.shape[0], Ho, Wo, self.Cout, dtype=torch.float32, device=x.device))
+        for d in self.descs(x, out, planes):
             launch_conv_gemm(d, cfg)
         return out

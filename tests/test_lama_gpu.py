@@ -299,3 +299,38 @@ def test_row_lookup_epilogue_is_validated(cuda):
     d4.lut_rows, d4.lut1, d4.lut2, d4.lut_ld = rows.data_ptr(), t.data_ptr(), t.data_ptr(), 32
     with pytest.raises(RuntimeError, match="fast or split tile"):
         ops.launch_conv_gemm(d4)
+
+
+def test_planar_tail_is_bit_identical_to_the_nhwc_tail(cuda, gemm_mode):
+    """The last up-convolution writing four 16-channel planes (column-split output map on the float4 epilogue) and the 7x7 output
+    convolution reading them group by group against the NHWC tensor between the two: same values at other addresses — the page must
+    be the same bytes; and each half against its NHWC form in isolation."""
+    from manga_image_translator_amd import ops, synth
+
+    _, _, eng = _setup(9, True, cuda)
+    gen = [synth.synth_page(i, 264, 272, n_boxes=5) for i in range(2)]
+    img = torch.from_numpy(np.stack([g[0] for g in gen])).to(cuda)
+    msk = torch.from_numpy(np.stack([g[2] for g in gen])).to(cuda)
+    assert eng.planar_tail
+    t1, t2 = {}, {}
+    out1 = eng.forward(img, msk, taps=t1).clone()
+    eng.planar_tail = False
+    try:
+        out2 = eng.forward(img, msk, taps=t2).clone()
+    finally:
+        eng.planar_tail = True
+    torch.cuda.synchronize()
+    assert torch.equal(t1["pred"], t2["pred"]) and torch.equal(out1, out2)
+    # the two halves alone
+    g = torch.Generator().manual_seed(5)
+    up = eng.ups[2]
+    x = torch.randn(2, 20, 28, up.Cin, generator=g).to(cuda)
+    nhwc = up(x)
+    planes = up(x, planes=4)
+    assert planes.shape == (4, 2, 40, 56, 16) and torch.equal(planes.permute(1, 2, 3, 0, 4).reshape(2, 40, 56, 64), nhwc)
+    o1 = torch.empty(2, 40, 56, 3, device=cuda)
+    o2 = torch.empty(2, 40, 56, 3, device=cuda)
+    eng.out_conv(nhwc, out=o1)
+    eng.out_conv(planes, out=o2)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
