@@ -244,6 +244,21 @@ int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, int64_t in_pl
                         int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k, int pad_mode, int act,
                         float act_alpha, void *stream);
 
+/* The ConvNeXt block's pointwise pair as ONE launch (round 5): out = post + scale2 * (W2 . gelu(W1 . x + b1)) + bias2 per row, i.e.
+ * pwconv1 -> GELU -> pwconv2 -> gamma -> + input of ConvNeXtBlock.forward (manga_translator/ocr/model_48px.py:203-214), in the
+ * split-bf16 p6 arithmetic of mit_conv_gemm's tiles; the 4C-wide hidden activations stay in registers (as two launches the C = 80 stage
+ * writes and re-reads [M, 320] fp32).  x [M, C] (row stride ldx floats), w1_planes = mit_gemm_split_pack of pwconv1's packed weight
+ * [K = C][ldw = 4C]; w2perm_planes = mit_gemm_split_pack of pwconv2's packed weight [K = 4C][ldn2] AFTER permuting its rows to the order
+ * in which the first contraction's accumulator registers hold the hidden index (k' = 32 hb + 16 s + 8 lh + j  <-  hidden
+ * 32 hb + (j & 3) + 8 (2 s + (j >> 2)) + 4 lh; manga_image_translator_amd/ocr48.py builds it); b1 [4C]; scale2 / bias2 [C] (gamma,
+ * gamma * bias; NULL = 1 / 0); post [M, C] or NULL (may be out itself).  mit_convnext_mlp_supported(C): 1 for the instantiated
+ * widths (80).  The hidden activations are bit-identical to the two-launch form's; the second contraction adds the same products with
+ * the 16 values of an MFMA step in other k slots (last-bit differences in the fp32 sums, same bound). */
+int mit_convnext_mlp_supported(int C);
+int mit_convnext_mlp(const float *x_dev, int64_t ldx, int M, int C, const uint16_t *w1_planes_dev, const float *b1_dev,
+                     const uint16_t *w2perm_planes_dev, int64_t ldn2, const float *scale2_dev, const float *bias2_dev,
+                     const float *post_dev, int64_t ldp, float *out_dev, int64_t ldo, void *stream);
+
 /* ---- Winograd F(4x4, 3x3) for the stride-1 3x3 convolutions of the FFC blocks (inpainting_lama_mpe.py:349-369: convl2l,
  * convg2l, convl2g under ReflectionPad; the reference calls nn.Conv2d = 9 multiplies per output, this form 2.25):
  *   mit_wino43_input : x NHWC [B,H,W,C] (strides in floats) -> V [36][T][C], T = B * ceil(H/4) * ceil(W/4), the B^T d B

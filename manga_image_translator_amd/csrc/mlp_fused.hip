@@ -1,0 +1,224 @@
+// mlp_fused.hip — the ConvNeXt block's pointwise pair as ONE kernel:  y = x_res + gamma * (W2 · gelu(W1 · t + b1) + b2)
+// (ConvNeXtBlock.forward, manga_translator/ocr/model_48px.py:203-214: pwconv1 -> GELU -> pwconv2 -> gamma -> + input), split-bf16 p6
+// arithmetic (conv_gemm_split.h) on v_mfma_f32_32x32x16_bf16.  The 4C-wide hidden activations never leave the registers.
+//
+// Why a kernel of its own: as two launches the C = 80 stage writes and re-reads [M, 320] fp32 (3.7 GB + 3.7 GB per 16-page group) for
+// 2 x 148 GFLOP — pwconv1 runs at 0.18 of the bf16 MFMA peak (a 5-step K loop behind a GELU epilogue and a 64 KB tile store), pwconv2
+// at 0.24-0.27.  Here a wave owns 32 pixels and walks the hidden dimension in blocks of 32:
+//
+//   GEMM 1 (transposed):  Ht[32 hidden, 32 pixels] = W1t[32 hidden, C] · Xt[C, 32 pixels]
+//       A operand = W1 planes (the cells mit_gemm_split_pack makes for pwconv1: [plane][k / 8][n = hidden][8 k]), B operand = the wave's
+//       X rows, loaded once (lane = pixel, k-group = lane >> 5: 8 consecutive channels = 32 contiguous bytes), split once, kept in
+//       registers for all hidden blocks.  The MFMA's C layout then has lane = PIXEL and registers = hidden index
+//       (r -> (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) — which is an A-operand layout for the second GEMM: a lane's eight values
+//       r = 8 s .. 8 s + 7 are "8 consecutive k" of MFMA step s, if the B operand lists its rows in the same order.
+//   bias + GELU + split into three bf16 planes: in registers (same gelu_fast, same split as the tiles').
+//   GEMM 2:  Y[32 pixels, C] += H[32 pixels, 32 hidden] · W2p[32 hidden, C], W2p = pwconv2's weight with its ROWS PERMUTED to that
+//       register order (k' = 32 hb + 16 s + 8 lh + j  <->  hidden 32 hb + (j & 3) + 8 (2 s + (j >> 2)) + 4 lh), packed into planes once.
+//
+// Weights of a hidden block (W1: 3 x C/8 x 32 cells, W2p: 3 x 4 x NPAD cells, 33 KB at C = 80) go global -> registers -> LDS, double
+// buffered, one barrier per hidden block (66 MFMAs per wave between barriers; the tiles have 24).  Plane pairs and k order are the
+// tiles': GEMM 1 adds exactly the products pwconv1's tile adds, in the same order (the operands' roles are swapped, a product is
+// commutative) — H is bit-identical to the two-launch form; GEMM 2 sees the same 16 hidden values per MFMA step in other k slots, so
+// its fp32 sums may differ in the last bits from the two-launch form (same error bound; parity tolerances unchanged, and the result
+// does not depend on batch or grid: this kernel is the only form the layer takes in GEMM mode 6).
+#include "conv_gemm_kernels.h"
+
+namespace {
+using namespace mitcg;
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__restrict__ x, const int64_t ldx, const u32x4 *__restrict__ w1p,
+                                                              const float *__restrict__ b1, const u32x4 *__restrict__ w2p, const int ldn2,
+                                                              const float *__restrict__ scale2, const float *__restrict__ bias2,
+                                                              const float *post, const int64_t ldp, float *out, const int64_t ldo, const int M) {
+    static_assert(C % 16 == 0 && C <= 96, "stage width");
+    constexpr int KS1 = C / 16;        // MFMA steps of GEMM 1
+    constexpr int K81 = C / 8;         // k cells of W1 per plane
+    constexpr int HID = 4 * C;
+    constexpr int NHB = HID / 32;      // hidden blocks
+    constexpr int NB = (C + 31) / 32;  // 32-column blocks of the output
+    constexpr int NPAD = NB * 32;
+    constexpr int W1_CELLS = 3 * K81 * 32, W2_CELLS = 3 * 4 * NPAD, BUF_CELLS = W1_CELLS + W2_CELLS;
+    constexpr int W1_IT = (W1_CELLS + 255) / 256, W2_IT = (W2_CELLS + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4 *wbuf = reinterpret_cast<u32x4 *>(smem);                 // [2][BUF_CELLS]: W1 block [3][K81][32], then W2p block [3][4][NPAD]
+    float *b1s = reinterpret_cast<float *>(wbuf + 2 * BUF_CELLS);  // [HID]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int row0 = (blockIdx.x * 4 + wave) * 32;  // the wave's 32 pixels
+    const int prow = row0 + li < M ? row0 + li : M - 1;
+
+    // this wave's X rows as three planes of B-operand fragments, for the whole kernel
+    u32x4 xh[KS1], xm[KS1], xl[KS1];
+    {
+        const float *xr = x + (int64_t)prow * ldx + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(xr + 16 * ks), v1 = *reinterpret_cast<const f32x4 *>(xr + 16 * ks + 4);
+            split8(v0, v1, xh[ks], xm[ks], xl[ks]);
+        }
+    }
+    for (int i = tid; i < HID; i += 256) b1s[i] = b1[i];
+
+    u32x4 st1[W1_IT], st2[W2_IT];
+    auto load_w1 = [&](const int hb) {
+#pragma unroll
+        for (int it = 0; it < W1_IT; ++it) {
+            const int i = tid + it * 256;
+            const int pl = i / (K81 * 32), rem = i - pl * (K81 * 32), k8 = rem >> 5, n = rem & 31;
+            st1[it] = w1p[i < W1_CELLS ? (int64_t)(pl * K81 + k8) * HID + 32 * hb + n : 0];
+        }
+    };
+    auto store_w1 = [&](const int buf) {
+#pragma unroll
+        for (int it = 0; it < W1_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < W1_CELLS) wbuf[buf * BUF_CELLS + i] = st1[it];
+        }
+    };
+    auto load_w2 = [&](const int hb) {
+#pragma unroll
+        for (int it = 0; it < W2_IT; ++it) {
+            const int i = tid + it * 256;
+            const int pl = i / (4 * NPAD), rem = i - pl * (4 * NPAD), kk = rem / NPAD, n = rem - kk * NPAD;
+            const bool ok = i < W2_CELLS && n < C;
+            const u32x4 v = w2p[ok ? (int64_t)(pl * (HID / 8) + 4 * hb + kk) * ldn2 + n : 0];
+            st2[it] = ok ? v : u32x4{0u, 0u, 0u, 0u};  // padded output columns multiply zeros
+        }
+    };
+    auto store_w2 = [&](const int buf) {
+#pragma unroll
+        for (int it = 0; it < W2_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < W2_CELLS) wbuf[buf * BUF_CELLS + W1_CELLS + i] = st2[it];
+        }
+    };
+
+    f32x16 acc2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+
+    load_w1(0);
+    load_w2(0);
+    store_w1(0);
+    store_w2(0);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int hb = 0; hb < NHB; ++hb) {
+        const int cur = hb & 1;
+        const u32x4 *w1s = wbuf + cur * BUF_CELLS;
+        const u32x4 *w2s = w1s + W1_CELLS;
+        const bool more = hb + 1 < NHB;
+        if (more) load_w1(hb + 1);
+        // ---- GEMM 1: Ht block = W1t · Xt ------------------------------------------------------------------------------
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            u32x4 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = w1s[(pl * K81 + 2 * ks + lh) * 32 + li];
+            const u32x4 xb[3] = {xh[ks], xm[ks], xl[ks]};
+#pragma unroll
+            for (int pr = 3; pr < 9; ++pr)  // the tiles' pair order; their A plane (activations) is this MFMA's B operand
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kSplitPB[pr]]), __builtin_bit_cast(bf16x8, xb[kSplitPA[pr]]), acc1, 0, 0, 0);
+        }
+        if (more) {
+            store_w1(cur ^ 1);
+            load_w2(hb + 1);
+        }
+        // ---- bias + GELU + split: the block's 16 hidden values of this lane's pixel become two A-operand fragments ------
+        u32x4 hh[2], hm[2], hl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s + j;
+                const float v = acc1[r] * 1.f + b1s[32 * hb + (r & 3) + 8 * (r >> 2) + 4 * lh];  // the tile's epilogue: acc * scale (none) + bias
+                g[j] = gelu_fast(v);
+            }
+            split8(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]}, hh[s], hm[s], hl[s]);
+        }
+        // ---- GEMM 2: Y += H block · W2p block ------------------------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32x4 ha[3] = {hh[s], hm[s], hl[s]};
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                u32x4 b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[pl] = w2s[(pl * 4 + 2 * s + lh) * NPAD + nb * 32 + li];
+#pragma unroll
+                for (int pr = 3; pr < 9; ++pr)
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ha[kSplitPA[pr]]), __builtin_bit_cast(bf16x8, b[kSplitPB[pr]]), acc2[nb], 0, 0, 0);
+            }
+        }
+        if (more) store_w2(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: gamma (scale2), bias, residual ---------------------------------------------------------------------------
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int c = nb * 32 + li;
+        if (c >= C) continue;
+        const float sc = scale2 ? scale2[c] : 1.f, bi = bias2 ? bias2[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= M) continue;
+            float v = acc2[nb][r] * sc + bi;
+            if (post) v += post[(int64_t)row * ldp + c];
+            out[(int64_t)row * ldo + c] = v;
+        }
+    }
+}
+
+template <int C>
+int launch_mlp(const float *x, int64_t ldx, const uint16_t *w1p, const float *b1, const uint16_t *w2p, int ldn2, const float *scale2,
+               const float *bias2, const float *post, int64_t ldp, float *out, int64_t ldo, int M, hipStream_t s) {
+    constexpr int NPAD = (C + 31) / 32 * 32;
+    const size_t smem = (size_t)2 * (3 * (C / 8) * 32 + 3 * 4 * NPAD) * 16 + (size_t)4 * C * sizeof(float);
+    auto kern = convnext_mlp_kernel<C>;
+    static DynSmemOptIn optin;
+    optin.ensure(reinterpret_cast<const void *>(kern), smem);
+    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), smem, s, x, ldx, reinterpret_cast<const u32x4 *>(w1p), b1,
+                       reinterpret_cast<const u32x4 *>(w2p), ldn2, scale2, bias2, post, ldp, out, ldo, M);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mit_convnext_mlp_supported(int C) { return C == 80 ? 1 : 0; }
+
+extern "C" int mit_convnext_mlp(const float *x_dev, int64_t ldx, int M, int C, const uint16_t *w1_planes_dev, const float *b1_dev,
+                                const uint16_t *w2perm_planes_dev, int64_t ldn2, const float *scale2_dev, const float *bias2_dev,
+                                const float *post_dev, int64_t ldp, float *out_dev, int64_t ldo, void *stream) {
+    if (!x_dev || !w1_planes_dev || !b1_dev || !w2perm_planes_dev || !out_dev) return mit_set_error("mit_convnext_mlp: null pointer");
+    if (!mit_convnext_mlp_supported(C)) return mit_set_error("mit_convnext_mlp: C = %d is not instantiated (80)", C);
+    if (M <= 0) return 0;
+    if (M > 0x7fffff00) return mit_set_error("mit_convnext_mlp: M too large");
+    if ((ldx & 3) || ldx < C || ldo < C || (post_dev && ldp < C) || ldn2 < C || ldn2 > 0x7fffffff)
+        return mit_set_error("mit_convnext_mlp: row strides must cover C (ldx %% 4 == 0)");
+    auto unaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
+    if (unaligned(x_dev) || unaligned(w1_planes_dev) || unaligned(w2perm_planes_dev)) return mit_set_error("mit_convnext_mlp: x and the plane tables must be 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // algorithmic bytes: the block input and the residual read once, the output written once (the hidden activations stay on chip);
+    // FLOPs: both contractions
+    MitProbeScope probe("convnext_mlp_kernel<80>", s, (double)M * C * 4.0 * 3.0, 2.0 * 2.0 * (double)M * C * (4.0 * C));
+    switch (C) {
+        case 80: launch_mlp<80>(x_dev, ldx, w1_planes_dev, b1_dev, w2perm_planes_dev, (int)ldn2, scale2_dev, bias2_dev, post_dev, ldp, out_dev, ldo, M, s); break;
+        default: return mit_set_error("mit_convnext_mlp: C = %d", C);
+    }
+    MIT_CHECK_LAUNCH("mit_convnext_mlp");
+    return 0;
+}

@@ -183,6 +183,9 @@ SYMBOLS = {
     "mit_gemm_split_min_tiles": (C.c_int64, [C.c_int64]),
     "mit_conv_small_cout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "mit_convnext_mlp_supported": (C.c_int, [C.c_int]),
+    "mit_convnext_mlp": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "mit_prof_enable": (C.c_int, [C.c_int]),
     "mit_prof_tag_next": (C.c_int, [C.c_double]),
     "mit_prof_read": (C.c_int, [C.POINTER(MitProfStat), C.c_int, C.POINTER(C.c_int)]),

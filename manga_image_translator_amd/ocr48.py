@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -113,6 +114,55 @@ class _Block:
         self.dw_scale, self.dw_bias = sc.to(device), bi.to(device)
         self.pw1 = ops.Conv2d(sd[p + ".pwconv1.weight"], sd[p + ".pwconv1.bias"], act=ACT_GELU, device=device)
         self.pw2 = ops.Conv2d(sd[p + ".pwconv2.weight"], sd[p + ".pwconv2.bias"], out_scale=sd[p + ".gamma"], device=device)
+        self.dim = dim
+        self._fused = None   # (w1 planes, w2 row-permuted planes, ldn2): built on first use in a split GEMM mode
+
+    def _fused_planes(self):
+        """Plane tables of the one-launch form (mit_convnext_mlp): pwconv1's planes as the tiles use them, and pwconv2's weight with
+        its rows in the order in which the first contraction's accumulator registers hold the hidden index."""
+        if self._fused is None:
+            w1, w2 = self.pw1, self.pw2
+            if w1.Kp != self.dim or w1.Np != 4 * self.dim or w2.Kp != 4 * self.dim:
+                raise RuntimeError(f"ConvNeXt block: unexpected packed shapes {w1.Kp}x{w1.Np}, {w2.Kp}x{w2.Np}")
+            p1, _ = ops._split_for(w1.w, w1.Np, w1.Kp, (0, 0))
+            if p1 is None:
+                raise RuntimeError("ConvNeXt block: pwconv1 carries no split planes (packed in GEMM mode 0)")
+            k = torch.arange(4 * self.dim)
+            hb, rem = k // 32, k % 32
+            s_, lh, j = rem // 16, (rem % 16) // 8, rem % 8
+            perm = 32 * hb + (j & 3) + 8 * (2 * s_ + (j >> 2)) + 4 * lh           # row k' of the permuted weight = row perm[k'] of W2
+            w2p = w2.w.view(w2.Kp, w2.Np)[perm.to(w2.w.device)].contiguous()
+            self._fused = (p1, ops.split_weight(w2p), w2.Np)
+        return self._fused
+
+    def mlp(self, t: torch.Tensor, h: torch.Tensor, x: torch.Tensor, rows: int):
+        """x += gamma * pwconv2(gelu(pwconv1(t))) (:207-213) on flat [rows, C] views: ONE launch with the hidden activations in
+        registers where the library has that width and the split-bf16 p6 mode is on (mit_convnext_mlp), else the two GEMM launches
+        through the [rows, 4C] buffer ``h``.  Which form runs depends only on the layer width and the GEMM mode — never on the batch."""
+        lib = _lib.load()
+        if fused_mlp_enabled() and ops.split_mode() == 6 and lib.mit_convnext_mlp_supported(self.dim):
+            p1, p2, ldn2 = self._fused_planes()
+            _lib.check(lib.mit_convnext_mlp(t.data_ptr(), self.dim, rows, self.dim, p1.data_ptr(), self.pw1.bias.data_ptr(), p2.data_ptr(), ldn2,
+                                            ops._ptr(self.pw2.scale), ops._ptr(self.pw2.bias), x.data_ptr(), self.dim, x.data_ptr(), self.dim,
+                                            C.c_void_p(ops.current_stream())), "mit_convnext_mlp")
+            return
+        t4, h4, x4 = t.view(1, 1, rows, self.dim), h.view(1, 1, rows, 4 * self.dim), x.view(1, 1, rows, self.dim)
+        self.pw1(t4, out=h4)
+        self.pw2(h4, out=x4, post=x4)
+
+
+_FUSED_MLP = [os.environ.get("MIT_OCR_FUSED_MLP", "1") not in ("", "0")]
+
+
+def fused_mlp_enabled() -> bool:
+    return _FUSED_MLP[0]
+
+
+def set_fused_mlp(on: bool) -> bool:
+    """Switch the one-launch ConvNeXt pointwise pair (tests, A/B); returns the previous setting.  MIT_OCR_FUSED_MLP=0 in the environment
+    starts with it off."""
+    prev, _FUSED_MLP[0] = _FUSED_MLP[0], bool(on)
+    return prev
 
 
 class Ocr48Engine:
@@ -208,8 +258,7 @@ class Ocr48Engine:
             for blk in blocks:
                 _lib.check(lib.mit_dwconv_nhwc(x.data_ptr(), blk.dw_w.data_ptr(), blk.dw_scale.data_ptr(), blk.dw_bias.data_ptr(),
                                                t.data_ptr(), B, H, W, Cc, blk.ks, st), "mit_dwconv_nhwc")
-                blk.pw1(t, out=h4)
-                blk.pw2(h4, out=x, post=x)  # input + gamma * pwconv2(...), in place (:211-213)
+                blk.mlp(t, h4, x, B * H * W)  # input + gamma * pwconv2(gelu(pwconv1(t))), in place (:207-213)
             x = down(x, out=self._buf(f"{tag}.d{si}", B, *down.out_hw(H, W), down.Cout))
         return x
 
@@ -283,7 +332,6 @@ class Ocr48Engine:
             x_flat = flat  # slab holding `cur`
             t_flat = self._buf(f"g.dw{si}", rows, Cc)
             h_flat = self._buf(f"g.h{si}", rows, 4 * Cc)
-            x4, t4, h4 = x_flat.view(1, 1, rows, Cc), t_flat.view(1, 1, rows, Cc), h_flat.view(1, 1, rows, 4 * Cc)
             heights = {h for _, h, _ in sh}
             common_h = heights.pop() if len(heights) == 1 else 0  # every chunk of a 48 px recogniser has the same height per stage
             for blk in blocks:
@@ -291,8 +339,7 @@ class Ocr48Engine:
                                                            blk.dw_bias.data_ptr(), t_flat.data_ptr(),
                                                            tab_dev.data_ptr() + int(tab_off[si]), nc, tabs[si][1], Cc, blk.ks,
                                                            common_h, st), "mit_dwconv_nhwc_ragged_rows")
-                blk.pw1(t4, out=h4)
-                blk.pw2(h4, out=x4, post=x4)
+                blk.mlp(t_flat, h_flat, x_flat, rows)
             nsh = [(n, *down.out_hw(h, w)) for n, h, w in sh]
             flat, views, starts = self._cat_views(f"g.d{si}", nsh, down.Cout)
             for xi, oi in zip(cur, views):

@@ -390,3 +390,44 @@ def test_few_row_decode_equals_the_tiled_form(cuda, ocr_setup, widths, T, suppre
         assert o["steps_run"] == outs[0]["steps_run"]
         for k in ("tokens", "length", "prob", "colors"):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("rows", [33, 128, 1000, 40000])
+def test_fused_convnext_mlp_matches_the_two_launch_form(cuda, ocr_setup, rows):
+    """mit_convnext_mlp (pwconv1 -> GELU -> pwconv2 -> gamma -> + input in one launch, hidden activations in registers; model_48px.py:203-214)
+    against the two GEMM launches it replaces and against a float64 evaluation of the block's formula.  The first contraction is the
+    tiles' own arithmetic; the second adds the same products with an MFMA step's 16 values in other k slots: differences of a few fp32
+    ulps of the sums at most.  Ragged row counts (not a multiple of the 32-pixel wave tile / 128-row workgroup) included."""
+    from manga_image_translator_amd import ocr48, ops
+
+    sd, D, eng = ocr_setup
+    blk = eng.stages[0][0]
+    assert blk.dim == 80
+    g = torch.Generator().manual_seed(rows)
+    t = torch.randn(rows, 80, generator=g).to(cuda)
+    x0 = torch.randn(rows, 80, generator=g).to(cuda)
+    h = torch.empty(rows, 320, device=cuda)
+    with ops.gemm_mode(6, min_tiles=1):
+        assert ocr48.fused_mlp_enabled()
+        x1 = x0.clone()
+        blk.mlp(t, h, x1, rows)
+        prev = ocr48.set_fused_mlp(False)
+        try:
+            x2 = x0.clone()
+            blk.mlp(t, h, x2, rows)
+        finally:
+            ocr48.set_fused_mlp(prev)
+        x1b = x0.clone()
+        blk.mlp(t, h, x1b, rows)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x1b)                                   # run-to-run identical
+    p = "backbone.block1.0"
+    w1, b1 = sd[p + ".pwconv1.weight"].double().reshape(320, 80), sd[p + ".pwconv1.bias"].double()
+    w2, b2 = sd[p + ".pwconv2.weight"].double().reshape(80, 320), sd[p + ".pwconv2.bias"].double()
+    gamma = sd[p + ".gamma"].double().reshape(-1)
+    hid = torch.nn.functional.gelu(t.cpu().double() @ w1.t() + b1)
+    ref = x0.cpu().double() + gamma * (hid @ w2.t() + b2)
+    ymax = float(ref.abs().max())
+    e_fused, e_two = float((x1.cpu().double() - ref).abs().max()) / ymax, float((x2.cpu().double() - ref).abs().max()) / ymax
+    assert e_fused < 4 * e_two + 2e-6, (e_fused, e_two)
+    assert float((x1 - x2).abs().max()) / ymax < 2e-6
