@@ -118,19 +118,33 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
         const bool more = hb + 1 < NHB;
         if (more) load_w1(hb + 1);
         // ---- GEMM 1: Ht block = W1t · Xt ------------------------------------------------------------------------------
+        // (fragment reads run one MFMA step ahead of their use: with two waves per SIMD nothing else hides the LDS latency)
+        float bb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bb[r] = b1s[32 * hb + (r & 3) + 8 * (r >> 2) + 4 * lh];
         f32x16 acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+        u32x4 a[3], an[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = w1s[(pl * K81 + lh) * 32 + li];
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
-            u32x4 a[3];
+            if (ks + 1 < KS1) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[pl] = w1s[(pl * K81 + 2 * ks + lh) * 32 + li];
+                for (int pl = 0; pl < 3; ++pl) an[pl] = w1s[(pl * K81 + 2 * (ks + 1) + lh) * 32 + li];
+            }
             const u32x4 xb[3] = {xh[ks], xm[ks], xl[ks]};
 #pragma unroll
             for (int pr = 3; pr < 9; ++pr)  // the tiles' pair order; their A plane (activations) is this MFMA's B operand
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kSplitPB[pr]]), __builtin_bit_cast(bf16x8, xb[kSplitPA[pr]]), acc1, 0, 0, 0);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = an[pl];
         }
+        // the second contraction's first fragments travel while the VALU works on the activations
+        u32x4 b[3], bn[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl] = w2s[(pl * 4 + lh) * NPAD + li];
         if (more) {
             store_w1(cur ^ 1);
             load_w2(hb + 1);
@@ -141,26 +155,24 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
         for (int s = 0; s < 2; ++s) {
             float g[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = 8 * s + j;
-                const float v = acc1[r] * 1.f + b1s[32 * hb + (r & 3) + 8 * (r >> 2) + 4 * lh];  // the tile's epilogue: acc * scale (none) + bias
-                g[j] = gelu_fast(v);
-            }
+            for (int j = 0; j < 8; ++j) g[j] = gelu_fast(acc1[8 * s + j] * 1.f + bb[8 * s + j]);  // the tile's epilogue: acc * scale (none) + bias
             split8(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]}, hh[s], hm[s], hl[s]);
         }
         // ---- GEMM 2: Y += H block · W2p block ------------------------------------------------------------------------------
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int i = 0; i < 2 * NB; ++i) {
+            const int s = i / NB, nb = i - s * NB;
+            if (i + 1 < 2 * NB) {
+                const int s1 = (i + 1) / NB, nb1 = (i + 1) - s1 * NB;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bn[pl] = w2s[(pl * 4 + 2 * s1 + lh) * NPAD + nb1 * 32 + li];
+            }
             const u32x4 ha[3] = {hh[s], hm[s], hl[s]};
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                u32x4 b[3];
+            for (int pr = 3; pr < 9; ++pr)
+                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ha[kSplitPA[pr]]), __builtin_bit_cast(bf16x8, b[kSplitPB[pr]]), acc2[nb], 0, 0, 0);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) b[pl] = w2s[(pl * 4 + 2 * s + lh) * NPAD + nb * 32 + li];
-#pragma unroll
-                for (int pr = 3; pr < 9; ++pr)
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ha[kSplitPA[pr]]), __builtin_bit_cast(bf16x8, b[kSplitPB[pr]]), acc2[nb], 0, 0, 0);
-            }
+            for (int pl = 0; pl < 3; ++pl) b[pl] = bn[pl];
         }
         if (more) store_w2(cur ^ 1);
         __syncthreads();
