@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
     constexpr int NB = (C + 31) / 32;  // 32-column blocks of the output
     constexpr int NPAD = NB * 32;
     constexpr int W1_CELLS = 3 * K81 * 32, W2_CELLS = 3 * 4 * NPAD, BUF_CELLS = W1_CELLS + W2_CELLS;
-    constexpr int W1_IT = (W1_CELLS + 255) / 256, W2_IT = (W2_CELLS + 255) / 256;
+    constexpr int W2_LOAD = 3 * 4 * C;  // the W2p cells that exist (columns n < C); the padded columns of the LDS block stay zero
+    constexpr int W1_IT = (W1_CELLS + 255) / 256, W2_IT = (W2_LOAD + 255) / 256;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u32x4 *wbuf = reinterpret_cast<u32x4 *>(smem);                 // [2][BUF_CELLS]: W1 block [3][K81][32], then W2p block [3][4][NPAD]
@@ -84,19 +85,23 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
 #pragma unroll
         for (int it = 0; it < W2_IT; ++it) {
             const int i = tid + it * 256;
-            const int pl = i / (4 * NPAD), rem = i - pl * (4 * NPAD), kk = rem / NPAD, n = rem - kk * NPAD;
-            const bool ok = i < W2_CELLS && n < C;
-            const u32x4 v = w2p[ok ? (int64_t)(pl * (HID / 8) + 4 * hb + kk) * ldn2 + n : 0];
-            st2[it] = ok ? v : u32x4{0u, 0u, 0u, 0u};  // padded output columns multiply zeros
+            const int pk = i / C, n = i - pk * C;  // pk = plane * 4 + k cell of the block
+            st2[it] = w2p[i < W2_LOAD ? (int64_t)((pk >> 2) * (HID / 8) + 4 * hb + (pk & 3)) * ldn2 + n : 0];
         }
     };
     auto store_w2 = [&](const int buf) {
 #pragma unroll
         for (int it = 0; it < W2_IT; ++it) {
             const int i = tid + it * 256;
-            if (i < W2_CELLS) wbuf[buf * BUF_CELLS + W1_CELLS + i] = st2[it];
+            const int pk = i / C, n = i - pk * C;
+            if (i < W2_LOAD) wbuf[buf * BUF_CELLS + W1_CELLS + pk * NPAD + n] = st2[it];
         }
     };
+    if (NPAD > C)  // padded output columns multiply zeros: written once, in both buffers
+        for (int i = tid; i < 2 * 12 * (NPAD - C); i += 256) {
+            const int buf = i / (12 * (NPAD - C)), rem = i - buf * (12 * (NPAD - C)), pk = rem / (NPAD - C), n = C + rem - pk * (NPAD - C);
+            wbuf[buf * BUF_CELLS + W1_CELLS + pk * NPAD + n] = u32x4{0u, 0u, 0u, 0u};
+        }
 
     f32x16 acc2[NB];
 #pragma unroll
@@ -116,7 +121,10 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
         const u32x4 *w1s = wbuf + cur * BUF_CELLS;
         const u32x4 *w2s = w1s + W1_CELLS;
         const bool more = hb + 1 < NHB;
-        if (more) load_w1(hb + 1);
+        if (more) {  // the next block's weights are requested now and parked in LDS at the end of this block: a whole block of latency cover
+            load_w1(hb + 1);
+            load_w2(hb + 1);
+        }
         // ---- GEMM 1: Ht block = W1t · Xt ------------------------------------------------------------------------------
         // (fragment reads run one MFMA step ahead of their use: with two waves per SIMD nothing else hides the LDS latency)
         float bb[16];
@@ -145,10 +153,6 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
         u32x4 b[3], bn[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) b[pl] = w2s[(pl * 4 + lh) * NPAD + li];
-        if (more) {
-            store_w1(cur ^ 1);
-            load_w2(hb + 1);
-        }
         // ---- bias + GELU + split: the block's 16 hidden values of this lane's pixel become two A-operand fragments ------
         u32x4 hh[2], hm[2], hl[2];
 #pragma unroll
@@ -174,7 +178,10 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) b[pl] = bn[pl];
         }
-        if (more) store_w2(cur ^ 1);
+        if (more) {
+            store_w1(cur ^ 1);
+            store_w2(cur ^ 1);
+        }
         __syncthreads();
     }
 
