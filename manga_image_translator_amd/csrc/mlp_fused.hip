@@ -27,7 +27,9 @@
 namespace {
 using namespace mitcg;
 
-template <int C>
+// ABL (timing ablations, WRONG results, MIT_MLP_ABLATE=<n> in the environment of a MIT_CONV_EXPERIMENTS build only): 1 = no GELU (bias add
+// only), 2 = no weight staging after the first block, 4 = no second contraction, 8 = no first contraction
+template <int C, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__restrict__ x, const int64_t ldx, const u32x4 *__restrict__ w1p,
                                                               const float *__restrict__ b1, const u32x4 *__restrict__ w2p, const int ldn2,
                                                               const float *__restrict__ scale2, const float *__restrict__ bias2,
@@ -51,18 +53,7 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int row0 = (blockIdx.x * 4 + wave) * 32;  // the wave's 32 pixels
-    const int prow = row0 + li < M ? row0 + li : M - 1;
 
-    // this wave's X rows as three planes of B-operand fragments, for the whole kernel
-    u32x4 xh[KS1], xm[KS1], xl[KS1];
-    {
-        const float *xr = x + (int64_t)prow * ldx + 8 * lh;
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(xr + 16 * ks), v1 = *reinterpret_cast<const f32x4 *>(xr + 16 * ks + 4);
-            split8(v0, v1, xh[ks], xm[ks], xl[ks]);
-        }
-    }
     for (int i = tid; i < HID; i += 256) b1s[i] = b1[i];
 
     u32x4 st1[W1_IT], st2[W2_IT];
@@ -97,11 +88,6 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
             if (i < W2_LOAD) wbuf[buf * BUF_CELLS + W1_CELLS + pk * NPAD + n] = st2[it];
         }
     };
-    if (NPAD > C)  // padded output columns multiply zeros: written once, in both buffers
-        for (int i = tid; i < 2 * 12 * (NPAD - C); i += 256) {
-            const int buf = i / (12 * (NPAD - C)), rem = i - buf * (12 * (NPAD - C)), pk = rem / (NPAD - C), n = C + rem - pk * (NPAD - C);
-            wbuf[buf * BUF_CELLS + W1_CELLS + pk * NPAD + n] = u32x4{0u, 0u, 0u, 0u};
-        }
 
     f32x16 acc2[NB];
 #pragma unroll
@@ -109,8 +95,43 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
 
-    load_w1(0);
+    load_w1(0);  // the first block's weights travel while the X tile is brought in
     load_w2(0);
+    // This workgroup's 128 X rows come in as whole 320-byte rows (coalesced float4 runs), pass through LDS — the area the weight blocks
+    // use afterwards — and leave as each wave's B-operand fragments: lane = pixel, k-group = lane >> 5, 8 consecutive channels per MFMA
+    // step, split into three planes once and kept in registers for all hidden blocks.
+    u32x4 xh[KS1], xm[KS1], xl[KS1];
+    {
+        constexpr int XP = C + 4;  // row pitch in floats
+        static_assert(128 * XP * 4 <= 2 * BUF_CELLS * 16, "X tile fits the weight buffers");
+        float *xs = smem;
+        constexpr int XQ = 128 * (C / 4), XIT = (XQ + 255) / 256;
+        f32x4 xv[XIT];
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int q = tid + 256 * it, row = q / (C / 4), c4 = q - row * (C / 4);
+            const int grow = blockIdx.x * 128 + row < M ? blockIdx.x * 128 + row : M - 1;
+            xv[it] = *reinterpret_cast<const f32x4 *>(x + (int64_t)grow * ldx + (q < XQ ? c4 : 0) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int q = tid + 256 * it, row = q / (C / 4), c4 = q - row * (C / 4);
+            if (q < XQ) *reinterpret_cast<f32x4 *>(xs + row * XP + c4 * 4) = xv[it];
+        }
+        __syncthreads();
+        const float *xr = xs + (wave * 32 + li) * XP + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(xr + 16 * ks), v1 = *reinterpret_cast<const f32x4 *>(xr + 16 * ks + 4);
+            split8(v0, v1, xh[ks], xm[ks], xl[ks]);
+        }
+        __syncthreads();  // every wave has its fragments: the area becomes the weight buffers
+    }
+    if (NPAD > C)  // padded output columns multiply zeros: written once, in both buffers
+        for (int i = tid; i < 2 * 12 * (NPAD - C); i += 256) {
+            const int buf = i / (12 * (NPAD - C)), rem = i - buf * (12 * (NPAD - C)), pk = rem / (NPAD - C), n = C + rem - pk * (NPAD - C);
+            wbuf[buf * BUF_CELLS + W1_CELLS + pk * NPAD + n] = u32x4{0u, 0u, 0u, 0u};
+        }
     store_w1(0);
     store_w2(0);
     __syncthreads();
@@ -120,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
         const int cur = hb & 1;
         const u32x4 *w1s = wbuf + cur * BUF_CELLS;
         const u32x4 *w2s = w1s + W1_CELLS;
-        const bool more = hb + 1 < NHB;
+        const bool more = hb + 1 < NHB && !(ABL & 2);
         if (more) {  // the next block's weights are requested now and parked in LDS at the end of this block: a whole block of latency cover
             load_w1(hb + 1);
             load_w2(hb + 1);
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) a[pl] = w1s[(pl * K81 + lh) * 32 + li];
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) {
+        for (int ks = 0; ks < ((ABL & 8) ? 1 : KS1); ++ks) {
             if (ks + 1 < KS1) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) an[pl] = w1s[(pl * K81 + 2 * (ks + 1) + lh) * 32 + li];
@@ -159,12 +180,15 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
         for (int s = 0; s < 2; ++s) {
             float g[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = gelu_fast(acc1[8 * s + j] * 1.f + bb[8 * s + j]);  // the tile's epilogue: acc * scale (none) + bias
+            for (int j = 0; j < 8; ++j) {
+                const float v = acc1[8 * s + j] * 1.f + bb[8 * s + j];  // the tile's epilogue: acc * scale (none) + bias
+                g[j] = (ABL & 1) ? v : gelu_fast(v);
+            }
             split8(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]}, hh[s], hm[s], hl[s]);
         }
         // ---- GEMM 2: Y += H block · W2p block ------------------------------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < 2 * NB; ++i) {
+        for (int i = 0; i < ((ABL & 4) ? 1 : 2 * NB); ++i) {
             const int s = i / NB, nb = i - s * NB;
             if (i + 1 < 2 * NB) {
                 const int s1 = (i + 1) / NB, nb1 = (i + 1) - s1 * NB;
@@ -186,28 +210,53 @@ __global__ __launch_bounds__(256, 2) void convnext_mlp_kernel(const float *__res
     }
 
     // ---- epilogue: gamma (scale2), bias, residual ---------------------------------------------------------------------------
+    // The accumulators (lane = column, registers = rows) pass through the wave's own slice of the now idle weight buffers and come
+    // back as float4 runs of one row: 10 dwordx4 residual loads and 10 dwordx4 stores per lane, 320 contiguous bytes per row, instead
+    // of 48 + 48 dword accesses.  All residual reads first, then all stores: `post` may be `out` itself, so the compiler keeps every
+    // load behind the stores that precede it in program order — interleaved they become memory round trips in a row (33 us of a
+    // 59 us workgroup in the first version of this kernel).  Same per-element arithmetic as the tiles' epilogue: acc * scale + bias, + post.
+    constexpr int PITCH = C + 4;
+    static_assert(32 * PITCH * 4 * 4 <= 2 * BUF_CELLS * 16, "transpose slices fit the weight buffers");
+    float *tb = smem + wave * (32 * PITCH);
+    // (the loop's last barrier is behind every wave's last weight read)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int c = nb * 32 + li;
-        if (c >= C) continue;
-        const float sc = scale2 ? scale2[c] : 1.f, bi = bias2 ? bias2[c] : 0.f;
+        if (c < C) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row >= M) continue;
-            float v = acc2[nb][r] * sc + bi;
-            if (post) v += post[(int64_t)row * ldp + c];
-            out[(int64_t)row * ldo + c] = v;
+            for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + c] = acc2[nb][r];
         }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-synchronous exchange: LDS serves a wave's accesses in order
+    constexpr int Q = 32 * (C / 4), QIT = (Q + 63) / 64;
+    f32x4 tv[QIT], pv[QIT];
+#pragma unroll
+    for (int it = 0; it < QIT; ++it) {
+        const int q = lane + 64 * it, row = q / (C / 4), c4 = q - row * (C / 4);
+        const bool ok = q < Q && row0 + row < M;
+        tv[it] = *reinterpret_cast<const f32x4 *>(tb + (q < Q ? row : 0) * PITCH + (q < Q ? c4 : 0) * 4);
+        pv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok && post) pv[it] = *reinterpret_cast<const f32x4 *>(post + (int64_t)(row0 + row) * ldp + c4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < QIT; ++it) {
+        const int q = lane + 64 * it, row = q / (C / 4), c4 = q - row * (C / 4);
+        if (!(q < Q && row0 + row < M)) continue;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (scale2) sc = *reinterpret_cast<const f32x4 *>(scale2 + c4 * 4);
+        if (bias2) bi = *reinterpret_cast<const f32x4 *>(bias2 + c4 * 4);
+        f32x4 v = tv[it] * sc + bi;
+        if (post) v += pv[it];
+        *reinterpret_cast<f32x4 *>(out + (int64_t)(row0 + row) * ldo + c4 * 4) = v;
     }
 }
 
-template <int C>
+template <int C, int ABL = 0>
 int launch_mlp(const float *x, int64_t ldx, const uint16_t *w1p, const float *b1, const uint16_t *w2p, int ldn2, const float *scale2,
                const float *bias2, const float *post, int64_t ldp, float *out, int64_t ldo, int M, hipStream_t s) {
     constexpr int NPAD = (C + 31) / 32 * 32;
     const size_t smem = (size_t)2 * (3 * (C / 8) * 32 + 3 * 4 * NPAD) * 16 + (size_t)4 * C * sizeof(float);
-    auto kern = convnext_mlp_kernel<C>;
+    auto kern = convnext_mlp_kernel<C, ABL>;
     static DynSmemOptIn optin;
     optin.ensure(reinterpret_cast<const void *>(kern), smem);
     hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), smem, s, x, ldx, reinterpret_cast<const u32x4 *>(w1p), b1,
@@ -226,14 +275,22 @@ extern "C" int mit_convnext_mlp(const float *x_dev, int64_t ldx, int M, int C, c
     if (!mit_convnext_mlp_supported(C)) return mit_set_error("mit_convnext_mlp: C = %d is not instantiated (80)", C);
     if (M <= 0) return 0;
     if (M > 0x7fffff00) return mit_set_error("mit_convnext_mlp: M too large");
-    if ((ldx & 3) || ldx < C || ldo < C || (post_dev && ldp < C) || ldn2 < C || ldn2 > 0x7fffffff)
-        return mit_set_error("mit_convnext_mlp: row strides must cover C (ldx %% 4 == 0)");
+    if ((ldx & 3) || (ldo & 3) || (ldp & 3) || ldx < C || ldo < C || (post_dev && ldp < C) || ldn2 < C || ldn2 > 0x7fffffff)
+        return mit_set_error("mit_convnext_mlp: row strides must cover C and be multiples of 4 floats");
     auto unaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
-    if (unaligned(x_dev) || unaligned(w1_planes_dev) || unaligned(w2perm_planes_dev)) return mit_set_error("mit_convnext_mlp: x and the plane tables must be 16-byte aligned");
+    if (unaligned(x_dev) || unaligned(w1_planes_dev) || unaligned(w2perm_planes_dev) || unaligned(out_dev) || unaligned(post_dev) ||
+        unaligned(scale2_dev) || unaligned(bias2_dev))
+        return mit_set_error("mit_convnext_mlp: x, out, post, scale / bias and the plane tables must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // algorithmic bytes: the block input and the residual read once, the output written once (the hidden activations stay on chip);
     // FLOPs: both contractions
     MitProbeScope probe("convnext_mlp_kernel<80>", s, (double)M * C * 4.0 * 3.0, 2.0 * 2.0 * (double)M * C * (4.0 * C));
+#ifdef MIT_CONV_EXPERIMENTS
+    static const int abl = getenv("MIT_MLP_ABLATE") ? atoi(getenv("MIT_MLP_ABLATE")) : 0;
+#define MIT_MLP_ABL(n) if (abl == n) { launch_mlp<80, n>(x_dev, ldx, w1_planes_dev, b1_dev, w2perm_planes_dev, (int)ldn2, scale2_dev, bias2_dev, post_dev, ldp, out_dev, ldo, M, s); MIT_CHECK_LAUNCH("mit_convnext_mlp"); return 0; }
+    MIT_MLP_ABL(1) MIT_MLP_ABL(2) MIT_MLP_ABL(4) MIT_MLP_ABL(8) MIT_MLP_ABL(3) MIT_MLP_ABL(12) MIT_MLP_ABL(15)
+#undef MIT_MLP_ABL
+#endif
     switch (C) {
         case 80: launch_mlp<80>(x_dev, ldx, w1_planes_dev, b1_dev, w2perm_planes_dev, (int)ldn2, scale2_dev, bias2_dev, post_dev, ldp, out_dev, ldo, M, s); break;
         default: return mit_set_error("mit_convnext_mlp: C = %d", C);
