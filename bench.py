@@ -239,7 +239,13 @@ def stage_legs(engine, pages, quads, masks, stages, dump=""):
         other_ms = 0.0
         for i in range(nk.value):
             k = kst[i]
-            other_ms += k.ms
+            if k.name.decode().startswith("convnext_mlp"):   # the fused pointwise pair: split-bf16 p6 contractions outside mit_conv_gemm —
+                conv_ms += k.ms                               # counted with the conv work of the stage (6 plane products per algorithmic FLOP)
+                conv_exec += k.alg_flops
+                peak_ms += k.alg_flops * 6 / (BF16_MATRIX_PEAK_TFLOPS * 1e9)
+                bf16_exec += k.alg_flops * 6
+            else:
+                other_ms += k.ms
             a = kern_tot.setdefault(k.name.decode(), [0, 0.0, 0.0, 0.0])
             a[0] += k.launches
             a[1] += k.ms
