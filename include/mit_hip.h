@@ -646,6 +646,10 @@ int mit_attention(const float *q_dev, int64_t q_rs, int64_t q_ts, const float *k
 int mit_attention_lines_xpos(const float *q_dev, const float *k_dev, const float *v_dev, float *out_dev, int64_t row_stride,
                              const int32_t *lines_dev, const int *klen_dev, int n_lines, int Lmax, int heads, int head_dim,
                              const MitXposTables *tables, void *stream);
+/* The decoder's self-attention kernel: 1 (default) = one workgroup per row stages the row's key history once for its four heads
+ * (attention_self_kernel), 0 = one single-wave workgroup per (head, row) (attention_kernel); bitwise the same results.  on < 0 only
+ * queries.  Returns the previous value.  Nothing in the reference corresponds to it (A/B switch). */
+int mit_attention_self_rows_set(int on);
 /* Longest line (Lmax) whose keys + per-wave score rows fit mit_attention_lines_xpos's LDS form for this head_dim (308 at head_dim 80);
  * longer lines take the chunk-by-chunk path (mit_xpos_rotate + mit_attention), which has no such limit.  0 for an unsupported head_dim. */
 int mit_attention_lines_xpos_max_len(int head_dim);

@@ -7,6 +7,7 @@
 // ocr/xpos_relative_position.py (:9-71).
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stdint.h>
 #include "../../include/mit_hip.h"
@@ -532,6 +533,106 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
                 if (t0 + u < valid) acc += ws[t0 + u] * vv[u];
         }
         if (opl.p) qs[d] = acc;   // planar output (Tq == 1): the head's HD values become HD / 8 cells of row r (qs is free by now)
+        else ob[d] = acc;
+    }
+    if (opl.p) {
+        wave_lds_fence();
+        for (int c = lane; c < (HD >> 3); c += 64) store_cells(opl, h * (HD >> 3) + c, r, qs + c * 8);
+    }
+}
+
+// ---- the decoder's SELF-attention (one query = the step's token, keys = the row's own history 0 .. step, rotated as they are read):
+// one workgroup per row, one wave per head.  attention_kernel gives every (head, row) a workgroup of one wave whose lane t walks key
+// t's 320-byte slice of a 1280-byte row by itself — 64 scattered streams per wave, 40 960 one-wave workgroups per launch, 27 % of the
+// HBM rate.  Here the row's whole history [Tk][heads * HD] (contiguous: <= 40 KB) is brought in by all 256 threads as coalesced float4
+// runs, parked in LDS with a pitch of heads * HD + 4 floats (lane t's float4 reads then fall on distinct banks), and every head's wave
+// evaluates exactly attention_kernel's expressions on it — per-key dot products in d order with the rotation folded in, the
+// lane-strided softmax, the t-ordered weighted sum — so the results are bitwise the same.
+__global__ __launch_bounds__(256) void attention_self_kernel(const float *__restrict__ Q, int64_t q_rs, const float *__restrict__ K, int64_t k_rs,
+                                                             int64_t k_ts, const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
+                                                             float *__restrict__ O, int64_t o_rs, int TkCap, int heads, int HD,
+                                                             const int *__restrict__ dstep, OcrAttXpos xp, OcrPlanes opl) {
+    const int Tk = dstep ? *dstep + 1 : TkCap;
+    const int step = dstep ? *dstep : xp.step;
+    const int minpos = -((step + 2) / 2);
+    const int E = heads * HD, KP = E + 4, HP = HD / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *qs_all = lds;                      // [heads][HD]
+    float *ws_all = qs_all + E;               // [heads][TkCap]
+    float *ks = ws_all + heads * TkCap;       // [TkCap][KP]   (E + heads * TkCap is a multiple of 4: 16-byte aligned rows)
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = blockIdx.x;
+    float *qs = qs_all + h * HD, *ws = ws_all + h * TkCap;
+    {   // the query of position `step`, rotated on the way into LDS (attention_kernel's expression, scale up)
+        const float *q = Q + (int64_t)r * q_rs + h * HD + (dstep ? (int64_t)step * xp.q_dyn : 0);
+        const int pp = step + minpos + xp.pmax;
+        for (int j = lane; j < HP; j += 64) {
+            const float sc = xp.scale_t[pp * HP + j];
+            const float c = xp.cos_t[step * HP + j] * sc, sn = xp.sin_t[step * HP + j] * sc;
+            const float2 x = *reinterpret_cast<const float2 *>(q + 2 * j);
+            qs[2 * j] = x.x * c + (-x.y) * sn;
+            qs[2 * j + 1] = x.y * c + x.x * sn;
+        }
+    }
+    {   // the row's key history, coalesced
+        const float *kb = K + (int64_t)r * k_rs;
+        const int E4 = E >> 2;
+        for (int i = tid; i < Tk * E4; i += 256) {
+            const int t = i / E4, c4 = i - t * E4;
+            *reinterpret_cast<float4 *>(ks + t * KP + c4 * 4) = *reinterpret_cast<const float4 *>(kb + (int64_t)t * k_ts + c4 * 4);
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = lane; t < Tk; t += 64) {
+        const float4 *kp = reinterpret_cast<const float4 *>(ks + t * KP + h * HD);
+        const float4 *cp = reinterpret_cast<const float4 *>(xp.cos_t + t * HP);
+        const float4 *sp = reinterpret_cast<const float4 *>(xp.sin_t + t * HP);
+        const float4 *ip = reinterpret_cast<const float4 *>(xp.iscale_t + (minpos + t + xp.pmax) * HP);
+        float dot = 0.f;
+        for (int d8 = 0; d8 < HD / 8; ++d8) {  // key t of the raw history, rotated (scale down) as it is read
+            const float4 k0 = kp[2 * d8], k1 = kp[2 * d8 + 1], cc = cp[d8], ss = sp[d8], ii = ip[d8];
+            float c, sn;
+            c = cc.x * ii.x, sn = ss.x * ii.x;
+            dot += qs[d8 * 8 + 0] * (k0.x * c + (-k0.y) * sn);
+            dot += qs[d8 * 8 + 1] * (k0.y * c + k0.x * sn);
+            c = cc.y * ii.y, sn = ss.y * ii.y;
+            dot += qs[d8 * 8 + 2] * (k0.z * c + (-k0.w) * sn);
+            dot += qs[d8 * 8 + 3] * (k0.w * c + k0.z * sn);
+            c = cc.z * ii.z, sn = ss.z * ii.z;
+            dot += qs[d8 * 8 + 4] * (k1.x * c + (-k1.y) * sn);
+            dot += qs[d8 * 8 + 5] * (k1.y * c + k1.x * sn);
+            c = cc.w * ii.w, sn = ss.w * ii.w;
+            dot += qs[d8 * 8 + 6] * (k1.z * c + (-k1.w) * sn);
+            dot += qs[d8 * 8 + 7] * (k1.w * c + k1.z * sn);
+        }
+        ws[t] = dot;
+        mx = fmaxf(mx, dot);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int t = lane; t < Tk; t += 64) {
+        const float e = expf(ws[t] - mx);
+        ws[t] = e;
+        sum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int t = lane; t < Tk; t += 64) ws[t] *= inv;
+    __syncthreads();
+    const float *vb = V + (int64_t)r * v_rs + h * HD;
+    float *ob = O ? O + (int64_t)r * o_rs + h * HD : nullptr;
+    constexpr int U = 8;  // values of V in flight per lane; the sum itself stays t-ordered
+    for (int d = lane; d < HD; d += 64) {
+        float acc = 0.f;
+        for (int t0 = 0; t0 < Tk; t0 += U) {
+            float vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) vv[u] = (t0 + u < Tk) ? vb[(int64_t)(t0 + u) * v_ts + d] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (t0 + u < Tk) acc += ws[t0 + u] * vv[u];
+        }
+        if (opl.p) qs[d] = acc;
         else ob[d] = acc;
     }
     if (opl.p) {
@@ -1270,6 +1371,15 @@ __global__ void memory_kv_lines_kernel(const float *__restrict__ Kf, const float
     }
 }
 
+// the decoder's self-attention on attention_self_kernel (1, default; MIT_ATT_NO_SELF in the environment starts with 0) or on
+// attention_kernel (0): same bits either way (tests/test_ocr_gpu.py), a switch for A/B runs
+static std::atomic<int> g_att_self_rows{getenv("MIT_ATT_NO_SELF") ? 0 : 1};
+extern "C" int mit_attention_self_rows_set(int on) {
+    const int prev = g_att_self_rows.load(std::memory_order_relaxed);
+    if (on >= 0) g_att_self_rows.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+
 void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, int64_t k_rs, int64_t k_ts, const float *V,
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
                     int kv_div, hipStream_t s, int heads, int head_dim, const int *dstep, const OcrAttXpos *xpos, const OcrPlanes *o_planes) {
@@ -1314,6 +1424,17 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
             }
             hipLaunchKernelGGL(attention_rows_kernel, dim3(heads, R, (Tq + (ATTR_THREADS / 64) * ATTR_GQ - 1) / ((ATTR_THREADS / 64) * ATTR_GQ)), dim3(ATTR_THREADS), sm, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
                                o_ts, klen, Tq, Tk, head_dim);
+            return;
+        }
+    }
+    if (g_att_self_rows.load(std::memory_order_relaxed) && Tq == 1 && kv_div == 1 && !klen && xp.cos_t && xp.rot_k && heads * 64 == 256 && head_dim % 8 == 0 && k_ts == (int64_t)heads * head_dim &&
+        !((q_rs | k_rs | k_ts | v_rs | v_ts) & 3) && !((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(Q)) & 15) && ((heads * Tk) & 3) == 0) {
+        const size_t sm = ((size_t)heads * head_dim + (size_t)heads * Tk + (size_t)Tk * (heads * head_dim + 4)) * sizeof(float);
+        if (sm <= 64 * 1024) {
+            // the decoder's self-attention: the row's key history staged once for its four heads (bitwise attention_kernel's results)
+            MitProbeScope probe("attention_self_kernel", s, 4.0 * heads * head_dim * ((double)R * 2.0 * Tk + 2.0 * (double)R),
+                                4.0 * (double)R * heads * Tk * head_dim);
+            hipLaunchKernelGGL(attention_self_kernel, dim3(R), dim3(256), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs, Tk, heads, head_dim, dstep, xp, opl);
             return;
         }
     }

@@ -270,6 +270,7 @@ SYMBOLS = {
                                 C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p]),
     "mit_attention_lines_xpos_max_len": (C.c_int, [C.c_int]),
+    "mit_attention_self_rows_set": (C.c_int, [C.c_int]),
     "mit_attention_lines_xpos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.POINTER(MitXposTables), C.c_void_p]),
     "mit_memory_kv_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,

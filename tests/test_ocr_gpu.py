@@ -431,3 +431,29 @@ def test_fused_convnext_mlp_matches_the_two_launch_form(cuda, ocr_setup, rows):
     e_fused, e_two = float((x1.cpu().double() - ref).abs().max()) / ymax, float((x2.cpu().double() - ref).abs().max()) / ymax
     assert e_fused < 4 * e_two + 2e-6, (e_fused, e_two)
     assert float((x1 - x2).abs().max()) / ymax < 2e-6
+
+
+@pytest.mark.parametrize("widths,T", [([50, 77, 120, 121, 64, 200], 14), ([40 + 5 * i for i in range(40)], 9)])
+def test_row_staged_self_attention_is_bitwise_the_per_head_kernel(cuda, ocr_setup, widths, T):
+    """attention_self_kernel (the decoder's self-attention with a row's key history staged once for its four heads) against
+    attention_kernel (one single-wave workgroup per head and row): the whole beam search — tokens, lengths, probabilities, colours —
+    must come out bit for bit the same (6 lines: the few-row decoder form with planar outputs; 40 lines: likewise, pooled)."""
+    from manga_image_translator_amd import lib as L_
+
+    sd, D, eng = ocr_setup
+    lib = L_.load()
+    crops = _crops(widths, seed=3)
+    outs = []
+    for on in (1, 0, 1):
+        prev = lib.mit_attention_self_rows_set(on)
+        try:
+            assert lib.mit_attention_self_rows_set(-1) == on
+            r = eng.recognize(crops, max_seq_length=T, suppress_eos=True)
+            torch.cuda.synchronize()
+        finally:
+            lib.mit_attention_self_rows_set(prev)
+        outs.append({k: v.clone() for k, v in r.items() if torch.is_tensor(v)})
+    assert {"tokens", "length", "prob", "colors"} <= set(outs[0])
+    for other in outs[1:]:
+        for k, v in outs[0].items():
+            assert torch.equal(v, other[k]), k
