@@ -13,6 +13,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python bench.py --no-cpu-baseline --no-dropin --no-fp32-leg --no-two-streams --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof rc=$?"
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/prof
+if [ "${3:-}" = "no-pmc" ]; then head -c 1500 $OUT/bench.json; echo; tail -3 $OUT/bench.err; exit 0; fi   # counters were taken by an earlier call of the round
 bash scripts/pmc_stage.sh detect,ocr,inpaint 64 $OUT/pmc_traffic.json > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
 bash scripts/pmc_mfma.sh 16 $OUT/mfma_busy.json > $OUT/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"; tail -1 $OUT/pmc_mfma.log
 MIT_GEMM_SPLIT=0 bash scripts/pmc_mfma.sh 16 $OUT/mfma_busy_fp32.json > $OUT/pmc_mfma_fp32.log 2>&1; tail -1 $OUT/pmc_mfma_fp32.log
