@@ -103,6 +103,22 @@ class _EncLayer:
         self.ln = [(sd[f"{p}.norm{i}.weight"].float().to(device), sd[f"{p}.norm{i}.bias"].float().to(device)) for i in (1, 2)]
 
 
+def fused_mlp_row_permutation(hidden: int) -> torch.Tensor:
+    """Row order of pwconv2's weight for ``mit_convnext_mlp``: row k' of the permuted matrix is row ``perm[k']`` of the original.
+
+    The first contraction is computed transposed, so its 32x32 accumulator holds, for a lane's pixel, the hidden indices
+    ``32 hb + (r & 3) + 8 (r >> 2) + 4 lh`` in registers r = 0..15 (lh = lane >> 5).  Registers r = 8 s .. 8 s + 7 are handed to MFMA
+    step s of the second contraction as the lane's "8 consecutive k"; the B operand therefore has to list the hidden rows in that
+    order: k' = 32 hb + 16 s + 8 lh + j  <-  32 hb + (j & 3) + 8 (2 s + (j >> 2)) + 4 lh.  Within every group of 16 rows (one MFMA
+    step) the permutation only reorders: each step still contracts the hidden values 16 (2 hb + s) .. + 15."""
+    if hidden % 32:
+        raise ValueError("hidden width must be a multiple of 32")
+    k = torch.arange(hidden)
+    hb, rem = k // 32, k % 32
+    s_, lh, j = rem // 16, (rem % 16) // 8, rem % 8
+    return 32 * hb + (j & 3) + 8 * (2 * s_ + (j >> 2)) + 4 * lh
+
+
 class _Block:
     """ConvNeXtBlock (:184-214)."""
 
@@ -127,10 +143,7 @@ class _Block:
             p1, _ = ops._split_for(w1.w, w1.Np, w1.Kp, (0, 0))
             if p1 is None:
                 raise RuntimeError("ConvNeXt block: pwconv1 carries no split planes (packed in GEMM mode 0)")
-            k = torch.arange(4 * self.dim)
-            hb, rem = k // 32, k % 32
-            s_, lh, j = rem // 16, (rem % 16) // 8, rem % 8
-            perm = 32 * hb + (j & 3) + 8 * (2 * s_ + (j >> 2)) + 4 * lh           # row k' of the permuted weight = row perm[k'] of W2
+            perm = fused_mlp_row_permutation(4 * self.dim)
             w2p = w2.w.view(w2.Kp, w2.Np)[perm.to(w2.w.device)].contiguous()
             self._fused = (p1, ops.split_weight(w2p), w2.Np)
         return self._fused
