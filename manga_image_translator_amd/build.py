@@ -40,10 +40,10 @@ HIPCC_FLAGS = [
 # neg modifiers from scalar source (winograd.hip: 30, map_to_u8_kernel: 2, …) — the very form that misbehaved beside MFMA co-tenants.
 # The units below use packed math on purpose (explicit ext_vector arithmetic whose operands are whole register pairs: the channel-pair
 # FMAs of the 7x7 64->3 convolution, the float4 epilogues of the conv_gemm tiles — the generic tile runs 2.1x slower without them
-# (profiles/r07h) —, the planar GEMM, the depthwise convolutions' float4 FMAs) and are checked by tests/test_build_flags.py to contain no packed-fp32 instruction with a
+# (profiles/r07h) —, the planar GEMM) and are checked by tests/test_build_flags.py to contain no packed-fp32 instruction with a
 # modifier; every other unit must contain none at all.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-PACKED_FP32_BY_DESIGN = {"conv_small_cout.hip", "pgemm.hip", "ocr_dwconv.hip"} | {f"conv_gemm_inst{i}.hip" for i in range(8)}
+PACKED_FP32_BY_DESIGN = {"conv_small_cout.hip", "pgemm.hip"} | {f"conv_gemm_inst{i}.hip" for i in range(8)}
 
 
 def flags_for(src_name: str) -> list:
