@@ -151,6 +151,12 @@ class DenseStages:
                 "mask_raw": np.asarray(mask_raw), "mask": np.asarray(mask), "inpainted": np.asarray(out), "device": self.device_name,
                 "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES")}
 
+    async def translate_batch(self, images, config=None, batch_size: int = 1):
+        """``/simple_execute/translate_batch`` (server/instance.py:22-26 sends ``{"images", "config", "batch_size"}``): the pages of a
+        request one after the other through ``translate`` — the plugins are the reference's page-at-a-time interface; the batched engines
+        (pipeline.PageEngine, coupled.CoupledPageEngine) are what a batch job calls directly."""
+        return [await self.translate(im, config) for im in images]
+
     async def device_info(self, image=None, config=None):   # (the executor's send calls always carry both attributes)
         await self._load()
         import torch
@@ -321,6 +327,18 @@ class ExecutorInstance:
                 if r.status != 200:
                     raise RuntimeError(f"worker {self.url}: HTTP {r.status}: {body[:300]!r}")
                 return pickle.loads(body)   # our own worker's reply
+
+    async def sent_batch(self, images, config, batch_size: int = 1):
+        """``ExecutorInstance.sent_batch`` (server/instance.py:22-26)."""
+        import aiohttp
+
+        data = pickle.dumps({"images": list(images), "config": config, "batch_size": int(batch_size)})
+        async with aiohttp.ClientSession() as s:
+            async with s.post(f"{self.url}/simple_execute/translate_batch", data=data, headers=self._headers()) as r:
+                body = await r.read()
+                if r.status != 200:
+                    raise RuntimeError(f"worker {self.url}: HTTP {r.status}: {body[:300]!r}")
+                return pickle.loads(body)
 
     async def sent_stream(self, image, config, sender: Callable[[int, bytes], None], method: str = "translate"):
         import aiohttp

@@ -23,6 +23,9 @@ class Stub:
             await h("finished", True)
         return {"sum": int(a.astype(np.int64).sum()), "shape": list(a.shape), "visible": os.environ.get("HIP_VISIBLE_DEVICES"), "pid": os.getpid()}
 
+    async def translate_batch(self, images, config=None, batch_size=1):
+        return [await self.translate(im, config) for im in images]
+
     async def fail(self, image, config=None):
         raise ValueError("stage exploded")
 

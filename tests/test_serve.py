@@ -100,6 +100,9 @@ def test_pool_starts_one_pinned_worker_per_gpu_and_serves_requests():
         asyncio.run(a.sent_stream(img, {}, lambda st, payload: frames.append((st, payload)), method="fail"))
         assert frames == [(2, b"stage exploded")]
 
+        batch = asyncio.run(b.sent_batch([img, img + 1, img + 2], {}, batch_size=2))      # server/instance.py:22-26
+        assert [o["sum"] for o in batch] == [int((img + i).sum()) for i in range(3)] and {o["visible"] for o in batch} == {"5"}
+
         outs = asyncio.run(pool.map([img + i for i in range(6)], {"sleep": 0.2}))
         assert [o["sum"] for o in outs] == [int((img + i).sum()) for i in range(6)]        # results in request order
         assert {o["visible"] for o in outs} == {"3", "5"}                                  # both workers took requests
