@@ -12,10 +12,23 @@ pytestmark = pytest.mark.gpu
 H, W, LINES, D = 512, 384, 5, 128
 
 
-def _port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def _port(n=2):
+    """First port of a run of ``n`` consecutive free ports (the pool numbers its workers base, base + 1, ...)."""
+    for _ in range(50):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            base = s.getsockname()[1]
+        ok = True
+        for k in range(1, n):
+            with socket.socket() as t:
+                try:
+                    t.bind(("127.0.0.1", base + k))
+                except OSError:
+                    ok = False
+                    break
+        if ok:
+            return base
+    raise RuntimeError("no run of free ports found")
 
 
 def test_two_workers_on_one_box_return_identical_pages(cuda):
