@@ -79,7 +79,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pages", type=int, default=64, help="pages per GPU per step (BASELINE config 3: 64)")
+    ap.add_argument("--pages", type=int, default=None, help="pages per GPU per step (default 64 = BASELINE config 3; 128 = config 4 when --gpus 8)")
+    ap.add_argument("--details", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_details.json"),
+                    help="the full record of the run (every sub-measurement) goes here and to stderr; stdout carries the <= 4 KB headline")
     ap.add_argument("--config4", action="store_true", help="BASELINE config 4 preset: 128 pages per GPU (1024 pages over 8 GPUs)")
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 on one GPU: ESRGAN 4x + lama_large (its own line)")
     ap.add_argument("--config1", action="store_true", help="BASELINE config 1 on one GPU: default detector + 48px + lama_mpe at 1024^2, B = 1 (its own line)")
@@ -116,8 +118,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", default="8,16,32,64,128", help="thread counts swept per stage")
     ap.add_argument("--prof-dump", default="", help="write one CSV line per conv_gemm launch of the instrumented passes to this path (suffix .<stage>)")
     args = ap.parse_args(argv)
-    if args.config4:
-        args.pages = 128
+    if args.config4 or (args.pages is None and args.gpus == 8):
+        args.pages = 128   # BASELINE config 4: 1024 pages over 8 GPUs; --gpus 8 without --pages IS that configuration
+    if args.pages is None:
+        args.pages = 64
     return args
 
 
@@ -910,6 +914,86 @@ def config1_line(args, device):
             "gemm_mode": {"mode": _ops.split_mode()}, "stages_ms_per_page": stages}
 
 
+HEADLINE_MAX_BYTES = 4096   # the driver keeps an 8 KB tail of stdout: the line it parses must fit with room to spare
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out: dict, details_path: str = "") -> dict:
+    """The ONE stdout line: the contract keys, ``roofline`` and ``cpu_baseline`` reduced to what the contract names, and one number per
+    sub-measurement.  Everything else the run measured stays in the full record (``bench_details.json`` + stderr)."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data"))
+    cfg = dict(out.get("config") or {})
+    cfg.pop("microbatch", None)
+    line["config"] = cfg
+    roof = out.get("roofline")
+    if roof:
+        r = _pick(roof, ("bound", "kernel", "unit", "achieved", "peak", "frac", "plane_pairs", "avg_launch_us", "launches",
+                         "alg_gflop_per_launch", "fp32_equivalent_tflops"))
+        t = roof.get("traffic")
+        r["traffic"] = None if not t else {**_pick(t, ("read_GB", "write_GB", "ratio_to_algorithmic", "source")), "per": "launch"}
+        r["stages"] = {k: _pick(v, ("ms_per_page", "frac_of_mfma_roofline")) | ({"mfma_busy": v["mfma_busy"].get("frac")} if v.get("mfma_busy") else {})
+                       for k, v in (roof.get("stages") or {}).items()}
+        if roof.get("whole_step"):
+            r["whole_step_frac_of_mfma_roofline"] = roof["whole_step"].get("frac_of_mfma_roofline")
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    cpu = out.get("cpu_baseline")
+    line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "sample", "seconds_per_stage")) if cpu else None
+    if "speedup_vs_cpu_baseline" in out:
+        line["speedup_vs_cpu_baseline"] = out["speedup_vs_cpu_baseline"]
+    par = out.get("parity_checked")
+    line["parity_checked"] = _pick(par, ("ok", "pages")) if par else None
+    if out.get("fp32_mfma"):
+        f = out["fp32_mfma"]
+        line["fp32_mfma"] = {**_pick(f, ("value", "unit", "ms_per_step")),
+                             **({"roofline_frac": f["roofline"].get("frac")} if f.get("roofline") else {})}
+    line["gemm_mode"] = _pick(out.get("gemm_mode") or {}, ("mode",))
+    if out.get("two_streams"):
+        line["two_streams"] = _pick(out["two_streams"], ("value", "results_equal_one_stream"))
+    if out.get("dropin"):
+        line["dropin"] = _pick(out["dropin"], ("value", "unit", "ms_per_page", "ms_per_stage"))
+    if out.get("coupled"):
+        line["coupled"] = {k: _pick(v, ("value", "unit", "ms_per_page")) for k, v in out["coupled"].items()
+                           if isinstance(v, dict) and "value" in v}
+    if out.get("other_configs"):
+        line["other_configs"] = {k: _pick(v, ("value", "unit", "pages_per_step")) for k, v in out["other_configs"].items() if v}
+    if out.get("gather"):
+        line["gather"] = _pick(out["gather"], ("verified_blocks", "overlap_with_compute", "bytes_per_step", "wait_ms_rank0_per_step"))
+    if out.get("leg_errors"):
+        line["leg_errors"] = {k: str(v)[:120] for k, v in out["leg_errors"].items()}
+    if details_path:
+        line["details"] = details_path
+    if len(json.dumps(line)) > HEADLINE_MAX_BYTES:   # never lose the contract keys to a long tail: drop the optional ones, last first
+        for k in ("other_configs", "coupled", "dropin", "two_streams", "fp32_mfma", "gather", "leg_errors"):
+            line.pop(k, None)
+            if len(json.dumps(line)) <= HEADLINE_MAX_BYTES:
+                break
+    return line
+
+
+def emit(out: dict, details_path: str) -> None:
+    """Full record -> ``details_path`` and stderr; compact headline -> the LAST line of stdout."""
+    full = json.dumps(out)
+    wrote = ""
+    if details_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(details_path)), exist_ok=True)
+            with open(details_path, "w") as f:
+                f.write(full + "\n")
+            wrote = details_path
+        except OSError as ex:
+            print(f"bench.py: could not write {details_path}: {ex}", file=sys.stderr)
+    print("bench.py full record: " + full, file=sys.stderr)
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(json.dumps(compact_line(out, wrote)), flush=True)
+
+
 def _free_port() -> int:
     import socket
 
@@ -1235,7 +1319,7 @@ def main():
             out["gather"] = gather_info
         if leg_errors:
             out["leg_errors"] = leg_errors
-        print(json.dumps(out))
+        emit(out, args.details)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -55,6 +55,49 @@ def test_committed_bench_lines_follow_the_contract(path):
         assert c2["batch"]["lines_per_page_after_ocr"]["min"] >= 24
 
 
+@pytest.mark.parametrize("path", LINES[-6:], ids=[os.path.basename(p) for p in LINES[-6:]])
+def test_headline_of_a_full_record_fits_the_drivers_tail(path):
+    """The driver keeps an 8 KB tail of stdout and parses its last line (BENCH_r05.parsed was null: a 20 KB line).  bench.py prints a
+    compact headline; here every recent committed full record is reduced the same way and must fit, parse from a tail, and keep
+    ``roofline`` and ``cpu_baseline`` with the contract's fields."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = json.load(open(path))
+    line = json.dumps(bench.compact_line(full, "bench_details.json"))
+    assert len(line) < bench.HEADLINE_MAX_BYTES == 4096
+    stdout = "warning: something a library printed earlier\n" * 400 + line + "\n"
+    d = json.loads(stdout[-8000:].strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["ms_per_step"] == full["ms_per_step"] and "model" not in d["config"]
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(c)
+
+
+def test_emit_prints_the_headline_last_and_keeps_the_full_record(tmp_path, capsys):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = json.load(open(LINES[-1]))
+    bench.emit(full, str(tmp_path / "sub" / "details.json"))
+    cap = capsys.readouterr()
+    last = cap.out.strip().splitlines()[-1]
+    assert len(cap.out) < 4200 and json.loads(last)["value"] == full["value"]
+    assert json.load(open(tmp_path / "sub" / "details.json")) == full          # nothing measured is lost
+    assert "conv_gemm_by_tile" in cap.err
+
+
+def test_gpus_8_without_pages_is_baseline_config_4():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.parse(["--gpus", "8"]).pages == 128 and bench.parse(["--gpus", "1"]).pages == 64
+    assert bench.parse(["--gpus", "8", "--pages", "64"]).pages == 64 and bench.parse(["--gpus", "4"]).pages == 64
+
+
 def test_bench_cli_parses_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0
