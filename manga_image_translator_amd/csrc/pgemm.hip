@@ -493,6 +493,90 @@ __global__ __launch_bounds__(64 * WAVES_M *WAVES_N, MINW) void pgemm_kernel(cons
         }
     zero_acc();
 
+    if constexpr ((VAR & 64) != 0) {
+        // ---- ping-pong form (round 6 experiment): eight waves = two per SIMD (waves w and w + 4 share one); the second
+        // half runs ONE barrier behind the first, so that between any two barriers one wave of a SIMD is in its compute segment (the 24
+        // MFMAs of a K-tile, nothing else, s_setprio 1) and its partner in its load segment (fragment reads of its next K-tile, the DMA
+        // pieces of K-tile + NS - 1, the counted wait).  Two barriers per K-tile; per accumulator the same pairs in the same order as
+        // every other tile.  Hazards (g = global barrier count, first half: L(t) in [2t, 2t+1], C(t) in [2t+1, 2t+2]; second half one
+        // later): a stage is re-filled in L(t) with K-tile t + NS - 1 after both halves' reads of K-tile t - 1 have completed
+        // (lgkmcnt(0) before the barrier that ends every L); every wave has waited for its own pieces of K-tile t + 1 before barrier
+        // 2t + 2, the first barrier ahead of anybody's reads of it.
+        static_assert(NW == 8 && NPROD == 6 && TM <= 2 && TN <= 2, "ping-pong form: 8 waves, 6 pairs, 64 x 64 wave tile");
+        const bool second = wave >= NW / 2;
+        bf16x8 af[3][TM], bf[3][TN];
+        int it = 0, slot = 0, fslot = NS - 1;
+        for (int ti = 0;; ++ti) {
+            wait_vmcnt<0>();
+            wg_barrier();
+            if (ti > 0) {
+                const int t = tile_lo + (ti - 1) * tile_step;
+                const int z = uni(t / tiles_per_z), tt = t - z * tiles_per_z;
+                const int mt = uni(tt / NT), nt = tt - mt * NT;
+                float *tbuf = reinterpret_cast<float *>(ring + fslot * STAGE) + wave * (32 * EPI_PITCH);
+                pg_epilogue<TM, TN, OUTP>(p, acc, tbuf, z, mt * BM + wm0, nt * BN + wn0, lane);
+                if (ti == tile_n) break;
+                if (OUTP == 0) wg_barrier();
+            }
+            zero_acc();
+            if (second) wg_barrier();  // the stagger
+            for (int kt = 0; kt < KT; ++kt, ++it) {
+                // -- load segment
+                const unsigned int aa = a_frag0 + (unsigned int)slot * (STAGE * 16u), ba = b_frag0 + (unsigned int)slot * (STAGE * 16u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    af[pl][0] = pl == 0 ? lds_read16<0>(aa) : pl == 1 ? lds_read16<(1 * KH * BM) * 16>(aa) : lds_read16<(2 * KH * BM) * 16>(aa);
+                    if constexpr (TM >= 2)
+                        af[pl][TM >= 2 ? 1 : 0] = pl == 0 ? lds_read16<32 * 16>(aa) : pl == 1 ? lds_read16<(1 * KH * BM + 32) * 16>(aa) : lds_read16<(2 * KH * BM + 32) * 16>(aa);
+                    bf[pl][0] = pl == 0 ? lds_read16<0>(ba) : pl == 1 ? lds_read16<(1 * KH * BN) * 16>(ba) : lds_read16<(2 * KH * BN) * 16>(ba);
+                    if constexpr (TN >= 2)
+                        bf[pl][TN >= 2 ? 1 : 0] = pl == 0 ? lds_read16<32 * 16>(ba) : pl == 1 ? lds_read16<(1 * KH * BN + 32) * 16>(ba) : lds_read16<(2 * KH * BN + 32) * 16>(ba);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bool do_issue = issued < total;
+                if (do_issue) {
+#pragma unroll
+                    for (int i = 0; i < G; ++i) issue_piece(fslot, i);
+                    issue_done();
+                }
+                issued += do_issue ? 1 : 0;
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int ahead = issued - it - 2;  // K-tiles issued behind K-tile it + 1
+                    if (ahead <= 0) wait_vmcnt<0>();
+                    else if (ahead == 1 || NS == 3) wait_vmcnt<G>();
+                    else wait_vmcnt<2 * G>();
+                }
+                lds_wait<0>();
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) lds_tie(af[pl][mi]);
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) lds_tie(bf[pl][ni]);
+                }
+                wg_barrier();
+                // -- compute segment
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int pr = 3; pr < 9; ++pr)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kSplitPA[pr]][mi], bf[kSplitPB[pr]][ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                wg_barrier();
+                fslot = slot;
+                slot = slot + 1 == NS ? 0 : slot + 1;
+            }
+            if (!second) wg_barrier();  // the halves meet again for the epilogue
+        }
+        return;
+    }
+
     // ---- the walk over this workgroup's output tiles and their K-tiles (`it` counts K-tiles over all of them; the DMA runs NS-1 of
     // them ahead, across tile boundaries).  The DMA pieces of K-tile `it` must have landed before its fragments are read.  In issue
     // order behind them: the K-tiles it+1 .. issued-1 and, after an epilogue, its stores.

@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9][a-z]_bench.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9][a-z]_bench.json")))
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -163,3 +163,17 @@ def test_split_tile_roofline_view():
     r = bench.split_tile_roofline("split128x128x16p6o", 161.8)
     assert r["plane_pairs"] == 6 and abs(r["executed_bf16_tflops"] - 970.8) < 0.1 and abs(r["frac_of_bf16_mfma_peak"] - 0.3883) < 1e-3
     assert bench.split_tile_roofline("split128x128x16p9m", 126.6)["plane_pairs"] == 9
+
+
+HEADLINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9][a-z]_bench_headline.json")))
+
+
+@pytest.mark.parametrize("path", HEADLINES, ids=[os.path.basename(p) for p in HEADLINES])
+def test_committed_stdout_of_a_driver_style_run_parses_from_an_8k_tail(path):
+    """What bench.py actually printed on the GPU box for the driver's command (round 6 on): the whole stdout, as the driver sees it."""
+    out = open(path).read()
+    assert len(out) < 4096
+    d = json.loads(out[-8000:].strip().splitlines()[-1])
+    assert d["metric"].startswith("pages/sec end-to-end") and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+    full = os.path.join(ROOT, "profiles", os.path.basename(path).replace("_headline", ""))
+    assert json.load(open(full))["value"] == d["value"]
