@@ -18,6 +18,7 @@ const CfgEntry kCfgs[] = {
 #define KNAME_launch_fast "conv_gemm_fast_kernel"
 #define KNAME_launch_gemv "conv_gemv_kernel"
 #define KNAME_launch_split "conv_gemm_split_kernel"
+#define KNAME_launch_split_pp "conv_gemm_split_pp_kernel"
 #define X(g, name, fast, BM, BN, BK, fn, ...) \
     {name, BM, BN, BK, fn<BM, BN, BK, __VA_ARGS__>, fast, KNAME_##fn "<" #BM ", " #BN ", " #BK ", " #__VA_ARGS__ ">"},
 #include "conv_gemm_cfgs.inc"
@@ -147,6 +148,13 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
             else if (t96 >= 0 && p.N > 64 && p.N <= 96 && K >= 256) c = t96;
             else if (t192 >= 0 && p.N == 192 && K >= 256) c = t192;
         }
+        // Ping-pong tile (round 6; conv_gemm_split_pp.h: eight waves, one workgroup per CU, compute and load segments alternating on
+        // every SIMD): 1.12-1.15x of the 128 x 128 tile on long-K layers whose N is a multiple of 256 (LaMa's stride-2 and transposed
+        // convolutions at 256 / 512 channels, the detector's 2048 -> 256 layers), 0.8-1.0x on short K (an 8-32 step loop does not
+        // amortise a lone workgroup's prologue and 128 KB epilogue) — profiles/r10d_split_check_pp.log.  Same bits as every p6 tile.
+        static const bool pp_off = getenv("MIT_CONV_NO_PP") != nullptr;  // A/B knob
+        static const int pp256 = cfg_by_name("split128x256x16p6pp");
+        if (split == 6 && p.Z == 1 && !pp_off && pp256 >= 0 && p.N % 256 == 0 && p.ntaps * p.Cin >= 1024 && ((M + 127) / 128) * (p.N / 256) >= 512) c = pp256;
         // under-filled launches (one page through the plugins, the decoder's Linears): 64 x 64 tiles quadruple the workgroup count;
         // the arithmetic per output element is that of the large tiles, so a result does not depend on the choice
         const int sm = split == 6 ? small6 : small9;

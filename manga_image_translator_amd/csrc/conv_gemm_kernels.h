@@ -177,7 +177,7 @@ __device__ __forceinline__ void epilogue_store_vec(const MitConvGemm &p, f32x16 
     }
 }
 
-template <int BM, int TM, int TN, int XE = 0, int SMEM_FLOATS = 0>
+template <int BM, int TM, int TN, int XE = 0, int SMEM_FLOATS = 0, int NTHR = 256>
 __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM][TN], float *smem, const int M, const int m0,
                                          const int n0, const int wm0, const int wn0, const int z1, const int z0,
                                          const int HoWo, const int tid) {
@@ -185,7 +185,7 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
     // mbcnt) so that no thread-index-derived register has to stay live, or be spilled to scratch, across the loop
     RowOff *rowoff = reinterpret_cast<RowOff *>(smem);  // BM entries (<= A/B staging area)
     const int64_t c_dyn = p.dyn ? (int64_t)(*p.dyn) * p.c_dyn : 0;  // device-side step offset (hipGraph-replayed sequences), else 0
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += NTHR) {
         const int m = m0 + r;
         RowOff ro = {-1, 0, 0};
         if (m < M) {
@@ -203,11 +203,12 @@ __device__ __forceinline__ void epilogue(const MitConvGemm &p, f32x16 (&acc)[TM]
     }
     constexpr int ROWOFF_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4;
     constexpr int LUT_FLOATS = BM * (int)sizeof(LutOff) / 4;   // the row-lookup offsets sit behind the transpose buffers
-    constexpr bool VEC_FITS = SMEM_FLOATS >= ROWOFF_FLOATS + 4 * 32 * EPI_PITCH + LUT_FLOATS && !(XE & 1);
-    LutOff *lutoff = reinterpret_cast<LutOff *>(smem + ROWOFF_FLOATS + 4 * 32 * EPI_PITCH);
+    constexpr int NWAVES = NTHR / 64;  // one transpose buffer per wave
+    constexpr bool VEC_FITS = SMEM_FLOATS >= ROWOFF_FLOATS + NWAVES * 32 * EPI_PITCH + LUT_FLOATS && !(XE & 1);
+    LutOff *lutoff = reinterpret_cast<LutOff *>(smem + ROWOFF_FLOATS + NWAVES * 32 * EPI_PITCH);
     const bool lut = VEC_FITS && p.lut_rows != nullptr;   // (the launcher admits lut_rows only on kernels and operands that take the vector path)
     if (VEC_FITS && lut) {
-        for (int r = tid; r < BM; r += 256) {
+        for (int r = tid; r < BM; r += NTHR) {
             const int m = m0 + r;
             const unsigned int packed = m < M ? (unsigned int)p.lut_rows[m] : 0u;
             lutoff[r] = LutOff{(int32_t)((packed & 0xffffu) * (unsigned int)p.lut_ld), (int32_t)((packed >> 16) * (unsigned int)p.lut_ld)};
@@ -859,3 +860,4 @@ void launch_gemv(const MitConvGemm &p, int M, int MT, int NT, int KT, hipStream_
 }  // namespace mitcg
 
 #include "conv_gemm_split.h"  // conv_gemm_split_kernel, gemm_split_pack_kernel, launch_split (the split-bf16 tiles: GEMM mode 6 | 9)
+#include "conv_gemm_split_pp.h"  // conv_gemm_split_pp_kernel, launch_split_pp: the eight-wave ping-pong form of the split tile

@@ -873,6 +873,8 @@ const PgTile kPgTiles[] = {
     PG_TILE_V("pg128x128s3p6d", 128, 128, 2, 2, 3, 6, 0, 2, 2, 16),  // 15: tile 0 with the DMA pieces in the shadow of the fragment reads
     PG_TILE_V("pg128x128s3p6dp", 128, 128, 2, 2, 3, 6, 0, 2, 2, 48), // 16: ... and s_setprio around the MFMAs
     PG_TILE_V("pg128x128s3p6p", 128, 128, 2, 2, 3, 6, 0, 2, 2, 32),  // 17: tile 0 with s_setprio around the MFMAs
+    PG_TILE_V("pg256x128s3p6pp", 256, 128, 4, 2, 3, 6, 0, 2, 1, 64),  // ping-pong halves (round 6 experiment): see the VAR & 64 loop
+    PG_TILE_V("pg128x256s3p6pp", 128, 256, 2, 4, 3, 6, 0, 2, 1, 64),
     // few-row launches (the decoder's Linears at one page): one wave per 32 x 32 block, operands streamed through registers
     PG_ROWS_TILE("pgrows32d6p6", 6, 6, 0),    // 18: six k steps ahead (mit_pgemm_rows: the native decoder loop)
     PG_ROWS_TILE("pgrows32d6p6P", 6, 6, 1),   // 19

@@ -54,6 +54,7 @@ int main(int argc, char **argv) {
     const int w6o = find_cfg("split64x256x16p6o");
     const int t192 = find_cfg("split128x192x16p6o"), t256 = find_cfg("split256x64x16p6o");
     const int t160 = find_cfg("split128x160x16p6o"), t96 = find_cfg("split128x96x16p6o");  // exact-N tiles for N = 160 k / N = 80  // wide-N tile (-1 in builds without it: skipped)
+    const int pp = find_cfg("split256x128x16p6pp"), pq = find_cfg("split128x256x16p6pp");  // round 6: the eight-wave ping-pong tiles
     const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c"), s64k = find_cfg("split64x64x32p6o");
     if (f_wide < 0 || f_narrow < 0 || s6 < 0 || s9 < 0 || s3 < 0 || n6 < 0 || n9 < 0 || s9m < 0) {
         fprintf(stderr, "tile names not found\n");
@@ -97,8 +98,23 @@ int main(int argc, char **argv) {
         {"decoder-like M=10240: 320->960", 1, 1, 10240, 320, 960, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6o, n6o, s64, s64k, s64, s64k}},
         {"decoder-like M=10240: 2048->320", 1, 1, 10240, 2048, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s64, s64k, s64, s64k}},
         {"detector-like 3x3 256->256, 1x32x32", 1, 32, 32, 256, 256, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s64, s64k, s64, s64k}},
-        {"ragged: M=1000, 48->200 3x3 zero", 1, 25, 40, 48, 200, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s6, n6, n9, s6m, n6m, s6o, n6o}},
+        {"ragged: M=1000, 48->200 3x3 zero", 1, 25, 40, 48, 200, 3, 1, MIT_PAD_ZERO, 1, MIT_ACT_LEAKY, f_wide, {s6, n6, n9, s6m, n6m, s6o, n6o, pp, pq}},
+        // round 6: the five shapes of the ping-pong experiment, each against the shipped 128 x 128 tile, twice
+        {"pp: long K 1x1 2304->512, M=46592, relu", 1, 182, 256, 2304, 512, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, pp, pq, s6o, pp, pq}},
+        {"pp: 3x3 s2 zero 256->512 (LaMa down3), 4x91x128", 4, 182, 256, 256, 512, 3, 2, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, pp, pq, s6o, pp, pq}},
+        {"pp: winograd Z=36, T=11776, 512->128", 1, 1, 11776, 512, 128, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6o, pp, s6o, pp}},
+        {"pp: winograd Z=36, T=11776, 128->384", 1, 1, 11776, 128, 384, 1, 1, MIT_PAD_ZERO, 36, MIT_ACT_NONE, f_wide, {s6o, pp, pq, s6o, pp, pq}},
+        {"pp: spectral 1x1 192->384, M=186368, relu", 1, 364, 512, 192, 384, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_RELU, f_wide, {s6o, t192, pp, pq, s6o, t192, pp, pq}},
+        {"pp: pw1 1x1 320->1280, M=131072, gelu", 1, 256, 512, 320, 1280, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_GELU, f_wide, {s6o, pp, pq, s6o, pp, pq}},
+        {"pp: pw2 1x1 1280->320, M=131072", 1, 256, 512, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6o, t160, pp, pq, s6o, t160, pp, pq}},
+        {"pp: 3x3 reflect 128->128, 2x96x160, relu", 2, 96, 160, 128, 128, 3, 1, MIT_PAD_REFLECT, 1, MIT_ACT_RELU, f_wide, {s6o, pp, s6o, pp}},
     };
+    if (const char *only = getenv("SC_CASE")) {  // substring filter on the case name
+        std::vector<Case> keep;
+        for (auto &c : cases)
+            if (strstr(c.name, only)) keep.push_back(c);
+        cases.swap(keep);
+    }
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     int bad = 0;
