@@ -47,6 +47,7 @@ except Exception:  # stand-alone: mirror the ModelWrapper lifecycle
         _key = "hip"
 
         _MODEL_SUB_DIR = ""
+        _MODEL_DIR = os.environ.get("MIT_MODEL_DIR", "models")   # ModelWrapper._MODEL_DIR (utils/inference.py:94): BASE_PATH/models there
 
         def __init__(self, *args, **kwargs):
             self._loaded = False
@@ -60,7 +61,7 @@ except Exception:  # stand-alone: mirror the ModelWrapper lifecycle
 
         @property
         def model_dir(self) -> str:
-            return os.path.join("models", self._MODEL_SUB_DIR)
+            return os.path.join(self._MODEL_DIR, self._MODEL_SUB_DIR)
 
         def _get_file_path(self, *args) -> str:
             return os.path.join(self.model_dir, *args)
@@ -101,10 +102,27 @@ except Exception:  # stand-alone: mirror the ModelWrapper lifecycle
                 raise Exception(f"{self._key}: Tried to forward pass without having loaded the model.")
             return await self._infer(*args, **kwargs)
 
-    _DetBase = _InpBase = _OcrBase = _UpBase = _Wrapper
+    # the sub-directories the reference's OfflineDetector / OfflineOCR / OfflineInpainter / OfflineUpscaler keep their files in
+    # (detection/common.py:138, ocr/common.py:54, inpainting/common.py:17, upscaling/common.py): a checkpoint tree laid out for the
+    # reference is found by the stand-alone plugins as it is
+    _DetBase = type("_DetBase", (_Wrapper,), {"_MODEL_SUB_DIR": "detection"})
+    _OcrBase = type("_OcrBase", (_Wrapper,), {"_MODEL_SUB_DIR": "ocr"})
+    _InpBase = type("_InpBase", (_Wrapper,), {"_MODEL_SUB_DIR": "inpainting"})
+    _UpBase = type("_UpBase", (_Wrapper,), {"_MODEL_SUB_DIR": "upscaling"})
 
 
 _RELEASE = "https://github.com/zyddnys/manga-image-translator/releases/download/beta-0.3/"
+
+
+def set_model_dir(path: str) -> None:
+    """Root directory of the checkpoint files for every plugin constructed afterwards — ``ModelWrapper._MODEL_DIR`` (utils/inference.py:94),
+    of the reference's class when the plugins subclass it, of the stand-alone mirror otherwise.  ``<path>/<_MODEL_SUB_DIR>/<file>`` as
+    the reference lays them out."""
+    if HAVE_REFERENCE:
+        from manga_translator.utils.inference import ModelWrapper as base  # type: ignore
+    else:
+        base = _Wrapper
+    base._MODEL_DIR = str(path)
 
 
 def _own_quad(q) -> Quadrilateral:

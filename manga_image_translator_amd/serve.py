@@ -12,8 +12,8 @@ What the reference has (nothing here replaces its server):
 
 What this module adds, and nothing more: the worker of that protocol with the HIP plugins inside, pinned to ONE GPU
 (``HIP_VISIBLE_DEVICES=<i>`` is set by the pool before the process imports torch), and a pool that starts one per visible GPU and
-registers each with a front server.  With ``manga_translator`` importable the worker IS the reference's ``MangaShare`` (the plugins are
-added to its registries first, ``plugins.register()``); without it (this image has no OpenCV, so the orchestrator cannot be imported) the
+registers each with a front server.  With ``manga_translator`` importable the worker IS the reference's ``MangaShare`` (``make_worker``: the
+plugins are added to its registries first, ``plugins.register()``); without it (this image has no OpenCV, so the orchestrator cannot be imported) the
 same endpoints serve ``DenseStages`` — the three dense stages chained the way the orchestrator chains them
 (``manga_translator.py:432-622``: detect -> OCR -> text-line merge -> mask refinement -> inpaint) — so the pool, the wire format and the
 GPU pinning are testable here.  The product path has no CPU fallback: a worker without a GPU fails at load.
@@ -55,16 +55,25 @@ def parse_frames(buffer: bytes) -> Tuple[List[Tuple[int, bytes]], bytes]:
     return out, buffer
 
 
-# the reference's allow-list (mode/share.py:14-24) plus this package's boundary types, which a request may carry as text lines
-SAFE_PICKLE_MODULES = frozenset({
-    "builtins", "collections", "numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.dtype", "numpy.dtypes", "numpy._core.numeric",
-    "numpy.core.numeric", "manga_translator", "manga_translator.utils", "manga_translator.utils.generic", "manga_translator.config",
+# The reference's allow-list is by MODULE (mode/share.py:14-24) and admits all of ``builtins`` — eval, exec, getattr, __import__ … —
+# so its "restricted" unpickler still executes whatever a request asks for.  Same modules here, but by (module, name): the container
+# and scalar types a request body is made of, numpy's array reconstruction, PIL images, and the reference's config / geometry classes.
+SAFE_PICKLE_MODULES = frozenset({   # modules whose classes are admitted wholesale: data-only packages of the reference and PIL (below)
+    "manga_translator", "manga_translator.utils", "manga_translator.utils.generic", "manga_translator.config",
 })
+SAFE_PICKLE_NAMES = frozenset({
+    ("builtins", n) for n in ("dict", "list", "tuple", "set", "frozenset", "int", "float", "complex", "bytes", "bytearray", "str", "bool", "slice",
+                              "range", "object")
+} | {("collections", "OrderedDict"), ("collections", "defaultdict"), ("collections", "deque")} | {
+    (m, n) for m in ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric")
+    for n in ("ndarray", "dtype", "_reconstruct", "scalar", "_frombuffer")
+} | {("numpy.dtypes", n) for n in ("UInt8DType", "Int8DType", "Int16DType", "UInt16DType", "Int32DType", "UInt32DType", "Int64DType", "UInt64DType",
+                                    "Float16DType", "Float32DType", "Float64DType", "BoolDType")})
 
 
 class RestrictedUnpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str):
-        if module in SAFE_PICKLE_MODULES or module.startswith("PIL."):
+        if (module, name) in SAFE_PICKLE_NAMES or module in SAFE_PICKLE_MODULES or module.startswith("PIL."):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"Deserialization of {module}.{name} is not allowed")
 
@@ -94,7 +103,10 @@ class DenseStages:
         if not torch.cuda.is_available():
             raise RuntimeError("a serving worker needs its GPU (HIP_VISIBLE_DEVICES selects it); there is no CPU path")
         ckpt = self.params.get("model_dir")
-        if ckpt:      # real checkpoints in the reference's layouts (plugins._load_*_checkpoint)
+        if ckpt:      # real checkpoints in the reference's layouts (plugins._load_*_checkpoint), under <model_dir>/<detection|ocr|inpainting>/
+            if not os.path.isdir(ckpt):
+                raise FileNotFoundError(f"--model-dir {ckpt!r} is not a directory")
+            P.set_model_dir(os.path.abspath(ckpt))
             self.det, self.ocr, self.inp = P.HipComicTextDetector(), P.HipModel48pxOCR(), P.HipLamaMPEInpainter()
         else:         # no checkpoint offline: seeded synthetic weights of the reference architectures (synth.py), identical in every worker
             d = int(self.params.get("dict_size", 512))
@@ -127,8 +139,8 @@ class DenseStages:
             tls = [Quadrilateral(np.asarray(p, dtype=np.int64), "", 1.0) for p in lines_in]
         ocr = cfg.get("ocr", {})
 
-        class _Cfg:
-            prob = float(ocr.get("prob", 0.0))
+        class _Cfg:   # OcrConfig.prob (config.py): None unless the request sets it — the plugin then keeps the reference's 0.2 (model_48px.py:104)
+            prob = None if ocr.get("prob") is None else float(ocr["prob"])
 
         steps = int(ocr.get("max_seq_length", 255))
         lines = await self.ocr.infer(page, tls, _Cfg(), False, int(ocr.get("ignore_bubble", 0)), steps, bool(ocr.get("suppress_eos", False))) if tls else []
@@ -195,8 +207,29 @@ def _make_engine(params: dict):
     return MangaTranslator(params)
 
 
+def make_worker(params: dict):
+    """The worker process's server object.  With the reference importable it IS the reference's ``MangaShare`` (mode/share.py:47-174) —
+    its endpoints, its unpickler, its ``MangaTranslator`` — and this package only adds its plugins to the registries first
+    (``plugins.register()``: ``ctd_hip`` / ``48px_hip`` / ``lama_mpe_hip`` … become choices of ``Config``).  Only where the reference cannot
+    be imported (this image: no OpenCV) the stand-alone mirror below serves the same protocol around ``DenseStages``."""
+    if not os.environ.get("MIT_SERVE_ENGINE"):
+        try:
+            from manga_translator.mode.share import MangaShare  # type: ignore
+        except Exception:
+            MangaShare = None
+        if MangaShare is not None:
+            from . import plugins as P
+
+            P.register()
+            if params.get("model_dir"):
+                P.set_model_dir(os.path.abspath(params["model_dir"]))
+            return MangaShare(params)
+    return HipShareWorker(params)
+
+
 class HipShareWorker:
-    """``MangaShare`` (mode/share.py:47-174) around ``_make_engine``: same endpoints, nonce rule, one-request lock and stream framing."""
+    """Stand-alone mirror of ``MangaShare`` (mode/share.py:47-174) around ``_make_engine``: same endpoints, nonce rule, one-request lock
+    and stream framing — pinned to the reference's own CLIENT (server/sent_data_internal.py) by tests/test_serve.py."""
 
     def __init__(self, params: Optional[dict] = None):
         params = dict(params or {})
@@ -206,7 +239,9 @@ class HipShareWorker:
         nonce = params.get("nonce", None)
         if not nonce:
             nonce = secrets.token_hex(16)
-        if nonce == "None":
+        if nonce == "None":   # the reference's way of switching the check off: only for a loopback listener (a request body is a pickle)
+            if self.host not in ("127.0.0.1", "localhost", "::1"):
+                raise ValueError(f"nonce 'None' (no authentication) is refused on host {self.host!r}: bind to 127.0.0.1 or set a nonce")
             nonce = None
         self.nonce = nonce
         self.lock = Lock()
@@ -385,16 +420,35 @@ class Executors:
         self.event.clear()
 
 
-def visible_gpus() -> List[str]:
-    """The device ids a pool starts workers on: the entries of HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set, else 0 … n-1 as
-    rocm reports them (counted in a child process so that THIS process never initialises a GPU it would then keep memory on)."""
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+def visible_gpus() -> List[Tuple[str, str]]:
+    """The devices a pool starts workers on, as (environment variable, value) pairs that pin ONE process to ONE of them.
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES entries are HIP ordinals (within whatever ROCR_VISIBLE_DEVICES leaves); an entry of
+    ROCR_VISIBLE_DEVICES (index or GPU-UUID) is a ROCr-level name and can only be narrowed at that level — ``HIP_VISIBLE_DEVICES=<entry>``
+    beside an inherited ROCR list would index INTO the filtered list and find nothing.  With none set: 0 … n-1 as rocm reports them
+    (counted in a child process so that THIS process never initialises a GPU it would then keep memory on)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v:
-            return [x for x in v.split(",") if x != ""]
+            return [("HIP_VISIBLE_DEVICES", x) for x in v.split(",") if x != ""]
+    v = os.environ.get("ROCR_VISIBLE_DEVICES")
+    if v:
+        return [("ROCR_VISIBLE_DEVICES", x) for x in v.split(",") if x != ""]
     out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
     n = int(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else 0
-    return [str(i) for i in range(n)]
+    return [("HIP_VISIBLE_DEVICES", str(i)) for i in range(n)]
+
+
+def pin_env(env: Dict[str, str], gpu) -> Dict[str, str]:
+    """``env`` narrowed to one device: ``gpu`` is a (variable, value) pair of ``visible_gpus()`` or a bare HIP ordinal."""
+    var, val = gpu if isinstance(gpu, tuple) else ("HIP_VISIBLE_DEVICES", str(gpu))
+    env = dict(env)
+    env.pop("CUDA_VISIBLE_DEVICES", None)
+    if var == "ROCR_VISIBLE_DEVICES":
+        env.pop("HIP_VISIBLE_DEVICES", None)     # the one device ROCr leaves is HIP ordinal 0
+        env["ROCR_VISIBLE_DEVICES"] = str(val)
+    else:
+        env["HIP_VISIBLE_DEVICES"] = str(val)    # an inherited ROCR_VISIBLE_DEVICES stays: the ordinal counts within it
+    return env
 
 
 class WorkerPool:
@@ -418,8 +472,7 @@ class WorkerPool:
         for k, gpu in enumerate(self.gpus):
             env = dict(os.environ)
             env.update(self.env)
-            env["HIP_VISIBLE_DEVICES"] = str(gpu)           # the worker sees exactly one device, as cuda:0
-            env.pop("CUDA_VISIBLE_DEVICES", None)
+            env = pin_env(env, gpu)                          # the worker sees exactly one device, as cuda:0
             env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
             port = self.base_port + k
             cmd = [sys.executable, "-m", "manga_image_translator_amd.serve", "worker", "--host", self.host, "--port", str(port),
@@ -503,13 +556,15 @@ def _main(argv=None) -> int:
     w.add_argument("--nonce", default=os.getenv("MT_WEB_NONCE") or None)
     w.add_argument("--model-dir", default=None, help="directory with the reference's checkpoints; synthetic weights without it")
     w.add_argument("--dict-size", type=int, default=512)
-    w.add_argument("--preload", action="store_true", help="load the plugins before the first request")
+    w.add_argument("--lazy", action="store_true", help="load the plugins at the first request instead of before listening (default: before, so "
+                                                      "that a worker without its GPU or its checkpoints never reports ready)")
+    w.add_argument("--preload", action="store_true", help=argparse.SUPPRESS)   # the default since round 6
     a = ap.parse_args(argv)
     params = {"host": a.host, "port": a.port, "nonce": a.nonce, "model_dir": a.model_dir, "dict_size": a.dict_size, "use_gpu": True}
-    worker = HipShareWorker(params)
+    worker = make_worker(params)
     loop = asyncio.new_event_loop()
     asyncio.set_event_loop(loop)
-    if a.preload and hasattr(worker.manga, "_load"):
+    if not a.lazy and hasattr(worker.manga, "_load"):    # DenseStages: GPU visible? checkpoints found? — fail before /is_locked answers
         loop.run_until_complete(worker.manga._load())
     loop.run_until_complete(worker.listen())
     return 0

@@ -20,21 +20,13 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 
-try:  # inside the reference's environment the boundary type's corner order IS the reference's function, not this module's restatement
-    from manga_translator.utils.generic import sort_pnts as _reference_sort_pnts  # type: ignore
-except Exception:  # stand-alone (this image: the reference package does not import without OpenCV)
-    _reference_sort_pnts = None
-
-
 def sort_pnts(pts: np.ndarray) -> Tuple[np.ndarray, bool]:
-    """Canonical corner order [tl, tr, br, bl] and the vertical flag (generic.py:324-354): the reference's own function when its package
-    imports, else the restatement below (pinned to it by tests/golden/textline.npz)."""
+    """Canonical corner order [tl, tr, br, bl] and the vertical flag (generic.py:324-354).  ONE path in every environment: this
+    restatement, pinned to the reference's function by tests/golden/textline.npz — the product never executes reference code
+    other than the plugin base classes it subclasses."""
     pts = np.asarray(pts)
     if pts.shape != (4, 2):
         raise ValueError(f"sort_pnts expects 4 points, got shape {pts.shape}")
-    if _reference_sort_pnts is not None:
-        out, vertical = _reference_sort_pnts(pts)
-        return np.asarray(out), bool(vertical)
     pairwise_vec = (pts[:, None] - pts[None]).reshape((16, -1))
     pairwise_vec_norm = np.linalg.norm(pairwise_vec, axis=1)
     long_side_ids = np.argsort(pairwise_vec_norm)[[8, 10]]

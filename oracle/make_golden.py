@@ -634,6 +634,38 @@ def golden_boxes():
     np.savez_compressed(os.path.join(GOLDEN, "boxes.npz"), **out)
 
 
+def share_stream_scene():
+    """A worker's ``/execute`` byte stream (mode/share.py:63-66 framing) and a schedule of network chunk boundaries that cuts inside
+    headers, inside payloads and between frames."""
+    rng = np.random.default_rng(41)
+    big = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    frames = [(1, "detection".encode()), (1, b""), (1, "文字認識 ocr".encode("utf-8")), (0, big), (1, b"x"), (2, "stage exploded".encode()), (0, b"")]
+    stream = b"".join(bytes([st]) + len(pl).to_bytes(4, "big") + pl for st, pl in frames)
+    cuts = sorted(set([0, 1, 3, 5, 6, 14, 15, 19, 20, 21, 40, 41 + 65536, len(stream) - 30, len(stream) - 5, len(stream) - 4, len(stream) - 1, len(stream)]))
+    return stream, cuts
+
+
+def golden_share_stream():
+    """server/sent_data_internal.py:36-66 (process_stream's loop body + handle_buffer + extract_header), the reference's own functions, run
+    over ``share_stream_scene``: what the front server's ``sender`` receives after every network chunk."""
+    import hashlib
+    import json
+
+    C = R.server_client()
+    stream, cuts = share_stream_scene()
+    calls, buffer, per_chunk = [], b"", []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        n0 = len(calls)
+        buffer += stream[a:b]                                            # process_stream: buffer += chunk
+        buffer = C.handle_buffer(buffer, lambda st, data: calls.append((int(st), bytes(data))))
+        per_chunk.append({"end": b, "delivered": len(calls) - n0, "left_in_buffer": len(buffer)})
+    out = {"stream_sha256": hashlib.sha256(stream).hexdigest(), "stream_len": len(stream), "cuts": cuts, "per_chunk": per_chunk,
+           "calls": [{"status": st, "len": len(d), "sha256": hashlib.sha256(d).hexdigest(), "head": d[:16].hex()} for st, d in calls],
+           "header_of_first_frame": list(C.extract_header(stream[:5]))}
+    with open(os.path.join(GOLDEN, "share_stream.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     if not R.available():
         raise SystemExit("/root/reference is not present: fixtures can only be regenerated in the build container")
@@ -654,6 +686,7 @@ def main():
     golden_mask_refinement()
     golden_boxes()
     golden_bubble()
+    golden_share_stream()
 
 
 if __name__ == "__main__":

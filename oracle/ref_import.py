@@ -575,3 +575,40 @@ def shapely_shim():
             return Polygon(lo[:-1] + up[:-1])
 
     return types.SimpleNamespace(Polygon=Polygon, MultiPoint=MultiPoint, Point=Point)
+
+
+class RefConfig:
+    """Stand-in for ``manga_translator.Config`` (a pydantic model the reference's client only pickles): plain attributes, picklable
+    under the module name the reference's own class has, so that the worker's restricted unpickler sees what it would see in production."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def __eq__(self, other):
+        return isinstance(other, RefConfig) and self.__dict__ == other.__dict__
+
+
+RefConfig.__module__ = "manga_translator"
+RefConfig.__qualname__ = RefConfig.__name__ = "Config"
+
+
+def server_client():
+    """reference module server/sent_data_internal.py (fetch_data_stream, process_stream, handle_buffer, extract_header): the client the
+    reference's front server drives a shared-mode worker with.  Its only package import is ``from manga_translator import Config``."""
+    if not os.path.isdir(os.path.join(REF_ROOT, "server")):
+        raise RuntimeError("/root/reference/server is not present on this machine")
+    if "_ref_server.sent_data_internal" in _loaded:
+        return _loaded["_ref_server.sent_data_internal"]
+    mt = _pkg("manga_translator")
+    had = getattr(mt, "Config", None)
+    mt.Config = RefConfig
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_server.sent_data_internal", os.path.join(REF_ROOT, "server", "sent_data_internal.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if had is not None and had is not RefConfig:
+            mt.Config = had
+    _loaded["_ref_server.sent_data_internal"] = mod
+    return mod
+

@@ -18,7 +18,8 @@ class Stub:
         a = np.asarray(image)
         for h in self.hooks:
             await h("detection", False)
-        await asyncio.sleep(float((config or {}).get("sleep", 0.0)))
+        cfg = config if isinstance(config, dict) else dict(vars(config)) if config is not None else {}   # the reference's client sends a Config object
+        await asyncio.sleep(float(cfg.get("sleep", 0.0)))
         for h in self.hooks:
             await h("finished", True)
         return {"sum": int(a.astype(np.int64).sum()), "shape": list(a.shape), "visible": os.environ.get("HIP_VISIBLE_DEVICES"), "pid": os.getpid()}

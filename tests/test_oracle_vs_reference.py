@@ -46,6 +46,18 @@ def test_textline_merge_fixture_regenerates(tmp_path, monkeypatch):
     assert new == old and len(new["cases"]) == 11 and all(c["ref_passes_own_test"] for c in new["cases"])
 
 
+def test_share_stream_fixture_regenerates(tmp_path, monkeypatch):
+    """The reference's own ``handle_buffer`` / ``extract_header`` (server/sent_data_internal.py), re-run over the committed stream scene,
+    reproduce tests/golden/share_stream.json (which pins serve.parse_frames: tests/test_serve.py)."""
+    import json
+    from oracle import make_golden as MG
+
+    monkeypatch.setattr(MG, "GOLDEN", str(tmp_path))
+    MG.golden_share_stream()
+    new, old = json.load(open(tmp_path / "share_stream.json")), json.load(open(os.path.join(GOLDEN, "share_stream.json")))
+    assert new == old and len(new["calls"]) == 7 and new["header_of_first_frame"] == [1, 9]
+
+
 def test_schemas_match_reference_modules():
     """Every synthetic state_dict has exactly the reference modules' parameter names and shapes."""
     from manga_image_translator_amd import ctd_schema, lama_schema, ocr_schema

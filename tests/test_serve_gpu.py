@@ -47,6 +47,21 @@ def test_two_workers_on_one_box_return_identical_pages(cuda):
         ia, ib = asyncio.run(a.sent(None, None, method="device_info")), asyncio.run(b.sent(None, None, method="device_info"))
         assert ia["visible_devices"] == ib["visible_devices"] == "0" and ia["n_visible"] == ib["n_visible"] == 1 and ia["pid"] != ib["pid"]
         ra, rb = asyncio.run(a.sent(page, cfg)), asyncio.run(b.sent(page, cfg))
+        # the streaming endpoint the reference's front server uses (server/instance.py:19-20 -> sent_data_internal.py:13-58): the frames
+        # end with ONE result frame whose payload is the pickled result, identical to /simple_execute's.  The client here is
+        # ExecutorInstance.sent_stream, whose parser is pinned to the reference's handle_buffer by tests/golden/share_stream.json (the
+        # reference tree itself does not exist on the GPU box); the image is what that client sends: a PIL image.
+        import pickle
+
+        from PIL import Image
+
+        frames = []
+        asyncio.run(a.sent_stream(Image.fromarray(page), cfg, lambda st, payload: frames.append((st, payload))))
+        assert [st for st, _ in frames][-1] == 0 and all(st == 1 for st, _ in frames[:-1])
+        rs = pickle.loads(frames[-1][1])
+        frames = []
+        asyncio.run(a.sent_stream(page[:, :, 0], cfg, lambda st, payload: frames.append((st, payload))))     # not HxWx3: the engine's error, as a frame
+        assert len(frames) == 1 and frames[0][0] == 2 and b"HxWx3" in frames[0][1]
 
         async def both():   # the two workers busy at the same time, on different pages, then swapped
             return await asyncio.gather(a.sent(page, cfg), b.sent(page2, cfg), )
@@ -56,6 +71,7 @@ def test_two_workers_on_one_box_return_identical_pages(cuda):
     for x, y in ((ra, rb), (ra, ca), (cb2, rb2), (outs[0], ra), (outs[1], rb2), (outs[2], ra), (outs[3], rb2)):
         assert np.array_equal(x["inpainted"], y["inpainted"]) and np.array_equal(x["mask"], y["mask"]) and np.array_equal(x["mask_raw"], y["mask_raw"])
         assert x["textlines"] == y["textlines"]
+    assert np.array_equal(rs["inpainted"], ra["inpainted"]) and np.array_equal(rs["mask"], ra["mask"]) and rs["textlines"] == ra["textlines"]
     assert ra["inpainted"].shape == (H, W, 3) and ra["inpainted"].dtype == np.uint8 and len(ra["textlines"]) >= 1
     assert not np.array_equal(ra["inpainted"], page)            # something was inpainted
     # the same chain in this process (the plugins called directly): what a worker returns is what the plugins compute
