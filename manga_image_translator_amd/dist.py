@@ -163,17 +163,25 @@ class PageGather:
         self.submits = 0
         self._host_wait_s = 0.0
         self._events: List = []      # (start, stop) device events bracketing a gather on the caller's stream (nccl)
+        self._event_ms = 0.0         # ... and the total of the pairs already folded (_fold_events)
         self._t_issue: Optional[float] = None
+        self._on_device = False
 
     @property
     def wait_ms(self) -> float:
         """Time this rank spent inside its gathers so far (issue -> received and checksummed): device events on the caller's stream when
         the tensors live on the GPU (the stream is what waits for RCCL), the host clock otherwise.  Reading it synchronises the events."""
-        ms = self._host_wait_s * 1e3
-        for e0, e1 in self._events:
-            e1.synchronize()
-            ms += e0.elapsed_time(e1)
-        return ms
+        self._fold_events(keep=0)
+        return self._host_wait_s * 1e3 + self._event_ms
+
+    def _fold_events(self, keep: int) -> None:
+        """Finished (start, stop) pairs beyond the newest ``keep`` go into the running total: a long job holds a bounded number of events.
+        A pair whose stop is not recorded yet (an async gather in flight) stays."""
+        done = [p for p in self._events if p[1] is not None]
+        for pair in done[:max(0, len(done) - keep)]:
+            pair[1].synchronize()
+            self._event_ms += pair[0].elapsed_time(pair[1])
+            self._events.remove(pair)
 
     def submit(self, packed: torch.Tensor) -> Optional[torch.Tensor]:
         prev = self.wait()
@@ -186,12 +194,9 @@ class PageGather:
         if dist.get_backend() != "nccl" and packed.is_cuda:  # gloo rehearsal: stage through host memory
             packed = packed.cpu()
         self.submits += 1
-        if packed.is_cuda:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self._events.append([e0, None])
-        else:
-            self._t_issue = _now()
+        self._on_device = bool(packed.is_cuda)
+        if not self.async_op:   # synchronous form: the clock runs from the issue (async: from the wait, in _finish — the interval
+            self._start_clock()  # issue -> _finish would span the next step's compute)
         cs = page_checksum(packed) if self.verify else None
         if rank == self.dst:
             n = packed.numel()
@@ -214,7 +219,18 @@ class PageGather:
             self._finish()
         return prev
 
+    def _start_clock(self) -> None:
+        if self._on_device:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._events.append([e0, None])
+            self._fold_events(keep=8)
+        else:
+            self._t_issue = _now()
+
     def _finish(self) -> None:
+        if self._work and self.async_op:
+            self._start_clock()
         for w in self._work:
             w.wait()  # nccl: the current stream waits for the collective (no host block); gloo: blocks
         self._work = []

@@ -141,8 +141,8 @@ class _Block:
             if w1.Kp != self.dim or w1.Np != 4 * self.dim or w2.Kp != 4 * self.dim:
                 raise RuntimeError(f"ConvNeXt block: unexpected packed shapes {w1.Kp}x{w1.Np}, {w2.Kp}x{w2.Np}")
             p1, _ = ops._split_for(w1.w, w1.Np, w1.Kp, (0, 0))
-            if p1 is None:
-                raise RuntimeError("ConvNeXt block: pwconv1 carries no split planes (packed in GEMM mode 0)")
+            if p1 is None:   # packed while GEMM mode 0 was on, then switched to 6 (mit_gemm_mode_set): no planes registered — the
+                return None  # two-launch form handles that (its tiles fall back to the fp32 MFMA), as it did before the fused kernel
             perm = fused_mlp_row_permutation(4 * self.dim)
             w2p = w2.w.view(w2.Kp, w2.Np)[perm.to(w2.w.device)].contiguous()
             self._fused = (p1, ops.split_weight(w2p), w2.Np)
@@ -153,8 +153,9 @@ class _Block:
         registers where the library has that width and the split-bf16 p6 mode is on (mit_convnext_mlp), else the two GEMM launches
         through the [rows, 4C] buffer ``h``.  Which form runs depends only on the layer width and the GEMM mode — never on the batch."""
         lib = _lib.load()
-        if fused_mlp_enabled() and ops.split_mode() == 6 and lib.mit_convnext_mlp_supported(self.dim):
-            p1, p2, ldn2 = self._fused_planes()
+        planes = self._fused_planes() if fused_mlp_enabled() and ops.split_mode() == 6 and lib.mit_convnext_mlp_supported(self.dim) else None
+        if planes is not None:
+            p1, p2, ldn2 = planes
             _lib.check(lib.mit_convnext_mlp(t.data_ptr(), self.dim, rows, self.dim, p1.data_ptr(), self.pw1.bias.data_ptr(), p2.data_ptr(), ldn2,
                                             ops._ptr(self.pw2.scale), ops._ptr(self.pw2.bias), x.data_ptr(), self.dim, x.data_ptr(), self.dim,
                                             C.c_void_p(ops.current_stream())), "mit_convnext_mlp")
