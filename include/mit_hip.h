@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MIT_ABI_VERSION 10
+#define MIT_ABI_VERSION 11
 #define MIT_MAX_TAPS 64
 
 /* activation codes for fused epilogues */
@@ -493,6 +493,25 @@ int mit_axpy(float *out_dev, float a, const float *x_dev, const float *y_dev, in
 int mit_boxes_from_bitmap(const float *pred, const uint8_t *bitmap, int H, int W, int dest_w, int dest_h, int max_candidates,
                           float unclip_ratio, float min_sside, float box_thresh, float min_sside_out, int roll_start,
                           int64_t *boxes_out, float *scores_out, int *n_out);
+/* The same chain ON THE GPU for a batch of pages (csrc/ctd_boxes.hip; replaces the per-page host call of
+ * SegDetectorRepresenter.boxes_from_bitmap, db_utils.py:127-216 / dbnet_utils.py:97-144): pred_dev f32 [B,H,W] with pred_bs elements
+ * between pages (0 = H * W; a channel of an NCHW map is 2 H W apart); the bitmap is bitmap_dev u8 [B,H,W] (non-zero = set, bitmap_bs
+ * between pages) or, when bitmap_dev is NULL, pred > thresh.  One union-find labelling of the padded bitmap
+ * finds every border's first pixel (outer borders: a foreground component's first pixel; hole borders: the left neighbour of an
+ * enclosed background component's first pixel — the pixels Suzuki-Abe's raster scan starts them at), one wave per border walks it and
+ * does minAreaRect / score / round-join offset / minAreaRect / scaling.  boxes_dev int64 [B,max_candidates,4,2] and scores_dev f32
+ * [B,max_candidates] in OpenCV's list order (last border found first; zeros = skipped, as the reference leaves them); counts_dev i32
+ * [B] = borders found (min with max_candidates = slots used); overflow_dev i32 [B] != 0: a border of that page exceeds what a wave
+ * holds in LDS (8192 points / 4096 corners) — run mit_boxes_from_bitmap for that page (same results).  Results equal the host
+ * routine's (tests/test_ctd_boxes_gpu.py).  workspace_dev: mit_boxes_from_bitmap_dev_workspace_bytes(B, H, W, max_candidates) bytes. */
+int64_t mit_boxes_from_bitmap_dev_workspace_bytes(int B, int H, int W, int max_candidates);
+/* Development aid: a device buffer of 8 x max_candidates x B int64 in which every border records wall_clock64() (100 MHz) at its phase
+ * boundaries (walk, rectangle, score, offset, end; [7] = contour length); NULL switches it off (scripts/bench_boxes.py --stamps). */
+int mit_boxes_debug_stamps(void *stamps_dev);
+int mit_boxes_from_bitmap_dev(const float *pred_dev, int64_t pred_bs, const uint8_t *bitmap_dev, int64_t bitmap_bs, float thresh, int B, int H, int W, int dest_w, int dest_h,
+                              int max_candidates, float unclip_ratio, float min_sside, float box_thresh, float min_sside_out, int roll_start,
+                              void *workspace_dev, int64_t workspace_bytes, int64_t *boxes_dev, float *scores_dev, int *counts_dev,
+                              int *overflow_dev, void *stream);
 /* Minimum distance between the quadrilaterals of index pairs (host code, no GPU): quads [n][4][2] doubles (vertex rings), pairs [m][2]
  * -> out [m]; 0 when the two rings touch, cross or contain one another, else the smallest vertex-to-edge distance.  What shapely's
  * Polygon(a.pts).distance(Polygon(b.pts)) returns in Quadrilateral.can_merge / quadrilateral_can_merge_region (utils/generic.py:660-662),

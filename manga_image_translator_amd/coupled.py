@@ -33,6 +33,7 @@ from . import ctd, hostglue, imgproc, lama, mask_refinement as MR, ocr48, textli
 from .textline import Quadrilateral
 
 BOX_THRESH = 0.6          # ctd.py:157-159
+GPU_BOXES = os.environ.get("MIT_BOXES_HOST", "0") in ("", "0")   # MIT_BOXES_HOST=1: the per-page host extraction of rounds 3-5 (A/B)
 MASK_DILATION_OFFSET = 20  # config.py:344
 KERNEL_SIZE = 3            # config.py:342
 
@@ -124,6 +125,10 @@ class CoupledPageEngine:
             if inject is not None:   # benchmark stand-in for trained weights: the maps a trained head would emit REPLACE the random-init
                 lines[:, 0] = inject["prob"][i:j]     # network's (its sigmoid output hovers around 0.5 everywhere: one page-sized blob);
                 mask_u8 = inject["mask"][i:j]         # the network has run in full by now, its cost is in the measurement
+            if GPU_BOXES:   # SegDetectorRepresenter (db_utils.py:40-216) where the map is (csrc/ctd_boxes.hip): enqueued behind the network,
+                keep.append((i, j, hostglue.boxes_from_bitmap_gpu_launch(lines[:, 0], 0.3, W, H, unclip_ratio=1.5, min_sside=2.0)))   # collected below
+                mask_full[i:j] = imgproc.resize_u8(mask_u8.contiguous(), (W, H))      # cv2.resize(mask, (w, h), INTER_LINEAR) (ctd.py:162)
+                continue
             host = torch.empty(lines.shape, dtype=torch.float32, pin_memory=True)   # [b,2,h,w]: box_score_fast needs the float map
             host.copy_(lines, non_blocking=True)
             ev = torch.cuda.Event()
@@ -132,7 +137,14 @@ class CoupledPageEngine:
             keep.append(host)
             for b in range(i, j):
                 futures[b] = self.pool.submit(self._boxes_of_page, host, b - i, ev, H, W)
-        textlines = [f.result() for f in futures]
+        if GPU_BOXES:
+            textlines = [None] * B
+            for i, j, h in keep:
+                for b, (boxes, scores) in zip(range(i, j), hostglue.boxes_from_bitmap_gpu_collect(h)):
+                    k = scores > BOX_THRESH
+                    textlines[b] = [Quadrilateral(pts.astype(np.int64), "", float(s)) for pts, s in zip(boxes[k], scores[k])]
+        else:
+            textlines = [f.result() for f in futures]
         refined = torch.empty_like(mask_full)
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 

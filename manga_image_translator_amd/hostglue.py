@@ -48,6 +48,75 @@ def dbnet_boxes(db: np.ndarray, h: int, w: int, text_threshold: float, box_thres
                              min_sside_out=5.0, roll_start=True)
 
 
+def boxes_from_bitmap_gpu_launch(pred, thresh: float, dest_width: int, dest_height: int, *, unclip_ratio: float, min_sside: float, box_thresh: float = 0.0,
+                                 min_sside_out: float = 0.0, roll_start: bool = False, max_candidates: int = 1000):
+    """Enqueue ``boxes_from_bitmap`` for a batch of maps that are ON THE DEVICE (csrc/ctd_boxes.hip: labelling, border walk, minAreaRect,
+    score, round-join offset — all on the GPU) on the current stream; nothing is waited for.  pred f32 [B,H,W] (any page stride, rows
+    dense: ``lines[:, 0]`` of an NCHW map as it is).  -> a handle for ``boxes_from_bitmap_gpu_collect``."""
+    import torch
+
+    from . import ops
+
+    if pred.dim() != 3 or pred.dtype != torch.float32 or not pred.is_cuda:
+        raise ValueError(f"boxes_from_bitmap_gpu expects a float32 CUDA tensor [B,H,W], got {pred.dtype} {tuple(pred.shape)} on {pred.device}")
+    B, H, W = pred.shape
+    if pred.stride(2) != 1 or pred.stride(1) != W:
+        pred = pred.contiguous()
+    lib = _lib.load()
+    dev = pred.device
+    ws_bytes = int(lib.mit_boxes_from_bitmap_dev_workspace_bytes(B, H, W, max_candidates))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    boxes = torch.empty(B, max_candidates, 4, 2, dtype=torch.int64, device=dev)
+    scores = torch.empty(B, max_candidates, dtype=torch.float32, device=dev)
+    meta = torch.empty(2, B, dtype=torch.int32, device=dev)   # counts, overflow flags
+    _lib.check(lib.mit_boxes_from_bitmap_dev(pred.data_ptr(), pred.stride(0), None, 0, float(thresh), B, H, W, int(dest_width), int(dest_height),
+                                             max_candidates, float(unclip_ratio), float(min_sside), float(box_thresh), float(min_sside_out), int(roll_start),
+                                             ws.data_ptr(), ws_bytes, boxes.data_ptr(), scores.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(),
+                                             C.c_void_p(ops.current_stream())), "mit_boxes_from_bitmap_dev")
+    meta_h = torch.empty(meta.shape, dtype=torch.int32, pin_memory=True)
+    meta_h.copy_(meta, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    kw = dict(unclip_ratio=unclip_ratio, min_sside=min_sside, box_thresh=box_thresh, min_sside_out=min_sside_out, roll_start=roll_start,
+              max_candidates=max_candidates)
+    return dict(pred=pred, ws=ws, boxes=boxes, scores=scores, meta_h=meta_h, ev=ev, args=(thresh, dest_width, dest_height), kw=kw)
+
+
+def boxes_from_bitmap_gpu_collect(h) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Wait for a launched extraction and bring the boxes over: per page (boxes int64 [n,4,2], scores f32 [n]), the arrays the host routine
+    returns for that page.  A page with a border longer than a wave's LDS holds (8192 points) is computed by the host routine (same results)."""
+    h["ev"].synchronize()
+    meta_h, max_candidates = h["meta_h"], h["kw"]["max_candidates"]
+    B = meta_h.shape[1]
+    counts = np.minimum(meta_h[0].numpy(), max_candidates)
+    kmax = int(counts.max()) if B else 0
+    boxes_h = h["boxes"][:, :kmax].cpu().numpy() if kmax else np.zeros((B, 0, 4, 2), np.int64)
+    scores_h = h["scores"][:, :kmax].cpu().numpy() if kmax else np.zeros((B, 0), np.float32)
+    out = []
+    for b in range(B):
+        if int(meta_h[1, b]) != 0:    # a border that does not fit a wave's LDS: this page on the host routine
+            out.append(boxes_from_bitmap(h["pred"][b].cpu().numpy(), *h["args"], **h["kw"]))
+        else:
+            n = int(counts[b])
+            out.append((boxes_h[b, :n].copy(), scores_h[b, :n].copy()))
+    return out
+
+
+def boxes_from_bitmap_gpu(pred, thresh: float, dest_width: int, dest_height: int, **kw) -> List[Tuple[np.ndarray, np.ndarray]]:
+    return boxes_from_bitmap_gpu_collect(boxes_from_bitmap_gpu_launch(pred, thresh, dest_width, dest_height, **kw))
+
+
+def ctd_boxes_gpu(lines, im_h: int, im_w: int) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """``ctd_boxes`` for a batch on the device: lines f32 [B,2,h,w] (the network's output as it is) -> per page (boxes, scores)."""
+    return boxes_from_bitmap_gpu(lines[:, 0], 0.3, im_w, im_h, unclip_ratio=1.5, min_sside=2.0)
+
+
+def dbnet_boxes_gpu(db, h: int, w: int, text_threshold: float, box_threshold: float, unclip_ratio: float) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """``dbnet_boxes`` for a batch on the device: db f32 [B,C,H,W]."""
+    return boxes_from_bitmap_gpu(db[:, 0], text_threshold, w, h, unclip_ratio=unclip_ratio, min_sside=3.0, box_thresh=box_threshold, min_sside_out=5.0,
+                                 roll_start=True)
+
+
 def contour_count(bitmap: np.ndarray) -> Tuple[int, int]:
     bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
     n, p = C.c_int(0), C.c_int64(0)

@@ -9,7 +9,7 @@ import ctypes as C
 from pathlib import Path
 
 MIT_MAX_TAPS = 64
-MIT_ABI_VERSION = 10
+MIT_ABI_VERSION = 11
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SILU, ACT_SIGMOID, ACT_GELU = range(6)
 ACT_POST_FIRST = 0x100
@@ -241,6 +241,10 @@ SYMBOLS = {
     "mit_axpy": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mit_boxes_from_bitmap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "mit_boxes_debug_stamps": (C.c_int, [C.c_void_p]),
+    "mit_boxes_from_bitmap_dev_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mit_boxes_from_bitmap_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                            C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mit_merge_mask_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mit_otsu_from_hist": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mit_find_contours_count": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),

@@ -197,11 +197,16 @@ class HipComicTextDetector(_DetBase):
             mask_u8 = torch.from_numpy((mask_f.squeeze() * 255).astype(np.uint8)).to(self.engine.device)[None]  # postprocess_mask (:155)
         else:
             mask_u8, lines, _ = self.engine.forward(page)    # postprocess_mask already applied on the GPU (ctd.py:30-44)
-            lines_map = lines.cpu().numpy()           # [1,2,h,w], cropped to the un-padded area (:152-153)
+            lines_map = None                          # [1,2,h,w] on the device, cropped to the un-padded area (:152-153)
         if self._refine is None:                         # cv2.resize(mask, (w, h), INTER_LINEAR) (:162) on the GPU as well
             mask_full = imgproc.resize_u8(mask_u8[:1].contiguous(), (im_w, im_h))[0]
-        boxes_fn = self._boxes or _native_ctd_boxes
-        boxes, scores = boxes_fn(lines_map, im_h, im_w)      # SegDetectorRepresenter(thresh=0.3) (:102,156)
+        # SegDetectorRepresenter(thresh=0.3) (:102,156): on the GPU where the map already is (csrc/ctd_boxes.hip: only the boxes cross
+        # PCIe); an injected extractor, or a rearranged strip whose stitched map was assembled on the host, takes the numpy map
+        if self._boxes is None and lines_map is None and not os.environ.get("MIT_BOXES_HOST"):   # (MIT_BOXES_HOST=1: the host routine, A/B)
+            boxes, scores = hostglue.ctd_boxes_gpu(lines, im_h, im_w)[0]
+        else:
+            boxes_fn = self._boxes or _native_ctd_boxes
+            boxes, scores = boxes_fn(lines_map if lines_map is not None else lines.cpu().numpy(), im_h, im_w)
         keep = np.where(scores > 0.6)                        # box_thresh (:157-159)
         boxes, scores = boxes[keep], scores[keep]
         textlines = [_RefQuadrilateral(pts.astype(int), "", float(s)) for pts, s in zip(boxes, scores)]
@@ -291,7 +296,13 @@ class HipDefaultDetector(_DetBase):
             ratio = 1 / target_ratio
             h, w = int(page.shape[1]), int(page.shape[2])
             db, mask = self.engine.forward(page)
-            db, mask = db.cpu().numpy(), mask[0].cpu().numpy()
+            if self._boxes is None and not os.environ.get("MIT_BOXES_HOST"):   # SegDetectorRepresenter (:73-77) where the map is: csrc/ctd_boxes.hip
+                from . import hostglue
+
+                boxes_fn = lambda d, hh, ww, tt, bt, ur: hostglue.dbnet_boxes_gpu(d, hh, ww, tt, bt, ur)[0]   # noqa: E731
+            else:
+                db = db.cpu().numpy()
+            mask = mask[0].cpu().numpy()
         boxes, scores = boxes_fn(db, h, w, text_threshold, box_threshold, unclip_ratio)
         if boxes.size == 0:
             polys, scores = [], []
