@@ -152,9 +152,11 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
         // every SIMD): 1.12-1.15x of the 128 x 128 tile on long-K layers whose N is a multiple of 256 (LaMa's stride-2 and transposed
         // convolutions at 256 / 512 channels, the detector's 2048 -> 256 layers), 0.8-1.0x on short K (an 8-32 step loop does not
         // amortise a lone workgroup's prologue and 128 KB epilogue) — profiles/r10d_split_check_pp.log.  Same bits as every p6 tile.
-        static const bool pp_off = getenv("MIT_CONV_NO_PP") != nullptr;  // A/B knob
+        // OPT-IN (MIT_CONV_PP=1): those layers are 7 % of a step's GEMM time, the step gains 0.6 % (inside the box-to-box noise,
+        // profiles/r10e_ab_pp_end_to_end.log), and they are the best launches of the tile the bench's roofline is priced on.
+        static const bool pp_on = getenv("MIT_CONV_PP") != nullptr && atoi(getenv("MIT_CONV_PP")) != 0;
         static const int pp256 = cfg_by_name("split128x256x16p6pp");
-        if (split == 6 && p.Z == 1 && !pp_off && pp256 >= 0 && p.N % 256 == 0 && p.ntaps * p.Cin >= 1024 && ((M + 127) / 128) * (p.N / 256) >= 512) c = pp256;
+        if (split == 6 && p.Z == 1 && pp_on && pp256 >= 0 && p.N % 256 == 0 && p.ntaps * p.Cin >= 1024 && ((M + 127) / 128) * (p.N / 256) >= 512) c = pp256;
         // under-filled launches (one page through the plugins, the decoder's Linears): 64 x 64 tiles quadruple the workgroup count;
         // the arithmetic per output element is that of the large tiles, so a result does not depend on the choice
         const int sm = split == 6 ? small6 : small9;
