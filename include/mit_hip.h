@@ -239,6 +239,10 @@ int mit_join_planes(const uint16_t *planes_dev, int64_t ld, int R, int K, float 
  * input arrives as Cin / 16 planes of [B,H,W,16] (in_pixstride = 16), in_planestride floats apart — what the producing convolution
  * writes through a column-split output map (MitTensorMap.nsplit = 16): a 16-channel group of a tile is then a run of whole 128-byte
  * lines instead of a quarter of every pixel's 256 bytes.
+ * Round 6: in_pixstride == 4 with in_planestride != 0 = planes of FOUR channels [Cin / 4][B][H][W][4]: each 4-channel slice's halo tile
+ * goes global -> LDS by global_load_lds_dwordx4 (no staging registers, 4 workgroups per CU; reflect padding only); a NEGATIVE
+ * in_planestride (-stride) says every plane stores its images parity-major, [2 (y & 1)][2 (x & 1)][H / 2][W / 2][4] — the layout in
+ * which the stride-2 transposed convolution that produces them writes consecutive pixels per launch.  Same bits in every layout.
  * Replaces ReflectionPad2d(3) + Conv2d(64, 3, 7) + sigmoid at the end of FFCResNetGenerator (inpainting_lama_mpe.py:597-600). */
 int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, int64_t in_planestride, const float *w4_dev, const float *w_pairs_dev, const float *bias_dev, float *out_dev,
                         int64_t out_pixstride, int B, int H, int W, int Cin, int Cout, int k, int pad_mode, int act,

@@ -210,6 +210,97 @@ __global__ __launch_bounds__(256) void conv_small_cout3_kernel(const float *__re
     }
 }
 
+// ---- the same packed arithmetic with the halo tile brought in by the LDS-DMA (round 6) ----
+// Input as 4-CHANNEL planes [Cin / 4][B][H][W][4] (the producer's column-split output map, nsplit = 4): a slice's tile row is one
+// contiguous run of 16-byte pixels, so the whole tile of a slice is 25 global_load_lds_dwordx4 pieces (per-lane source addresses carry
+// the reflection and the even | odd split of the LDS row) — no staging registers (the register-staged kernel holds 112 for a
+// 16-channel group), 28 KB of LDS per workgroup, four workgroups per CU whose DMA waits and compute phases cover each other.
+// Same accumulation order as conv_small_cout3_kernel: bit-identical results.  Reflect padding only (an out-of-image cell has no source).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+template <int K>
+__global__ __launch_bounds__(256, 4) void conv_small_cout3_dma_kernel(const float *__restrict__ in, int64_t in_plane /* floats between 4-channel planes */,
+                                                                      const f32x2 *__restrict__ wq, const float *__restrict__ bias, float *__restrict__ out,
+                                                                      int64_t out_pix, int H, int W, int Cin, int Cout, int act, float alpha, int parity_major) {
+    constexpr int R = K / 2;
+    constexpr int TR = TH3 + 2 * R, HW_ = TW3 + 2 * R, HALF = HW_ / 2;
+    constexpr int CELLS = TR * HW_, PIECES = (CELLS + 63) / 64, PPW = (PIECES + 3) / 4, BUF_CELLS = PPW * 4 * 64;
+    __shared__ f32x4 tile[BUF_CELLS];  // [TR][even pixels | odd pixels] of the current 4-channel slice (+ the surplus lanes' pad cells)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = blockIdx.x * TW3, y0 = blockIdx.y * TH3, b = blockIdx.z;
+    int src_off[PPW];  // this lane's source pixel of each of its wave's pieces (floats into a plane's image of batch entry b)
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        int c = (wave * PPW + j) * 64 + lane;
+        c = c < CELLS ? c : CELLS - 1;  // surplus lanes copy a duplicate into the pad cells
+        const int ly = c / HW_, slot = c - ly * HW_;
+        const int lx = slot < HALF ? 2 * slot : 2 * (slot - HALF) + 1;
+        int yy = y0 + ly - R, xx = x0 + lx - R;
+        yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+        xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);  // still outside after one reflection: tile overhang, never used
+        xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        // parity-major planes: [2 (y parity)][2 (x parity)][H / 2][W / 2][4] — the even | odd halves of an LDS row then read consecutive pixels
+        src_off[j] = parity_major ? ((((yy & 1) * 2 + (xx & 1)) * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * 4 : (yy * W + xx) * 4;
+    }
+    f32x2 acc[2][2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[r][j][n] = f32x2{0.f, 0.f};
+    const float *ib = in + (int64_t)b * H * W * 4;
+    for (int s4 = 0; s4 < (Cin >> 2); ++s4) {
+        const float *pl = ib + (int64_t)s4 * in_plane;
+        __syncthreads();  // the previous slice has been consumed
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(pl + src_off[j]), (lds_void_t *)(tile + (wave * PPW + j) * 64), 16, 0, 0);
+        __syncthreads();  // (its fence waits for the DMA: vmcnt(0))
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            f32x4 win[2][K + 1];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i <= K; ++i) win[r][i] = tile[(ty + r * (TH3 / 2) + ky) * HW_ + tx + (i >> 1) + (i & 1) * HALF];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x2 *wt = wq + ((int64_t)(ky * K + kx) * (Cin >> 2) + s4) * 8;
+                const f32x2 w00 = wt[0], w01 = wt[1], w10 = wt[2], w11 = wt[3], w20 = wt[4], w21 = wt[5];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 v = win[r][kx + j];
+                        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+                        acc[r][j][0] = __builtin_elementwise_fma(lo, w00, acc[r][j][0]);
+                        acc[r][j][1] = __builtin_elementwise_fma(lo, w10, acc[r][j][1]);
+                        acc[r][j][2] = __builtin_elementwise_fma(lo, w20, acc[r][j][2]);
+                        acc[r][j][0] = __builtin_elementwise_fma(hi, w01, acc[r][j][0]);
+                        acc[r][j][1] = __builtin_elementwise_fma(hi, w11, acc[r][j][1]);
+                        acc[r][j][2] = __builtin_elementwise_fma(hi, w21, acc[r][j][2]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = x0 + 2 * tx + j;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0 + ty + r * (TH3 / 2);
+            if (x < W && y < H) {
+                float *o = out + (((int64_t)b * H + y) * W + x) * out_pix;
+                for (int n = 0; n < Cout; ++n) o[n] = act_fn((acc[r][j][n].x + acc[r][j][n].y) + (bias ? bias[n] : 0.f), act, alpha);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, int64_t in_planestride, const float *w4_dev, const float *w_pairs_dev, const float *bias_dev,
@@ -222,8 +313,14 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, in
     if ((in_pixstride & 3) || (reinterpret_cast<uintptr_t>(in_dev) & 15) || (reinterpret_cast<uintptr_t>(w4_dev) & 15) || (reinterpret_cast<uintptr_t>(w_pairs_dev) & 31))
         return mit_set_error("mit_conv_small_cout: input pixels and weights must be 16-byte aligned");
     if (pad_mode == MIT_PAD_REFLECT && (k / 2 >= H || k / 2 >= W)) return mit_set_error("mit_conv_small_cout: reflect pad larger than input");
-    if (in_planestride && ((in_planestride & 3) || in_pixstride < 16 || !(Cout <= 3 && w_pairs_dev)))
-        return mit_set_error("mit_conv_small_cout: planar input (16-channel planes) needs the packed kernel (Cout <= 3 with w_pairs), pixel stride >= 16 and a plane stride %% 4 == 0");
+    const int parity_major = in_planestride < 0;                    // (a negative plane stride marks the parity-major form of 4-channel planes)
+    if (parity_major) in_planestride = -in_planestride;
+    const bool planes4 = in_planestride != 0 && in_pixstride == 4;  // 4-channel planes: the LDS-DMA kernel
+    if (parity_major && (!planes4 || (H & 1) || (W & 1))) return mit_set_error("mit_conv_small_cout: parity-major planes need 4-channel planes of even height and width");
+    if (in_planestride && ((in_planestride & 3) || (in_pixstride < 16 && !planes4) || !(Cout <= 3 && w_pairs_dev)))
+        return mit_set_error("mit_conv_small_cout: planar input (16- or 4-channel planes) needs the packed kernel (Cout <= 3 with w_pairs), pixel stride 4 or >= 16 and a plane stride %% 4 == 0");
+    if (planes4 && (pad_mode != MIT_PAD_REFLECT || (int64_t)H * W * 4 > 0x7fffffffLL))
+        return mit_set_error("mit_conv_small_cout: 4-channel planes need reflect padding and H * W * 4 < 2^31");
     dim3 grid(mit_div_up(W, TW), mit_div_up(H, TH), B), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w4_dev);
@@ -240,6 +337,16 @@ extern "C" int mit_conv_small_cout(const float *in_dev, int64_t in_pixstride, in
         dim3 grid3(mit_div_up(W, TW3), mit_div_up(H, TH3), B);
         const f32x2 *wp = reinterpret_cast<const f32x2 *>(w_pairs_dev);
         if (Cin & 3) return mit_set_error("mit_conv_small_cout: Cin %% 4");
+        if (planes4) {
+            switch (k) {
+                case 3: hipLaunchKernelGGL(conv_small_cout3_dma_kernel<3>, grid3, block, 0, s, in_dev, in_planestride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, act, act_alpha, parity_major); break;
+                case 5: hipLaunchKernelGGL(conv_small_cout3_dma_kernel<5>, grid3, block, 0, s, in_dev, in_planestride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, act, act_alpha, parity_major); break;
+                case 7: hipLaunchKernelGGL(conv_small_cout3_dma_kernel<7>, grid3, block, 0, s, in_dev, in_planestride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, act, act_alpha, parity_major); break;
+                default: return mit_set_error("mit_conv_small_cout: k must be 3, 5 or 7 (got %d)", k);
+            }
+            MIT_CHECK_LAUNCH("mit_conv_small_cout");
+            return 0;
+        }
         switch (k) {
             case 3: hipLaunchKernelGGL(conv_small_cout3_kernel<3>, grid3, block, 0, s, in_dev, in_pixstride, in_planestride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;
             case 5: hipLaunchKernelGGL(conv_small_cout3_kernel<5>, grid3, block, 0, s, in_dev, in_pixstride, in_planestride, wp, bias_dev, out_dev, out_pixstride, H, W, Cin, Cout, refl, act, act_alpha); break;

@@ -257,7 +257,10 @@ class LamaEngine:
                         acc = acc + dirw[k]
                 t2[bits] = acc * a6
             self.mpe["lut1"], self.mpe["lut2"] = (emb * a5).contiguous().to(dev), t2.contiguous().to(dev)
-        self.planar_tail = os.environ.get("MIT_LAMA_PLANAR_TAIL", "1") not in ("", "0")
+        # layout between the last up-convolution and the 7x7 output convolution: 4 = sixteen 4-channel planes (the output convolution's
+        # LDS-DMA kernel, round 6), 16 (or 1) = four 16-channel planes (its register-staged kernel, round 5), 0 = NHWC — same values
+        pt = os.environ.get("MIT_LAMA_PLANAR_TAIL", "4")
+        self.planar_tail = {"": 0, "0": 0, "1": 16, "16": 16, "4": 4}.get(pt, 4)
         self.mpe_in_stem = os.environ.get("MIT_LAMA_MPE_SEPARATE", "") in ("", "0")   # False: the separate mit_lama_mpe_add pass (A/B, tests)
         self._ws = ops.Workspace(self.device)
         self._tw: Dict[int, torch.Tensor] = {}
@@ -501,13 +504,16 @@ class LamaEngine:
         u2 = self._buf("d1", B, H // 2, W // 2, 128)
         self.ups[1](u1, out=u2)
         pred = self._buf("pred", B, H, W, 3)
-        if self.planar_tail:   # the last up-convolution writes four 16-channel planes, the 7x7 output convolution reads them group by group
-            u3 = self._buf("full64", 4, B, H, W, 16)
-            self.ups[2](u2, out=u3, planes=4)
+        if self.planar_tail:   # the last up-convolution writes 64 / P planes of P channels, the 7x7 output convolution reads them slice by slice
+            P = self.planar_tail
+            pm = P == 4 and H % 2 == 0 and W % 2 == 0   # 4-channel planes as four dense parity sub-images: both sides move consecutive pixels
+            u3 = self._buf("full64", 64 // P, B, H, W, P)
+            self.ups[2](u2, out=u3, planes=64 // P, parity_major=pm)
+            self.out_conv(u3, out=pred, parity_major=pm)
         else:                  # MIT_LAMA_PLANAR_TAIL=0: NHWC between the two (A/B, tests) — same values, other addresses
             u3 = self._buf("full64", B, H, W, 64)
             self.ups[2](u2, out=u3)
-        self.out_conv(u3, out=pred)
+            self.out_conv(u3, out=pred)
         if taps is not None:
             taps["pred"] = pred.clone()
         out = torch.empty(B, H, W, 3, dtype=torch.uint8, device=self.device)

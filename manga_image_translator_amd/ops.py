@@ -517,13 +517,21 @@ class ConvSmallCout:
         self.w_pairs = (w4.reshape(kh * kw, Cin // 4, 4, 4).permute(0, 1, 3, 2).to(device).contiguous() if Cout <= 3 else None)
         self.bias = None if bias is None else bias.detach().to(torch.float32).to(device).contiguous()
 
-    def __call__(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-        """``x``: [B,H,W,C] NHWC, or the same activations as 16-channel planes [C / 16, B, H, W, 16] (contiguous; what
-        ``ConvTranspose2d(..., planes=)`` writes) — the packed kernel then loads whole lines per channel group."""
+    def __call__(self, x: torch.Tensor, out: torch.Tensor, parity_major: bool = False) -> torch.Tensor:
+        """``parity_major``: the P = 4 planes hold each image as four dense sub-images [2][2][H / 2][W / 2][4] (what
+        ``ConvTranspose2d(..., planes=, parity_major=True)`` writes).
+        ``x``: [B,H,W,C] NHWC, or the same activations as planes [C / P, B, H, W, P], P = 16 or 4 (contiguous; what
+        ``ConvTranspose2d(..., planes=)`` writes) — the packed kernel then loads whole lines per channel group (P = 16) or takes each
+        4-channel slice's tile straight into LDS by DMA (P = 4)."""
         plane = 0
-        if x.dim() == 5:
-            if self.w_pairs is None or x.shape[4] != 16 or x.shape[0] * 16 < self.Cin or not x.is_contiguous():
-                raise ValueError(f"ConvSmallCout: planar input must be contiguous [Cin / 16, B, H, W, 16] for Cout <= 3 (got {tuple(x.shape)})")
+        if x.dim() == 5:   # planes of 16 channels (register-staged kernel) or of 4 (LDS-DMA kernel: a slice's tile rows are contiguous runs)
+            pc = x.shape[4]
+            if self.w_pairs is None or pc not in (4, 16) or x.shape[0] * pc < self.Cin or not x.is_contiguous():
+                raise ValueError(f"ConvSmallCout: planar input must be contiguous [Cin / P, B, H, W, P] with P = 4 or 16 for Cout <= 3 (got {tuple(x.shape)})")
+            if pc == 4 and self.pad_mode != PAD_REFLECT:
+                raise ValueError("ConvSmallCout: 4-channel planes are read by the LDS-DMA kernel, which implements reflect padding only")
+            if parity_major and (pc != 4 or x.shape[2] % 2 or x.shape[3] % 2):
+                raise ValueError("ConvSmallCout: the parity-major layout needs 4-channel planes of even height and width")
             plane = x.stride(0)
             # (an NHWC-shaped handle on plane 0 for the shape checks below; the kernel addresses the planes itself)
             x = x[0].as_strided((x.shape[1], x.shape[2], x.shape[3], self.Cin), (x.stride(1), x.stride(2), x.stride(3), 1))
@@ -536,7 +544,9 @@ class ConvSmallCout:
                 and out.stride(1) * H == out.stride(0)):
             raise ValueError("ConvSmallCout: pixel-dense tensors required")
         lib = _lib.load()
-        _lib.check(lib.mit_conv_small_cout(x.data_ptr(), x.stride(2), plane, self.w4.data_ptr(), _ptr(self.w_pairs), _ptr(self.bias), out.data_ptr(),
+        if parity_major and not plane:
+            raise ValueError("ConvSmallCout: parity_major without planar input")
+        _lib.check(lib.mit_conv_small_cout(x.data_ptr(), x.stride(2), -plane if parity_major else plane, self.w4.data_ptr(), _ptr(self.w_pairs), _ptr(self.bias), out.data_ptr(),
                                            out.stride(2), B, H, W, self.Cin, self.Cout, self.k, self.pad_mode, self.act,
                                            self.alpha, C.c_void_p(current_stream())), "mit_conv_small_cout")
         return out
@@ -638,7 +648,7 @@ class ConvTranspose2d:
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         return ((H - 1) * self.s - 2 * self.p + self.k[0] + self.op, (W - 1) * self.s - 2 * self.p + self.k[1] + self.op)
 
-    def descs(self, x: torch.Tensor, out: torch.Tensor, planes: int = 0) -> List[MitConvGemm]:
+    def descs(self, x: torch.Tensor, out: torch.Tensor, planes: int = 0, parity_major: bool = False) -> List[MitConvGemm]:
         """``planes`` = P > 0: ``out`` is [P, B, Ho, Wo, Cout / P] (contiguous) and every launch writes through a column-split map
         (MitTensorMap.nsplit = Cout / P): channel group g of a pixel goes to plane g.  The consumer that reads channel groups (the 7x7
         output convolution) then finds each group in whole lines."""
@@ -656,11 +666,17 @@ class ConvTranspose2d:
         Ho, Wo = self.out_hw(H, W)
         if tuple(out.shape) != (B, Ho, Wo, self.Cout):
             raise ValueError(f"ConvTranspose2d: output shape {tuple(out.shape)} != {(B, Ho, Wo, self.Cout)}")
+        if parity_major and not (planes and self.s == 2 and Ho % 2 == 0 and Wo % 2 == 0):
+            raise ValueError("ConvTranspose2d: the parity-major layout is for planar output of a stride-2 layer with even output size")
         ds = []
         for py, px, pk in self.sub:
             ov = out[:, py::self.s, px::self.s]
             if ov.shape[1] == 0 or ov.shape[2] == 0:
                 continue
+            if parity_major:   # every plane holds the image as four dense sub-images, one per output parity class: [2 (py)][2 (px)][Ho / 2][Wo / 2][P]
+                pc, h2, w2 = self.Cout // planes, Ho // 2, Wo // 2   # — a class's launch then writes consecutive pixels (an interleaved
+                ov = out.as_strided((B, h2, w2, self.Cout), (Ho * Wo * pc, w2 * pc, pc, 1),      # image would put them 2 P floats apart)
+                                    out.storage_offset() + (py * 2 + px) * h2 * w2 * pc)
             ds.append(conv_gemm_desc(
                 a=x, NB=B, Hi=H, Wi=W, Cin=self.Cin, a_strides=(x.stride(0), x.stride(1), x.stride(2)),
                 Ho=ov.shape[1], Wo=ov.shape[2], sy=1, sx=1, taps=pk.taps, pad_mode=PAD_ZERO, w=pk.w, ldw=pk.Np,
@@ -668,11 +684,11 @@ class ConvTranspose2d:
                 alpha=self.alpha))
         return ds
 
-    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, cfg: int = -1, planes: int = 0) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, cfg: int = -1, planes: int = 0, parity_major: bool = False) -> torch.Tensor:
         if out is None:
             Ho, Wo = self.out_hw(x.shape[1], x.shape[2])
             out = (torch.empty(planes, x.shape[0], Ho, Wo, self.Cout // planes, dtype=torch.float32, device=x.device) if planes else
                    torch.empty(x.shape[0], Ho, Wo, self.Cout, dtype=torch.float32, device=x.device))
-        for d in self.descs(x, out, planes):
+        for d in self.descs(x, out, planes, parity_major):
             launch_conv_gemm(d, cfg)
         return out

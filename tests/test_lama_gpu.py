@@ -311,16 +311,19 @@ def test_planar_tail_is_bit_identical_to_the_nhwc_tail(cuda, gemm_mode):
     gen = [synth.synth_page(i, 264, 272, n_boxes=5) for i in range(2)]
     img = torch.from_numpy(np.stack([g[0] for g in gen])).to(cuda)
     msk = torch.from_numpy(np.stack([g[2] for g in gen])).to(cuda)
-    assert eng.planar_tail
-    t1, t2 = {}, {}
+    assert eng.planar_tail == 4        # the shipped tail: sixteen 4-channel planes, the output convolution's LDS-DMA kernel (round 6)
+    t1, t2, t3 = {}, {}, {}
     out1 = eng.forward(img, msk, taps=t1).clone()
-    eng.planar_tail = False
     try:
+        eng.planar_tail = 0            # NHWC between the two
         out2 = eng.forward(img, msk, taps=t2).clone()
+        eng.planar_tail = 16           # four 16-channel planes, the register-staged kernel (round 5)
+        out3 = eng.forward(img, msk, taps=t3).clone()
     finally:
-        eng.planar_tail = True
+        eng.planar_tail = 4
     torch.cuda.synchronize()
     assert torch.equal(t1["pred"], t2["pred"]) and torch.equal(out1, out2)
+    assert torch.equal(t1["pred"], t3["pred"]) and torch.equal(out1, out3)
     # the two halves alone
     g = torch.Generator().manual_seed(5)
     up = eng.ups[2]
@@ -328,9 +331,17 @@ def test_planar_tail_is_bit_identical_to_the_nhwc_tail(cuda, gemm_mode):
     nhwc = up(x)
     planes = up(x, planes=4)
     assert planes.shape == (4, 2, 40, 56, 16) and torch.equal(planes.permute(1, 2, 3, 0, 4).reshape(2, 40, 56, 64), nhwc)
+    planes4 = up(x, planes=16)
+    assert planes4.shape == (16, 2, 40, 56, 4) and torch.equal(planes4.permute(1, 2, 3, 0, 4).reshape(2, 40, 56, 64), nhwc)
     o1 = torch.empty(2, 40, 56, 3, device=cuda)
     o2 = torch.empty(2, 40, 56, 3, device=cuda)
+    o3 = torch.empty(2, 40, 56, 3, device=cuda)
     eng.out_conv(nhwc, out=o1)
     eng.out_conv(planes, out=o2)
+    eng.out_conv(planes4, out=o3)      # tile overhang on both axes (40 x 56 against 16 x 64 tiles), reflection on all four sides
+    pm = up(x, planes=16, parity_major=True)   # every plane as four dense parity sub-images [2][2][20][28][4]
+    want = planes4.view(16, 2, 20, 2, 28, 2, 4).permute(0, 1, 3, 5, 2, 4, 6).reshape(16, 2, 40, 56, 4)
+    o4 = torch.empty(2, 40, 56, 3, device=cuda)
+    eng.out_conv(pm, out=o4, parity_major=True)
     torch.cuda.synchronize()
-    assert torch.equal(o1, o2)
+    assert torch.equal(o1, o2) and torch.equal(o1, o3) and torch.equal(pm, want) and torch.equal(o1, o4)
