@@ -202,7 +202,8 @@ class HipComicTextDetector(_DetBase):
             mask_full = imgproc.resize_u8(mask_u8[:1].contiguous(), (im_w, im_h))[0]
         # SegDetectorRepresenter(thresh=0.3) (:102,156): on the GPU where the map already is (csrc/ctd_boxes.hip: only the boxes cross
         # PCIe); an injected extractor, or a rearranged strip whose stitched map was assembled on the host, takes the numpy map
-        if self._boxes is None and lines_map is None and not os.environ.get("MIT_BOXES_HOST"):   # (MIT_BOXES_HOST=1: the host routine, A/B)
+        if self._boxes is None and lines_map is None and lines.is_cuda and not os.environ.get("MIT_BOXES_HOST"):   # (MIT_BOXES_HOST=1: the host routine, A/B;
+            # a map that lives on the host — an injected stand-in engine, tests/boundary_checks.py — goes to the host routine as well)
             boxes, scores = hostglue.ctd_boxes_gpu(lines, im_h, im_w)[0]
         else:
             boxes_fn = self._boxes or _native_ctd_boxes
@@ -296,7 +297,7 @@ class HipDefaultDetector(_DetBase):
             ratio = 1 / target_ratio
             h, w = int(page.shape[1]), int(page.shape[2])
             db, mask = self.engine.forward(page)
-            if self._boxes is None and not os.environ.get("MIT_BOXES_HOST"):   # SegDetectorRepresenter (:73-77) where the map is: csrc/ctd_boxes.hip
+            if self._boxes is None and db.is_cuda and not os.environ.get("MIT_BOXES_HOST"):   # SegDetectorRepresenter (:73-77) where the map is: csrc/ctd_boxes.hip
                 from . import hostglue
 
                 boxes_fn = lambda d, hh, ww, tt, bt, ur: hostglue.dbnet_boxes_gpu(d, hh, ww, tt, bt, ur)[0]   # noqa: E731
