@@ -57,6 +57,12 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     constexpr bool ORD = (VAR & 256) != 0;  // with MID: fragment reads issued in the order the plane pairs consume them; next row offsets fetched in step 0
     // (multi-tile forms — 2 / 4 consecutive output tiles per workgroup, and a grid-strided persistent form with the next tile's set-up
     // issued ahead of the epilogue — were measured in round 3 and removed: 0.45-1.02x of this form, profiles/r03d_split_check_experiments.log)
+    // VAR bit 1024 (round 6 experiment): the W fragments do not pass through LDS at all — W planes are stored in MFMA-operand cells, so a
+    // lane's B operand of (plane, k-group lh, column) is ONE 16-byte global load (L2-resident weights, 512 contiguous bytes per
+    // half-wave); the fragments of K-tile t + 1 are requested at the top of tile t.  Takes the 13-cycle ds_write_b128 of W (half of the
+    // VGPR -> LDS store traffic that bounds this tile) and half of the fragment reads off the LDS; costs W's L2 -> L1 traffic twice
+    // (the two waves of a column read the same cells) and nine registers.
+    constexpr bool BDIR = (VAR & 1024) != 0;
     constexpr bool ASM_SUB = (VAR & 64) != 0;  // residuals through v_sub_f32 inline asm: keeps the SLP vectoriser from packing them into v_pk_add_f32
     constexpr int SA = BM, SB = BN;
     constexpr int A_TILE = 3 * KH * SA, B_TILE = 3 * KH * SB;  // cells per buffer
@@ -161,8 +167,10 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
         for (int i = 0; i < A_ITERS; ++i)  // rows that contribute zeros are masked when the tile is split (store_tile), not here: a select
             a_reg[i] = *reinterpret_cast<const f32x4 *>(ak + (a_off[i] < 0 ? 0 : a_off[i]));  // on the loaded value would wait for the load
         const u32x4 *wk = ws + (int64_t)ld_k8 * ldn;  // split_eligible(): every K-tile lies inside the packed planes
+        if (!BDIR) {
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) b_reg[i] = wk[bok(i) ? bsrc(i) : 0];  // columns past ldw get arbitrary finite-or-not values: never stored
+            for (int i = 0; i < B_ITERS; ++i) b_reg[i] = wk[bok(i) ? bsrc(i) : 0];  // columns past ldw get arbitrary finite-or-not values: never stored
+        }
         ld_k8 += KH;
         ld_ci0 += BK;
         const bool wrap = ld_ci0 >= p.Cin;
@@ -188,9 +196,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             as2[((2 * KH + kh) * SA + ml) * 2 + half] = l;
         }
         u32x4 *bs = Bs + buf * B_TILE;
+        if (!BDIR) {
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i)
-            if ((i + 1) * 256 <= B_CELLS || tid + i * 256 < B_CELLS) bs[bdst(i)] = b_reg[i];
+            for (int i = 0; i < B_ITERS; ++i)
+                if ((i + 1) * 256 <= B_CELLS || tid + i * 256 < B_CELLS) bs[bdst(i)] = b_reg[i];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             }
         } else if (st < STAGE_WRITE_STEPS) {
             const int j = st - 3 * A_ITERS;
-            if ((j + 1) * 256 <= B_CELLS || tid + j * 256 < B_CELLS) (Bs + buf * B_TILE)[bdst(j)] = b_reg[j];
+            if (!BDIR && ((j + 1) * 256 <= B_CELLS || tid + j * 256 < B_CELLS)) (Bs + buf * B_TILE)[bdst(j)] = b_reg[j];
         } else if (st == STAGE_WRITE_STEPS) {
             if (!ORD) {
                 const int *rt = rowtab + ld_tap * BM + am;
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             a_reg[i] = *reinterpret_cast<const f32x4 *>(a_thr + ld_ci0 + (a_off[i] < 0 ? 0 : a_off[i]));
         } else if (st < STAGE_STEPS) {
             const int j = st - STAGE_WRITE_STEPS - 1 - A_ITERS;
-            b_reg[j] = (ws + (int64_t)ld_k8 * ldn)[bok(j) ? bsrc(j) : 0];
+            if (!BDIR) b_reg[j] = (ws + (int64_t)ld_k8 * ldn)[bok(j) ? bsrc(j) : 0];
             if (st == STAGE_STEPS - 1) {
                 ld_k8 += KH;
                 ld_ci0 += BK;
@@ -256,6 +266,25 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     };
 
     bf16x8 af[KS][3][TM], bf[KS][3][TN];
+    // BDIR: the W fragments of the next K-tile, straight from the packed planes: cell (plane, k cell 2 ks + lh of the tile, column)
+    u32x4 bnext[BDIR ? KS : 1][3][BDIR ? TN : 1];
+    int bcol[BDIR ? TN : 1];  // this lane's cell of tile 0, plane 0, per 32-column block (columns past ldw: a valid duplicate, never stored)
+    if (BDIR) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn0 + ni * 32 + li;
+            bcol[ni] = lh * ldn + (n < ldn ? n : ldn - 1);
+        }
+    }
+    auto load_bnext = [&](const int kt) {
+        const u32x4 *wk = ws + (int64_t)kt * KH * ldn;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bnext[ks][pl][ni] = wk[(int64_t)(pl * K8 + 2 * ks) * ldn + bcol[ni]];
+    };
     // One K-tile: fragment reads, then (PIPE) the staging of tile kt + 1 and the loads of tile kt + 2 scheduled among the MFMAs.
     auto tile = [&](const int kt, auto do_store, auto do_load) {
         constexpr bool DO_STORE = decltype(do_store)::value, DO_LOAD = decltype(do_load)::value;
@@ -274,9 +303,11 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
                     for (int mi = 0; mi < TM; ++mi)
                         af[ks][pa][mi] = __builtin_bit_cast(bf16x8, as[(pa * KH + 2 * ks + lh) * SA + ((wm0 + mi * 32 + li) ^ split_swz<BK>(2 * ks + lh))]);
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni) bf[ks][pb][ni] = __builtin_bit_cast(bf16x8, bs[(pb * KH + 2 * ks) * SB + ni * 32]);
+                    for (int ni = 0; ni < TN; ++ni)
+                        bf[ks][pb][ni] = BDIR ? __builtin_bit_cast(bf16x8, bnext[BDIR ? ks : 0][pb][BDIR ? ni : 0]) : __builtin_bit_cast(bf16x8, bs[(pb * KH + 2 * ks) * SB + ni * 32]);
                 }
         }
+        if (BDIR && DO_STORE) load_bnext(kt + 1);  // (the fragments just taken are copies: their registers are free for the next tile's)
         if (PIPE && MID) {
             constexpr int NM = KS * NPROD * TM * TN;
             constexpr int NSTEP = DO_STORE ? (DO_LOAD ? STAGE_STEPS : STAGE_WRITE_STEPS) : 0;
@@ -327,6 +358,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     constexpr int SMEM_F = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
 
     load_tile();
+    if (BDIR) load_bnext(0);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll

@@ -54,7 +54,8 @@ int main(int argc, char **argv) {
     const int w6o = find_cfg("split64x256x16p6o");
     const int t192 = find_cfg("split128x192x16p6o"), t256 = find_cfg("split256x64x16p6o");
     const int t160 = find_cfg("split128x160x16p6o"), t96 = find_cfg("split128x96x16p6o");  // exact-N tiles for N = 160 k / N = 80  // wide-N tile (-1 in builds without it: skipped)
-    const int pp = find_cfg("split256x128x16p6pp"), pq = find_cfg("split128x256x16p6pp");  // round 6: the eight-wave ping-pong tiles
+    const int pp = find_cfg("split256x128x16p6pp"), pq = find_cfg("split128x256x16p6pp");
+    const int bd = find_cfg("split128x128x16p6b");  // round 6: W fragments straight from global  // round 6: the eight-wave ping-pong tiles
     const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c"), s64k = find_cfg("split64x64x32p6o");
     if (f_wide < 0 || f_narrow < 0 || s6 < 0 || s9 < 0 || s3 < 0 || n6 < 0 || n9 < 0 || s9m < 0) {
         fprintf(stderr, "tile names not found\n");
@@ -109,6 +110,12 @@ int main(int argc, char **argv) {
         {"pp: pw2 1x1 1280->320, M=131072", 1, 256, 512, 1280, 320, 1, 1, MIT_PAD_ZERO, 1, MIT_ACT_NONE, f_wide, {s6o, t160, pp, pq, s6o, t160, pp, pq}},
         {"pp: 3x3 reflect 128->128, 2x96x160, relu", 2, 96, 160, 128, 128, 3, 1, MIT_PAD_REFLECT, 1, MIT_ACT_RELU, f_wide, {s6o, pp, s6o, pp}},
     };
+    for (auto &c : cases)   // the direct-W tile wherever the shipped wide tile is measured
+        if (!strncmp(c.name, "pp:", 3) || !strncmp(c.name, "ragged", 6) || !strncmp(c.name, "probe", 5)) {
+            c.cfgs.push_back(bd);
+            c.cfgs.push_back(s6o);
+            c.cfgs.push_back(bd);
+        }
     if (const char *only = getenv("SC_CASE")) {  // substring filter on the case name
         std::vector<Case> keep;
         for (auto &c : cases)
