@@ -567,7 +567,7 @@ def dropin_leg(weights, host_inputs, n_pages, device_str="cuda"):
     ms = {k: round(1e3 * float(np.mean(v)), 2) for k, v in per.items()}
     total = sum(ms.values())
     return dict(value=round(1e3 / total, 3), unit="pages/s", pages=n, batch=1, ms_per_page=round(total, 2), ms_per_stage=ms,
-                includes="host<->device copies, ctd box extraction (native host C++), mask resize + refine_mask (GPU), OCR direction vote "
+                includes="host<->device copies, ctd box extraction (GPU, csrc/ctd_boxes.hip), mask resize + refine_mask (GPU), OCR direction vote "
                          "and per-line planning, plugin result decoding",
                 detector_boxes_found_per_page=n_found,
                 note="synthetic weights: the detector's boxes are whatever the random network fires on, so its host-glue time is not "
