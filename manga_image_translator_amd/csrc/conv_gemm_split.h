@@ -25,10 +25,14 @@ namespace mitcg {
 __device__ constexpr int kSplitPA[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
 __device__ constexpr int kSplitPB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
 
-// A cells are row-swizzled per k slab (row ^ kh * 32 / KQ) instead of padded: the 8-byte halves one ds_write_b64 half-wave writes
-// (32 / KQ rows x all slabs) then cover the 64 banks once, while a 16-lane ds_read_b128 group still reads one aligned 256-byte run.
+// A cells are row-swizzled per k slab (row ^ kh * 64 / BK) instead of padded.  ds_write_b64 is served in groups of 16 consecutive lanes
+// over 32 four-byte banks (MI355X_MICROARCH.md, LDS table): a group's 16 eight-byte halves — 16 / KQ rows x all KH slabs x 2 halves —
+// must fall on 16 different bank pairs, i.e. (row ^ swz) mod 8 must differ between the slabs: kh * 8 / KH.  (Until round 6 the swizzle
+// was kh * 32 / KQ, laid out for 64 banks: slab 1 landed on slab 0's banks — a 2-way conflict on every A store, 19 % of the kernel's
+// LDS cycles in SQ_LDS_BANK_CONFLICT, profiles/r10p_pmc_split_tile.json.)  A ds_read_b128 lane group still reads 16 distinct cells
+// of one aligned 256-byte run (the XOR permutes rows inside aligned blocks of 8).
 template <int BK>
-__device__ __forceinline__ constexpr int split_swz(int kh) { return kh * (32 / (BK / 4)); }
+__device__ __forceinline__ constexpr int split_swz(int kh) { return kh * (64 / BK); }
 
 // VAR bit 1: software pipeline — the next tile's operands (loaded one iteration ahead) are split and written to the other LDS buffer
 // among this tile's MFMAs, and the loads of the tile after it are issued behind them.
