@@ -1,4 +1,7 @@
-"""Host-side glue between the detector networks and the text lines, on the native (C++) routines of libmit_hip.so.
+"""Glue between the detector networks and the text lines, on the native routines of libmit_hip.so: the GPU chain
+(``boxes_from_bitmap_gpu`` / ``ctd_boxes_gpu`` / ``dbnet_boxes_gpu`` -> csrc/ctd_boxes.hip, what the plugins and the coupled engine call
+for maps that are on the device) and its host form (``boxes_from_bitmap`` -> csrc/hostglue.hip: injected or host-assembled maps, and the
+fallback for a border that does not fit a workgroup's LDS).
 
 ``boxes_from_bitmap`` stands in for ``SegDetectorRepresenter.__call__`` of the reference
 (/root/reference/manga_translator/detection/ctd_utils/utils/db_utils.py:40-171 for ``ctd``,
