@@ -2,6 +2,7 @@
 // The kernels are in conv_gemm_kernels.h; their instantiations are compiled in conv_gemm_inst<group>.hip.
 #include "conv_gemm_kernels.h"
 #include <string.h>
+#include <string>
 #include <atomic>
 
 using namespace mitcg;
@@ -53,6 +54,35 @@ bool split_eligible(const MitConvGemm &p, int BK) {
     if (p.w_zs1 != 0 || (p.Kw & 7) || p.ntaps * p.Cin > p.Kw) return false;
     if ((int64_t)3 * (p.Kw >> 3) * p.ldw > 0x7fffffffLL) return false;  // 32-bit cell indices
     return fast_eligible(p, BK);
+}
+
+// the "u" tiles (operand loads through buffer instructions: 32-bit byte offsets against a 2 GB descriptor, conv_gemm_split.h VAR bit
+// 2048): every byte offset of A — relative to the slice base the kernel forms — and of the packed W planes must stay below 2^31
+bool buf_eligible(const MitConvGemm &p) {
+    if (p.a_bs < 0 || p.a_ys < 0 || p.a_xs < 0) return false;
+    int tmax = 0;
+    for (int t = 0; t < p.ntaps; ++t)
+        if (p.tap_off[t] > tmax) tmax = p.tap_off[t];
+    const int64_t maxoff = (int64_t)(p.NB - 1) * p.a_bs + (int64_t)(p.Hi - 1) * p.a_ys + (int64_t)(p.Wi - 1) * p.a_xs + p.Cin + tmax;
+    if (maxoff * 4 >= 0x80000000LL) return false;
+    return (int64_t)3 * (p.Kw >> 3) * p.ldw * 16 < 0x80000000LL;
+}
+// the buffer-load twin of a shipped p6 tile ("...p6o" -> "...p6u"), or the tile itself (MIT_CONV_NO_BUF=1: A/B knob)
+int buf_twin(int c) {
+    static const std::vector<int> twin = [] {
+        std::vector<int> t(kNumCfgs);
+        const bool off = getenv("MIT_CONV_NO_BUF") != nullptr;
+        for (int i = 0; i < kNumCfgs; ++i) {
+            t[i] = i;
+            const std::string n = kCfgs[i].name;
+            if (!off && n.size() > 3 && n.compare(n.size() - 3, 3, "p6o") == 0) {
+                const int u = cfg_by_name((n.substr(0, n.size() - 1) + "u").c_str());
+                if (u >= 0) t[i] = u;
+            }
+        }
+        return t;
+    }();
+    return c >= 0 && c < kNumCfgs ? twin[c] : c;
 }
 
 // conv_gemv_kernel preconditions: <= 4 output columns, plain (unbatched, unsplit) maps, the whole weight panel in LDS
@@ -117,7 +147,7 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
         const int sp = gemm_mode_now();
         if ((sp == 6 || sp == 9) && p.w_split && split_eligible(p, 16) && ((M + 127) / 128) * p.Z >= split_min_now()) {
             const int c = sp == 6 ? n32_split6 : n32_split9;
-            if (c >= 0) return c;
+            if (c >= 0) return buf_eligible(p) ? buf_twin(c) : c;
         }
         if (f16 && n32_fast >= 0) return n32_fast;
         return kCfgGen32;
@@ -170,7 +200,7 @@ int pick_cfg(const MitConvGemm &p, int64_t M) {
             const int smk = split == 6 ? small6k : small9k;
             if (smk >= 0 && ((M + 63) / 64) * ((p.N + 63) / 64) <= 512 && split_eligible(p, 32)) c = smk;
         }
-        if (c >= 0) return c;
+        if (c >= 0) return buf_eligible(p) ? buf_twin(c) : c;  // same arithmetic, operand loads through buffer instructions where offsets fit
     }
     if (f16 && m192 >= 0 && M > 128 && M <= 192 && p.Z >= 8) return m192;  // batched launches (Z entries of M = 184 rows: W-axis DFTs): 2 x 128 rows would run a 40 % empty second tile.  Unbatched, one row of 192 x 64 tiles leaves the chip empty (the decoder at B = 1: M = 160)
     if (f16 && bigk >= 0 && p.N % 128 == 0 && p.N <= 128 && p.ntaps * p.Cin >= 4096 && M >= 256 * 1024) return bigk;
@@ -317,16 +347,26 @@ extern "C" int mit_conv_gemm_cfg(const MitConvGemm *d, int cfg, void *stream) {
         if (p.lut_ld > 0x7fff) return mit_set_error("mit_conv_gemm: lut_ld too large (row offsets are 16-bit row x lut_ld in 32 bits)");
     }
     if (p.Z > 65535) return mit_set_error("mit_conv_gemm: Z too large");
-    if (cfg < 0 && p.Z == 1 && p.NB > 1 && p.Cin % 16 == 0 && p.ntaps <= FAST_MAX_TAPS && p.a_bs > 0 && !fast_eligible(p, 16)) {
-        // The fast kernels index A with 32-bit element offsets.  A batch whose activations exceed 2^31 elements (16 pages of
-        // 2048 x 1456 x 64: LaMa's first stride-2 conv) is cut into runs of whole images that fit, instead of falling to the generic kernel.
+    // The fast kernels index A with 32-bit element offsets.  A batch whose activations exceed 2^31 elements (16 pages of
+    // 2048 x 1456 x 64: LaMa's first stride-2 conv) is cut into runs of whole images that fit, instead of falling to the generic kernel.
+    // Round 6: in the split mode the runs are cut to what the buffer-load tiles address (2^31 BYTES per run: buf_eligible) when one
+    // image fits that — every run is still thousands of workgroups, and each takes the "u" tile instead of its "o" twin.
+    static const bool cut_for_buf = getenv("MIT_CONV_NO_BUF") == nullptr && getenv("MIT_CONV_NO_BUF_CUT") == nullptr;
+    bool want_buf = false;
+    if (cfg < 0 && cut_for_buf && p.Z == 1 && p.NB > 1 && gemm_mode_now() == 6 && p.w_split != nullptr && split_eligible(p, 16)) {
+        MitConvGemm one = p;
+        one.NB = 1;
+        want_buf = buf_eligible(one);
+    }
+    auto run_ok = [&](const MitConvGemm &q) { return fast_eligible(q, 16) && (!want_buf || buf_eligible(q)); };
+    if (cfg < 0 && p.Z == 1 && p.NB > 1 && p.Cin % 16 == 0 && p.ntaps <= FAST_MAX_TAPS && p.a_bs > 0 && !run_ok(p)) {
         MitConvGemm one = p;
         one.NB = 1;
         if (fast_eligible(one, 16)) {
             int nbc = p.NB;
             while (nbc > 1) {
                 one.NB = nbc;
-                if (fast_eligible(one, 16)) break;
+                if (run_ok(one)) break;
                 nbc = (nbc + 1) / 2;
             }
             for (int b0 = 0; b0 < p.NB; b0 += nbc) {

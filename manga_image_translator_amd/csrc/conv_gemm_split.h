@@ -67,6 +67,12 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     // VGPR -> LDS store traffic that bounds this tile) and half of the fragment reads off the LDS; costs W's L2 -> L1 traffic twice
     // (the two waves of a column read the same cells) and nine registers.
     constexpr bool BDIR = (VAR & 1024) != 0;
+    // VAR bit 2048 (round 6): operand loads through BUFFER instructions — one resource descriptor per operand (SGPRs), a 32-bit byte
+    // offset per lane, the K-tile cursor as the scalar offset.  Rows that contribute zeros carry offset 2^31, past the descriptor's 2^31
+    // bytes, which the hardware's range check answers with zeros: no clamp, no compare, no select on the loaded values, no 64-bit address arithmetic — 16 of the
+    // 77 VALU instructions a wave issues per K-tile beside its 24 MFMAs (profiles/r10p_pmc_split_tile.json).  The launcher takes it
+    // only when every A and W byte offset is below 2^31 (buf_eligible in conv_gemm.hip).
+    constexpr bool BUF = (VAR & 2048) != 0;
     constexpr bool ASM_SUB = (VAR & 64) != 0;  // residuals through v_sub_f32 inline asm: keeps the SLP vectoriser from packing them into v_pk_add_f32
     constexpr int SA = BM, SB = BN;
     constexpr int A_TILE = 3 * KH * SA, B_TILE = 3 * KH * SB;  // cells per buffer
@@ -104,6 +110,9 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     const int aq = tid % KQ;
     const int am = tid / KQ;
     const float *__restrict__ a_thr = a_base + aq * 4;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a_base), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(ws), 0, 0x80000000u, 0x00020000);
+    const int aq16 = aq * 16;
     // this thread's W cells: the same (plane, kh, n) in every K-tile of an output tile.  B_UNI (a plane of the K-tile is exactly one
     // cell per thread: the 128 x 128 x 16 tile): the thread's cells differ only by the plane, so one source index, one LDS index and one
     // flag stand for all of them (the other planes are a wave-uniform stride away) — six registers less on the tile that needs them
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
                 }
                 if (ok) off = (int)((int64_t)nb * p.a_bs + (int64_t)iy * p.a_ys + (int64_t)ix * p.a_xs + p.tap_off[tp]);
             }
-            rowtab[idx] = off;
+            rowtab[idx] = BUF ? (off < 0 ? (int)0x80000000u : off * 4) : off;  // BUF: byte offsets; 2^31 (+ a lane's k offset) is past the descriptor
         }
 #pragma unroll
         for (int i = 0; i < B_IDX; ++i) {
@@ -168,12 +177,17 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
         for (int i = 0; i < A_ITERS; ++i) a_off[i] = rt[i * A_MSTEP];
         const float *ak = a_thr + ld_ci0;
 #pragma unroll
-        for (int i = 0; i < A_ITERS; ++i)  // rows that contribute zeros are masked when the tile is split (store_tile), not here: a select
-            a_reg[i] = *reinterpret_cast<const f32x4 *>(ak + (a_off[i] < 0 ? 0 : a_off[i]));  // on the loaded value would wait for the load
+        for (int i = 0; i < A_ITERS; ++i) {  // rows that contribute zeros are masked when the tile is split (store_tile), not here: a select
+            if (BUF) a_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i] + aq16, ld_ci0 * 4, 0));
+            else a_reg[i] = *reinterpret_cast<const f32x4 *>(ak + (a_off[i] < 0 ? 0 : a_off[i]));  // on the loaded value would wait for the load
+        }
         const u32x4 *wk = ws + (int64_t)ld_k8 * ldn;  // split_eligible(): every K-tile lies inside the packed planes
         if (!BDIR) {
 #pragma unroll
-            for (int i = 0; i < B_ITERS; ++i) b_reg[i] = wk[bok(i) ? bsrc(i) : 0];  // columns past ldw get arbitrary finite-or-not values: never stored
+            for (int i = 0; i < B_ITERS; ++i) {
+                if (BUF) b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, bok(i) ? bsrc(i) * 16 : -1, ld_k8 * ldn * 16, 0);
+                else b_reg[i] = wk[bok(i) ? bsrc(i) : 0];  // columns past ldw get arbitrary finite-or-not values: never stored
+            }
         }
         ld_k8 += KH;
         ld_ci0 += BK;
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
                 const u32x4 raw = __builtin_bit_cast(u32x4, a_reg[i]);
                 h = u32x2{raw.x, raw.y}, m = u32x2{raw.z, raw.w}, l = u32x2{raw.x ^ raw.z, raw.y ^ raw.w};
             } else {
-                split3<ASM_SUB>(a_off[i] < 0 ? zero : a_reg[i], h, m, l);
+                split3<ASM_SUB>(!BUF && a_off[i] < 0 ? zero : a_reg[i], h, m, l);
             }
             as2[((0 * KH + kh) * SA + ml) * 2 + half] = h;
             as2[((1 * KH + kh) * SA + ml) * 2 + half] = m;
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             static_assert((A_MSTEP & (A_MSTEP - 1)) == 0 && (BK / 4) * (32 / (BK / 4)) <= A_MSTEP || A_ITERS == 1, "row swizzle must stay inside a chunk's rows");
             const int ml = ((am ^ split_swz<BK>(kh)) + i * A_MSTEP);
             f32x4 &r = a_reg[i];  // the residuals replace the loaded values in place: the chunk is reloaded only after its last split step
-            if (ph == 0) {
+            if (ph == 0 && !BUF) {
                 const unsigned int keep = ~(unsigned int)(a_off[i] >> 31);  // rows that contribute zeros (offset -1): all bits cleared
                 r.x = __uint_as_float(__float_as_uint(r.x) & keep);
                 r.y = __uint_as_float(__float_as_uint(r.y) & keep);
@@ -255,10 +269,14 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
             }
         } else if (st <= STAGE_WRITE_STEPS + A_ITERS) {
             const int i = st - STAGE_WRITE_STEPS - 1;
-            a_reg[i] = *reinterpret_cast<const f32x4 *>(a_thr + ld_ci0 + (a_off[i] < 0 ? 0 : a_off[i]));
+            if (BUF) a_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i] + aq16, ld_ci0 * 4, 0));
+            else a_reg[i] = *reinterpret_cast<const f32x4 *>(a_thr + ld_ci0 + (a_off[i] < 0 ? 0 : a_off[i]));
         } else if (st < STAGE_STEPS) {
             const int j = st - STAGE_WRITE_STEPS - 1 - A_ITERS;
-            if (!BDIR) b_reg[j] = (ws + (int64_t)ld_k8 * ldn)[bok(j) ? bsrc(j) : 0];
+            if (!BDIR) {
+                if (BUF) b_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, bok(j) ? bsrc(j) * 16 : -1, ld_k8 * ldn * 16, 0);
+                else b_reg[j] = (ws + (int64_t)ld_k8 * ldn)[bok(j) ? bsrc(j) : 0];
+            }
             if (st == STAGE_STEPS - 1) {
                 ld_k8 += KH;
                 ld_ci0 += BK;

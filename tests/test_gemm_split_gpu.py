@@ -34,19 +34,19 @@ CASES = [
     # B, Cin, Cout, H, W, k, stride, pad mode, act, fp32 tile, split tiles (every tile of the default build; the rejected schedules of
     # MIT_CONV_EXPERIMENTS builds are checked by scripts/split_check)
     (2, 128, 128, 40, 56, 3, 1, "reflect", 1, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9", "split128x128x16p3", "split128x128x16p9m", "split128x128x16p6o",
-      "split64x64x16p6o", "split64x64x16p9m", "split64x64x32p6o", "split64x64x32p9m", "split128x256x16p6pp")),
+      "split64x64x16p6o", "split64x64x16p9m", "split64x64x32p6o", "split64x64x32p9m", "split128x256x16p6pp", "split128x128x16p6u", "split64x64x16p6u", "split64x64x32p6u")),
     (1, 320, 1280, 12, 200, 1, 1, "zero", 5, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9", "split128x128x16p9m", "split128x128x16p6o", "split64x64x32p6o")),
-    (4, 64, 64, 64, 48, 3, 2, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p9", "split128x64x16p6o", "split128x256x16p6pp")),
-    (1, 48, 200, 25, 40, 3, 1, "zero", 2, "fast128x128x16w4c", ("split128x128x16p6", "split128x64x16p9", "split128x128x16p6o", "split128x64x16p6o", "split64x64x16p6o", "split128x256x16p6pp")),   # ragged M and N
-    (1, 16, 40, 9, 11, 1, 1, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p6o", "split128x128x16p6", "split128x128x16p6o", "split64x64x16p6o", "split128x256x16p6pp")),   # one K-tile, tiny problem
-    (1, 32, 96, 20, 24, 1, 1, "zero", 1, "fast128x64x16w5c", ("split128x64x16p6", "split128x128x16p9m", "split128x128x16p6o", "split128x64x16p6o", "split64x64x32p6o", "split128x256x16p6pp")),  # 2 K-tiles (1 of 32)
-    (1, 48, 128, 20, 24, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9m", "split128x128x16p6o", "split128x64x16p6o", "split64x64x16p6o", "split64x64x16p9m", "split128x256x16p6pp")),  # 3 K-tiles: every peeled iteration kind
+    (4, 64, 64, 64, 48, 3, 2, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p9", "split128x64x16p6o", "split128x256x16p6pp", "split128x64x16p6u")),
+    (1, 48, 200, 25, 40, 3, 1, "zero", 2, "fast128x128x16w4c", ("split128x128x16p6", "split128x64x16p9", "split128x128x16p6o", "split128x64x16p6o", "split64x64x16p6o", "split128x256x16p6pp", "split128x128x16p6u", "split128x64x16p6u", "split64x64x16p6u")),   # ragged M and N
+    (1, 16, 40, 9, 11, 1, 1, "zero", 0, "fast128x64x16w5c", ("split128x64x16p6", "split128x64x16p6o", "split128x128x16p6", "split128x128x16p6o", "split64x64x16p6o", "split128x256x16p6pp", "split128x128x16p6u", "split128x64x16p6u")),   # one K-tile, tiny problem
+    (1, 32, 96, 20, 24, 1, 1, "zero", 1, "fast128x64x16w5c", ("split128x64x16p6", "split128x128x16p9m", "split128x128x16p6o", "split128x64x16p6o", "split64x64x32p6o", "split128x256x16p6pp", "split128x128x16p6u", "split64x64x32p6u")),  # 2 K-tiles (1 of 32)
+    (1, 48, 128, 20, 24, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x128x16p6", "split128x128x16p9m", "split128x128x16p6o", "split128x64x16p6o", "split64x64x16p6o", "split64x64x16p9m", "split128x256x16p6pp", "split128x128x16p6u", "split128x64x16p6u", "split64x64x16p6u")),  # 3 K-tiles: every peeled iteration kind
     # the exact-N tiles (round 5): wave tile 32 x BN; whole and ragged column counts, ragged M
-    (1, 640, 160, 30, 37, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x64x16p6o", "split128x160x16p6o", "split128x128x16p6o")),      # ConvNeXt stage-2 pw2
+    (1, 640, 160, 30, 37, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x64x16p6o", "split128x160x16p6o", "split128x128x16p6o", "split128x160x16p6u")),      # ConvNeXt stage-2 pw2
     (1, 1280, 320, 12, 50, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x64x16p6o", "split128x160x16p6o")),                           # stage-3 pw2: two column tiles
-    (1, 320, 80, 24, 41, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x128x16p6o", "split128x96x16p6o", "split128x64x16p6o")),        # stage-1 pw2: 80 of 96 columns
-    (2, 384, 192, 16, 23, 1, 1, "zero", 1, "fast128x128x16w4c", ("split128x64x16p6o", "split128x192x16p6o", "split128x128x16p6o")),      # LaMa spectral conv1
-    (1, 64, 200, 9, 13, 3, 1, "reflect", 2, "fast128x128x16w4c", ("split128x128x16p6o", "split128x160x16p6o", "split128x192x16p6o", "split128x96x16p6o")),  # ragged last column tile of each
+    (1, 320, 80, 24, 41, 1, 1, "zero", 0, "fast128x128x16w4c", ("split128x128x16p6o", "split128x96x16p6o", "split128x64x16p6o", "split128x96x16p6u")),        # stage-1 pw2: 80 of 96 columns
+    (2, 384, 192, 16, 23, 1, 1, "zero", 1, "fast128x128x16w4c", ("split128x64x16p6o", "split128x192x16p6o", "split128x128x16p6o", "split128x192x16p6u")),      # LaMa spectral conv1
+    (1, 64, 200, 9, 13, 3, 1, "reflect", 2, "fast128x128x16w4c", ("split128x128x16p6o", "split128x160x16p6o", "split128x192x16p6o", "split128x96x16p6o", "split128x160x16p6u", "split128x192x16p6u", "split128x96x16p6u")),  # ragged last column tile of each
     # the ping-pong tile (round 6) where pick_cfg takes it: N % 256 == 0, long K (stride-2 3x3: 4, 5, 6+ K-tiles per tap run); odd M
     (2, 128, 512, 27, 41, 3, 2, "zero", 1, "fast128x128x16w4c", ("split128x128x16p6o", "split128x256x16p6pp", "split128x64x16p6o")),
     (1, 80, 256, 17, 19, 3, 1, "reflect", 0, "fast128x128x16w4c", ("split128x128x16p6o", "split128x256x16p6pp")),
@@ -78,7 +78,7 @@ def test_conv2d_split_tiles(case):
     for t in tiles:
         y = layer(xd, cfg=_cfg(t)).cpu()
         assert torch.isfinite(y).all(), t
-        if t.endswith(("p6o", "p9m", "p6pp")):  # the tiles the automatic choice can return: the result must not depend on which
+        if t.endswith(("p6o", "p9m", "p6pp", "p6u")):  # the tiles the automatic choice can return: the result must not depend on which
             shipped.setdefault("p9m" if t.endswith("p9m") else "p6", []).append((t, y))
         errs[t] = _rel(y, want, ymax)
         tol = 1e-2 if t.endswith("p3") else 4 * e32 + 2e-6
@@ -111,10 +111,15 @@ def test_batched_winograd_gemm_split():
     want = torch.einsum("ztc,zcn->ztn", v.double().cpu(), layer.u.double().cpu()[:, :128, :192])
     ymax = float(want.abs().max())
     e32 = _rel(m32.cpu(), want, ymax)
-    for t in ("split128x64x16p6", "split128x64x16p9", "split128x128x16p6", "split128x128x16p9m", "split128x128x16p6o", "split128x64x16p6o"):
+    first6 = None
+    for t in ("split128x64x16p6", "split128x64x16p9", "split128x128x16p6", "split128x128x16p9m", "split128x128x16p6o", "split128x64x16p6o",
+              "split128x128x16p6u", "split128x64x16p6u"):   # "u": buffer loads — the slice base moves with z, the offsets stay relative to it
         ms.fill_(float("nan"))
         ops.launch_conv_gemm(layer.gemm_desc(v, ms), _cfg(t))
         assert _rel(ms.cpu(), want, ymax) <= 4 * e32 + 2e-6, t
+        if "p6" in t:
+            first6 = ms.clone() if first6 is None else first6
+            assert torch.equal(ms, first6), t
 
 
 def test_split_tile_refused_without_planes():
