@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     // 77 VALU instructions a wave issues per K-tile beside its 24 MFMAs (profiles/r10p_pmc_split_tile.json).  The launcher takes it
     // only when every A and W byte offset is below 2^31 (buf_eligible in conv_gemm.hip).
     constexpr bool BUF = (VAR & 2048) != 0;
+    constexpr bool UNR2 = (VAR & 4096) != 0;  // see tile()
     constexpr bool ASM_SUB = (VAR & 64) != 0;  // residuals through v_sub_f32 inline asm: keeps the SLP vectoriser from packing them into v_pk_add_f32
     constexpr int SA = BM, SB = BN;
     constexpr int A_TILE = 3 * KH * SA, B_TILE = 3 * KH * SB;  // cells per buffer
@@ -308,9 +309,13 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
                 for (int ni = 0; ni < TN; ++ni) bnext[ks][pl][ni] = wk[(int64_t)(pl * K8 + 2 * ks) * ldn + bcol[ni]];
     };
     // One K-tile: fragment reads, then (PIPE) the staging of tile kt + 1 and the loads of tile kt + 2 scheduled among the MFMAs.
-    auto tile = [&](const int kt, auto do_store, auto do_load) {
+    auto tile = [&](const int kt, auto do_store, auto do_load, auto par_c) {
         constexpr bool DO_STORE = decltype(do_store)::value, DO_LOAD = decltype(do_load)::value;
-        const int cur = kt & 1;
+        // VAR bit 4096: the steady loop runs two K-tiles per trip with the LDS buffer parity as a compile-time constant, so that
+        // every ds_read / ds_write address is a loop-invariant register plus an immediate (the run-time parity cost a multiply and
+        // an add3 per access: 11 VALU and 5 SALU per K-tile)
+        constexpr int PAR = decltype(par_c)::value;
+        const int cur = PAR < 0 ? (kt & 1) : PAR;
         if (!PIPE && DO_STORE && !X_NOLOAD) load_tile();
         const u32x4 *as = As + cur * A_TILE;
         const u32x4 *bs = Bs + cur * B_TILE + lh * SB + wn0 + li;
@@ -374,6 +379,9 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     };
     const std::integral_constant<bool, true> yes;
     const std::integral_constant<bool, false> no;
+    const std::integral_constant<int, 0> par0;
+    const std::integral_constant<int, 1> par1;
+    const std::integral_constant<int, -1> parx;
 
     constexpr int EPI_FLOATS = (BM * (int)sizeof(RowOff) + 15) / 16 * 4 + 4 * 32 * EPI_PITCH + BM * (int)sizeof(LutOff) / 4;
     constexpr int STAGE_FLOATS = (2 * A_TILE + 2 * B_TILE) * 4;
@@ -393,12 +401,18 @@ __global__ __launch_bounds__(256, MINW) void conv_gemm_split_kernel(const MitCon
     {
         int kt = 0;
         if (PIPE) {
-            for (; kt + 2 < KT; ++kt) tile(kt, yes, yes);
-            if (kt + 1 < KT) tile(kt++, yes, no);
+            if (UNR2) {
+                for (; kt + 3 < KT; kt += 2) {
+                    tile(kt, yes, yes, par0);
+                    tile(kt + 1, yes, yes, par1);
+                }
+            }
+            for (; kt + 2 < KT; ++kt) tile(kt, yes, yes, parx);
+            if (kt + 1 < KT) tile(kt++, yes, no, parx);
         } else {
-            for (; kt + 1 < KT; ++kt) tile(kt, yes, no);
+            for (; kt + 1 < KT; ++kt) tile(kt, yes, no, parx);
         }
-        tile(kt, no, no);
+        tile(kt, no, no, parx);
     }
     if (X_NOBAR) __syncthreads();  // the epilogue reuses the staging area
     // the thread index rebuilt from the SGPR wave index and mbcnt: nothing derived from threadIdx.x has to survive the K loop (the

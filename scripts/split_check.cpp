@@ -55,7 +55,8 @@ int main(int argc, char **argv) {
     const int t192 = find_cfg("split128x192x16p6o"), t256 = find_cfg("split256x64x16p6o");
     const int t160 = find_cfg("split128x160x16p6o"), t96 = find_cfg("split128x96x16p6o");  // exact-N tiles for N = 160 k / N = 80  // wide-N tile (-1 in builds without it: skipped)
     const int pp = find_cfg("split256x128x16p6pp"), pq = find_cfg("split128x256x16p6pp");
-    const int bd = find_cfg("split128x128x16p6u");  // round 6: operand loads through buffer instructions  // round 6: the eight-wave ping-pong tiles
+    const int bd = find_cfg("split128x128x16p6u");  // round 6: operand loads through buffer instructions
+    const int bv = find_cfg("split128x128x16p6v");  // ... + two K-tiles per loop trip with constant LDS buffer parity  // round 6: the eight-wave ping-pong tiles
     const int gen32 = find_cfg("128x32x16"), f64 = find_cfg("fast64x64x16w8c"), s64k = find_cfg("split64x64x32p6o");
     if (f_wide < 0 || f_narrow < 0 || s6 < 0 || s9 < 0 || s3 < 0 || n6 < 0 || n9 < 0 || s9m < 0) {
         fprintf(stderr, "tile names not found\n");
@@ -113,8 +114,10 @@ int main(int argc, char **argv) {
     for (auto &c : cases)   // the direct-W tile wherever the shipped wide tile is measured
         if (!strncmp(c.name, "pp:", 3) || !strncmp(c.name, "ragged", 6) || !strncmp(c.name, "probe", 5)) {
             c.cfgs.push_back(bd);
+            c.cfgs.push_back(bv);
             c.cfgs.push_back(s6o);
             c.cfgs.push_back(bd);
+            c.cfgs.push_back(bv);
         }
     if (const char *only = getenv("SC_CASE")) {  // substring filter on the case name
         std::vector<Case> keep;
