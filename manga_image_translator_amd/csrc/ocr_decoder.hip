@@ -177,6 +177,24 @@ int pgemm(const MitLinear &lin, const uint16_t *a_planes, int64_t lda, int M, fl
     else d.c_planes = c_planes, d.ld_cp = ld_cp;
     return mit_pgemm_rows(d, x, s);
 }
+// The same with A = LayerNorm(x) computed by the GEMM's own waves (pgemm_rows_ln.hip; K == 320): bit for bit ocrk_layernorm + pgemm.
+int pgemm_ln(const MitLinear &lin, const float *xin, int64_t ldx, const float *ln_w, const float *ln_b, int M, float *Cp, int64_t ldc, int act,
+             uint16_t *c_planes, int64_t ld_cp, hipStream_t s, int nsplit = 0, int64_t nhi = 0, const int *dyn = nullptr, int64_t c_dyn = 0) {
+    MitPGemm d;
+    memset(&d, 0, sizeof(d));
+    d.w_planes = lin.w_split; d.ldw = lin.ldw;
+    d.M = M; d.N = lin.N; d.K = lin.K; d.Z = 1;
+    d.c = Cp; d.ldc = ldc;
+    d.scale = lin.scale; d.bias = lin.bias; d.act = act;
+    d.nprod = 0;
+    PgRowsExt x;
+    memset(&x, 0, sizeof(x));
+    x.nsplit = nsplit; x.nhi = nhi; x.dyn = dyn; x.c_dyn = c_dyn;
+    if (Cp) x.also_planes = c_planes, x.also_ld = ld_cp;
+    else d.c_planes = c_planes, d.ld_cp = ld_cp;
+    const PgRowsLn ln{xin, ldx, ln_w, ln_b, 1e-5f};
+    return mit_pgemm_rows_ln(d, x, ln, s);
+}
 inline bool rows_ok(const MitLinear &l) { return l.w_split && l.Kp == l.K && (l.K % 16) == 0 && (l.N % 8) == 0; }
 
 __global__ void fill_int_kernel(int *p, int64_t n, int v) {
@@ -265,6 +283,7 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
     MIT_CHECK_HIP(hipMemsetAsync(w.done_count, 0, 4, s));
     MIT_CHECK_HIP(hipMemsetAsync(w.decoded, 0, (size_t)R * TE * 4, s));
     MIT_CHECK_HIP(hipMemsetAsync(a->res_len, 0, (size_t)N * 4, s));
+    ocrk_embed(hist[0], hist_ld, dec->embd, w.tgt, R, E, s);   // step 0: the start tokens; every later step's rows come from the beam kernel
 
     int cur = 0, steps = 0;
     // One beam-search step as a launch sequence.  ``dyn`` == nullptr: the step-dependent arguments are host values (the classic form);
@@ -282,10 +301,12 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
         const MitOcrDecoderLayer &ly = dec->layers[l];
         rows_path = rows_ok(ly.qkv) && rows_ok(ly.out) && rows_ok(ly.q2) && rows_ok(ly.out2) && rows_ok(ly.ff1) && rows_ok(ly.ff2);
     }
+    // LayerNorm inside the Linear that consumes it (read per call: tests switch it in-process; MIT_OCR_LN_FUSED=0 = the two-launch form)
+    const char *lnf_env = getenv("MIT_OCR_LN_FUSED");
+    const bool ln_fused = rows_path && !(lnf_env && *lnf_env && atoi(lnf_env) == 0);
     auto body = [&](const int step, const int *dyn, hipStream_t st) -> int {
         const int64_t so = dyn ? 0 : (int64_t)step * E;  // host-side step offset; the dyn form adds step * E on the device
-        if (dyn) ocrk_embed(hist[0], hist_ld, dec->embd, w.tgt, R, E, st, hist[1], dyn);
-        else ocrk_embed(hist[cur] + step, hist_ld, dec->embd, w.tgt, R, E, st);
+        // (w.tgt holds the embedded tokens of this step: the start tokens before the loop, then written by the previous step's beam kernel)
         const int Tk = dyn ? T : step + 1;  // dyn: capacity (grid / LDS); the kernels stop at *dyn + 1
         if (rows_path) {
             // few rows (one page .. a group of pages): every Linear on the one-wave-per-block planar GEMM (pgemm_rows.h) — the LayerNorms,
@@ -298,20 +319,32 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
                 float *qc = w.qkv + (int64_t)(l * 3 + 0) * R * TE;
                 float *kc = w.qkv + (int64_t)(l * 3 + 1) * R * TE;
                 float *vc = w.qkv + (int64_t)(l * 3 + 2) * R * TE;
-                if (ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
-                if (pgemm(ly.qkv, w.nrm_p, Rp, R, qc + so, TE, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st, E, (int64_t)R * TE, dyn, E)) return 1;
+                if (ln_fused) {
+                    if (pgemm_ln(ly.qkv, w.tgt, E, ly.ln1_w, ly.ln1_b, R, qc + so, TE, MIT_ACT_NONE, nullptr, 0, st, E, (int64_t)R * TE, dyn, E)) return 1;
+                } else {
+                    if (ocrk_layernorm(w.tgt, E, ly.ln1_w, ly.ln1_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
+                    if (pgemm(ly.qkv, w.nrm_p, Rp, R, qc + so, TE, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st, E, (int64_t)R * TE, dyn, E)) return 1;
+                }
                 OcrAttXpos xs{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 1, E};
                 ocrk_attention(qc + so, TE, E, kc, TE, E, vc, TE, E, nullptr, 0, 0, nullptr, R, 1, Tk, 1, st, 4, 80, dyn, &xs, &att_pl);
                 if (pgemm(ly.out, w.att_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
-                if (ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
-                if (pgemm(ly.q2, w.nrm_p, Rp, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st)) return 1;
+                if (ln_fused) {
+                    if (pgemm_ln(ly.q2, w.tgt, E, ly.ln2_w, ly.ln2_b, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, st)) return 1;
+                } else {
+                    if (ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
+                    if (pgemm(ly.q2, w.nrm_p, Rp, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st)) return 1;
+                }
                 const float *mk = a->mem_k + (int64_t)l * N * L * E;
                 const float *mv = a->mem_v + (int64_t)l * N * L * E;
                 OcrAttXpos xc{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 0, 0};
                 ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, nullptr, 0, 0, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc, &att_pl);
                 if (pgemm(ly.out2, w.att_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
-                if (ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
-                if (pgemm(ly.ff1, w.nrm_p, Rp, R, nullptr, 0, MIT_ACT_RELU, nullptr, 0, w.ffh_p, Rp, st)) return 1;
+                if (ln_fused) {
+                    if (pgemm_ln(ly.ff1, w.tgt, E, ly.ln3_w, ly.ln3_b, R, nullptr, 0, MIT_ACT_RELU, w.ffh_p, Rp, st)) return 1;
+                } else {
+                    if (ocrk_layernorm(w.tgt, E, ly.ln3_w, ly.ln3_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
+                    if (pgemm(ly.ff1, w.nrm_p, Rp, R, nullptr, 0, MIT_ACT_RELU, nullptr, 0, w.ffh_p, Rp, st)) return 1;
+                }
                 if (l < 4) {
                     if (pgemm(ly.ff2, w.ffh_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
                 } else {  // last layer: the step's output into the activation cache (:570), and as planes for the prediction head
@@ -359,13 +392,13 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
         ocrk_logsoftmax_top5(w.logits, Dp, R, D, a->suppress_eos ? a->end_tok : -1, w.vals, w.idx, nullptr, st);
         if (dyn) {
             ocrk_beam_dyn(w.vals, w.idx, hist[0], hist[1], hist_ld, logp[0], logp[1], w.done, a->res_row, a->res_len, a->res_prob, a->res_tok,
-                          w.done_count, N, dyn, a->start_tok, a->end_tok, a->max_finished, st);
+                          w.done_count, N, dyn, a->start_tok, a->end_tok, a->max_finished, st, dec->embd, w.tgt, E);
             ocrk_step_advance(w.dstep, st);
         } else if (step == 0) {
-            ocrk_beam_init(w.vals, w.idx, hist[cur], hist_ld, logp[cur], N, a->start_tok, st);
+            ocrk_beam_init(w.vals, w.idx, hist[cur], hist_ld, logp[cur], N, a->start_tok, st, dec->embd, w.tgt, E);
         } else {
             ocrk_beam_step(w.vals, w.idx, hist[cur], hist[cur ^ 1], hist_ld, logp[cur], logp[cur ^ 1], w.done, a->res_row,
-                           a->res_len, a->res_prob, a->res_tok, w.done_count, N, step, a->end_tok, a->max_finished, st);
+                           a->res_len, a->res_prob, a->res_tok, w.done_count, N, step, a->end_tok, a->max_finished, st, dec->embd, w.tgt, E);
             cur ^= 1;
         }
         if (a->trace_hist)

@@ -34,14 +34,17 @@ void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, 
                 const int *dstep = nullptr);
 void ocrk_beam_dyn(const float *vals, const int *idx, int *hist0, int *hist1, int hist_ld, float *logp0, float *logp1, int *done,
                    int *res_row, int *res_len, float *res_prob, int *res_tok, int *done_count, int N, const int *dstep, int start_tok,
-                   int end_tok, int max_finished, hipStream_t s);
+                   int end_tok, int max_finished, hipStream_t s, const float *next_E = nullptr, float *next_out = nullptr, int next_D = 0);
 void ocrk_step_advance(int *dstep, hipStream_t s);
 void ocrk_logsoftmax_top5(const float *logits, int64_t ld, int R, int D, int suppress_tok, float *vals, int *idx,
                           float *logp_out, hipStream_t s);
+// next_E / next_out / next_D (beam kernels, optional): the embedding rows [R][next_D] of the tokens just chosen = the residual stream of
+// the next step, written by the bookkeeping kernel instead of a separate ocrk_embed launch at the head of that step
 void ocrk_beam_init(const float *vals, const int *idx, int *hist, int hist_ld, float *logp, int N, int start_tok,
-                    hipStream_t s);
+                    hipStream_t s, const float *next_E = nullptr, float *next_out = nullptr, int next_D = 0);
 void ocrk_beam_step(const float *vals, const int *idx, const int *hist_in, int *hist_out, int hist_ld, const float *logp_in,
                     float *logp_out, int *done, int *res_row, int *res_len, float *res_prob, int *res_tok, int *done_count,
-                    int N, int step, int end_tok, int max_finished, hipStream_t s);
+                    int N, int step, int end_tok, int max_finished, hipStream_t s, const float *next_E = nullptr, float *next_out = nullptr,
+                    int next_D = 0);
 void ocrk_beam_finalize(const int *hist, int hist_ld, const float *logp, int *done, int *res_row, int *res_len,
                         float *res_prob, int *res_tok, int N, int len, hipStream_t s);

@@ -10,6 +10,7 @@
 #include <atomic>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/mit_hip.h"
 #include "common.h"
 #include "ocr_kernels.h"
@@ -882,60 +883,122 @@ __global__ void embed_kernel(const int *__restrict__ tok, int64_t tok_stride, co
 
 // ---- log_softmax + top-5 over the dictionary, one block per row ----
 // ties resolve to the lower index.
+// NJ > 0 (D <= 256 NJ): a thread's NJ elements (d = tid, tid + 256, ...) are loaded ONCE, all loads in flight together, and every pass
+// runs on registers — the loop form (NJ == 0) re-reads the row per pass and its candidate insertion serialises the loads (24 dependent
+// round trips per row at the 48px dictionary: 24 us per launch, 8 of it now).  Per thread the same elements in the same order, across
+// threads the same pairing (tid, tid + s) for s = 128 .. 1: the max, the sum, the log-probabilities and the five winners are bitwise those
+// of the loop form.
+__device__ __forceinline__ bool top5_better(const float a, const int da, const float b, const int db) { return a > b || (a == b && da < db); }
+
+template <int NJ>
 __global__ __launch_bounds__(256) void logsoftmax_top5_kernel(const float *__restrict__ logits, int64_t ld, int D,
                                                                int suppress_tok, float *__restrict__ vals,
                                                                int *__restrict__ idx, float *__restrict__ logp_out) {
     __shared__ float red[256];
     __shared__ float cv[256 * 5];
     __shared__ int ci[256 * 5];
-    const int r = blockIdx.x, tid = threadIdx.x;
+    __shared__ float bc[2];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *x = logits + (int64_t)r * ld;
     float tv[5];
     int ti[5];
+#pragma unroll
     for (int j = 0; j < 5; ++j) {
         tv[j] = -INFINITY;
         ti[j] = 0x7fffffff;
     }
-    float mx = -INFINITY;
-    for (int d = tid; d < D; d += 256) {
-        float v = x[d];
-        if (d == suppress_tok) v = -INFINITY;
-        mx = fmaxf(mx, v);
-        if (v > tv[4] || (v == tv[4] && d < ti[4])) {
-            int j = 4;
-            while (j > 0 && (v > tv[j - 1] || (v == tv[j - 1] && d < ti[j - 1]))) {
-                tv[j] = tv[j - 1];
-                ti[j] = ti[j - 1];
-                --j;
-            }
-            tv[j] = v;
-            ti[j] = d;
+    float mx = -INFINITY, lse;
+    if constexpr (NJ > 0) {
+        float v[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = tid + 256 * j;
+            v[j] = d < D ? x[d] : -INFINITY;
+            if (d == suppress_tok) v[j] = -INFINITY;
         }
-    }
-    red[tid] = mx;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int d = tid + 256 * j;
+            if (d < D) {
+                mx = fmaxf(mx, v[j]);
+                if (top5_better(v[j], d, tv[4], ti[4])) {   // insertion = replace the last, bubble up (static register indices)
+                    tv[4] = v[j], ti[4] = d;
+#pragma unroll
+                    for (int q = 4; q > 0; --q) {
+                        if (top5_better(tv[q], ti[q], tv[q - 1], ti[q - 1])) {
+                            const float fv = tv[q]; tv[q] = tv[q - 1]; tv[q - 1] = fv;
+                            const int fi = ti[q]; ti[q] = ti[q - 1]; ti[q - 1] = fi;
+                        }
+                    }
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) red[wave] = mx;
         __syncthreads();
-    }
-    mx = red[0];
-    __syncthreads();
-    float sum = 0.f;
-    for (int d = tid; d < D; d += 256) {
-        const float v = (d == suppress_tok) ? -INFINITY : x[d];
-        sum += expf(v - mx);
-    }
-    red[tid] = sum;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         __syncthreads();
-    }
-    const float lse = logf(red[0]);
-    if (logp_out) {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (tid + 256 * j < D) sum += expf(v[j] - mx);
+        red[tid] = sum;
+        __syncthreads();
+        if (wave == 0) {   // the tree red[t] += red[t + s], s = 128 .. 1, with the last six levels inside the wave
+            float sm = (red[lane] + red[lane + 128]) + (red[lane + 64] + red[lane + 192]);
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_down(sm, o);
+            if (lane == 0) bc[0] = logf(sm);
+        }
+        __syncthreads();
+        lse = bc[0];
+        if (logp_out) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int d = tid + 256 * j;
+                if (d < D) logp_out[(int64_t)r * D + d] = (v[j] - mx) - lse;
+            }
+        }
+    } else {
+        for (int d = tid; d < D; d += 256) {
+            float v = x[d];
+            if (d == suppress_tok) v = -INFINITY;
+            mx = fmaxf(mx, v);
+            if (v > tv[4] || (v == tv[4] && d < ti[4])) {
+                int j = 4;
+                while (j > 0 && (v > tv[j - 1] || (v == tv[j - 1] && d < ti[j - 1]))) {
+                    tv[j] = tv[j - 1];
+                    ti[j] = ti[j - 1];
+                    --j;
+                }
+                tv[j] = v;
+                ti[j] = d;
+            }
+        }
+        red[tid] = mx;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+            __syncthreads();
+        }
+        mx = red[0];
+        __syncthreads();
+        float sum = 0.f;
         for (int d = tid; d < D; d += 256) {
             const float v = (d == suppress_tok) ? -INFINITY : x[d];
-            logp_out[(int64_t)r * D + d] = (v - mx) - lse;
+            sum += expf(v - mx);
+        }
+        red[tid] = sum;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        lse = logf(red[0]);
+        if (logp_out) {
+            for (int d = tid; d < D; d += 256) {
+                const float v = (d == suppress_tok) ? -INFINITY : x[d];
+                logp_out[(int64_t)r * D + d] = (v - mx) - lse;
+            }
         }
     }
     for (int j = 0; j < 5; ++j) {
@@ -977,23 +1040,48 @@ __global__ __launch_bounds__(256) void logsoftmax_top5_kernel(const float *__res
     }
 }
 
-// ---- beam bookkeeping: one thread per sample (25 candidates) ----
-// step 0 (:693-699): beam j of a sample takes the j-th best token of its (identical) row.
-__device__ __forceinline__ void beam_init_body(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist,
-                                               int hist_ld, float *__restrict__ logp, int N, int start_tok) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    for (int j = 0; j < 5; ++j) {
-        const int row = n * 5 + j;
-        hist[(int64_t)row * hist_ld + 0] = start_tok;
-        hist[(int64_t)row * hist_ld + 1] = idx[(n * 5) * 5 + j];
-        logp[row] = vals[(n * 5) * 5 + j];
+// ---- beam bookkeeping: one wave per sample (25 candidates on lanes 0 .. 24) ----
+// The reference's bookkeeping (:693-699, :716-771) is integer work plus one float add per candidate; a thread per sample walked the
+// 25 candidates and copied five histories by itself (42 us per step at one page).  Here the lanes of a wave hold the candidates, the
+// top-5 are five wave-wide arg-max rounds (value descending, lower flat index first on ties — torch.topk's order on this path), the
+// histories are copied lane-parallel.  `next` (optional): the embedding rows of the tokens just chosen, written as the residual stream of
+// the NEXT step (what embed_kernel would do as the first launch of that step).
+struct BeamNextEmbed {
+    const float *E;   // embedding table [dict][D]; NULL: none
+    float *out;       // [R][D]
+    int D;
+};
+
+__device__ __forceinline__ void beam_embed_rows(const BeamNextEmbed &next, const int n, const int (&tok)[5], const int lane) {
+    if (!next.E) return;
+    const int D4 = next.D >> 2;
+    for (int i = lane; i < 5 * D4; i += 64) {
+        const int k = i / D4, d4 = i - k * D4;
+        const int t = k == 0 ? tok[0] : k == 1 ? tok[1] : k == 2 ? tok[2] : k == 3 ? tok[3] : tok[4];
+        reinterpret_cast<float4 *>(next.out + (int64_t)(n * 5 + k) * next.D)[d4] = reinterpret_cast<const float4 *>(next.E + (int64_t)t * next.D)[d4];
     }
 }
 
-__global__ void beam_init_kernel(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist,
-                                 int hist_ld, float *__restrict__ logp, int N, int start_tok) {
-    beam_init_body(vals, idx, hist, hist_ld, logp, N, start_tok);
+// step 0 (:693-699): beam j of a sample takes the j-th best token of its (identical) row.
+__device__ __forceinline__ void beam_init_body(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist,
+                                               int hist_ld, float *__restrict__ logp, int N, int start_tok, const BeamNextEmbed next) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    if (n >= N) return;
+    int tok[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) tok[j] = idx[(n * 5) * 5 + j];
+    if (lane < 5) {
+        const int row = n * 5 + lane;
+        hist[(int64_t)row * hist_ld + 0] = start_tok;
+        hist[(int64_t)row * hist_ld + 1] = idx[(n * 5) * 5 + lane];
+        logp[row] = vals[(n * 5) * 5 + lane];
+    }
+    beam_embed_rows(next, n, tok, lane);
+}
+
+__global__ __launch_bounds__(64) void beam_init_kernel(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist,
+                                                       int hist_ld, float *__restrict__ logp, int N, int start_tok, BeamNextEmbed next) {
+    beam_init_body(vals, idx, hist, hist_ld, logp, N, start_tok, next);
 }
 
 // steps >= 1 (:716-771). hist_in/out [R][hist_ld]: tokens 0..step valid on input, 0..step+1 on output.
@@ -1002,74 +1090,91 @@ __device__ __forceinline__ void beam_step_body(const float *__restrict__ vals, c
                                                const float *__restrict__ logp_in, float *__restrict__ logp_out, int *__restrict__ done,
                                                int *__restrict__ res_row, int *__restrict__ res_len, float *__restrict__ res_prob,
                                                int *__restrict__ res_tok, int *__restrict__ done_count, int N, int step, int end_tok,
-                                               int max_finished) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+                                               int max_finished, const BeamNextEmbed next) {
+    const int n = blockIdx.x, lane = threadIdx.x;
     if (n >= N) return;
-    float cl[25];
-    int ct[25];
-    for (int b = 0; b < 5; ++b) {
-        const int row = n * 5 + b;
+    const bool was_done = done[n] != 0;   // (every lane reads it before lane 0 of this wave — its only writer — may set it)
+    float cl = -INFINITY;   // candidate c = b * 5 + j on lane c: beam b's j-th best continuation
+    int ct = 0;
+    if (lane < 25) {
+        const int b = lane / 5, j = lane - b * 5, row = n * 5 + b;
         const bool fin = hist_in[(int64_t)row * hist_ld + step] == end_tok;
-        for (int j = 0; j < 5; ++j) {
-            const float v = fin ? 0.f : vals[row * 5 + j];
-            ct[b * 5 + j] = fin ? end_tok : idx[row * 5 + j];
-            cl[b * 5 + j] = logp_in[row] + v;
-        }
+        const float v = fin ? 0.f : vals[row * 5 + j];
+        ct = fin ? end_tok : idx[row * 5 + j];
+        cl = logp_in[row] + v;
     }
-    int sel[5];
-    bool used[25];
-    for (int c = 0; c < 25; ++c) used[c] = false;
+    bool used = lane >= 25;
+    int sel[5], tok[5];
+    float sl[5];
+#pragma unroll
     for (int k = 0; k < 5; ++k) {  // topk, descending, lower flat index first on ties
-        int best = -1;
-        for (int c = 0; c < 25; ++c)
-            if (!used[c] && (best < 0 || cl[c] > cl[best])) best = c;
-        used[best] = true;
-        sel[k] = best;
+        float v = used ? -INFINITY : cl;
+        int c = used ? 1 << 20 : lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o);
+            const int oc = __shfl_xor(c, o);
+            if (ov > v || (ov == v && oc < c)) v = ov, c = oc;
+        }
+        sel[k] = c;
+        if (lane == c) used = true;
+        sl[k] = __shfl(cl, c);
+        tok[k] = __shfl(ct, c);
     }
     int fcount = 0;
+#pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int row = n * 5 + k;
         const int src = n * 5 + sel[k] / 5;
-        for (int t = 0; t <= step; ++t) hist_out[(int64_t)row * hist_ld + t] = hist_in[(int64_t)src * hist_ld + t];
-        hist_out[(int64_t)row * hist_ld + step + 1] = ct[sel[k]];
-        logp_out[row] = cl[sel[k]];
-        fcount += ct[sel[k]] == end_tok;
+        for (int t = lane; t <= step; t += 64) hist_out[(int64_t)row * hist_ld + t] = hist_in[(int64_t)src * hist_ld + t];
+        if (lane == 0) {
+            hist_out[(int64_t)row * hist_ld + step + 1] = tok[k];
+            logp_out[row] = sl[k];
+        }
+        fcount += tok[k] == end_tok;
     }
-    if (!done[n] && fcount >= max_finished) {
-        done[n] = 1;
-        atomicAdd(done_count, 1);
+    if (!was_done && fcount >= max_finished) {
         const int row = n * 5 + 0;  // argmax of the (descending) top-k
-        res_row[n] = row;
-        res_len[n] = step + 2;
-        res_prob[n] = expf(cl[sel[0]]);
-        for (int t = 0; t <= step + 1; ++t) res_tok[(int64_t)n * hist_ld + t] = hist_out[(int64_t)row * hist_ld + t];
+        const int src = n * 5 + sel[0] / 5;
+        for (int t = lane; t <= step; t += 64) res_tok[(int64_t)n * hist_ld + t] = hist_in[(int64_t)src * hist_ld + t];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            res_tok[(int64_t)n * hist_ld + step + 1] = tok[0];
+            res_row[n] = row;
+            res_len[n] = step + 2;
+            res_prob[n] = expf(sl[0]);
+            done[n] = 1;
+            atomicAdd(done_count, 1);
+        }
     }
+    beam_embed_rows(next, n, tok, lane);
 }
 
-__global__ void beam_step_kernel(const float *__restrict__ vals, const int *__restrict__ idx,
+__global__ __launch_bounds__(64) void beam_step_kernel(const float *__restrict__ vals, const int *__restrict__ idx,
                                  const int *__restrict__ hist_in, int *__restrict__ hist_out, int hist_ld,
                                  const float *__restrict__ logp_in, float *__restrict__ logp_out, int *__restrict__ done,
                                  int *__restrict__ res_row, int *__restrict__ res_len, float *__restrict__ res_prob,
                                  int *__restrict__ res_tok, int *__restrict__ done_count, int N, int step, int end_tok,
-                                 int max_finished) {
+                                 int max_finished, BeamNextEmbed next) {
     beam_step_body(vals, idx, hist_in, hist_out, hist_ld, logp_in, logp_out, done, res_row, res_len, res_prob, res_tok, done_count, N, step,
-                   end_tok, max_finished);
+                   end_tok, max_finished, next);
 }
 
 // The same bookkeeping with the step read from device memory (one launch sequence serves every step, so it can be replayed from a
 // hipGraph): step 0 initialises buffer 0; step s >= 1 reads buffer (s - 1) & 1 and writes buffer s & 1.
-__global__ void beam_dyn_kernel(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist0, int *__restrict__ hist1,
+__global__ __launch_bounds__(64) void beam_dyn_kernel(const float *__restrict__ vals, const int *__restrict__ idx, int *__restrict__ hist0, int *__restrict__ hist1,
                                 int hist_ld, float *__restrict__ logp0, float *__restrict__ logp1, int *__restrict__ done,
                                 int *__restrict__ res_row, int *__restrict__ res_len, float *__restrict__ res_prob, int *__restrict__ res_tok,
-                                int *__restrict__ done_count, int N, const int *__restrict__ dstep, int start_tok, int end_tok, int max_finished) {
+                                int *__restrict__ done_count, int N, const int *__restrict__ dstep, int start_tok, int end_tok, int max_finished,
+                                BeamNextEmbed next) {
     const int step = *dstep;
     if (step == 0) {
-        beam_init_body(vals, idx, hist0, hist_ld, logp0, N, start_tok);
+        beam_init_body(vals, idx, hist0, hist_ld, logp0, N, start_tok, next);
         return;
     }
     const bool odd_in = ((step - 1) & 1) != 0;
     beam_step_body(vals, idx, odd_in ? hist1 : hist0, odd_in ? hist0 : hist1, hist_ld, odd_in ? logp1 : logp0, odd_in ? logp0 : logp1, done,
-                   res_row, res_len, res_prob, res_tok, done_count, N, step, end_tok, max_finished);
+                   res_row, res_len, res_prob, res_tok, done_count, N, step, end_tok, max_finished, next);
 }
 
 __global__ void step_advance_kernel(int *__restrict__ dstep) {
@@ -1452,9 +1557,9 @@ void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, 
 
 void ocrk_beam_dyn(const float *vals, const int *idx, int *hist0, int *hist1, int hist_ld, float *logp0, float *logp1, int *done,
                    int *res_row, int *res_len, float *res_prob, int *res_tok, int *done_count, int N, const int *dstep, int start_tok,
-                   int end_tok, int max_finished, hipStream_t s) {
-    hipLaunchKernelGGL(beam_dyn_kernel, dim3((N + 63) / 64), dim3(64), 0, s, vals, idx, hist0, hist1, hist_ld, logp0, logp1, done, res_row,
-                       res_len, res_prob, res_tok, done_count, N, dstep, start_tok, end_tok, max_finished);
+                   int end_tok, int max_finished, hipStream_t s, const float *next_E, float *next_out, int next_D) {
+    hipLaunchKernelGGL(beam_dyn_kernel, dim3(N), dim3(64), 0, s, vals, idx, hist0, hist1, hist_ld, logp0, logp1, done, res_row,
+                       res_len, res_prob, res_tok, done_count, N, dstep, start_tok, end_tok, max_finished, BeamNextEmbed{next_E, next_out, next_D});
 }
 
 void ocrk_step_advance(int *dstep, hipStream_t s) { hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, dstep); }
@@ -1462,19 +1567,28 @@ void ocrk_step_advance(int *dstep, hipStream_t s) { hipLaunchKernelGGL(step_adva
 void ocrk_logsoftmax_top5(const float *logits, int64_t ld, int R, int D, int suppress_tok, float *vals, int *idx,
                           float *logp_out, hipStream_t s) {
     MitProbeScope probe("logsoftmax_top5_kernel", s, 4.0 * (double)R * D + (logp_out ? 4.0 * (double)R * D : 0.0));
-    hipLaunchKernelGGL(logsoftmax_top5_kernel, dim3(R), dim3(256), 0, s, logits, ld, D, suppress_tok, vals, idx, logp_out);
+    const char *loop_form = getenv("MIT_OCR_TOP5_LOOP");   // the loop form for every D (tests: both forms bit for bit)
+    if (loop_form && atoi(loop_form))
+        hipLaunchKernelGGL(logsoftmax_top5_kernel<0>, dim3(R), dim3(256), 0, s, logits, ld, D, suppress_tok, vals, idx, logp_out);
+    else if (D <= 256 * 8)
+        hipLaunchKernelGGL(logsoftmax_top5_kernel<8>, dim3(R), dim3(256), 0, s, logits, ld, D, suppress_tok, vals, idx, logp_out);
+    else if (D <= 256 * 24)
+        hipLaunchKernelGGL(logsoftmax_top5_kernel<24>, dim3(R), dim3(256), 0, s, logits, ld, D, suppress_tok, vals, idx, logp_out);
+    else
+        hipLaunchKernelGGL(logsoftmax_top5_kernel<0>, dim3(R), dim3(256), 0, s, logits, ld, D, suppress_tok, vals, idx, logp_out);
 }
 
 void ocrk_beam_init(const float *vals, const int *idx, int *hist, int hist_ld, float *logp, int N, int start_tok,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(beam_init_kernel, dim3((N + 63) / 64), dim3(64), 0, s, vals, idx, hist, hist_ld, logp, N, start_tok);
+                    hipStream_t s, const float *next_E, float *next_out, int next_D) {
+    hipLaunchKernelGGL(beam_init_kernel, dim3(N), dim3(64), 0, s, vals, idx, hist, hist_ld, logp, N, start_tok, BeamNextEmbed{next_E, next_out, next_D});
 }
 
 void ocrk_beam_step(const float *vals, const int *idx, const int *hist_in, int *hist_out, int hist_ld, const float *logp_in,
                     float *logp_out, int *done, int *res_row, int *res_len, float *res_prob, int *res_tok, int *done_count,
-                    int N, int step, int end_tok, int max_finished, hipStream_t s) {
-    hipLaunchKernelGGL(beam_step_kernel, dim3((N + 63) / 64), dim3(64), 0, s, vals, idx, hist_in, hist_out, hist_ld, logp_in,
-                       logp_out, done, res_row, res_len, res_prob, res_tok, done_count, N, step, end_tok, max_finished);
+                    int N, int step, int end_tok, int max_finished, hipStream_t s, const float *next_E, float *next_out, int next_D) {
+    hipLaunchKernelGGL(beam_step_kernel, dim3(N), dim3(64), 0, s, vals, idx, hist_in, hist_out, hist_ld, logp_in,
+                       logp_out, done, res_row, res_len, res_prob, res_tok, done_count, N, step, end_tok, max_finished,
+                       BeamNextEmbed{next_E, next_out, next_D});
 }
 
 void ocrk_beam_finalize(const int *hist, int hist_ld, const float *logp, int *done, int *res_row, int *res_len,

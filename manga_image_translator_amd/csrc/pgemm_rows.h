@@ -16,3 +16,13 @@ struct PgRowsExt {
 // C = epilogue(A @ W) for planar A, one wave per 32 x 32 block (Z == 1).  d.c and / or d.c_planes | x.also_planes; d.tile is ignored,
 // d.nprod 6 | 9.  Returns 0, or 1 with mit_last_error() set.
 int mit_pgemm_rows(const MitPGemm &d, const PgRowsExt &x, hipStream_t s);
+
+// A = LayerNorm(x) instead of planes (pgemm_rows_ln.hip): x fp32 [M][ldx] (ldx % 4 == 0), K == 320; d.a_planes / d.lda are ignored.
+// Bit for bit ocrk_layernorm(planes) followed by mit_pgemm_rows.
+struct PgRowsLn {
+    const float *x;
+    int64_t ldx;
+    const float *w, *b;   // LayerNorm weight / bias [K]
+    float eps;
+};
+int mit_pgemm_rows_ln(const MitPGemm &d, const PgRowsExt &x, const PgRowsLn &ln, hipStream_t s);

@@ -457,3 +457,49 @@ def test_row_staged_self_attention_is_bitwise_the_per_head_kernel(cuda, ocr_setu
     for other in outs[1:]:
         for k, v in outs[0].items():
             assert torch.equal(v, other[k]), k
+
+
+@pytest.mark.parametrize("R,D,suppress", [(7, 6004, 2), (160, 6004, -1), (5, 2047, 0), (3, 300, -1), (4, 7000, 5)])
+def test_register_form_of_logsoftmax_top5_is_bitwise_the_loop_form(cuda, R, D, suppress):
+    """logsoftmax_top5_kernel<NJ>: a thread's elements loaded once and every pass on registers (all loads in flight together) against the
+    loop form (MIT_OCR_TOP5_LOOP=1: three passes over the row, loads serialised by the candidate insertion): same elements per thread in
+    the same order, same pairing across threads — the five values and the five indices must be identical, with ties
+    (lower index first), a suppressed token and rows of -inf padding."""
+    import ctypes as C
+    import os
+    from manga_image_translator_amd import lib as L, ops
+
+    lib = L.load()
+    g = torch.Generator().manual_seed(R * 131 + D)
+    Dp = (D + 3) // 4 * 4
+    x = torch.randn(R, Dp, generator=g) * 4
+    x[:, ::97] = x[:, 5:6]              # exact ties spread over the threads
+    x[R // 2:, ::97] = 20.0             # ... and, on half of the rows, ties among the winners
+    x[0, : min(D, 40)] = float("-inf")  # a run of -inf entries
+    x = x.to(cuda)
+    outs = []
+    prev = os.environ.get("MIT_OCR_TOP5_LOOP")
+    try:
+        for loop in ("1", "0"):
+            os.environ["MIT_OCR_TOP5_LOOP"] = loop
+            vals = torch.empty(R, 5, device=cuda)
+            idx = torch.empty(R, 5, dtype=torch.int32, device=cuda)
+            L.check(lib.mit_logsoftmax_top5(x.data_ptr(), Dp, R, D, suppress, vals.data_ptr(), idx.data_ptr(),
+                                            C.c_void_p(ops.current_stream())), "mit_logsoftmax_top5")
+            torch.cuda.synchronize()
+            outs.append((vals.clone(), idx.clone()))
+    finally:
+        if prev is None:
+            os.environ.pop("MIT_OCR_TOP5_LOOP", None)
+        else:
+            os.environ["MIT_OCR_TOP5_LOOP"] = prev
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # and against torch (values within fp32 rounding; indices exactly, ties to the lower index)
+    ref = x[:, :D].clone()
+    if suppress >= 0:
+        ref[:, suppress] = float("-inf")
+    lp = torch.log_softmax(ref.double(), 1)
+    order = torch.argsort(-lp, dim=1, stable=True)[:, :5]
+    assert torch.equal(outs[1][1].long().cpu(), order.cpu())
+    assert (outs[1][0].double() - torch.gather(lp, 1, order)).abs().max() < 2e-5
