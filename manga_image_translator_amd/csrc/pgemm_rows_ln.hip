@@ -2,18 +2,21 @@
 //
 // The B = 1 decoder step (ocr_decoder.hip, rows path) is a chain of ≈ 60 dependent launches of 5-16 us; three per layer are LayerNorms
 // (TransformerDecoderLayer norm1 / norm2 / norm3, manga_translator/ocr/model_48px.py:548-572 via nn.LayerNorm) whose only consumer is
-// the Linear that follows.  A wave of pgemm_rows_kernel owns a 32 x 32 block of the output and needs WHOLE rows of A (K = E = 320), so
-// it can normalise its 32 rows itself: lane (li, lh) loads the halves k = 16 ks + 8 lh .. + 7 of row m0 + li as fp32 (160 registers),
-// the two lanes of a row exchange eight partial sums per moment, and every k step splits its freshly normalised cell into the three
-// bf16 planes right before the MFMAs.  Every column block redoes the (tiny) statistics of its rows; the 15 LayerNorm launches of a step
-// disappear.
+// the Linear that follows.  A 32 x 32 output block needs WHOLE rows of A (K = E = 320), so the workgroup that owns a row block can
+// normalise it itself: four waves = four column blocks of one 32-row block; wave w normalises rows 8 w .. 8 w + 7 (eight lanes per row,
+// each holding five whole k-cells: 32-byte runs, coalesced), splits its cells into the three bf16 planes and parks them in LDS in the
+// MFMA operand layout (65 KB); behind one barrier every wave's K loop is three ds_read_b128 and six MFMAs per step.  The 15 LayerNorm
+// launches of a step disappear.
+// (Measured on the way, per launch at 160 rows against 5.7 + 5.7 us for the two launches: one wave per block with the row halves in
+// registers — 40 strided 16-byte loads per lane, every column block redoing the statistics — 11.7 us; four waves sharing fp32 rows
+// in LDS, each splitting its own operand cells in the K loop — 8.9 us; this form: profiles/r11*.)
 //
 // Bit-exactness: layernorm_kernel<true> (ocr_kernels.hip) gives lane l of its wave the elements d = l, l + 64, ... (summed in that
-// order from 0) and reduces the 64 partials by an xor butterfly (32, 16, ..., 1).  Element d lives here on lane (li, (d >> 3) & 1), so
-// the partials l = 16 a + 8 lh + j (a < 4, j < 8) are all in this lane; butterfly levels 32 and 16 pair a with a ^ 2 and a ^ 1 (same
-// lane), level 8 pairs the two lanes of the row (one cross-lane exchange per j), levels 4, 2, 1 pair j with j ^ 4, j ^ 2, j ^ 1 (same
-// lane).  Same additions in the same tree => the mean, the variance, the normalised values, hence the planes (bf16_split.h, the shared
-// split) and the product are those of layernorm_kernel + pgemm_rows_kernel, bit for bit.  tests/test_pgemm_gpu.py checks exactly that.
+// order from 0) and reduces the 64 partials by an xor butterfly (32, 16, ..., 1).  Here lane (rr, q) of a wave holds, for row 8 w + rr,
+// the partials l = 8 q + j (j < 8): butterfly levels 32, 16, 8 pair q with q ^ 4, q ^ 2, q ^ 1 (the row's eight lanes: ds_swizzle /
+// DPP quad permutes), levels 4, 2, 1 pair j with j ^ 4, j ^ 2, j ^ 1 (registers).  Same additions in the same tree => the mean, the variance, the normalised values,
+// hence the planes (bf16_split.h, the shared split) and the product are those of layernorm_kernel + pgemm_rows_kernel, bit for bit
+// (tests/test_ocr_gpu.py::test_layernorm_inside_the_few_row_gemm_is_bit_identical).
 //
 // Compiled WITHOUT packed-fp32 code generation (build.py: not in PACKED_FP32_BY_DESIGN) — the statistics are scalar fp32 chains.
 #include "conv_gemm_kernels.h"
@@ -27,20 +30,36 @@ namespace {
 
 constexpr int LN_K = 320, LN_KTS = LN_K / 16;
 
+constexpr int LN_CP = 34;   // cells per (plane, k-cell) slab in LDS: 32 rows + 2 of padding (the 16 lanes of a write pass fall on 16 distinct 16-byte slots)
+
+__device__ __forceinline__ float lane_xor1(const float v) {   // quad_perm [1, 0, 3, 2]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_xor2(const float v) {   // quad_perm [2, 3, 0, 1]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_xor4(const float v) {   // ds_swizzle, bit mode: and 0x1f, or 0, xor 4
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (4 << 10) | 0x1f));
+}
+
 template <int NPROD, int D>
-__global__ __launch_bounds__(64) void pgemm_rows_ln_kernel(const MitPGemm p, const PgRowsExt x, const PgRowsLn ln, const int MT, const int NT) {
-    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
-    // block -> (column block, row block) as pgemm_rows_kernel: the row blocks of a column block (same W cells) on one XCD
-    const int total = MT * NT, per = (total + 7) >> 3;
+__global__ __launch_bounds__(256) void pgemm_rows_ln_kernel(const MitPGemm p, const PgRowsExt x, const PgRowsLn ln, const int MT, const int NT4,
+                                                            const int NT) {
+    constexpr int K8 = LN_K >> 3;
+    __shared__ __attribute__((aligned(16))) u32x4 apl[3 * K8 * LN_CP];   // the block's normalised rows as planes: cell (pl, k8, row) at (pl K8 + k8) LN_CP + row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    // block -> (group of four column blocks, row block): the row blocks of a column group (same W cells) on one XCD
+    const int total = MT * NT4, per = (total + 7) >> 3;
     const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (t >= total || (int)(blockIdx.x >> 3) >= per) return;
-    const int nt = t / MT, mt = t - nt * MT;
+    const int nt4 = t / MT, mt = t - nt4 * MT;
+    const int nt = nt4 * 4 + wave;
+    const bool has_tile = nt < NT;
     const int m0 = mt * 32, n0 = nt * 32;
-    constexpr int K8 = LN_K >> 3;
     const unsigned int w_step = (unsigned int)p.ldw * 32u;                               // bytes per k step (two k cells)
     const unsigned int w_plane = (unsigned int)K8 * (unsigned int)p.ldw * 16u;
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w_planes), 0, 3 * w_plane, 0x00020000);
-    const unsigned int w_off = ((unsigned int)lh * (unsigned int)p.ldw + (unsigned int)(n0 + li)) * 16u;
+    const unsigned int w_off = ((unsigned int)lh * (unsigned int)p.ldw + (unsigned int)(n0 + li)) * 16u;   // (past the planes: the descriptor answers 0)
 
     u32x4 fw[D][3];
     auto issue = [&](const int d, const int ks) __attribute__((always_inline)) {
@@ -49,74 +68,99 @@ __global__ __launch_bounds__(64) void pgemm_rows_ln_kernel(const MitPGemm p, con
     };
 #pragma unroll
     for (int d = 0; d < D && d < LN_KTS; ++d) issue(d, d);   // the first W cells travel while the rows are normalised
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- this lane's half rows: k = 16 ks + 8 lh + j.  Rows past M repeat row M - 1 (loaded, normalised, never stored).
-    const int row = min(m0 + li, p.M - 1);
-    const float *xr = ln.x + (int64_t)row * ln.ldx + 8 * lh;
-    f32x4 v[LN_KTS][2];
+    {   // ---- rows 8 wave .. + 7 of the block: lane (rr, q) holds the cells k8 = 8 b + q, i.e. d = 64 b + 8 q + j.  Rows past M repeat
+        // row M - 1 (normalised, never stored).
+        const int rr = lane >> 3, q = lane & 7;
+        const int row = min(m0 + 8 * wave + rr, p.M - 1);
+        const float *xr = ln.x + (int64_t)row * ln.ldx + 8 * q;
+        f32x4 v[5][2];
 #pragma unroll
-    for (int ks = 0; ks < LN_KTS; ++ks) {
-        v[ks][0] = *reinterpret_cast<const f32x4 *>(xr + 16 * ks);
-        v[ks][1] = *reinterpret_cast<const f32x4 *>(xr + 16 * ks + 4);
-    }
-    // butterfly of layernorm_kernel over the 64 partials, of which this lane holds l = 16 a + 8 lh + j
-    auto reduce = [&](float (&pt)[4][8]) __attribute__((always_inline)) -> float {
-        float q[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            q[j] = (pt[0][j] + pt[2][j]) + (pt[1][j] + pt[3][j]);   // levels 32 (a ^ 2) and 16 (a ^ 1)
-            q[j] += __shfl_xor(q[j], 32);                           // level 8: the row's other lane
+        for (int b = 0; b < 5; ++b) {
+            v[b][0] = *reinterpret_cast<const f32x4 *>(xr + 64 * b);
+            v[b][1] = *reinterpret_cast<const f32x4 *>(xr + 64 * b + 4);
         }
-        const float r0 = q[0] + q[4], r1 = q[1] + q[5], r2 = q[2] + q[6], r3 = q[3] + q[7];   // level 4
-        return (r0 + r2) + (r1 + r3);                                                         // levels 2 and 1
-    };
-    float pt[4][8];
+        const float *gw = ln.w + 8 * q, *gb = ln.b + 8 * q;   // LayerNorm weight / bias of this lane's cells: requested before the statistics
+        f32x4 wv[5][2], bv[5][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 5; ++b)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int b = 0; b < LN_KTS / 4; ++b) s += v[a + 4 * b][j >> 2][j & 3];
-            pt[a][j] = s;
-        }
-    const float mean = reduce(pt) / (float)LN_K;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int b = 0; b < LN_KTS / 4; ++b) {
-                const float tt = v[a + 4 * b][j >> 2][j & 3] - mean;
-                s += tt * tt;
+            for (int hf = 0; hf < 2; ++hf) {
+                wv[b][hf] = *reinterpret_cast<const f32x4 *>(gw + 64 * b + 4 * hf);
+                bv[b][hf] = *reinterpret_cast<const f32x4 *>(gb + 64 * b + 4 * hf);
             }
-            pt[a][j] = s;
+        __builtin_amdgcn_sched_barrier(0);
+        // layernorm_kernel's butterfly over the partials l = 8 q + j: levels 32, 16, 8 = q ^ 4, q ^ 2, q ^ 1 (lanes), 4, 2, 1 = j (registers)
+        auto reduce = [&](float (&pt)[8]) __attribute__((always_inline)) -> float {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pt[j] += lane_xor4(pt[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pt[j] += lane_xor2(pt[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pt[j] += lane_xor1(pt[j]);
+            const float r0 = pt[0] + pt[4], r1 = pt[1] + pt[5], r2 = pt[2] + pt[6], r3 = pt[3] + pt[7];
+            return (r0 + r2) + (r1 + r3);
+        };
+        float pt[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float sm = 0.f;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) sm += v[b][j >> 2][j & 3];
+            pt[j] = sm;
         }
-    const float rstd = 1.0f / sqrtf(reduce(pt) / (float)LN_K + ln.eps);
-    const float *gw = ln.w + 8 * lh, *gb = ln.b + 8 * lh;
+        const float mean = reduce(pt) / (float)LN_K;
 #pragma unroll
-    for (int ks = 0; ks < LN_KTS; ++ks) {
+        for (int j = 0; j < 8; ++j) {
+            float sm = 0.f;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const f32x4 wv = *reinterpret_cast<const f32x4 *>(gw + 16 * ks + 4 * hf), bv = *reinterpret_cast<const f32x4 *>(gb + 16 * ks + 4 * hf);
+            for (int b = 0; b < 5; ++b) {
+                const float tt = v[b][j >> 2][j & 3] - mean;
+                sm += tt * tt;
+            }
+            pt[j] = sm;
+        }
+        const float rstd = 1.0f / sqrtf(reduce(pt) / (float)LN_K + ln.eps);
+        u32x4 *dst = apl + q * LN_CP + 8 * wave + rr;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[ks][hf][c] = (v[ks][hf][c] - mean) * rstd * wv[c] + bv[c];
+        for (int b = 0; b < 5; ++b) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[b][hf][c] = (v[b][hf][c] - mean) * rstd * wv[b][hf][c] + bv[b][hf][c];
+            }
+            u32x4 h, m, l;
+            split8(v[b][0], v[b][1], h, m, l);
+            dst[(8 * b) * LN_CP] = h;
+            dst[(K8 + 8 * b) * LN_CP] = m;
+            dst[(2 * K8 + 8 * b) * LN_CP] = l;
         }
     }
+    __syncthreads();
+    if (!has_tile) return;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const u32x4 *ya = apl + lh * LN_CP + li;   // this lane's operand cells of step ks: (pl, 2 ks + lh, li)
+    // the A cells of step ks + 1 leave LDS while the six MFMAs of step ks run; the W cells stay D steps ahead (the fences keep both where
+    // they are written: left alone the scheduler sinks every load to its use, which empties the ring — 14.5 us per launch instead of 7)
+    u32x4 fa[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) fa[0][pl] = ya[(pl * K8) * LN_CP];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < LN_KTS; ++ks) {
-        u32x4 fa[3];
-        split8(v[ks][0], v[ks][1], fa[0], fa[1], fa[2]);
-        const int d = ks % D;
+        const int d = ks % D, cur = ks & 1;
+        if (ks + 1 < LN_KTS) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fa[cur ^ 1][pl] = ya[(pl * K8 + 2 * (ks + 1)) * LN_CP];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pr = 9 - NPROD; pr < 9; ++pr)   // transposed result (rows = output columns), as pgemm_rows_kernel
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[d][kSplitPB[pr]]), __builtin_bit_cast(bf16x8, fa[kSplitPA[pr]]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[d][kSplitPB[pr]]), __builtin_bit_cast(bf16x8, fa[cur][kSplitPA[pr]]), acc, 0, 0, 0);
         if (ks + D < LN_KTS) issue(d, ks + D);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -125,9 +169,9 @@ __global__ __launch_bounds__(64) void pgemm_rows_ln_kernel(const MitPGemm p, con
 
 template <int NPROD>
 void launch(const MitPGemm &p, const PgRowsExt &x, const PgRowsLn &ln, hipStream_t s) {
-    const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32;
-    const int total = MT * NT, per = (total + 7) / 8;
-    hipLaunchKernelGGL((pgemm_rows_ln_kernel<NPROD, 6>), dim3(per * 8), dim3(64), 0, s, p, x, ln, MT, NT);
+    const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32, NT4 = (NT + 3) / 4;
+    const int total = MT * NT4, per = (total + 7) / 8;
+    hipLaunchKernelGGL((pgemm_rows_ln_kernel<NPROD, 6>), dim3(per * 8), dim3(256), 0, s, p, x, ln, MT, NT4, NT);
 }
 
 }  // namespace

@@ -503,3 +503,43 @@ def test_register_form_of_logsoftmax_top5_is_bitwise_the_loop_form(cuda, R, D, s
     order = torch.argsort(-lp, dim=1, stable=True)[:, :5]
     assert torch.equal(outs[1][1].long().cpu(), order.cpu())
     assert (outs[1][0].double() - torch.gather(lp, 1, order)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("widths,T,suppress", [([50, 77, 120, 121, 64, 200], 14, True), ([90, 33], 9, False), ([40 + 5 * i for i in range(40)], 6, True)])
+def test_layernorm_inside_the_few_row_gemm_is_bit_identical(cuda, ocr_setup, widths, T, suppress):
+    """pgemm_rows_ln_kernel (the decoder's norm1 / norm2 / norm3 computed by the waves of the Linear that consumes them, same butterfly
+    as layernorm_kernel) against the two-launch form (MIT_OCR_LN_FUSED=0) and against the tiled form of full batches: every result
+    tensor identical, launch by launch and replayed from a graph; 6, 2 and 40 lines = 30, 10 and 200 rows (ragged last row block)."""
+    import os
+    from manga_image_translator_amd import lib as L
+
+    sd, D, eng = ocr_setup
+    crops = _crops(widths, seed=23)
+    mks, mvs, lens = [], [], []
+    for indices, ws, region in eng.make_chunks(crops):
+        mk, mv, kl, _ = eng.encode(torch.from_numpy(region).to(cuda), ws)
+        mks.append(mk.clone()); mvs.append(mv.clone()); lens.append(kl.clone())
+    Lmax = max(m.shape[2] for m in mks)
+    pad = lambda m: m if m.shape[2] == Lmax else torch.cat([m, m.new_zeros(5, m.shape[1], Lmax - m.shape[2], 320)], 2)
+    mem_k, mem_v, klen = torch.cat([pad(m) for m in mks], 1).contiguous(), torch.cat([pad(m) for m in mvs], 1).contiguous(), torch.cat(lens)
+    lib = L.load()
+    prev_rows = lib.mit_ocr48_decode_rows_max_set(-1)
+    prev_env = os.environ.get("MIT_OCR_LN_FUSED")
+    outs = []
+    try:
+        for fused, rows_max, graph in (("0", prev_rows, False), ("1", prev_rows, False), ("1", prev_rows, True), ("1", 0, False)):
+            os.environ["MIT_OCR_LN_FUSED"] = fused
+            lib.mit_ocr48_decode_rows_max_set(rows_max)
+            o = eng.decode(mem_k, mem_v, klen, max_seq_length=T, suppress_eos=suppress, graph=graph)
+            torch.cuda.synchronize()
+            outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    finally:
+        lib.mit_ocr48_decode_rows_max_set(prev_rows)
+        if prev_env is None:
+            os.environ.pop("MIT_OCR_LN_FUSED", None)
+        else:
+            os.environ["MIT_OCR_LN_FUSED"] = prev_env
+    for o in outs[1:]:
+        assert o["steps_run"] == outs[0]["steps_run"]
+        for k in ("tokens", "length", "prob", "colors"):
+            assert torch.equal(o[k], outs[0][k]), k
