@@ -25,6 +25,8 @@ namespace {
 constexpr int E = 320;
 constexpr int FF = 2048;
 
+constexpr int FF2_SPLITK_MAX_ROWS = 640;   // rows (lines x beams) up to which the few-row FFN output Linear cuts K across four waves
+
 struct Ws {
     float *tgt, *nrm, *qkv, *att, *q2, *ffh, *decoded, *p1, *logits, *vals, *logp, *cfeat, *part;
     int *idx, *hist, *done, *done_count, *dstep;
@@ -160,7 +162,7 @@ int gemm(const MitLinear &lin, const float *A, int64_t lda, float *Cp, int64_t l
 // The same Linear on planar activations (pgemm_rows.h): C fp32 (optional, with the column split / step offset of gemm()) and / or planes.
 int pgemm(const MitLinear &lin, const uint16_t *a_planes, int64_t lda, int M, float *Cp, int64_t ldc, int act, const float *post,
           int64_t ldpost, uint16_t *c_planes, int64_t ld_cp, hipStream_t s, int nsplit = 0, int64_t nhi = 0, const int *dyn = nullptr,
-          int64_t c_dyn = 0) {
+          int64_t c_dyn = 0, int splitk = 0) {
     MitPGemm d;
     memset(&d, 0, sizeof(d));
     d.a_planes = a_planes; d.lda = lda;
@@ -172,7 +174,7 @@ int pgemm(const MitLinear &lin, const uint16_t *a_planes, int64_t lda, int M, fl
     d.nprod = 0;  // the GEMM mode of the moment
     PgRowsExt x;
     memset(&x, 0, sizeof(x));
-    x.nsplit = nsplit; x.nhi = nhi; x.dyn = dyn; x.c_dyn = c_dyn;
+    x.nsplit = nsplit; x.nhi = nhi; x.dyn = dyn; x.c_dyn = c_dyn; x.splitk = splitk;
     if (Cp) x.also_planes = c_planes, x.also_ld = ld_cp;
     else d.c_planes = c_planes, d.ld_cp = ld_cp;
     return mit_pgemm_rows(d, x, s);
@@ -304,6 +306,12 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
     // LayerNorm inside the Linear that consumes it (read per call: tests switch it in-process; MIT_OCR_LN_FUSED=0 = the two-launch form)
     const char *lnf_env = getenv("MIT_OCR_LN_FUSED");
     const bool ln_fused = rows_path && !(lnf_env && *lnf_env && atoi(lnf_env) == 0);
+    // The FFN's second Linear (K = 2048) with K cut across four waves: for FEW rows only (a page or two, where its 10 us accumulator chain
+    // is a sixth of the step) — its sums round differently from the k-sequential chain every other form uses, so a page decoded alone
+    // differs from the same page inside a large group in the last bits of the log-probabilities (tests: tokens equal, 1e-5 on the
+    // probabilities).  MIT_OCR_FF2_SPLITK=0 keeps the one-chain kernel (bit for bit the tiled form); read per call.
+    const char *sk_env = getenv("MIT_OCR_FF2_SPLITK");
+    const int ff2_splitk = (rows_path && R <= FF2_SPLITK_MAX_ROWS && !(sk_env && *sk_env && atoi(sk_env) == 0)) ? 1 : 0;
     auto body = [&](const int step, const int *dyn, hipStream_t st) -> int {
         const int64_t so = dyn ? 0 : (int64_t)step * E;  // host-side step offset; the dyn form adds step * E on the device
         // (w.tgt holds the embedded tokens of this step: the start tokens before the loop, then written by the previous step's beam kernel)
@@ -346,9 +354,9 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
                     if (pgemm(ly.ff1, w.nrm_p, Rp, R, nullptr, 0, MIT_ACT_RELU, nullptr, 0, w.ffh_p, Rp, st)) return 1;
                 }
                 if (l < 4) {
-                    if (pgemm(ly.ff2, w.ffh_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
+                    if (pgemm(ly.ff2, w.ffh_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st, 0, 0, nullptr, 0, ff2_splitk)) return 1;
                 } else {  // last layer: the step's output into the activation cache (:570), and as planes for the prediction head
-                    if (pgemm(ly.ff2, w.ffh_p, Rp, R, w.decoded + so, TE, MIT_ACT_NONE, w.tgt, E, w.dec_p, Rp, st, 0, 0, dyn, E)) return 1;
+                    if (pgemm(ly.ff2, w.ffh_p, Rp, R, w.decoded + so, TE, MIT_ACT_NONE, w.tgt, E, w.dec_p, Rp, st, 0, 0, dyn, E, ff2_splitk)) return 1;
                 }
             }
             if (pgemm(dec->pred1, w.dec_p, Rp, R, nullptr, 0, MIT_ACT_GELU, nullptr, 0, w.p1_p, Rp, st)) return 1;

@@ -758,6 +758,67 @@ __global__ __launch_bounds__(64) void pgemm_rows_kernel(const MitPGemm p, const 
     pg_rows_epilogue(p, x, acc, m0, n0, z, lane);
 }
 
+// ---- the same block with K cut into four: the FFN's second Linear (K = 2048) at one page is ONE accumulator chain of 768 MFMAs per
+// wave — 10 us that no prefetch shortens.  Four waves of a workgroup take a quarter of the k steps each (their own prefetch rings), three
+// of them park their accumulators in LDS, wave 0 adds them in the fixed order ((p0 + p1) + p2) + p3 and runs the epilogue: 12.0 us per
+// launch instead of 16.0.  Deterministic, but NOT the k-sequential sum of the other tiles: a page decoded with this kernel differs from
+// the same page inside a 16-page group in the last bits of this Linear's output (fp32 rounding of three extra additions per element).
+// ocr_decoder.hip uses it for few rows only and says so; MIT_OCR_FF2_SPLITK=0 keeps the one-chain kernel.
+// Measured and dropped (profiles/r11j, r11k): the four slices as four one-wave workgroups on four CUs with a last-arriver reduction
+// through a workspace (release fence + device-scope counter per slice) — 12.8 us; sixteen slices — 28.9 us: every device-scope
+// release fence writes the XCD's L2 back, which costs more than the 786 KB of operand cells cost one CU's L2 port.
+template <int NPROD, int D, int KTW>   // KTW: k steps per wave (K = 4 * 16 * KTW)
+__global__ __launch_bounds__(256) void pgemm_rows_splitk_kernel(const MitPGemm p, const PgRowsExt x, const int MT, const int NT) {
+    __shared__ __attribute__((aligned(16))) float part[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int total = MT * NT, per = (total + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total || (int)(blockIdx.x >> 3) >= per) return;
+    const int nt = t / MT, mt = t - nt * MT;
+    const int m0 = mt * 32, n0 = nt * 32;
+    const int K8 = p.K >> 3;
+    const unsigned int a_step = (unsigned int)p.lda * 32u, w_step = (unsigned int)p.ldw * 32u;
+    const unsigned int a_plane = (unsigned int)K8 * (unsigned int)p.lda * 16u, w_plane = (unsigned int)K8 * (unsigned int)p.ldw * 16u;
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.a_planes), 0, 3 * a_plane, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w_planes), 0, 3 * w_plane, 0x00020000);
+    const unsigned int ks0 = (unsigned int)wave * KTW;
+    const unsigned int a_off = ((unsigned int)lh * (unsigned int)p.lda + (unsigned int)(m0 + li)) * 16u + ks0 * a_step;
+    const unsigned int w_off = ((unsigned int)lh * (unsigned int)p.ldw + (unsigned int)(n0 + li)) * 16u + ks0 * w_step;
+    u32x4 fa[D][3], fw[D][3];
+    auto issue = [&](const int d, const int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            fa[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off, pl * a_plane + (unsigned int)ks * a_step, 0);
+            fw[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off, pl * w_plane + (unsigned int)ks * w_step, 0);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < D && d < KTW; ++d) issue(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KTW; ++ks) {
+#pragma unroll
+        for (int pr = 9 - NPROD; pr < 9; ++pr)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[ks % D][kSplitPB[pr]]), __builtin_bit_cast(bf16x8, fa[ks % D][kSplitPA[pr]]), acc, 0, 0, 0);
+        if (ks + D < KTW) issue(ks % D, ks + D);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += part[w][r][lane];
+    pg_rows_epilogue(p, x, acc, m0, n0, 0, lane);
+}
+
 template <int NPROD, int D>
 void pg_rows_launch_ext(const MitPGemm &p, const PgRowsExt &x, hipStream_t s) {
     const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32, KT = p.K / 16;
@@ -909,8 +970,12 @@ int mit_pgemm_rows(const MitPGemm &d, const PgRowsExt &x, hipStream_t s) {
     const double flops = 2.0 * p.M * (double)p.N * p.K;
     const double bytes = (double)p.M * p.K * 6.0 + (double)p.K * p.N * 6.0 + (double)p.M * p.N * ((p.c ? 4.0 : 0.0) + (planes ? 6.0 : 0.0));
     MitProbeScope probe("pgemm_rows_kernel", s, bytes, flops);
-    if (p.nprod == 6) pg_rows_launch_ext<6, 6>(p, x, s);
-    else if (p.nprod == 9) pg_rows_launch_ext<9, 6>(p, x, s);
+    if (x.splitk && p.K == 2048 && (p.nprod == 6 || p.nprod == 9)) {   // four waves x a quarter of K (see pgemm_rows_splitk_kernel)
+        const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32, total = MT * NT, per = (total + 7) / 8;
+        if (p.nprod == 6) hipLaunchKernelGGL((pgemm_rows_splitk_kernel<6, 6, 32>), dim3(per * 8), dim3(256), 0, s, p, x, MT, NT);
+        else hipLaunchKernelGGL((pgemm_rows_splitk_kernel<9, 6, 32>), dim3(per * 8), dim3(256), 0, s, p, x, MT, NT);
+    } else if (p.nprod == 6) pg_rows_launch_ext<6, PG_ROWS_DEPTH>(p, x, s);
+    else if (p.nprod == 9) pg_rows_launch_ext<9, PG_ROWS_DEPTH>(p, x, s);
     else return mit_set_error("mit_pgemm_rows: nprod must be 6 or 9 (got %d)", p.nprod);
     MIT_CHECK_LAUNCH("mit_pgemm_rows");
     return 0;

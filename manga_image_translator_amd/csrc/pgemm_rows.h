@@ -12,7 +12,11 @@ struct PgRowsExt {
     int64_t c_dyn;
     uint16_t *also_planes;  // planar copy of the result beside the fp32 output (N % 8 == 0)
     int64_t also_ld;
+    int splitk;             // != 0 and K == 2048: four waves sum a quarter of K each (fixed order; not the k-sequential rounding)
 };
+// k steps a few-row GEMM wave requests ahead (4 / 6 / 8 / 10 measured within a few per cent of each other, in scripts/pgemm_check and in
+// the decoder: a launch is bound by its accumulator chain and its start-up, not by round trips to the memory side)
+constexpr int PG_ROWS_DEPTH = 6;
 // C = epilogue(A @ W) for planar A, one wave per 32 x 32 block (Z == 1).  d.c and / or d.c_planes | x.also_planes; d.tile is ignored,
 // d.nprod 6 | 9.  Returns 0, or 1 with mit_last_error() set.
 int mit_pgemm_rows(const MitPGemm &d, const PgRowsExt &x, hipStream_t s);

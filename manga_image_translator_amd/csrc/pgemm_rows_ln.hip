@@ -171,7 +171,7 @@ template <int NPROD>
 void launch(const MitPGemm &p, const PgRowsExt &x, const PgRowsLn &ln, hipStream_t s) {
     const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32, NT4 = (NT + 3) / 4;
     const int total = MT * NT4, per = (total + 7) / 8;
-    hipLaunchKernelGGL((pgemm_rows_ln_kernel<NPROD, 6>), dim3(per * 8), dim3(256), 0, s, p, x, ln, MT, NT4, NT);
+    hipLaunchKernelGGL((pgemm_rows_ln_kernel<NPROD, PG_ROWS_DEPTH>), dim3(per * 8), dim3(256), 0, s, p, x, ln, MT, NT4, NT);
 }
 
 }  // namespace

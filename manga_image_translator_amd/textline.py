@@ -20,10 +20,9 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 
-def sort_pnts(pts: np.ndarray) -> Tuple[np.ndarray, bool]:
-    """Canonical corner order [tl, tr, br, bl] and the vertical flag (generic.py:324-354).  ONE path in every environment: this
-    restatement, pinned to the reference's function by tests/golden/textline.npz — the product never executes reference code
-    other than the plugin base classes it subclasses."""
+def _sort_pnts_np(pts: np.ndarray) -> Tuple[np.ndarray, bool]:
+    """generic.py:324-354 operation for operation (numpy on 16 x 2 and 4 x 2 arrays: ~40-80 us per quadrilateral).  sort_pnts hands it
+    every input whose result could depend on how numpy's (unstable) argsort orders equal keys."""
     pts = np.asarray(pts)
     if pts.shape != (4, 2):
         raise ValueError(f"sort_pnts expects 4 points, got shape {pts.shape}")
@@ -45,6 +44,59 @@ def sort_pnts(pts: np.ndarray) -> Tuple[np.ndarray, bool]:
     pts_sorted[[0, 3]] = sorted(pts[[0, 1]], key=lambda x: x[1])
     pts_sorted[[1, 2]] = sorted(pts[[2, 3]], key=lambda x: x[1])
     return pts_sorted, is_vertical
+
+
+def sort_pnts(pts: np.ndarray) -> Tuple[np.ndarray, bool]:
+    """Canonical corner order [tl, tr, br, bl] and the vertical flag (generic.py:324-354).  ONE path in every environment: this
+    restatement, pinned to the reference's function by tests/golden/textline.npz — the product never executes reference code
+    other than the plugin base classes it subclasses.
+
+    The reference's numpy formulation costs 40-80 us per quadrilateral (a page's 32 lines: 1.5-2.5 ms of every B = 1 OCR call).  This is
+    the same decision sequence on Python scalars: the entries 8 and 10 of the ascending pairwise-vector norms, the sign fix, the
+    |mean| comparison, the two-level corner ordering.  Wherever the outcome could depend on the ORDER numpy's argsort gives equal keys
+    (a tie class at position 8 or 10 holding non-parallel vectors — e.g. an exact square —, a zero inner product, equal sort keys
+    between the corner groups) the input goes to _sort_pnts_np, so both agree on every input (tests/test_textline.py fuzzes that)."""
+    pts = np.asarray(pts)
+    if pts.shape != (4, 2):
+        raise ValueError(f"sort_pnts expects 4 points, got shape {pts.shape}")
+    p = pts.tolist()
+    vec = [(p[i][0] - p[j][0], p[i][1] - p[j][1]) for i in range(4) for j in range(4)]
+    nrm = [math.sqrt(float(dx) * float(dx) + float(dy) * float(dy)) for dx, dy in vec]
+    order = sorted(range(16), key=nrm.__getitem__)
+
+    def tie_class_parallel(k):
+        a, j = vec[order[k]], k
+        while j > 0 and nrm[order[j - 1]] == nrm[order[k]]:
+            j -= 1
+        while j < 16 and nrm[order[j]] == nrm[order[k]]:
+            b = vec[order[j]]
+            if a[0] * b[1] - a[1] * b[0] != 0:
+                return False
+            j += 1
+        return True
+
+    if not (tie_class_parallel(8) and tie_class_parallel(10)):
+        return _sort_pnts_np(pts)
+    a, b = vec[order[8]], vec[order[10]]
+    inner = a[0] * b[0] + a[1] * b[1]
+    if inner == 0:
+        return _sort_pnts_np(pts)
+    if inner < 0:
+        a = (-a[0], -a[1])
+    is_vertical = bool(abs((a[0] + b[0]) / 2) <= abs((a[1] + b[1]) / 2))
+    if is_vertical:
+        o = sorted(range(4), key=lambda i: p[i][1])
+        if p[o[1]][1] == p[o[2]][1] or (p[o[0]][0] == p[o[1]][0] and p[o[0]] != p[o[1]]) or (p[o[2]][0] == p[o[3]][0] and p[o[2]] != p[o[3]]):
+            return _sort_pnts_np(pts)
+        top = sorted(o[:2], key=lambda i: p[i][0])
+        bot = sorted(o[2:], key=lambda i: p[i][0])[::-1]
+        return pts[[top[0], top[1], bot[0], bot[1]]], is_vertical
+    o = sorted(range(4), key=lambda i: p[i][0])
+    if p[o[1]][0] == p[o[2]][0]:
+        return _sort_pnts_np(pts)
+    le = sorted(o[:2], key=lambda i: p[i][1])
+    ri = sorted(o[2:], key=lambda i: p[i][1])
+    return pts[[le[0], ri[0], ri[1], le[1]]], is_vertical
 
 
 @dataclass
@@ -286,6 +338,49 @@ def quadrilateral_can_merge_region(a: Quadrilateral, b: Quadrilateral, ratio=1.9
     return False
 
 
+def prefill_geometry(quads: Sequence[Quadrilateral]) -> bool:
+    """Fills the cached geometry of all quads of a page in ONE vectorised pass: structure, font_size, aspect_ratio, aabb, extent,
+    is_approximate_axis_aligned — what the direction vote and the merge graph read from every line (per quad these are ~25 numpy calls
+    on 2-vectors, 70 us a line in the interpreter).  The same numpy operations on [n, ...] arrays, elementwise identical; the one
+    operation that is not elementwise — np.linalg.norm's float32 dot product, which a BLAS may fuse — is exact whenever the structure
+    vectors stay below 2048 (squares and their sum fit the 24-bit significand), so the fill is limited to such pages and to uniform
+    integer / float point arrays; anything else keeps the lazy per-quad properties.  Returns whether the fill was applied."""
+    todo = [q for q in quads if "font_size" not in q.__dict__]
+    if len(todo) < 2:
+        return False
+    dt = todo[0].pts.dtype
+    if any(q.pts.dtype != dt or q.pts.shape != (4, 2) or "structure" in q.__dict__ for q in todo):
+        return False
+    P = np.stack([q.pts for q in todo])
+    p1 = ((P[:, 0] + P[:, 1]) / 2).astype(int)
+    p2 = ((P[:, 2] + P[:, 3]) / 2).astype(int)
+    p3 = ((P[:, 1] + P[:, 2]) / 2).astype(int)
+    p4 = ((P[:, 3] + P[:, 0]) / 2).astype(int)
+    v1 = p2.astype(np.float32) - p1.astype(np.float32)
+    v2 = p4.astype(np.float32) - p3.astype(np.float32)
+    if max(float(np.abs(v1).max()), float(np.abs(v2).max())) > 2048:
+        return False
+    n1 = np.sqrt(v1[:, 0] * v1[:, 0] + v1[:, 1] * v1[:, 1])
+    n2 = np.sqrt(v2[:, 0] * v2[:, 0] + v2[:, 1] * v2[:, 1])
+    if not (n1.min() > 0 and n2.min() > 0):
+        return False
+    ar, fs = n2 / n1, np.minimum(n2, n1)
+    u1, u2 = v1 / n1[:, None], v2 / n2[:, None]
+    approx = (np.abs(u1[:, 1]) < 0.05) | (np.abs(u1[:, 0]) < 0.05) | (np.abs(u2[:, 1]) < 0.05) | (np.abs(u2[:, 0]) < 0.05)
+    mx, mn = P.max(axis=1), P.min(axis=1)
+    Pf = P.astype(np.float64)
+    fmn, fmx = Pf.min(axis=1), Pf.max(axis=1)
+    for i, q in enumerate(todo):
+        d = q.__dict__
+        d["structure"] = [p1[i], p2[i], p3[i], p4[i]]
+        d["font_size"] = float(fs[i])
+        d["aspect_ratio"] = float(ar[i])
+        d["is_approximate_axis_aligned"] = bool(approx[i])
+        d["aabb"] = BBox(int(mn[i, 0]), int(mn[i, 1]), int(mx[i, 0] - mn[i, 0]), int(mx[i, 1] - mn[i, 1]))
+        d["extent"] = (float(fmn[i, 0]), float(fmn[i, 1]), float(fmx[i, 0]), float(fmx[i, 1]))
+    return True
+
+
 def near_pairs(quads: Sequence[Quadrilateral], discard_connection_gap: float = 2) -> List[Tuple[int, int]]:
     """The pairs (u < v, in itertools.combinations order) that pass ``quadrilateral_can_merge_region``'s own first test — bounding-box
     gap against ``discard_connection_gap`` x the smaller font size — evaluated for all pairs at once: of the O(n^2) pairs of a page
@@ -315,6 +410,7 @@ def generate_text_direction(quads: Sequence[Quadrilateral]):
             i = parent[i]
         return i
 
+    prefill_geometry(quads)
     pairs = near_pairs(quads)
     for (u, v), d in zip(pairs, quad_pair_distances(quads, pairs)):
         if quadrilateral_can_merge_region(quads[u], quads[v], aspect_ratio_tol=1, dist=d):

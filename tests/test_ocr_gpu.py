@@ -378,6 +378,9 @@ def test_few_row_decode_equals_the_tiled_form(cuda, ocr_setup, widths, T, suppre
     prev = lib.mit_ocr48_decode_rows_max_set(-1)
     assert prev >= 5 * len(widths), "the few-row form must be the default at these sizes"
     outs = []
+    import os
+    prev_sk = os.environ.get("MIT_OCR_FF2_SPLITK")
+    os.environ["MIT_OCR_FF2_SPLITK"] = "0"   # the one-chain FFN kernel: the k-sequential sum of the tiles (the K-cut form has its own test)
     try:
         for rows_max, graph in ((0, False), (prev, False), (prev, True)):
             lib.mit_ocr48_decode_rows_max_set(rows_max)
@@ -386,6 +389,7 @@ def test_few_row_decode_equals_the_tiled_form(cuda, ocr_setup, widths, T, suppre
             outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
     finally:
         lib.mit_ocr48_decode_rows_max_set(prev)
+        os.environ.pop("MIT_OCR_FF2_SPLITK", None) if prev_sk is None else os.environ.__setitem__("MIT_OCR_FF2_SPLITK", prev_sk)
     for o in outs[1:]:
         assert o["steps_run"] == outs[0]["steps_run"]
         for k in ("tokens", "length", "prob", "colors"):
@@ -525,6 +529,8 @@ def test_layernorm_inside_the_few_row_gemm_is_bit_identical(cuda, ocr_setup, wid
     lib = L.load()
     prev_rows = lib.mit_ocr48_decode_rows_max_set(-1)
     prev_env = os.environ.get("MIT_OCR_LN_FUSED")
+    prev_sk = os.environ.get("MIT_OCR_FF2_SPLITK")
+    os.environ["MIT_OCR_FF2_SPLITK"] = "0"
     outs = []
     try:
         for fused, rows_max, graph in (("0", prev_rows, False), ("1", prev_rows, False), ("1", prev_rows, True), ("1", 0, False)):
@@ -535,6 +541,7 @@ def test_layernorm_inside_the_few_row_gemm_is_bit_identical(cuda, ocr_setup, wid
             outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
     finally:
         lib.mit_ocr48_decode_rows_max_set(prev_rows)
+        os.environ.pop("MIT_OCR_FF2_SPLITK", None) if prev_sk is None else os.environ.__setitem__("MIT_OCR_FF2_SPLITK", prev_sk)
         if prev_env is None:
             os.environ.pop("MIT_OCR_LN_FUSED", None)
         else:
@@ -543,3 +550,39 @@ def test_layernorm_inside_the_few_row_gemm_is_bit_identical(cuda, ocr_setup, wid
         assert o["steps_run"] == outs[0]["steps_run"]
         for k in ("tokens", "length", "prob", "colors"):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("widths,T,suppress", [([50, 77, 120, 121, 64, 200], 14, True), ([90, 33], 9, False), ([40 + 5 * i for i in range(32)], 12, True)])
+def test_k_cut_ffn_linear_of_the_few_row_decode(cuda, ocr_setup, widths, T, suppress):
+    """pgemm_rows_splitk_kernel (the FFN's K = 2048 Linear with K cut across four waves, summed in a fixed order; the default up to 640
+    rows) against the one-chain kernel (MIT_OCR_FF2_SPLITK=0): a different fp32 rounding of the same sums — tokens and lengths must be
+    identical, probabilities within 1e-4 relative (the oracle bar on log-probabilities is 5e-4), colour heads within 1e-4; run to run the
+    K-cut form is bit-reproducible ."""
+    import os
+
+    sd, D, eng = ocr_setup
+    crops = _crops(widths, seed=31)
+    mks, mvs, lens = [], [], []
+    for indices, ws, region in eng.make_chunks(crops):
+        mk, mv, kl, _ = eng.encode(torch.from_numpy(region).to(cuda), ws)
+        mks.append(mk.clone()); mvs.append(mv.clone()); lens.append(kl.clone())
+    Lmax = max(m.shape[2] for m in mks)
+    pad = lambda m: m if m.shape[2] == Lmax else torch.cat([m, m.new_zeros(5, m.shape[1], Lmax - m.shape[2], 320)], 2)
+    mem_k, mem_v, klen = torch.cat([pad(m) for m in mks], 1).contiguous(), torch.cat([pad(m) for m in mvs], 1).contiguous(), torch.cat(lens)
+    prev_sk = os.environ.get("MIT_OCR_FF2_SPLITK")
+    outs = []
+    try:
+        for sk in ("0", "1", "1"):
+            os.environ["MIT_OCR_FF2_SPLITK"] = sk
+            o = eng.decode(mem_k, mem_v, klen, max_seq_length=T, suppress_eos=suppress)
+            torch.cuda.synchronize()
+            outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    finally:
+        os.environ.pop("MIT_OCR_FF2_SPLITK", None) if prev_sk is None else os.environ.__setitem__("MIT_OCR_FF2_SPLITK", prev_sk)
+    for k in ("tokens", "length", "prob", "colors"):
+        assert torch.equal(outs[1][k], outs[2][k]), k
+    assert outs[1]["steps_run"] == outs[0]["steps_run"]
+    assert torch.equal(outs[1]["tokens"], outs[0]["tokens"]) and torch.equal(outs[1]["length"], outs[0]["length"])
+    assert ((outs[1]["prob"] - outs[0]["prob"]).abs() <= 1e-4 * outs[0]["prob"].abs() + 1e-12).all()
+    assert (outs[1]["colors"] - outs[0]["colors"]).abs().max() < 1e-4
+    assert not torch.equal(outs[1]["colors"], outs[0]["colors"]) or len(widths) < 3   # (the K-cut kernel really ran)

@@ -208,3 +208,89 @@ def test_native_quad_pair_distances_property():
         assert d_ba == TL.polygon_distance(qb, qa)
 
     check()
+
+
+def test_scalar_sort_pnts_agrees_with_the_numpy_formulation_on_every_input():
+    """textline.sort_pnts (the decision sequence on Python scalars, handing tie cases to the numpy formulation) against
+    textline._sort_pnts_np (generic.py:324-354 operation for operation) on generic quadrilaterals, axis-aligned and rotated rectangles,
+    jittered rectangles, exact squares and tiny-grid points (many equal keys, repeated points), int64 / float32 / float64."""
+    from manga_image_translator_amd import textline as TL
+
+    rng = np.random.default_rng(7)
+    fallbacks = [0]
+    orig = TL._sort_pnts_np
+
+    def counting(p):
+        fallbacks[0] += 1
+        return orig(p)
+
+    n_rect_fast = 0
+    try:
+        TL._sort_pnts_np = counting
+        for it in range(16000):
+            kind = it % 8
+            if kind == 0:
+                q = rng.integers(0, 2000, (4, 2))
+            elif kind == 1:
+                x, y, w, h = rng.integers(0, 1000, 4)
+                q = np.array([[x, y], [x + w + 1, y], [x + w + 1, y + h + 1], [x, y + h + 1]])[rng.permutation(4)]
+            elif kind in (2, 7):
+                c = rng.uniform(100, 900, 2); w, h = rng.uniform(5, 400, 2); t = rng.uniform(0, np.pi)
+                R = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+                q = (np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) @ R.T + c)[rng.permutation(4)]
+                if kind == 7:
+                    q = np.rint(q).astype(np.int64)
+            elif kind == 3:
+                q = rng.uniform(0, 1000, (4, 2)).astype(np.float32)
+            elif kind == 4:
+                c = rng.integers(100, 900, 2); w, h = rng.integers(1, 300, 2)
+                q = (np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) + c + rng.integers(-2, 3, (4, 2)))[rng.permutation(4)].astype(np.int64)
+            elif kind == 5:
+                s = rng.integers(1, 200); x, y = rng.integers(0, 500, 2)
+                q = np.array([[x, y], [x + s, y], [x + s, y + s], [x, y + s]])[rng.permutation(4)]
+            else:
+                q = rng.integers(0, 6, (4, 2))
+            before = fallbacks[0]
+            got, gv = TL.sort_pnts(q)
+            n_rect_fast += kind == 1 and fallbacks[0] == before
+            want, wv = orig(q)
+            assert gv == wv and got.dtype == want.dtype and np.array_equal(got, want), q.tolist()
+    finally:
+        TL._sort_pnts_np = orig
+    assert n_rect_fast > 1900   # the detector's (and the bench's) axis-aligned boxes take the scalar path
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.float64, np.float32])
+def test_prefilled_geometry_equals_the_lazy_properties(dtype):
+    """textline.prefill_geometry (one vectorised pass over a page's quads) against the per-quad cached properties it replaces —
+    structure, font_size, aspect_ratio, aabb, extent, is_approximate_axis_aligned — bit for bit, and the direction vote on top of both."""
+    from manga_image_translator_amd import textline as TL
+
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        n = int(rng.integers(2, 40))
+        raw = []
+        for i in range(n):
+            c = rng.uniform(100, 1900, 2); w, h = rng.uniform(4, 300, 2); t = rng.uniform(0, np.pi) if i % 3 else 0.0
+            R = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+            q = np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) @ R.T + c
+            raw.append(np.rint(q).astype(dtype) if dtype is np.int64 else q.astype(dtype))
+        lazy = [TL.Quadrilateral(q) for q in raw]
+        fill = [TL.Quadrilateral(q) for q in raw]
+        assert TL.prefill_geometry(fill)
+        for a, b in zip(lazy, fill):
+            assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(a.structure, b.structure))
+            for name in ("font_size", "aspect_ratio", "aabb", "extent", "is_approximate_axis_aligned"):
+                va, vb = getattr(a, name), b.__dict__[name]
+                assert type(va) is type(vb) and va == vb, name
+        lazy2 = [TL.Quadrilateral(q) for q in raw]
+        orig, TL.prefill_geometry = TL.prefill_geometry, lambda quads: False
+        try:
+            want = [(id_, d) for id_, d in ((lazy2.index(q), d) for q, d in TL.generate_text_direction(lazy2))]
+        finally:
+            TL.prefill_geometry = orig
+        fill2 = [TL.Quadrilateral(q) for q in raw]
+        got = [(fill2.index(q), d) for q, d in TL.generate_text_direction(fill2)]
+        assert got == want
+    big = [TL.Quadrilateral(np.array([[0, 0], [9000, 0], [9000, 50], [0, 50]]) + i) for i in range(3)]
+    assert not TL.prefill_geometry(big)   # vectors past 2048: the lazy path (norm's dot product is no longer exact)
