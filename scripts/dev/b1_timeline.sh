@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${1:-r11a}; mkdir -p $OUT
-PROF_B1_NO_CPROFILE=1 python scripts/prof_b1.py ocr > $OUT/prof_b1.json 2> $OUT/prof_b1.err; echo rc=$?
+PROF_B1_NO_CPROFILE=1 python scripts/prof_b1.py ${2:-ocr} > $OUT/prof_b1.json 2> $OUT/prof_b1.err; echo rc=$?
 cat $OUT/prof_b1.json
-PROF_B1_NO_CPROFILE=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o b1 -- python scripts/prof_b1.py ocr > $OUT/prof_b1_under_rocprof.json 2> $OUT/rocprof.err; echo rc=$?
+PROF_B1_NO_CPROFILE=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o b1 -- python scripts/prof_b1.py ${2:-ocr} > $OUT/prof_b1_under_rocprof.json 2> $OUT/rocprof.err; echo rc=$?
 f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); python - "$f" $OUT <<'P'
 import csv, sys, collections, json
 rows = list(csv.DictReader(open(sys.argv[1])))
