@@ -54,4 +54,8 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &h,
     l = u32x4{l0.x, l0.y, l1.x, l1.y};
 }
 
+// plane pairs of a split product, smallest products first; a tile with NPROD products takes the last NPROD entries (conv_gemm_split.h)
+__device__ constexpr int kSplitPA[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+__device__ constexpr int kSplitPB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+
 }  // namespace mitcg

@@ -21,9 +21,7 @@ namespace mitcg {
 // Range precondition: finite operands with |x| <= the largest bf16 (3.39e38).  hi = bf16(x) of a larger (or infinite) x is Inf and
 // the residual x - Inf is -Inf / NaN, so such an operand yields NaN here where the fp32 MFMA yields Inf or a finite value.  Activations
 // and weights of the networks on this path are many orders of magnitude inside the range.
-// plane pairs, smallest products first; NPROD takes the last NPROD entries
-__device__ constexpr int kSplitPA[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
-__device__ constexpr int kSplitPB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+// (plane pairs kSplitPA / kSplitPB, smallest products first; NPROD takes the last NPROD entries: bf16_split.h)
 
 // A cells are row-swizzled per k slab (row ^ kh * 64 / BK) instead of padded.  ds_write_b64 is served in groups of 16 consecutive lanes
 // over 32 four-byte banks (MI355X_MICROARCH.md, LDS table): a group's 16 eight-byte halves — 16 / KQ rows x all KH slabs x 2 halves —

@@ -310,6 +310,9 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
     // is a sixth of the step) — its sums round differently from the k-sequential chain every other form uses, so a page decoded alone
     // differs from the same page inside a large group in the last bits of the log-probabilities (tests: tokens equal, 1e-5 on the
     // probabilities).  MIT_OCR_FF2_SPLITK=0 keeps the one-chain kernel (bit for bit the tiled form); read per call.
+    // norm2 + q projection inside the cross-attention kernel (MIT_OCR_Q2_FUSED=0 = separate launches; bit-identical either way; gemm mode 6 only)
+    const char *q2_env = getenv("MIT_OCR_Q2_FUSED");
+    const bool q2_fused = ln_fused && gmode == 6 && !(q2_env && *q2_env && atoi(q2_env) == 0);
     const char *sk_env = getenv("MIT_OCR_FF2_SPLITK");
     const int ff2_splitk = (rows_path && R <= FF2_SPLITK_MAX_ROWS && !(sk_env && *sk_env && atoi(sk_env) == 0)) ? 1 : 0;
     auto body = [&](const int step, const int *dyn, hipStream_t st) -> int {
@@ -336,16 +339,24 @@ extern "C" int mit_ocr48_decode(const MitOcr48Decoder *dec, MitOcr48DecodeArgs *
                 OcrAttXpos xs{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 1, E};
                 ocrk_attention(qc + so, TE, E, kc, TE, E, vc, TE, E, nullptr, 0, 0, nullptr, R, 1, Tk, 1, st, 4, 80, dyn, &xs, &att_pl);
                 if (pgemm(ly.out, w.att_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
-                if (ln_fused) {
-                    if (pgemm_ln(ly.q2, w.tgt, E, ly.ln2_w, ly.ln2_b, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, st)) return 1;
-                } else {
-                    if (ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
-                    if (pgemm(ly.q2, w.nrm_p, Rp, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st)) return 1;
-                }
                 const float *mk = a->mem_k + (int64_t)l * N * L * E;
                 const float *mv = a->mem_v + (int64_t)l * N * L * E;
                 OcrAttXpos xc{dec->xpos.cos_t, dec->xpos.sin_t, dec->xpos.scale_t, dec->xpos.iscale_t, dec->xpos.pmax, step, 0, 0};
-                ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, nullptr, 0, 0, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc, &att_pl);
+                // norm2 + the q projection inside the cross-attention kernel where that form exists (a page or a few; else two launches)
+                bool q_inside = false;
+                if (q2_fused && ly.q2.bias && ly.q2.N == E) {
+                    const OcrAttQProj qp{w.tgt, E, ly.ln2_w, ly.ln2_b, 1e-5f, ly.q2.w_split, ly.q2.ldw, ly.q2.scale, ly.q2.bias};
+                    q_inside = ocrk_cross_attention_qproj(qp, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, a->mem_len, R, L, st, dyn, &xc, &att_pl);
+                }
+                if (!q_inside) {
+                    if (ln_fused) {
+                        if (pgemm_ln(ly.q2, w.tgt, E, ly.ln2_w, ly.ln2_b, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, st)) return 1;
+                    } else {
+                        if (ocrk_layernorm(w.tgt, E, ly.ln2_w, ly.ln2_b, nullptr, 0, R, E, 1e-5f, st, &nrm_pl)) return 1;
+                        if (pgemm(ly.q2, w.nrm_p, Rp, R, w.q2, E, MIT_ACT_NONE, nullptr, 0, nullptr, 0, st)) return 1;
+                    }
+                    ocrk_attention(w.q2, E, E, mk, (int64_t)L * E, E, mv, (int64_t)L * E, E, nullptr, 0, 0, a->mem_len, R, 1, L, 5, st, 4, 80, dyn, &xc, &att_pl);
+                }
                 if (pgemm(ly.out2, w.att_p, Rp, R, w.tgt, E, MIT_ACT_NONE, w.tgt, E, nullptr, 0, st)) return 1;
                 if (ln_fused) {
                     if (pgemm_ln(ly.ff1, w.tgt, E, ly.ln3_w, ly.ln3_b, R, nullptr, 0, MIT_ACT_RELU, w.ffh_p, Rp, st)) return 1;

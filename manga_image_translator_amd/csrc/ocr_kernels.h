@@ -30,6 +30,20 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
                     int64_t v_rs, int64_t v_ts, float *O, int64_t o_rs, int64_t o_ts, const int *klen, int R, int Tq, int Tk,
                     int kv_div, hipStream_t s, int heads = 4, int head_dim = 80, const int *dstep = nullptr,
                     const OcrAttXpos *xpos = nullptr, const OcrPlanes *o_planes = nullptr);   // o_planes: instead of O (Tq == 1, head_dim % 8 == 0)
+// The q projection of the decoder's cross-attention inside its attention kernel (few rows; heads 4 x 80, 5 beams per line):
+// q = LayerNorm(x) @ W + bias, W as the planes of pgemm_rows.h.  Bit for bit mit_pgemm_rows_ln + ocrk_attention.
+struct OcrAttQProj {
+    const float *x;           // residual stream [R][ldx]
+    int64_t ldx;
+    const float *ln_w, *ln_b;
+    float eps;
+    const uint16_t *w_planes; // [3][K / 8][ldw][8], K = 320
+    int64_t ldw;
+    const float *scale;       // [N] or NULL: the Linear's epilogue is acc * scale + bias
+    const float *bias;        // [N]
+};
+bool ocrk_cross_attention_qproj(const OcrAttQProj &qp, const float *K, int64_t k_rs, int64_t k_ts, const float *V, int64_t v_rs, int64_t v_ts,
+                                const int *klen, int R, int Tk, hipStream_t s, const int *dstep, const OcrAttXpos *xpos, const OcrPlanes *o_planes);
 void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s, const int *tok1 = nullptr,
                 const int *dstep = nullptr);
 void ocrk_beam_dyn(const float *vals, const int *idx, int *hist0, int *hist1, int hist_ld, float *logp0, float *logp1, int *done,

@@ -15,8 +15,11 @@
 #include "common.h"
 #include "ocr_kernels.h"
 #include "bf16_split.h"
+#include "ln_rows8.h"
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -680,19 +683,31 @@ __device__ __forceinline__ void att_chunk_store(const float4 (&reg)[STAGE], floa
     }
 }
 
-template <int KCHUNK, int STAGE, int HD, int G>
+// QF (the decoder's cross-attention at few rows): the queries are not read from Q but COMPUTED here — q = LayerNorm(x) @ Wq + bias for
+// the line's G beams and this head's HD columns (TransformerDecoderLayer norm2 + multihead_attn's q projection, model_48px.py:548-572):
+// wave 3 normalises the G rows (ln_rows8.h: layernorm_kernel's bits) and parks their planes in LDS, waves 0 .. 2 run pgemm_rows_kernel's
+// K loop on 32 columns each (same cells, same pair and k order, same bias add) while the line's keys travel, and the results go
+// through the rotation into qs as the loaded queries would.  One launch less per layer and step, bit for bit the two-launch form.
+constexpr int ATT_QF_K8 = mitln::LN_K / 8, ATT_QF_ROWS = 8, ATT_QF_DEPTH = 6;
+constexpr size_t ATT_QF_LDS = (size_t)3 * ATT_QF_K8 * ATT_QF_ROWS * 16;
+
+template <int KCHUNK, int STAGE, int HD, int G, bool QF = false>
 __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const float *__restrict__ Q, int64_t q_rs,
                                                                           const float *__restrict__ K, int64_t k_rs, int64_t k_ts,
                                                                           const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
                                                                           float *__restrict__ O, int64_t o_rs,
                                                                           const int *__restrict__ klen, int Tk,
-                                                                          const int *__restrict__ dstep, OcrAttXpos xp, OcrPlanes opl) {
+                                                                          const int *__restrict__ dstep, OcrAttXpos xp, OcrPlanes opl, OcrAttQProj qp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int KP = HD + 4;                // 16-byte aligned rows; lane t reads row t as float4s (pitch 84: conflict-free per 16 lanes)
     constexpr int HD4 = HD / 4;
     float *qs = lds;                          // [G][HD]
     float *ks = qs + G * HD;                  // [KCHUNK][KP]   keys, then values
     float *ws = ks + KCHUNK * KP;             // [G][Tk]
+    // QF: [3][K8][ATT_QF_ROWS] cells of the normalised rows, in the key area — free until the first chunk (in registers so far) is parked
+    // there, behind the barrier that also publishes qs
+    mitcg::u32x4 *apl = reinterpret_cast<mitcg::u32x4 *>(ks);
+    static_assert(!QF || (ATT_QF_LDS <= (size_t)KCHUNK * KP * 4 && (G * HD) % 4 == 0), "the planes fit the key area, 16-byte aligned");
     const int h = blockIdx.x, kr = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = kr * G;
@@ -705,7 +720,99 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
     if (EAGER) att_chunk_load<STAGE>(stage, kb, k_ts, 0, min(KCHUNK, Tk), HD4, tid);
     const int valid = klen ? min(klen[kr], Tk) : Tk;
     if (!EAGER) att_chunk_load<STAGE>(stage, kb, k_ts, 0, min(KCHUNK, valid), HD4, tid);
-    if (xp.cos_t) {  // the beams' queries of position `step`, rotated on the way into LDS (xpos_rotate_kernel's expression, scale up)
+    if constexpr (QF) {
+        using namespace mitcg;
+        static_assert(G <= ATT_QF_ROWS && HD % 8 == 0 && HD <= 96, "three 32-column blocks per head, one 8-row slab");
+        constexpr int K8 = ATT_QF_K8, KTS = mitln::LN_K / 16, D = ATT_QF_DEPTH;
+        const int li = lane & 31, lh = lane >> 5;
+        const unsigned int w_step = (unsigned int)qp.ldw * 32u, w_plane = (unsigned int)K8 * (unsigned int)qp.ldw * 16u;
+        const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(qp.w_planes), 0, 3 * w_plane, 0x00020000);
+        // (columns past the head's HD, or past the matrix: cells of other columns / zeros from the descriptor — computed, never used)
+        const unsigned int w_off = ((unsigned int)lh * (unsigned int)qp.ldw + (unsigned int)(h * HD + 32 * wave + li)) * 16u;
+        u32x4 fw[D][3];
+        auto issue = [&](const int d, const int kstep) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fw[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off, pl * w_plane + (unsigned int)kstep * w_step, 0);
+        };
+        if (wave < 3) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) issue(d, d);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave == 3) {   // rows r0 .. r0 + G - 1, eight lanes each (the groups past G repeat row G - 1 and store nothing)
+            const int rr = lane >> 3, q = lane & 7, row = r0 + (rr < G ? rr : G - 1);
+            f32x4 v[5][2];
+            mitln::ln_row_cells(qp.x + (int64_t)row * qp.ldx + 8 * q, qp.ln_w + 8 * q, qp.ln_b + 8 * q, qp.eps, v);
+            if (rr < G) {
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {
+                    u32x4 ph, pm, pl_;
+                    split8(v[b][0], v[b][1], ph, pm, pl_);
+                    apl[(0 * K8 + 8 * b + q) * ATT_QF_ROWS + rr] = ph;
+                    apl[(1 * K8 + 8 * b + q) * ATT_QF_ROWS + rr] = pm;
+                    apl[(2 * K8 + 8 * b + q) * ATT_QF_ROWS + rr] = pl_;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave < 3) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            const u32x4 *ya = apl + lh * ATT_QF_ROWS + (li < G ? li : 0);
+            u32x4 fa[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fa[0][pl] = li < G ? ya[(pl * K8) * ATT_QF_ROWS] : zero;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kstep = 0; kstep < KTS; ++kstep) {
+                const int d = kstep % D, cur = kstep & 1;
+                if (kstep + 1 < KTS) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fa[cur ^ 1][pl] = li < G ? ya[(pl * K8 + 2 * (kstep + 1)) * ATT_QF_ROWS] : zero;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pr = 3; pr < 9; ++pr)   // the six plane pairs, transposed result (rows = output columns), as pgemm_rows_kernel
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[d][kSplitPB[pr]]), __builtin_bit_cast(bf16x8, fa[cur][kSplitPA[pr]]), acc, 0, 0, 0);
+                if (kstep + D < KTS) issue(d, kstep + D);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int step = dstep ? *dstep : xp.step;
+            constexpr int HP = HD / 2;
+            const int pp = step + -((step + 2) / 2) + xp.pmax;
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {   // after the swap: beam li, the head's columns c0 .. c0 + 7
+                float val[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * pq + e]), __float_as_uint(acc[8 * pq + 4 + e]), false, false);
+                    val[e] = __uint_as_float(sw[0]);
+                    val[4 + e] = __uint_as_float(sw[1]);
+                }
+                const int c0 = 32 * wave + 8 * (2 * pq + lh);
+                if (li < G && c0 < HD) {
+                    const float *bp = qp.bias + h * HD + c0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) val[e] = val[e] * (qp.scale ? qp.scale[h * HD + c0 + e] : 1.f) + bp[e];   // the Linear's epilogue: acc * scale + bias
+                    if (xp.cos_t) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = c0 / 2 + e;
+                            const float sc = xp.scale_t[pp * HP + j];
+                            const float c = xp.cos_t[step * HP + j] * sc, sn = xp.sin_t[step * HP + j] * sc;
+                            qs[li * HD + 2 * j] = val[2 * e] * c + (-val[2 * e + 1]) * sn;
+                            qs[li * HD + 2 * j + 1] = val[2 * e + 1] * c + val[2 * e] * sn;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) qs[li * HD + c0 + e] = val[e];
+                    }
+                }
+            }
+        }
+    } else if (xp.cos_t) {  // the beams' queries of position `step`, rotated on the way into LDS (xpos_rotate_kernel's expression, scale up)
         const int step = dstep ? *dstep : xp.step;
         constexpr int HP = HD / 2;
         const int pp = step + -((step + 2) / 2) + xp.pmax;
@@ -1501,13 +1608,13 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
         if ((int64_t)heads * (R / kv_div) <= lat_max && ATT_KCHUNK_L * (head_dim / 4) <= ATT_STAGE_L * ATT_THREADS && lds_bytes(ATT_KCHUNK_L) <= 64 * 1024) {
             MitProbeScope probe("attention_shared_kv_kernel", s, bytes, flops);
             hipLaunchKernelGGL((attention_shared_kv_kernel<ATT_KCHUNK_L, ATT_STAGE_L, 80, 5>), dim3(heads, R / kv_div), dim3(ATT_THREADS), lds_bytes(ATT_KCHUNK_L), s, Q, q_rs,
-                               K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs, klen, Tk, dstep, xp, opl);
+                               K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs, klen, Tk, dstep, xp, opl, OcrAttQProj{});
             return;
         }
         if (ATT_KCHUNK * (head_dim / 4) <= ATT_STAGE * ATT_THREADS && lds_bytes(ATT_KCHUNK) <= 64 * 1024) {
             MitProbeScope probe("attention_shared_kv_kernel", s, bytes, flops);
             hipLaunchKernelGGL((attention_shared_kv_kernel<ATT_KCHUNK, ATT_STAGE, 80, 5>), dim3(heads, R / kv_div), dim3(ATT_THREADS), lds_bytes(ATT_KCHUNK), s, Q, q_rs, K,
-                               k_rs, k_ts, V, v_rs, v_ts, O, o_rs, klen, Tk, dstep, xp, opl);
+                               k_rs, k_ts, V, v_rs, v_ts, O, o_rs, klen, Tk, dstep, xp, opl, OcrAttQProj{});
             return;
         }
     }
@@ -1548,6 +1655,27 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
                         4.0 * (double)R * Tq * heads * Tk * head_dim);
     hipLaunchKernelGGL(attention_kernel, dim3(Tq, heads, R), dim3(64), smem, s, Q, q_rs, q_ts, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs,
                        o_ts, klen, Tk, kv_div, head_dim, dstep, xp, opl);   // dstep: Tk = the LDS capacity, the kernel attends to *dstep + 1 keys
+}
+
+// The decoder's cross-attention with its q projection inside (QF form above).  Returns false — nothing launched — when the problem is
+// not the few-row case the form exists for (the caller then runs the Linear and ocrk_attention).
+bool ocrk_cross_attention_qproj(const OcrAttQProj &qp, const float *K, int64_t k_rs, int64_t k_ts, const float *V, int64_t v_rs, int64_t v_ts,
+                                const int *klen, int R, int Tk, hipStream_t s, const int *dstep, const OcrAttXpos *xpos, const OcrPlanes *o_planes) {
+    constexpr int heads = 4, head_dim = 80, kv_div = 5;
+    OcrAttXpos xp{};
+    if (xpos) xp = *xpos;
+    if (!o_planes || !o_planes->p || !qp.x || !qp.w_planes || !qp.bias || !qp.ln_w || !qp.ln_b || (qp.ldx & 3) || xp.rot_k) return false;
+    if ((reinterpret_cast<uintptr_t>(qp.x) | reinterpret_cast<uintptr_t>(qp.w_planes) | reinterpret_cast<uintptr_t>(qp.ln_w) | reinterpret_cast<uintptr_t>(qp.ln_b)) & 15) return false;
+    if ((uint64_t)3 * (mitln::LN_K / 8) * (uint64_t)qp.ldw * 16u >= (1ull << 32)) return false;
+    if (R % kv_div || R / kv_div > 65535) return false;
+    static const int64_t lat_max = getenv("MIT_ATT_LATENCY_MAX_WGS") ? atoll(getenv("MIT_ATT_LATENCY_MAX_WGS")) : 512;
+    const size_t lds_bytes = ((size_t)kv_div * head_dim + (size_t)ATT_KCHUNK_L * (head_dim + 4) + (size_t)kv_div * Tk) * sizeof(float);
+    if ((int64_t)heads * (R / kv_div) > lat_max || lds_bytes > 64 * 1024) return false;
+    const double bytes = 4.0 * heads * head_dim * ((double)(R / kv_div) * 2.0 * Tk + 2.0 * R), flops = 4.0 * (double)R * heads * Tk * head_dim;
+    MitProbeScope probe("attention_shared_kv_kernel", s, bytes, flops + 2.0 * R * 320.0 * 320.0);
+    hipLaunchKernelGGL((attention_shared_kv_kernel<ATT_KCHUNK_L, ATT_STAGE_L, 80, 5, true>), dim3(heads, R / kv_div), dim3(ATT_THREADS), lds_bytes, s, nullptr, 0,
+                       K, k_rs, k_ts, V, v_rs, v_ts, nullptr, 0, klen, Tk, dstep, xp, *o_planes, qp);
+    return true;
 }
 
 void ocrk_embed(const int *tok, int64_t tok_stride, const float *E, float *out, int R, int D, hipStream_t s, const int *tok1,

@@ -22,25 +22,16 @@
 #include "conv_gemm_kernels.h"
 #include "pgemm_rows.h"
 #include "pgemm_rows_epi.h"
+#include "ln_rows8.h"
 #include "common.h"
 
 using namespace mitcg;
 
 namespace {
 
-constexpr int LN_K = 320, LN_KTS = LN_K / 16;
+constexpr int LN_K = mitln::LN_K, LN_KTS = LN_K / 16;
 
 constexpr int LN_CP = 34;   // cells per (plane, k-cell) slab in LDS: 32 rows + 2 of padding (the 16 lanes of a write pass fall on 16 distinct 16-byte slots)
-
-__device__ __forceinline__ float lane_xor1(const float v) {   // quad_perm [1, 0, 3, 2]
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_xor2(const float v) {   // quad_perm [2, 3, 0, 1]
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_xor4(const float v) {   // ds_swizzle, bit mode: and 0x1f, or 0, xor 4
-    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (4 << 10) | 0x1f));
-}
 
 template <int NPROD, int D>
 __global__ __launch_bounds__(256) void pgemm_rows_ln_kernel(const MitPGemm p, const PgRowsExt x, const PgRowsLn ln, const int MT, const int NT4,
@@ -74,62 +65,11 @@ __global__ __launch_bounds__(256) void pgemm_rows_ln_kernel(const MitPGemm p, co
         // row M - 1 (normalised, never stored).
         const int rr = lane >> 3, q = lane & 7;
         const int row = min(m0 + 8 * wave + rr, p.M - 1);
-        const float *xr = ln.x + (int64_t)row * ln.ldx + 8 * q;
         f32x4 v[5][2];
-#pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            v[b][0] = *reinterpret_cast<const f32x4 *>(xr + 64 * b);
-            v[b][1] = *reinterpret_cast<const f32x4 *>(xr + 64 * b + 4);
-        }
-        const float *gw = ln.w + 8 * q, *gb = ln.b + 8 * q;   // LayerNorm weight / bias of this lane's cells: requested before the statistics
-        f32x4 wv[5][2], bv[5][2];
-#pragma unroll
-        for (int b = 0; b < 5; ++b)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                wv[b][hf] = *reinterpret_cast<const f32x4 *>(gw + 64 * b + 4 * hf);
-                bv[b][hf] = *reinterpret_cast<const f32x4 *>(gb + 64 * b + 4 * hf);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        // layernorm_kernel's butterfly over the partials l = 8 q + j: levels 32, 16, 8 = q ^ 4, q ^ 2, q ^ 1 (lanes), 4, 2, 1 = j (registers)
-        auto reduce = [&](float (&pt)[8]) __attribute__((always_inline)) -> float {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pt[j] += lane_xor4(pt[j]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pt[j] += lane_xor2(pt[j]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pt[j] += lane_xor1(pt[j]);
-            const float r0 = pt[0] + pt[4], r1 = pt[1] + pt[5], r2 = pt[2] + pt[6], r3 = pt[3] + pt[7];
-            return (r0 + r2) + (r1 + r3);
-        };
-        float pt[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float sm = 0.f;
-#pragma unroll
-            for (int b = 0; b < 5; ++b) sm += v[b][j >> 2][j & 3];
-            pt[j] = sm;
-        }
-        const float mean = reduce(pt) / (float)LN_K;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float sm = 0.f;
-#pragma unroll
-            for (int b = 0; b < 5; ++b) {
-                const float tt = v[b][j >> 2][j & 3] - mean;
-                sm += tt * tt;
-            }
-            pt[j] = sm;
-        }
-        const float rstd = 1.0f / sqrtf(reduce(pt) / (float)LN_K + ln.eps);
+        mitln::ln_row_cells(ln.x + (int64_t)row * ln.ldx + 8 * q, ln.w + 8 * q, ln.b + 8 * q, ln.eps, v);   // (ln_rows8.h: layernorm_kernel's bits)
         u32x4 *dst = apl + q * LN_CP + 8 * wave + rr;
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[b][hf][c] = (v[b][hf][c] - mean) * rstd * wv[b][hf][c] + bv[b][hf][c];
-            }
             u32x4 h, m, l;
             split8(v[b][0], v[b][1], h, m, l);
             dst[(8 * b) * LN_CP] = h;

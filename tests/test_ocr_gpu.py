@@ -586,3 +586,35 @@ def test_k_cut_ffn_linear_of_the_few_row_decode(cuda, ocr_setup, widths, T, supp
     assert ((outs[1]["prob"] - outs[0]["prob"]).abs() <= 1e-4 * outs[0]["prob"].abs() + 1e-12).all()
     assert (outs[1]["colors"] - outs[0]["colors"]).abs().max() < 1e-4
     assert not torch.equal(outs[1]["colors"], outs[0]["colors"]) or len(widths) < 3   # (the K-cut kernel really ran)
+
+
+@pytest.mark.parametrize("widths,T,suppress", [([50, 77, 120, 121, 64, 200], 14, True), ([90, 33], 9, False), ([40 + 5 * i for i in range(40)], 6, True)])
+def test_q_projection_inside_the_cross_attention_is_bit_identical(cuda, ocr_setup, widths, T, suppress):
+    """attention_shared_kv_kernel<..., QF> (norm2 and multihead_attn's q projection computed inside the decoder's cross-attention kernel:
+    one wave normalises the line's five beams with layernorm_kernel's butterfly, three waves run pgemm_rows_kernel's K loop on the head's
+    columns) against the separate launches (MIT_OCR_Q2_FUSED=0): every result tensor identical, launch by launch and from a graph."""
+    import os
+
+    sd, D, eng = ocr_setup
+    crops = _crops(widths, seed=41)
+    mks, mvs, lens = [], [], []
+    for indices, ws, region in eng.make_chunks(crops):
+        mk, mv, kl, _ = eng.encode(torch.from_numpy(region).to(cuda), ws)
+        mks.append(mk.clone()); mvs.append(mv.clone()); lens.append(kl.clone())
+    Lmax = max(m.shape[2] for m in mks)
+    pad = lambda m: m if m.shape[2] == Lmax else torch.cat([m, m.new_zeros(5, m.shape[1], Lmax - m.shape[2], 320)], 2)
+    mem_k, mem_v, klen = torch.cat([pad(m) for m in mks], 1).contiguous(), torch.cat([pad(m) for m in mvs], 1).contiguous(), torch.cat(lens)
+    prev = os.environ.get("MIT_OCR_Q2_FUSED")
+    outs = []
+    try:
+        for q2, graph in (("0", False), ("1", False), ("1", True)):
+            os.environ["MIT_OCR_Q2_FUSED"] = q2
+            o = eng.decode(mem_k, mem_v, klen, max_seq_length=T, suppress_eos=suppress, graph=graph)
+            torch.cuda.synchronize()
+            outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    finally:
+        os.environ.pop("MIT_OCR_Q2_FUSED", None) if prev is None else os.environ.__setitem__("MIT_OCR_Q2_FUSED", prev)
+    for o in outs[1:]:
+        assert o["steps_run"] == outs[0]["steps_run"]
+        for k in ("tokens", "length", "prob", "colors"):
+            assert torch.equal(o[k], outs[0][k]), k
