@@ -21,6 +21,16 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef MIT_CONV_EXPERIMENTS   // phase stamps of workgroup (0, 0) of the cross-attention kernel (100 MHz clock): scripts/dev only
+__device__ unsigned long long g_att_stamps[32];
+#define MIT_ATT_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_att_stamps[i] = wall_clock64(); g_att_stamps[8 + (i)] = clock64(); } } while (0)
+#define MIT_ATT_STAMP2(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_att_stamps[16 + (i)] = wall_clock64(); } while (0)
+extern "C" int mit_dev_att_stamps(unsigned long long *out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_att_stamps), sizeof(g_att_stamps)) == hipSuccess ? 0 : 1; }
+#else
+#define MIT_ATT_STAMP(i) do { } while (0)
+#define MIT_ATT_STAMP2(i) do { } while (0)
+#endif
+
 namespace {
 
 // eight consecutive fp32 values (16-byte aligned, LDS) -> the three cells of (k-cell k8, row) of a planar output
@@ -717,6 +727,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
     // the first keys travel while the queries are prepared; the latency form does not even wait for the line's length (rows past it are
     // padding inside the line's block: loaded, stored, never used)
     constexpr bool EAGER = KCHUNK > 64;
+    MIT_ATT_STAMP(0);
     if (EAGER) att_chunk_load<STAGE>(stage, kb, k_ts, 0, min(KCHUNK, Tk), HD4, tid);
     const int valid = klen ? min(klen[kr], Tk) : Tk;
     if (!EAGER) att_chunk_load<STAGE>(stage, kb, k_ts, 0, min(KCHUNK, valid), HD4, tid);
@@ -734,11 +745,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) fw[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off, pl * w_plane + (unsigned int)kstep * w_step, 0);
         };
+        const int step = dstep ? *dstep : xp.step;
+        constexpr int HP = HD / 2;
+        const int pp = step + -((step + 2) / 2) + xp.pmax;
+        // what the epilogue needs from global memory — the Linear's scale / bias and the rotation's table entries of this lane's columns —
+        // is requested here, ahead of the K loop (behind it, it was a dependent round trip of its own)
+        float e_sc[2][8], e_bi[2][8], e_c[2][4], e_s[2][4];
         if (wave < 3) {
 #pragma unroll
             for (int d = 0; d < D; ++d) issue(d, d);
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {
+                const int c0 = 32 * wave + 8 * (2 * pq + lh), cc = c0 < HD ? c0 : 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    e_sc[pq][e] = qp.scale ? qp.scale[h * HD + cc + e] : 1.f;
+                    e_bi[pq][e] = qp.bias[h * HD + cc + e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = cc / 2 + e;
+                    const float sc = xp.cos_t ? xp.scale_t[pp * HP + j] : 1.f;
+                    e_c[pq][e] = xp.cos_t ? xp.cos_t[step * HP + j] * sc : 1.f;
+                    e_s[pq][e] = xp.cos_t ? xp.sin_t[step * HP + j] * sc : 0.f;
+                }
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
         if (wave == 3) {   // rows r0 .. r0 + G - 1, eight lanes each (the groups past G repeat row G - 1 and store nothing)
             const int rr = lane >> 3, q = lane & 7, row = r0 + (rr < G ? rr : G - 1);
             f32x4 v[5][2];
@@ -755,6 +787,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
             }
         }
         __syncthreads();
+        MIT_ATT_STAMP2(0);
         if (wave < 3) {
             f32x16 acc;
 #pragma unroll
@@ -779,9 +812,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
                 if (kstep + D < KTS) issue(d, kstep + D);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int step = dstep ? *dstep : xp.step;
-            constexpr int HP = HD / 2;
-            const int pp = step + -((step + 2) / 2) + xp.pmax;
+            MIT_ATT_STAMP2(1);
 #pragma unroll
             for (int pq = 0; pq < 2; ++pq) {   // after the swap: beam li, the head's columns c0 .. c0 + 7
                 float val[8];
@@ -793,17 +824,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
                 }
                 const int c0 = 32 * wave + 8 * (2 * pq + lh);
                 if (li < G && c0 < HD) {
-                    const float *bp = qp.bias + h * HD + c0;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) val[e] = val[e] * (qp.scale ? qp.scale[h * HD + c0 + e] : 1.f) + bp[e];   // the Linear's epilogue: acc * scale + bias
-                    if (xp.cos_t) {
+                    for (int e = 0; e < 8; ++e) val[e] = val[e] * e_sc[pq][e] + e_bi[pq][e];   // the Linear's epilogue: acc * scale + bias
+                    if (xp.cos_t) {   // (xpos_rotate_kernel's expression with c = cos * scale, sn = sin * scale)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int j = c0 / 2 + e;
-                            const float sc = xp.scale_t[pp * HP + j];
-                            const float c = xp.cos_t[step * HP + j] * sc, sn = xp.sin_t[step * HP + j] * sc;
-                            qs[li * HD + 2 * j] = val[2 * e] * c + (-val[2 * e + 1]) * sn;
-                            qs[li * HD + 2 * j + 1] = val[2 * e + 1] * c + val[2 * e] * sn;
+                            qs[li * HD + 2 * j] = val[2 * e] * e_c[pq][e] + (-val[2 * e + 1]) * e_s[pq][e];
+                            qs[li * HD + 2 * j + 1] = val[2 * e + 1] * e_c[pq][e] + val[2 * e] * e_s[pq][e];
                         }
                     } else {
 #pragma unroll
@@ -829,17 +857,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
         for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = Q[(int64_t)(r0 + i / HD) * q_rs + h * HD + (i % HD)];
     }
 
+    MIT_ATT_STAMP(1);
     // ---- pass 1: scores.  The next chunk's keys travel to registers while this chunk's dot products run; behind the last chunk of keys
     // the first chunk of VALUES does (its latency is hidden by the last dot products and the softmax).  A thread owns one key of the
     // chunk — its row read from LDS once, into registers — and every KT-th ... query of the line.
     constexpr int KT = KCHUNK > 128 ? 256 : (KCHUNK > 64 ? 128 : 64), NGRP = ATT_THREADS / KT;
-    const int tl = tid % KT, gsub = tid / KT;
+    // (NGRP == 1: compile-time zero — with a run-time tid / KT the compiler cannot see that every query index is below G and wraps each
+    // query's sums in an exec-masked branch of its own: five dependent chains one after the other instead of interleaved)
+    const int tl = NGRP == 1 ? tid : tid % KT, gsub = NGRP == 1 ? 0 : tid / KT;
     bool v_ahead = false;
     for (int t0 = 0; t0 < Tk; t0 += KCHUNK) {
         const int nk = max(0, min(KCHUNK, valid - t0));
         __syncthreads();  // previous chunk consumed (and qs visible)
         if (!v_ahead) att_chunk_store<STAGE>(stage, ks, (EAGER && t0 == 0) ? min(KCHUNK, Tk) : nk, HD4, KP, tid);
         __syncthreads();
+        MIT_ATT_STAMP(2);
         if (t0 + KCHUNK < valid) {
             att_chunk_load<STAGE>(stage, kb, k_ts, t0 + KCHUNK, min(KCHUNK, valid - t0 - KCHUNK), HD4, tid);
         } else if (!v_ahead) {
@@ -857,19 +889,34 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
                 float dot[NQ];
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) dot[qi] = 0.f;
+                // The queries' values (one address for every lane: a broadcast read) run ONE d-group ahead of their products, fenced: left
+                // to itself the compiler issues each read right before its use and waits for it — a hundred LDS round trips in a row, 4.6 us
+                // of a 12 us workgroup (scripts/dev/att_stamps.py) — although the five sums of a group are 40 independent VALU
+                // instructions that cover the next group's latency.
+                float4 qv[2][NQ];
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) qv[0][qi] = *reinterpret_cast<const float4 *>(qs + min(gsub + qi * NGRP, G - 1) * HD);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int d4 = 0; d4 < HD4; ++d4) {  // d ascending, one rounding per product and per sum, as in attention_kernel
+                    if (d4 + 1 < HD4) {
+#pragma unroll
+                        for (int qi = 0; qi < NQ; ++qi)
+                            qv[(d4 + 1) & 1][qi] = *reinterpret_cast<const float4 *>(qs + min(gsub + qi * NGRP, G - 1) * HD + (d4 + 1) * 4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi) {
                         const int g = gsub + qi * NGRP;
                         if (g < G) {
-                            const float4 qv = *reinterpret_cast<const float4 *>(qs + g * HD + d4 * 4);  // same address in every lane: broadcast
-                            dot[qi] += qv.x * kv[d4].x;
-                            dot[qi] += qv.y * kv[d4].y;
-                            dot[qi] += qv.z * kv[d4].z;
-                            dot[qi] += qv.w * kv[d4].w;
+                            const float4 q4 = qv[d4 & 1][qi];
+                            dot[qi] += q4.x * kv[d4].x;
+                            dot[qi] += q4.y * kv[d4].y;
+                            dot[qi] += q4.z * kv[d4].z;
+                            dot[qi] += q4.w * kv[d4].w;
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) {
@@ -882,22 +929,46 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
         }
     }
     __syncthreads();
-    for (int g = wave; g < G; g += ATT_THREADS / 64) {  // softmax: one wave per query, lanes strided over the keys
-        float *w = ws + (int64_t)g * Tk;
-        float mx = -INFINITY;
-        for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, w[t]);
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f;
-        for (int t = lane; t < Tk; t += 64) {
-            const float e = expf(w[t] - mx);
-            w[t] = e;
-            sum += e;
+    MIT_ATT_STAMP(3);
+    {   // softmax: one wave per query, lanes strided over the keys; a wave with two queries (G = 5: wave 0) runs them side by side so
+        // that their shuffle and exp latencies overlap (2.0 -> 1 us of the workgroup); per query the same operations in the same order
+        constexpr int NW = ATT_THREADS / 64, QW = (G + NW - 1) / NW;
+        float *wq[QW];
+        bool on[QW];
+        float mx[QW], sum[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            on[i] = wave + i * NW < G;
+            wq[i] = ws + (int64_t)(on[i] ? wave + i * NW : min(wave, G - 1)) * Tk;   // (an idle slot re-reads a row of this wave's, stores nothing)
+            mx[i] = -INFINITY;
+            sum[i] = 0.f;
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float iv = 1.0f / sum;
-        for (int t = lane; t < Tk; t += 64) w[t] *= iv;  // the (weight * 1/sum) factor of the weighted sum, formed once
+        for (int t = lane; t < Tk; t += 64)
+#pragma unroll
+            for (int i = 0; i < QW; ++i) mx[i] = fmaxf(mx[i], wq[i][t]);
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < QW; ++i) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+        for (int t = lane; t < Tk; t += 64)
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                const float e = expf(wq[i][t] - mx[i]);
+                if (on[i]) wq[i][t] = e;
+                sum[i] += e;
+            }
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < QW; ++i) sum[i] += __shfl_xor(sum[i], o);
+        float iv[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) iv[i] = 1.0f / sum[i];
+        for (int t = lane; t < Tk; t += 64)
+#pragma unroll
+            for (int i = 0; i < QW; ++i)
+                if (on[i]) wq[i][t] *= iv[i];  // the (weight * 1/sum) factor of the weighted sum, formed once
     }
 
+    MIT_ATT_STAMP(4);
     // ---- pass 2: weighted sum of the values, t-ordered per (query, d); thread (d, half) owns the queries g = half, half + 2, ...
     // Waves 0 / 1: half = wave, d = lane; wave 2: d = 64 .. 79 of both halves (a wave's weight reads are then one address: a broadcast).
     // Branch-free inner loop: a (d, half) whose last query index falls past G sums a duplicate of query G - 1 that is never stored.
@@ -918,6 +989,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
         __syncthreads();  // previous chunk consumed (and the softmax weights visible)
         att_chunk_store<STAGE>(stage, ks, nk, HD4, KP, tid);
         __syncthreads();
+        MIT_ATT_STAMP(5);
         if (t0 + KCHUNK < valid) att_chunk_load<STAGE>(stage, vb, v_ts, t0 + KCHUNK, min(KCHUNK, valid - t0 - KCHUNK), HD4, tid);
         if (owner) {
             constexpr int U = 8;  // values and weights of U keys read ahead of their (t-ordered) multiply-adds
@@ -943,6 +1015,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
             }
         }
     }
+    MIT_ATT_STAMP(6);
     if (opl.p) {  // planar output: the G x HD block passes through LDS (qs: last read in pass 1) to become cells of 8
         if (owner) {
 #pragma unroll
@@ -957,6 +1030,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_shared_kv_kernel(const 
             const int g = i / HC, c = i - g * HC;
             store_cells(opl, h * HC + c, r0 + g, qs + g * HD + c * 8);
         }
+        MIT_ATT_STAMP(7);
         return;
     }
     if (owner) {
