@@ -562,66 +562,129 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
 // runs, parked in LDS with a pitch of heads * HD + 4 floats (lane t's float4 reads then fall on distinct banks), and every head's wave
 // evaluates exactly attention_kernel's expressions on it — per-key dot products in d order with the rotation folded in, the
 // lane-strided softmax, the t-ordered weighted sum — so the results are bitwise the same.
+// Round 6 (scripts/dev/att_stamps.py: 12.3 us inside the kernel at Tk = 32, of which 4.6 staging the keys, 2.2 scores, 4.7 weighted sum):
+// every global load of a phase is now in flight at once — the keys and, behind them, the values travel to REGISTERS first (up to
+// SELF_ST float4 per thread; the values are parked in the key area once the scores are done), and the rotation factors cos * iscale,
+// sin * iscale of (key t, pair j) — the same for all four heads, read by every lane from three tables inside its dot-product loop
+// before — are formed once per workgroup into LDS.  Same expressions, same order per (query, key) and per (query, d): same bits.
+constexpr int SELF_ST = 11;    // float4 per thread of a staged [Tk][E] block: Tk * E / 4 <= 256 * SELF_ST (Tk <= 35 at E = 320); past it: a plain loop
+constexpr int SELF_TP_PAD = 4; // table row pitch HP + 4 floats: lane t's float4 reads fall on distinct 16-byte slots (HP = 40)
+template <int heads, int HD>   // compile-time: the staging loops divide by E / 4 and HD / 2 some forty times per thread
 __global__ __launch_bounds__(256) void attention_self_kernel(const float *__restrict__ Q, int64_t q_rs, const float *__restrict__ K, int64_t k_rs,
                                                              int64_t k_ts, const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
-                                                             float *__restrict__ O, int64_t o_rs, int TkCap, int heads, int HD,
+                                                             float *__restrict__ O, int64_t o_rs, int TkCap,
                                                              const int *__restrict__ dstep, OcrAttXpos xp, OcrPlanes opl) {
+    static_assert(heads * 64 == 256 && HD % 8 == 0, "one wave per head");
+    MIT_ATT_STAMP2(4);
     const int Tk = dstep ? *dstep + 1 : TkCap;
     const int step = dstep ? *dstep : xp.step;
     const int minpos = -((step + 2) / 2);
-    const int E = heads * HD, KP = E + 4, HP = HD / 2;
+    constexpr int E = heads * HD, KP = E + 4, HP = HD / 2, TP = HP + SELF_TP_PAD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *qs_all = lds;                      // [heads][HD]
     float *ws_all = qs_all + E;               // [heads][TkCap]
-    float *ks = ws_all + heads * TkCap;       // [TkCap][KP]   (E + heads * TkCap is a multiple of 4: 16-byte aligned rows)
+    float *ks = ws_all + heads * TkCap;       // [TkCap][KP]   keys, then values   (E + heads * TkCap is a multiple of 4: 16-byte aligned rows)
+    float *tc = ks + TkCap * KP;              // [TkCap][TP]   cos * iscale of (key t, pair j)
+    float *tsn = tc + TkCap * TP;             // [TkCap][TP]   sin * iscale
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = blockIdx.x;
     float *qs = qs_all + h * HD, *ws = ws_all + h * TkCap;
-    {   // the query of position `step`, rotated on the way into LDS (attention_kernel's expression, scale up)
-        const float *q = Q + (int64_t)r * q_rs + h * HD + (dstep ? (int64_t)step * xp.q_dyn : 0);
-        const int pp = step + minpos + xp.pmax;
-        for (int j = lane; j < HP; j += 64) {
-            const float sc = xp.scale_t[pp * HP + j];
-            const float c = xp.cos_t[step * HP + j] * sc, sn = xp.sin_t[step * HP + j] * sc;
-            const float2 x = *reinterpret_cast<const float2 *>(q + 2 * j);
-            qs[2 * j] = x.x * c + (-x.y) * sn;
-            qs[2 * j + 1] = x.y * c + x.x * sn;
+    constexpr int E4 = E >> 2;
+    const int n4 = Tk * E4;
+    // ---- every global load of the kernel is requested here, in one batch: the key history, the value history (it waits in registers
+    // until the scores are done), the query and the table entries of the rotations.  The pins below keep them here: the loads are from
+    // read-only memory, so left alone the optimiser sinks each one to its use — the values' became eleven round trips in a row inside
+    // the store loop behind the scores (3.3 us of a 12 us workgroup, scripts/dev/att_stamps.py).
+    f32x4 stk[SELF_ST], stv[SELF_ST];
+    const float *kb = K + (int64_t)r * k_rs, *vbase = V + (int64_t)r * v_rs;
+    auto stage_load = [&](f32x4 (&st)[SELF_ST], const float *base, const int64_t ts) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SELF_ST; ++j) {
+            const int i = tid + j * 256, ii = i < n4 ? i : 0, t = ii / E4, c4 = ii - t * E4;
+            st[j] = *reinterpret_cast<const f32x4 *>(base + (int64_t)t * ts + c4 * 4);
         }
-    }
-    {   // the row's key history, coalesced
-        const float *kb = K + (int64_t)r * k_rs;
-        const int E4 = E >> 2;
-        for (int i = tid; i < Tk * E4; i += 256) {
+    };
+    auto stage_store = [&](f32x4 (&st)[SELF_ST], const float *base, const int64_t ts) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SELF_ST; ++j) {
+            const int i = tid + j * 256;
+            if (i < n4) {
+                const int t = i / E4, c4 = i - t * E4;
+                *reinterpret_cast<f32x4 *>(ks + t * KP + c4 * 4) = st[j];
+            }
+        }
+        for (int i = tid + SELF_ST * 256; i < n4; i += 256) {   // (histories longer than the register stage holds)
             const int t = i / E4, c4 = i - t * E4;
-            *reinterpret_cast<float4 *>(ks + t * KP + c4 * 4) = *reinterpret_cast<const float4 *>(kb + (int64_t)t * k_ts + c4 * 4);
+            *reinterpret_cast<f32x4 *>(ks + t * KP + c4 * 4) = *reinterpret_cast<const f32x4 *>(base + (int64_t)t * ts + c4 * 4);
+        }
+    };
+    stage_load(stk, kb, k_ts);
+    stage_load(stv, vbase, v_ts);
+    // the query of position `step` (lane j < HP: pair j of this wave's head) and its rotation factors
+    static_assert(HP <= 64, "one pair per lane");
+    const int jq = lane < HP ? lane : 0;
+    const int pp = step + minpos + xp.pmax;
+    float q_sc = xp.scale_t[pp * HP + jq], q_c = xp.cos_t[step * HP + jq], q_s = xp.sin_t[step * HP + jq];
+    float2 q_x = *reinterpret_cast<const float2 *>(Q + (int64_t)r * q_rs + h * HD + (dstep ? (int64_t)step * xp.q_dyn : 0) + 2 * jq);
+    // rotation factors of the raw key history: entries i = t * HP + j of the tables
+    constexpr int TT = 6;   // entries per thread held in registers (Tk * HP <= 256 * TT: Tk <= 38 at HP = 40); past it: a plain loop
+    float fc[TT], fs[TT], fi[TT];
+    const int nt = Tk * HP;
+#pragma unroll
+    for (int u = 0; u < TT; ++u) {
+        const int i = tid + u * 256, ii = i < nt ? i : 0, t = ii / HP, j = ii - t * HP;
+        fi[u] = xp.iscale_t[(minpos + t + xp.pmax) * HP + j];
+        fc[u] = xp.cos_t[ii];      // (t * HP + j == ii)
+        fs[u] = xp.sin_t[ii];
+    }
+#pragma unroll
+    for (int j = 0; j < SELF_ST; ++j) asm volatile("" : "+v"(stk[j]), "+v"(stv[j]));
+#pragma unroll
+    for (int u = 0; u < TT; ++u) asm volatile("" : "+v"(fc[u]), "+v"(fs[u]), "+v"(fi[u]));
+    asm volatile("" : "+v"(q_sc), "+v"(q_c), "+v"(q_s), "+v"(q_x.x), "+v"(q_x.y));
+    if (lane < HP) {   // the query, rotated on the way into LDS (attention_kernel's expression, scale up)
+        const float c = q_c * q_sc, sn = q_s * q_sc;
+        qs[2 * lane] = q_x.x * c + (-q_x.y) * sn;
+        qs[2 * lane + 1] = q_x.y * c + q_x.x * sn;
+    }
+#pragma unroll
+    for (int u = 0; u < TT; ++u) {   // c = cos * iscale, sn = sin * iscale (scale down), once per workgroup for its four heads
+        const int i = tid + u * 256;
+        if (i < nt) {
+            const int t = i / HP, j = i - t * HP;
+            tc[t * TP + j] = fc[u] * fi[u];
+            tsn[t * TP + j] = fs[u] * fi[u];
         }
     }
+    for (int i = tid + TT * 256; i < nt; i += 256) {
+        const int t = i / HP, j = i - t * HP;
+        const float is = xp.iscale_t[(minpos + t + xp.pmax) * HP + j];
+        tc[t * TP + j] = xp.cos_t[t * HP + j] * is;
+        tsn[t * TP + j] = xp.sin_t[t * HP + j] * is;
+    }
+    stage_store(stk, kb, k_ts);
     __syncthreads();
+    MIT_ATT_STAMP2(5);
     float mx = -INFINITY;
     for (int t = lane; t < Tk; t += 64) {
         const float4 *kp = reinterpret_cast<const float4 *>(ks + t * KP + h * HD);
-        const float4 *cp = reinterpret_cast<const float4 *>(xp.cos_t + t * HP);
-        const float4 *sp = reinterpret_cast<const float4 *>(xp.sin_t + t * HP);
-        const float4 *ip = reinterpret_cast<const float4 *>(xp.iscale_t + (minpos + t + xp.pmax) * HP);
+        const float4 *cp = reinterpret_cast<const float4 *>(tc + t * TP);
+        const float4 *sp = reinterpret_cast<const float4 *>(tsn + t * TP);
         float dot = 0.f;
         for (int d8 = 0; d8 < HD / 8; ++d8) {  // key t of the raw history, rotated (scale down) as it is read
-            const float4 k0 = kp[2 * d8], k1 = kp[2 * d8 + 1], cc = cp[d8], ss = sp[d8], ii = ip[d8];
-            float c, sn;
-            c = cc.x * ii.x, sn = ss.x * ii.x;
-            dot += qs[d8 * 8 + 0] * (k0.x * c + (-k0.y) * sn);
-            dot += qs[d8 * 8 + 1] * (k0.y * c + k0.x * sn);
-            c = cc.y * ii.y, sn = ss.y * ii.y;
-            dot += qs[d8 * 8 + 2] * (k0.z * c + (-k0.w) * sn);
-            dot += qs[d8 * 8 + 3] * (k0.w * c + k0.z * sn);
-            c = cc.z * ii.z, sn = ss.z * ii.z;
-            dot += qs[d8 * 8 + 4] * (k1.x * c + (-k1.y) * sn);
-            dot += qs[d8 * 8 + 5] * (k1.y * c + k1.x * sn);
-            c = cc.w * ii.w, sn = ss.w * ii.w;
-            dot += qs[d8 * 8 + 6] * (k1.z * c + (-k1.w) * sn);
-            dot += qs[d8 * 8 + 7] * (k1.w * c + k1.z * sn);
+            const float4 k0 = kp[2 * d8], k1 = kp[2 * d8 + 1], cc = cp[d8], ss = sp[d8];
+            dot += qs[d8 * 8 + 0] * (k0.x * cc.x + (-k0.y) * ss.x);
+            dot += qs[d8 * 8 + 1] * (k0.y * cc.x + k0.x * ss.x);
+            dot += qs[d8 * 8 + 2] * (k0.z * cc.y + (-k0.w) * ss.y);
+            dot += qs[d8 * 8 + 3] * (k0.w * cc.y + k0.z * ss.y);
+            dot += qs[d8 * 8 + 4] * (k1.x * cc.z + (-k1.y) * ss.z);
+            dot += qs[d8 * 8 + 5] * (k1.y * cc.z + k1.x * ss.z);
+            dot += qs[d8 * 8 + 6] * (k1.z * cc.w + (-k1.w) * ss.w);
+            dot += qs[d8 * 8 + 7] * (k1.w * cc.w + k1.z * ss.w);
         }
         ws[t] = dot;
         mx = fmaxf(mx, dot);
     }
+    MIT_ATT_STAMP2(6);
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.f;
     for (int t = lane; t < Tk; t += 64) {
@@ -632,27 +695,27 @@ __global__ __launch_bounds__(256) void attention_self_kernel(const float *__rest
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float inv = 1.0f / sum;
     for (int t = lane; t < Tk; t += 64) ws[t] *= inv;
+    MIT_ATT_STAMP2(10);
+    __syncthreads();           // every head is done with the keys (and the weights are visible)
+    MIT_ATT_STAMP2(11);
+    stage_store(stv, vbase, v_ts);  // the values take their place
+    MIT_ATT_STAMP2(12);
     __syncthreads();
-    const float *vb = V + (int64_t)r * v_rs + h * HD;
+    MIT_ATT_STAMP2(7);
     float *ob = O ? O + (int64_t)r * o_rs + h * HD : nullptr;
-    constexpr int U = 8;  // values of V in flight per lane; the sum itself stays t-ordered
+    const float *vs = ks + h * HD;
     for (int d = lane; d < HD; d += 64) {
         float acc = 0.f;
-        for (int t0 = 0; t0 < Tk; t0 += U) {
-            float vv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) vv[u] = (t0 + u < Tk) ? vb[(int64_t)(t0 + u) * v_ts + d] : 0.f;
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (t0 + u < Tk) acc += ws[t0 + u] * vv[u];
-        }
+        for (int t = 0; t < Tk; ++t) acc += ws[t] * vs[t * KP + d];   // t-ordered
         if (opl.p) qs[d] = acc;
         else ob[d] = acc;
     }
+    MIT_ATT_STAMP2(8);
     if (opl.p) {
         wave_lds_fence();
         for (int c = lane; c < (HD >> 3); c += 64) store_cells(opl, h * (HD >> 3) + c, r, qs + c * 8);
     }
+    MIT_ATT_STAMP2(9);
 }
 
 // ---- the same attention for ONE query position of G = kv_div consecutive rows that share a K / V block (the beams of a line
@@ -1713,14 +1776,14 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
             return;
         }
     }
-    if (g_att_self_rows.load(std::memory_order_relaxed) && Tq == 1 && kv_div == 1 && !klen && xp.cos_t && xp.rot_k && heads * 64 == 256 && head_dim % 8 == 0 && k_ts == (int64_t)heads * head_dim &&
+    if (g_att_self_rows.load(std::memory_order_relaxed) && Tq == 1 && kv_div == 1 && !klen && xp.cos_t && xp.rot_k && heads == 4 && head_dim == 80 && k_ts == (int64_t)heads * head_dim &&
         !((q_rs | k_rs | k_ts | v_rs | v_ts) & 3) && !((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(Q)) & 15) && ((heads * Tk) & 3) == 0) {
-        const size_t sm = ((size_t)heads * head_dim + (size_t)heads * Tk + (size_t)Tk * (heads * head_dim + 4)) * sizeof(float);
+        const size_t sm = ((size_t)heads * head_dim + (size_t)heads * Tk + (size_t)Tk * (heads * head_dim + 4) + (size_t)2 * Tk * (head_dim / 2 + SELF_TP_PAD)) * sizeof(float);
         if (sm <= 64 * 1024) {
             // the decoder's self-attention: the row's key history staged once for its four heads (bitwise attention_kernel's results)
             MitProbeScope probe("attention_self_kernel", s, 4.0 * heads * head_dim * ((double)R * 2.0 * Tk + 2.0 * (double)R),
                                 4.0 * (double)R * heads * Tk * head_dim);
-            hipLaunchKernelGGL(attention_self_kernel, dim3(R), dim3(256), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs, Tk, heads, head_dim, dstep, xp, opl);
+            hipLaunchKernelGGL((attention_self_kernel<4, 80>), dim3(R), dim3(256), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs, Tk, dstep, xp, opl);
             return;
         }
     }

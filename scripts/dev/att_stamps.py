@@ -26,3 +26,8 @@ for q2 in ("0", "1"):
     c = [int(x) for x in st[8:16]]
     print(f"MIT_OCR_Q2_FUSED={q2}: " + ", ".join(f"{n} +{(b - a) * 10} ns" for n, a, b in zip(names[1:], t, t[1:])) + f"; total {(t[7] - t[0]) * 10} ns; "
           f"[q phase: rows normalised +{(int(st[16]) - t[0]) * 10} ns, K loop +{(int(st[17]) - int(st[16])) * 10} ns] shader clock {(c[7] - c[0]) / max(1, (t[7] - t[0]) * 10) :.2f} GHz ({c[7] - c[0]} cycles)")
+
+s2 = [int(x) for x in st[20:26]]
+print("self-attention (row 0, last step): " + ", ".join(f"{n} +{(b - a) * 10} ns" for n, a, b in zip(
+    ["q + key history staged", "scores", "softmax", "weighted sum", "stored"], s2, s2[1:])) + f"; total {(s2[5] - s2[0]) * 10} ns")
+print("  inside 'softmax': compute +%d ns, barrier +%d ns, values parked +%d ns, barrier +%d ns" % tuple((int(st[16 + b]) - int(st[16 + a])) * 10 for a, b in ((6, 10), (10, 11), (11, 12), (12, 7))))
