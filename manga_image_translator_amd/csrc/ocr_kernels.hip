@@ -1158,8 +1158,12 @@ __global__ __launch_bounds__(256) void logsoftmax_top5_kernel(const float *__res
         for (int j = 0; j < NJ; ++j) {
             const int d = tid + 256 * j;
             v[j] = d < D ? x[d] : -INFINITY;
-            if (d == suppress_tok) v[j] = -INFINITY;
         }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(v[j]));   // all NJ loads requested before the first use (read-only loads are sunk to their uses otherwise)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (tid + 256 * j == suppress_tok) v[j] = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int d = tid + 256 * j;
