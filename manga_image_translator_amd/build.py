@@ -46,9 +46,19 @@ NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 PACKED_FP32_BY_DESIGN = {"conv_small_cout.hip", "pgemm.hip"} | {f"conv_gemm_inst{i}.hip" for i in range(8)}
 
 
+# Kernel-argument preloading (gfx940+): the leading scalar arguments of a kernel arrive in user SGPRs with the wave instead of behind a scalar
+# load from the kernarg segment.  Used where a launch is a few microseconds long and begins with that round trip: the few-row GEMMs and
+# the attention / bookkeeping kernels of the B = 1 decoder (their signatures lead with the values the first requests need).  The code object keeps the
+# load-based prologue for firmware without the feature.
+KERNARG_PRELOAD = {"pgemm.hip": 12, "pgemm_rows_ln.hip": 12, "ocr_kernels.hip": 12}
+
+
 def flags_for(src_name: str) -> list:
     """Compiler flags of one translation unit."""
-    return HIPCC_FLAGS + ([] if src_name in PACKED_FP32_BY_DESIGN else NO_PACKED_FP32)
+    f = HIPCC_FLAGS + ([] if src_name in PACKED_FP32_BY_DESIGN else NO_PACKED_FP32)
+    if src_name in KERNARG_PRELOAD:
+        f = f + ["-mllvm", f"-amdgpu-kernarg-preload-count={KERNARG_PRELOAD[src_name]}"]
+    return f
 
 
 if os.environ.get("MIT_WITH_SLP"):  # A/B only: the build of rounds 1-4 (reproduces the co-tenancy failures)

@@ -570,10 +570,12 @@ __global__ void attention_kernel(const float *__restrict__ Q, int64_t q_rs, int6
 constexpr int SELF_ST = 11;    // float4 per thread of a staged [Tk][E] block: Tk * E / 4 <= 256 * SELF_ST (Tk <= 35 at E = 320); past it: a plain loop
 constexpr int SELF_TP_PAD = 4; // table row pitch HP + 4 floats: lane t's float4 reads fall on distinct 16-byte slots (HP = 40)
 template <int heads, int HD>   // compile-time: the staging loops divide by E / 4 and HD / 2 some forty times per thread
-__global__ __launch_bounds__(256) void attention_self_kernel(const float *__restrict__ Q, int64_t q_rs, const float *__restrict__ K, int64_t k_rs,
-                                                             int64_t k_ts, const float *__restrict__ V, int64_t v_rs, int64_t v_ts,
-                                                             float *__restrict__ O, int64_t o_rs, int TkCap,
-                                                             const int *__restrict__ dstep, OcrAttXpos xp, OcrPlanes opl) {
+// (argument order: what the first batch of loads needs comes first — twelve dwords are preloaded into SGPRs with the wave, build.py;
+// the token stride of K and V is E, checked by the launcher)
+__global__ __launch_bounds__(256) void attention_self_kernel(const float *__restrict__ K, int64_t k_rs, const float *__restrict__ V, int64_t v_rs,
+                                                             const float *__restrict__ Q, int64_t q_rs, int TkCap, const int *__restrict__ dstep,
+                                                             float *__restrict__ O, int64_t o_rs, OcrAttXpos xp, OcrPlanes opl) {
+    constexpr int64_t k_ts = (int64_t)heads * HD, v_ts = k_ts;
     static_assert(heads * 64 == 256 && HD % 8 == 0, "one wave per head");
     MIT_ATT_STAMP2(4);
     const int Tk = dstep ? *dstep + 1 : TkCap;
@@ -1780,14 +1782,14 @@ void ocrk_attention(const float *Q, int64_t q_rs, int64_t q_ts, const float *K, 
             return;
         }
     }
-    if (g_att_self_rows.load(std::memory_order_relaxed) && Tq == 1 && kv_div == 1 && !klen && xp.cos_t && xp.rot_k && heads == 4 && head_dim == 80 && k_ts == (int64_t)heads * head_dim &&
+    if (g_att_self_rows.load(std::memory_order_relaxed) && Tq == 1 && kv_div == 1 && !klen && xp.cos_t && xp.rot_k && heads == 4 && head_dim == 80 && k_ts == (int64_t)heads * head_dim && v_ts == k_ts &&
         !((q_rs | k_rs | k_ts | v_rs | v_ts) & 3) && !((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(Q)) & 15) && ((heads * Tk) & 3) == 0) {
         const size_t sm = ((size_t)heads * head_dim + (size_t)heads * Tk + (size_t)Tk * (heads * head_dim + 4) + (size_t)2 * Tk * (head_dim / 2 + SELF_TP_PAD)) * sizeof(float);
         if (sm <= 64 * 1024) {
             // the decoder's self-attention: the row's key history staged once for its four heads (bitwise attention_kernel's results)
             MitProbeScope probe("attention_self_kernel", s, 4.0 * heads * head_dim * ((double)R * 2.0 * Tk + 2.0 * (double)R),
                                 4.0 * (double)R * heads * Tk * head_dim);
-            hipLaunchKernelGGL((attention_self_kernel<4, 80>), dim3(R), dim3(256), sm, s, Q, q_rs, K, k_rs, k_ts, V, v_rs, v_ts, O, o_rs, Tk, dstep, xp, opl);
+            hipLaunchKernelGGL((attention_self_kernel<4, 80>), dim3(R), dim3(256), sm, s, K, k_rs, V, v_rs, Q, q_rs, Tk, dstep, O, o_rs, xp, opl);
             return;
         }
     }

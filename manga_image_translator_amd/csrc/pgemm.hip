@@ -33,6 +33,14 @@
 
 using namespace mitcg;
 
+#ifdef MIT_CONV_EXPERIMENTS   // phase stamps of workgroup 0 of the few-row GEMM (100 MHz clock): scripts/dev only
+__device__ unsigned long long g_rows_stamps[16];
+#define MIT_ROWS_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_rows_stamps[i] = wall_clock64(); } while (0)
+extern "C" int mit_dev_rows_stamps(unsigned long long *out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rows_stamps), sizeof(g_rows_stamps)) == hipSuccess ? 0 : 1; }
+#else
+#define MIT_ROWS_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -688,8 +696,13 @@ __global__ __launch_bounds__(256) void join_planes_kernel(const u32x4 *__restric
 
 // KTS: K / 16 as a compile-time constant (the decoder's K = 320 and 2048): the k loop fully unrolled, so that hipcc counts the loads in
 // flight exactly — at the header of a run-time loop it waits for vmcnt(0), which empties the prefetch ring once per D steps (KTS = 0).
+// Leading scalar arguments = what the first operand requests need (pointers, slab strides, tile counts): with kernel-argument preloading
+// (build.py: -amdgpu-kernarg-preload-count for this unit) they arrive in SGPRs with the wave instead of behind a scalar load from the
+// kernarg segment in device memory — the round trip every one of these 6 us launches began with.
 template <int NPROD, int D, int KTS>
-__global__ __launch_bounds__(64) void pgemm_rows_kernel(const MitPGemm p, const PgRowsExt x, const int MT, const int NT, const int KT) {
+__global__ __launch_bounds__(64) void pgemm_rows_kernel(const uint16_t *pa, const uint16_t *pw, const unsigned int lda_u, const unsigned int ldw_u, const int Kq,
+                                                        const int MT, const int NT, const int KT, const MitPGemm p, const PgRowsExt x) {
+    MIT_ROWS_STAMP(0);
     const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
     // block -> (column block, row block): the row blocks of a column block (same W cells) on one XCD, blocks dealt round-robin to the XCDs
     const int total = MT * NT, per = (total + 7) >> 3;
@@ -697,22 +710,27 @@ __global__ __launch_bounds__(64) void pgemm_rows_kernel(const MitPGemm p, const 
     if (t >= total || (int)(blockIdx.x >> 3) >= per) return;
     const int nt = t / MT, mt = t - nt * MT;
     const int m0 = mt * 32, n0 = nt * 32;
-    const int K8 = p.K >> 3;
-    const unsigned int a_step = (unsigned int)p.lda * 32u, w_step = (unsigned int)p.ldw * 32u;     // bytes per k step (two k cells)
-    const unsigned int a_plane = (unsigned int)K8 * (unsigned int)p.lda * 16u, w_plane = (unsigned int)K8 * (unsigned int)p.ldw * 16u;
+    const int K8 = Kq >> 3;
+    const unsigned int a_step = lda_u * 32u, w_step = ldw_u * 32u;     // bytes per k step (two k cells)
+    const unsigned int a_plane = (unsigned int)K8 * lda_u * 16u, w_plane = (unsigned int)K8 * ldw_u * 16u;
     const int z = blockIdx.y;
-    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.a_planes + (int64_t)z * p.a_zs), 0, 3 * a_plane, 0x00020000);
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w_planes + (int64_t)z * p.w_zs), 0, 3 * w_plane, 0x00020000);
-    const unsigned int a_off = ((unsigned int)lh * (unsigned int)p.lda + (unsigned int)(m0 + li)) * 16u;
-    const unsigned int w_off = ((unsigned int)lh * (unsigned int)p.ldw + (unsigned int)(n0 + li)) * 16u;
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(z ? pa + (int64_t)z * p.a_zs : pa), 0, 3 * a_plane, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(z ? pw + (int64_t)z * p.w_zs : pw), 0, 3 * w_plane, 0x00020000);
+    const unsigned int a_off = ((unsigned int)lh * lda_u + (unsigned int)(m0 + li)) * 16u;
+    const unsigned int w_off = ((unsigned int)lh * ldw_u + (unsigned int)(n0 + li)) * 16u;
 
     u32x4 fa[D][3], fw[D][3];
-    auto issue = [&](const int d, const int ks) __attribute__((always_inline)) {
+    // (k steps are requested in ascending order: running offsets — with ks * step per request the fully unrolled K = 2048 form hoists
+    // its 768 scalar products to the top and spills SGPRs to scratch)
+    unsigned int a_run = 0, w_run = 0;
+    auto issue = [&](const int d, const int /*ks: ascending, one step per call*/) __attribute__((always_inline)) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            fa[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off, pl * a_plane + (unsigned int)ks * a_step, 0);
-            fw[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off, pl * w_plane + (unsigned int)ks * w_step, 0);
+            fa[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off, pl * a_plane + a_run, 0);
+            fw[d][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off, pl * w_plane + w_run, 0);
         }
+        a_run += a_step;
+        w_run += w_step;
     };
     f32x16 acc;
 #pragma unroll
@@ -726,12 +744,20 @@ __global__ __launch_bounds__(64) void pgemm_rows_kernel(const MitPGemm p, const 
 #pragma unroll
         for (int d = 0; d < D && d < KTS; ++d) issue(d, d);
         __builtin_amdgcn_sched_barrier(0);   // (the fences keep the loads D steps ahead: left alone the scheduler sinks each load to its use)
+        MIT_ROWS_STAMP(1);
 #pragma unroll
         for (int ks = 0; ks < KTS; ++ks) {
             consume(ks % D);
             if (ks + D < KTS) issue(ks % D, ks + D);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef MIT_CONV_EXPERIMENTS
+            if (ks == 0) { asm volatile("" : "+v"(acc)); MIT_ROWS_STAMP(2); }
+#endif
         }
+#ifdef MIT_CONV_EXPERIMENTS
+        asm volatile("" : "+v"(acc));
+        MIT_ROWS_STAMP(3);
+#endif
     } else {
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -756,6 +782,7 @@ __global__ __launch_bounds__(64) void pgemm_rows_kernel(const MitPGemm p, const 
     }
 
     pg_rows_epilogue(p, x, acc, m0, n0, z, lane);
+    MIT_ROWS_STAMP(4);
 }
 
 // ---- the same block with K cut into four: the FFN's second Linear (K = 2048) at one page is ONE accumulator chain of 768 MFMAs per
@@ -767,8 +794,9 @@ __global__ __launch_bounds__(64) void pgemm_rows_kernel(const MitPGemm p, const 
 // Measured and dropped (profiles/r11j, r11k): the four slices as four one-wave workgroups on four CUs with a last-arriver reduction
 // through a workspace (release fence + device-scope counter per slice) — 12.8 us; sixteen slices — 28.9 us: every device-scope
 // release fence writes the XCD's L2 back, which costs more than the 786 KB of operand cells cost one CU's L2 port.
-template <int NPROD, int D, int KTW>   // KTW: k steps per wave (K = 4 * 16 * KTW)
-__global__ __launch_bounds__(256) void pgemm_rows_splitk_kernel(const MitPGemm p, const PgRowsExt x, const int MT, const int NT) {
+template <int NPROD, int D, int KTW>   // KTW: k steps per wave (K = 4 * 16 * KTW); leading scalars: see pgemm_rows_kernel
+__global__ __launch_bounds__(256) void pgemm_rows_splitk_kernel(const uint16_t *pa, const uint16_t *pw, const unsigned int lda_u, const unsigned int ldw_u,
+                                                               const int Kq, const int MT, const int NT, const MitPGemm p, const PgRowsExt x) {
     __shared__ __attribute__((aligned(16))) float part[3][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int total = MT * NT, per = (total + 7) >> 3;
@@ -776,14 +804,14 @@ __global__ __launch_bounds__(256) void pgemm_rows_splitk_kernel(const MitPGemm p
     if (t >= total || (int)(blockIdx.x >> 3) >= per) return;
     const int nt = t / MT, mt = t - nt * MT;
     const int m0 = mt * 32, n0 = nt * 32;
-    const int K8 = p.K >> 3;
-    const unsigned int a_step = (unsigned int)p.lda * 32u, w_step = (unsigned int)p.ldw * 32u;
-    const unsigned int a_plane = (unsigned int)K8 * (unsigned int)p.lda * 16u, w_plane = (unsigned int)K8 * (unsigned int)p.ldw * 16u;
-    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.a_planes), 0, 3 * a_plane, 0x00020000);
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w_planes), 0, 3 * w_plane, 0x00020000);
+    const int K8 = Kq >> 3;
+    const unsigned int a_step = lda_u * 32u, w_step = ldw_u * 32u;
+    const unsigned int a_plane = (unsigned int)K8 * lda_u * 16u, w_plane = (unsigned int)K8 * ldw_u * 16u;
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(pa), 0, 3 * a_plane, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(pw), 0, 3 * w_plane, 0x00020000);
     const unsigned int ks0 = (unsigned int)wave * KTW;
-    const unsigned int a_off = ((unsigned int)lh * (unsigned int)p.lda + (unsigned int)(m0 + li)) * 16u + ks0 * a_step;
-    const unsigned int w_off = ((unsigned int)lh * (unsigned int)p.ldw + (unsigned int)(n0 + li)) * 16u + ks0 * w_step;
+    const unsigned int a_off = ((unsigned int)lh * lda_u + (unsigned int)(m0 + li)) * 16u + ks0 * a_step;
+    const unsigned int w_off = ((unsigned int)lh * ldw_u + (unsigned int)(n0 + li)) * 16u + ks0 * w_step;
     u32x4 fa[D][3], fw[D][3];
     auto issue = [&](const int d, const int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -824,9 +852,9 @@ void pg_rows_launch_ext(const MitPGemm &p, const PgRowsExt &x, hipStream_t s) {
     const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32, KT = p.K / 16;
     const int total = MT * NT, per = (total + 7) / 8;
     const dim3 grid(per * 8, p.Z > 0 ? p.Z : 1);
-    if (KT == 20) hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 20>), grid, dim3(64), 0, s, p, x, MT, NT, KT);
-    else if (KT == 128) hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 128>), grid, dim3(64), 0, s, p, x, MT, NT, KT);
-    else hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 0>), grid, dim3(64), 0, s, p, x, MT, NT, KT);
+    if (KT == 20) hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 20>), grid, dim3(64), 0, s, p.a_planes, p.w_planes, (unsigned int)p.lda, (unsigned int)p.ldw, p.K, MT, NT, KT, p, x);
+    else if (KT == 128) hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 128>), grid, dim3(64), 0, s, p.a_planes, p.w_planes, (unsigned int)p.lda, (unsigned int)p.ldw, p.K, MT, NT, KT, p, x);
+    else hipLaunchKernelGGL((pgemm_rows_kernel<NPROD, D, 0>), grid, dim3(64), 0, s, p.a_planes, p.w_planes, (unsigned int)p.lda, (unsigned int)p.ldw, p.K, MT, NT, KT, p, x);
 }
 
 // ---- tiles and launch -------------------------------------------------------------------------------------------------------------
@@ -972,8 +1000,8 @@ int mit_pgemm_rows(const MitPGemm &d, const PgRowsExt &x, hipStream_t s) {
     MitProbeScope probe("pgemm_rows_kernel", s, bytes, flops);
     if (x.splitk && p.K == 2048 && (p.nprod == 6 || p.nprod == 9)) {   // four waves x a quarter of K (see pgemm_rows_splitk_kernel)
         const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32, total = MT * NT, per = (total + 7) / 8;
-        if (p.nprod == 6) hipLaunchKernelGGL((pgemm_rows_splitk_kernel<6, 6, 32>), dim3(per * 8), dim3(256), 0, s, p, x, MT, NT);
-        else hipLaunchKernelGGL((pgemm_rows_splitk_kernel<9, 6, 32>), dim3(per * 8), dim3(256), 0, s, p, x, MT, NT);
+        if (p.nprod == 6) hipLaunchKernelGGL((pgemm_rows_splitk_kernel<6, 6, 32>), dim3(per * 8), dim3(256), 0, s, p.a_planes, p.w_planes, (unsigned int)p.lda, (unsigned int)p.ldw, p.K, MT, NT, p, x);
+        else hipLaunchKernelGGL((pgemm_rows_splitk_kernel<9, 6, 32>), dim3(per * 8), dim3(256), 0, s, p.a_planes, p.w_planes, (unsigned int)p.lda, (unsigned int)p.ldw, p.K, MT, NT, p, x);
     } else if (p.nprod == 6) pg_rows_launch_ext<6, PG_ROWS_DEPTH>(p, x, s);
     else if (p.nprod == 9) pg_rows_launch_ext<9, PG_ROWS_DEPTH>(p, x, s);
     else return mit_set_error("mit_pgemm_rows: nprod must be 6 or 9 (got %d)", p.nprod);

@@ -34,8 +34,10 @@ constexpr int LN_K = mitln::LN_K, LN_KTS = LN_K / 16;
 constexpr int LN_CP = 34;   // cells per (plane, k-cell) slab in LDS: 32 rows + 2 of padding (the 16 lanes of a write pass fall on 16 distinct 16-byte slots)
 
 template <int NPROD, int D>
-__global__ __launch_bounds__(256) void pgemm_rows_ln_kernel(const MitPGemm p, const PgRowsExt x, const PgRowsLn ln, const int MT, const int NT4,
-                                                            const int NT) {
+// (leading scalar arguments: what the first requests — W cells, the rows — need; preloaded into SGPRs with the wave, see build.py)
+__global__ __launch_bounds__(256) void pgemm_rows_ln_kernel(const uint16_t *pw, const float *lnx, const unsigned int ldw_u, const int ldx_i, const int Mrows,
+                                                            const int MT, const int NT4, const int NT, const float *lnw, const float *lnb,
+                                                            const MitPGemm p, const PgRowsExt x, const float eps) {
     constexpr int K8 = LN_K >> 3;
     __shared__ __attribute__((aligned(16))) u32x4 apl[3 * K8 * LN_CP];   // the block's normalised rows as planes: cell (pl, k8, row) at (pl K8 + k8) LN_CP + row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -47,10 +49,10 @@ __global__ __launch_bounds__(256) void pgemm_rows_ln_kernel(const MitPGemm p, co
     const int nt = nt4 * 4 + wave;
     const bool has_tile = nt < NT;
     const int m0 = mt * 32, n0 = nt * 32;
-    const unsigned int w_step = (unsigned int)p.ldw * 32u;                               // bytes per k step (two k cells)
-    const unsigned int w_plane = (unsigned int)K8 * (unsigned int)p.ldw * 16u;
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w_planes), 0, 3 * w_plane, 0x00020000);
-    const unsigned int w_off = ((unsigned int)lh * (unsigned int)p.ldw + (unsigned int)(n0 + li)) * 16u;   // (past the planes: the descriptor answers 0)
+    const unsigned int w_step = ldw_u * 32u;                               // bytes per k step (two k cells)
+    const unsigned int w_plane = (unsigned int)K8 * ldw_u * 16u;
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(pw), 0, 3 * w_plane, 0x00020000);
+    const unsigned int w_off = ((unsigned int)lh * ldw_u + (unsigned int)(n0 + li)) * 16u;   // (past the planes: the descriptor answers 0)
 
     u32x4 fw[D][3];
     auto issue = [&](const int d, const int ks) __attribute__((always_inline)) {
@@ -64,9 +66,9 @@ __global__ __launch_bounds__(256) void pgemm_rows_ln_kernel(const MitPGemm p, co
     {   // ---- rows 8 wave .. + 7 of the block: lane (rr, q) holds the cells k8 = 8 b + q, i.e. d = 64 b + 8 q + j.  Rows past M repeat
         // row M - 1 (normalised, never stored).
         const int rr = lane >> 3, q = lane & 7;
-        const int row = min(m0 + 8 * wave + rr, p.M - 1);
+        const int row = min(m0 + 8 * wave + rr, Mrows - 1);
         f32x4 v[5][2];
-        mitln::ln_row_cells(ln.x + (int64_t)row * ln.ldx + 8 * q, ln.w + 8 * q, ln.b + 8 * q, ln.eps, v);   // (ln_rows8.h: layernorm_kernel's bits)
+        mitln::ln_row_cells(lnx + (int64_t)row * ldx_i + 8 * q, lnw + 8 * q, lnb + 8 * q, eps, v);   // (ln_rows8.h: layernorm_kernel's bits)
         u32x4 *dst = apl + q * LN_CP + 8 * wave + rr;
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
@@ -111,7 +113,8 @@ template <int NPROD>
 void launch(const MitPGemm &p, const PgRowsExt &x, const PgRowsLn &ln, hipStream_t s) {
     const int MT = (p.M + 31) / 32, NT = (p.N + 31) / 32, NT4 = (NT + 3) / 4;
     const int total = MT * NT4, per = (total + 7) / 8;
-    hipLaunchKernelGGL((pgemm_rows_ln_kernel<NPROD, PG_ROWS_DEPTH>), dim3(per * 8), dim3(256), 0, s, p, x, ln, MT, NT4, NT);
+    hipLaunchKernelGGL((pgemm_rows_ln_kernel<NPROD, PG_ROWS_DEPTH>), dim3(per * 8), dim3(256), 0, s, p.w_planes, ln.x, (unsigned int)p.ldw, (int)ln.ldx, p.M, MT, NT4, NT, ln.w, ln.b,
+                       p, x, ln.eps);
 }
 
 }  // namespace

@@ -31,3 +31,10 @@ s2 = [int(x) for x in st[20:26]]
 print("self-attention (row 0, last step): " + ", ".join(f"{n} +{(b - a) * 10} ns" for n, a, b in zip(
     ["q + key history staged", "scores", "softmax", "weighted sum", "stored"], s2, s2[1:])) + f"; total {(s2[5] - s2[0]) * 10} ns")
 print("  inside 'softmax': compute +%d ns, barrier +%d ns, values parked +%d ns, barrier +%d ns" % tuple((int(st[16 + b]) - int(st[16 + a])) * 10 for a, b in ((6, 10), (10, 11), (11, 12), (12, 7))))
+
+lib.mit_dev_rows_stamps.restype = C.c_int
+rs = (C.c_ulonglong * 16)()
+assert lib.mit_dev_rows_stamps(rs) == 0
+r_ = [int(x) for x in rs[:5]]
+print("few-row GEMM (last launch, workgroup 0): " + ", ".join(f"{n} +{(b - a) * 10} ns" for n, a, b in zip(
+    ["ring requested", "first step done", "K loop done", "epilogue done"], r_, r_[1:])) + f"; total {(r_[4] - r_[0]) * 10} ns")
