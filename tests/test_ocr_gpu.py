@@ -618,3 +618,38 @@ def test_q_projection_inside_the_cross_attention_is_bit_identical(cuda, ocr_setu
         assert o["steps_run"] == outs[0]["steps_run"]
         for k in ("tokens", "length", "prob", "colors"):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("n_lines,T", [(1, 8), (129, 5), (140, 5)])
+def test_few_row_decode_at_the_edges_of_its_forms(cuda, ocr_setup, n_lines, T):
+    """One line (5 rows: a single ragged row block), 129 lines (past the 128 the q-projecting cross-attention takes: separate launches) and
+    140 lines (700 rows: past the 640 the K-cut FFN Linear takes: the one-chain K = 2048 kernel) against the tiled form, with the K-cut
+    off — every result tensor identical."""
+    import os
+    from manga_image_translator_amd import lib as L
+
+    sd, D, eng = ocr_setup
+    crops = _crops([48 + (7 * i) % 90 for i in range(n_lines)], seed=53)
+    mks, mvs, lens = [], [], []
+    for indices, ws, region in eng.make_chunks(crops):
+        mk, mv, kl, _ = eng.encode(torch.from_numpy(region).to(cuda), ws)
+        mks.append(mk.clone()); mvs.append(mv.clone()); lens.append(kl.clone())
+    Lmax = max(m.shape[2] for m in mks)
+    pad = lambda m: m if m.shape[2] == Lmax else torch.cat([m, m.new_zeros(5, m.shape[1], Lmax - m.shape[2], 320)], 2)
+    mem_k, mem_v, klen = torch.cat([pad(m) for m in mks], 1).contiguous(), torch.cat([pad(m) for m in mvs], 1).contiguous(), torch.cat(lens)
+    lib = L.load()
+    prev = lib.mit_ocr48_decode_rows_max_set(-1)
+    prev_sk = os.environ.get("MIT_OCR_FF2_SPLITK")
+    os.environ["MIT_OCR_FF2_SPLITK"] = "0"
+    outs = []
+    try:
+        for rows_max in (0, prev):
+            lib.mit_ocr48_decode_rows_max_set(rows_max)
+            o = eng.decode(mem_k, mem_v, klen, max_seq_length=T, suppress_eos=True)
+            torch.cuda.synchronize()
+            outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()})
+    finally:
+        lib.mit_ocr48_decode_rows_max_set(prev)
+        os.environ.pop("MIT_OCR_FF2_SPLITK", None) if prev_sk is None else os.environ.__setitem__("MIT_OCR_FF2_SPLITK", prev_sk)
+    for k in ("tokens", "length", "prob", "colors"):
+        assert torch.equal(outs[1][k], outs[0][k]), k
