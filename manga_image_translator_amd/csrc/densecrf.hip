@@ -294,15 +294,67 @@ __device__ __forceinline__ float2 load_val(const long long *__restrict__ acc, co
     return src[s];
 }
 
-__global__ __launch_bounds__(256) void crf_blur_kernel(const unsigned long long *__restrict__ keys, const int2 *__restrict__ nbr_j,
-                                                        const long long *__restrict__ acc, const float2 *__restrict__ src,
-                                                        float2 *__restrict__ dst, int first, int64_t CAP) {
+// ---- dense numbering of the lattice points ------------------------------------------------------------------------------------
+// The hash tables are sized for the worst case (2 (d + 1) slots per pixel: 9 M slots for a page's crops) while the bilateral lattice
+// holds a few per cent of that: scanning the whole table in each of the d + 1 blur passes of every iteration (45 launches per call) and
+// clearing 16 bytes per SLOT per iteration was 2.4 ms per page of the coupled path.  After the neighbour tables are built the occupied
+// slots get consecutive ids (in whatever order the waves arrive: the ids only name the points — every sum is per point and the splat
+// adds integers — so the results do not depend on it), the pixels' vertex offsets and the neighbour entries are rewritten to ids, and
+// everything an iteration touches (accumulators, value buffers, blur) is as long as the number of points.
+constexpr int COMPACT_PER_WAVE = 2048;   // slots a wave numbers with ONE add on the shared counter (one per 64 slots: 140 k adds on one address, 0.95 ms)
+__global__ __launch_bounds__(256) void crf_compact_kernel(const unsigned long long *__restrict__ keys, int64_t CAP, int *__restrict__ dense_id,
+                                                           int *__restrict__ counter) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * COMPACT_PER_WAVE;
+    if (w0 >= CAP) return;
+    int cnt = 0;
+    for (int it = 0; it < COMPACT_PER_WAVE / 64; ++it) {
+        const int64_t s = w0 + it * 64 + lane;
+        cnt += __popcll(__ballot(s < CAP && keys[s] != EMPTY));
+    }
+    int base = 0;
+    if (lane == 0 && cnt) base = atomicAdd(counter, cnt);
+    base = __shfl(base, 0);
+    for (int it = 0; it < COMPACT_PER_WAVE / 64; ++it) {
+        const int64_t s = w0 + it * 64 + lane;
+        const bool occ = s < CAP && keys[s] != EMPTY;
+        const unsigned long long m = __ballot(occ);
+        if (s < CAP) dense_id[s] = occ ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+        base += __popcll(m);
+    }
+}
+
+// active[id] = slot (written into the key table's memory: the keys are not read any more), the slot's neighbour entries become ids
+__global__ __launch_bounds__(256) void crf_relabel_kernel(const int *__restrict__ dense_id, int64_t CAP, int ndir, int2 *__restrict__ nbr,
+                                                           int *__restrict__ active) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= CAP || keys[s] == EMPTY) return;
-    const int2 n = nbr_j[s];
-    const float2 o = load_val(acc, src, first, (int)s), a = load_val(acc, src, first, n.x), b = load_val(acc, src, first, n.y);
+    if (s >= CAP) return;
+    const int id = dense_id[s];
+    if (id < 0) return;
+    active[id] = (int)s;
+    for (int j = 0; j < ndir; ++j) {
+        int2 n = nbr[(int64_t)j * CAP + s];
+        n.x = n.x < 0 ? -1 : dense_id[n.x];
+        n.y = n.y < 0 ? -1 : dense_id[n.y];
+        nbr[(int64_t)j * CAP + s] = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void crf_relabel_offsets_kernel(const int *__restrict__ dense_id, int64_t n, int *__restrict__ offset) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) offset[i] = dense_id[offset[i]];
+}
+
+// one blur pass over the NV lattice points (ids); nbr_j is indexed by SLOT and holds ids
+__global__ __launch_bounds__(256) void crf_blur_kernel(const int *__restrict__ active, const int2 *__restrict__ nbr_j,
+                                                        const long long *__restrict__ acc, const float2 *__restrict__ src,
+                                                        float2 *__restrict__ dst, int first, int NV) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NV) return;
+    const int2 n = nbr_j[active[i]];
+    const float2 o = load_val(acc, src, first, i), a = load_val(acc, src, first, n.x), b = load_val(acc, src, first, n.y);
     const float sx = a.x + b.x, sy = a.y + b.y;
-    dst[s] = make_float2((float)((double)o.x + 0.5 * (double)sx), (float)((double)o.y + 0.5 * (double)sy));
+    dst[i] = make_float2((float)((double)o.x + 0.5 * (double)sx), (float)((double)o.y + 0.5 * (double)sy));
 }
 
 template <int D>
@@ -342,7 +394,7 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const float2 *__restric
 
 struct Layout {
     int64_t NP, cap2, cap5;
-    size_t crops, pt_off, tb2_off, tb5_off, overflow, unary, q, msg_g, msg_b, off2, bary2, off5, bary5, keys2, keys5, nbr2, nbr5, acc, valA, valB,
+    size_t crops, pt_off, tb2_off, tb5_off, overflow, counts, unary, q, msg_g, msg_b, off2, bary2, off5, bary5, keys2, keys5, nbr2, nbr5, acc, valA, valB,
         total;
 };
 
@@ -374,6 +426,7 @@ int make_layout(const MitCrfCrop *crops, int n, Layout *L, std::vector<int64_t> 
     L->tb2_off = take(8 * (size_t)(n + 1));
     L->tb5_off = take(8 * (size_t)(n + 1));
     L->overflow = take(4);
+    L->counts = take(8);
     L->unary = take(8 * (size_t)L->NP);
     L->q = take(8 * (size_t)L->NP);
     L->msg_g = take(8 * (size_t)L->NP);
@@ -443,8 +496,7 @@ extern "C" int mit_densecrf_refine(const uint8_t *page_dev, int H, int W, const 
     MIT_CHECK_HIP(hipMemsetAsync(at(L.overflow), 0, 4, st));
     MIT_CHECK_HIP(hipMemsetAsync(at(L.keys2), 0xff, 8 * (size_t)L.cap2, st));
     MIT_CHECK_HIP(hipMemsetAsync(at(L.keys5), 0xff, 8 * (size_t)L.cap5, st));
-    MIT_CHECK_HIP(hipMemsetAsync(at(L.valA), 0, 8 * (size_t)L.cap5, st));
-    MIT_CHECK_HIP(hipMemsetAsync(at(L.valB), 0, 8 * (size_t)L.cap5, st));
+    MIT_CHECK_HIP(hipMemsetAsync(at(L.counts), 0, 8, st));
     const MitCrfCrop *d_crops = static_cast<const MitCrfCrop *>(at(L.crops));
     const int64_t *d_pt = static_cast<const int64_t *>(at(L.pt_off)), *d_t2 = static_cast<const int64_t *>(at(L.tb2_off)),
                   *d_t5 = static_cast<const int64_t *>(at(L.tb5_off));
@@ -471,27 +523,43 @@ extern "C" int mit_densecrf_refine(const uint8_t *page_dev, int H, int W, const 
         hipLaunchKernelGGL(crf_neighbors_kernel<2>, dim3(blocks(L.cap2)), dim3(256), 0, st, keys2, d_t2, n_crops, L.cap2, nbr2);
         hipLaunchKernelGGL(crf_neighbors_kernel<5>, dim3(blocks(L.cap5)), dim3(256), 0, st, keys5, d_t5, n_crops, L.cap5, nbr5);
         hipLaunchKernelGGL(crf_unary_kernel, dim3(blocks(NP)), dim3(256), 0, st, mask_dev, unary_lut_dev, NP, unary, q);
+        // dense ids (see crf_compact_kernel): the id tables sit in the accumulator area until the first iteration clears it, the id ->
+        // slot lists take the key tables' place
+        int *d_counts = static_cast<int *>(at(L.counts));
+        int *id5 = reinterpret_cast<int *>(acc), *id2 = id5 + L.cap5;
+        int *act2 = reinterpret_cast<int *>(keys2), *act5 = reinterpret_cast<int *>(keys5);
+        hipLaunchKernelGGL(crf_compact_kernel, dim3((unsigned)((L.cap2 + 4 * COMPACT_PER_WAVE - 1) / (4 * COMPACT_PER_WAVE))), dim3(256), 0, st, keys2, L.cap2, id2, d_counts);
+        hipLaunchKernelGGL(crf_compact_kernel, dim3((unsigned)((L.cap5 + 4 * COMPACT_PER_WAVE - 1) / (4 * COMPACT_PER_WAVE))), dim3(256), 0, st, keys5, L.cap5, id5, d_counts + 1);
+        hipLaunchKernelGGL(crf_relabel_kernel, dim3(blocks(L.cap2)), dim3(256), 0, st, id2, L.cap2, 3, nbr2, act2);
+        hipLaunchKernelGGL(crf_relabel_kernel, dim3(blocks(L.cap5)), dim3(256), 0, st, id5, L.cap5, 6, nbr5, act5);
+        hipLaunchKernelGGL(crf_relabel_offsets_kernel, dim3(blocks(3 * NP)), dim3(256), 0, st, id2, 3 * NP, off2);
+        hipLaunchKernelGGL(crf_relabel_offsets_kernel, dim3(blocks(6 * NP)), dim3(256), 0, st, id5, 6 * NP, off5);
+        int nv[2] = {0, 0};
+        MIT_CHECK_HIP(hipMemcpyAsync(nv, d_counts, 8, hipMemcpyDeviceToHost, st));
+        MIT_CHECK_HIP(hipStreamSynchronize(st));
+        const int nv2 = nv[0], nv5 = nv[1], nvmax = nv2 > nv5 ? nv2 : nv5;
+        if (nv2 <= 0 || nv5 <= 0 || nv2 > L.cap2 || nv5 > L.cap5) return mit_set_error("mit_densecrf_refine: lattice point count out of range (%d, %d)", nv2, nv5);
+        MIT_CHECK_HIP(hipMemsetAsync(valA, 0, 8 * (size_t)nvmax, st));
+        MIT_CHECK_HIP(hipMemsetAsync(valB, 0, 8 * (size_t)nvmax, st));
         for (int it = 0; it < iterations; ++it) {
             // Gaussian term (d = 2)
-            MIT_CHECK_HIP(hipMemsetAsync(acc, 0, 16 * (size_t)L.cap2, st));
+            MIT_CHECK_HIP(hipMemsetAsync(acc, 0, 16 * (size_t)nv2, st));
             hipLaunchKernelGGL(crf_splat_kernel<2>, dim3(blocks(NP)), dim3(256), 0, st, q, off2, bary2, NP, acc);
             float2 *src = valA, *dst = valB;
             for (int j = 0; j <= 2; ++j) {
-                hipLaunchKernelGGL(crf_blur_kernel, dim3(blocks(L.cap2)), dim3(256), 0, st, keys2, nbr2 + (int64_t)j * L.cap2, acc, src, dst, j == 0,
-                                   L.cap2);
+                hipLaunchKernelGGL(crf_blur_kernel, dim3(blocks(nv2)), dim3(256), 0, st, act2, nbr2 + (int64_t)j * L.cap2, acc, src, dst, j == 0, nv2);
                 float2 *t = src;
                 src = dst;
                 dst = t;
             }
             hipLaunchKernelGGL(crf_slice_kernel<2>, dim3(blocks(NP)), dim3(256), 0, st, src, off2, bary2, NP, lc2.alpha, msg_g);
             // bilateral term (d = 5)
-            MIT_CHECK_HIP(hipMemsetAsync(acc, 0, 16 * (size_t)L.cap5, st));
+            MIT_CHECK_HIP(hipMemsetAsync(acc, 0, 16 * (size_t)nv5, st));
             hipLaunchKernelGGL(crf_splat_kernel<5>, dim3(blocks(NP)), dim3(256), 0, st, q, off5, bary5, NP, acc);
             src = valA;
             dst = valB;
             for (int j = 0; j <= 5; ++j) {
-                hipLaunchKernelGGL(crf_blur_kernel, dim3(blocks(L.cap5)), dim3(256), 0, st, keys5, nbr5 + (int64_t)j * L.cap5, acc, src, dst, j == 0,
-                                   L.cap5);
+                hipLaunchKernelGGL(crf_blur_kernel, dim3(blocks(nv5)), dim3(256), 0, st, act5, nbr5 + (int64_t)j * L.cap5, acc, src, dst, j == 0, nv5);
                 float2 *t = src;
                 src = dst;
                 dst = t;
