@@ -103,11 +103,33 @@ __global__ __launch_bounds__(256) void refine_prepare_kernel(const uint8_t *__re
             }
         pred_bin[p] = cr > 60 ? 255 : 0;  // merge_mask_list: erode(cross 3x3), threshold(pred_thresh * 2 = 60) (:77-81)
     }
-    const int64_t h = (int64_t)l * 1024;
-    wave_count(hist, h + gr, ok && er > 127);
-    wave_count(hist, h + 256 + c0, ok);
-    wave_count(hist, h + 512 + c1, ok);
-    wave_count(hist, h + 768 + c2, ok);
+    // The four histograms of the workgroup's FIRST line are counted in LDS (a workgroup's 256 consecutive pixels belong to one line, two
+    // at a line's end) and added to the line's 1024 global counters once per bin; pixels of a following line go to global memory
+    // directly.  (Counted per wave with one global atomic per distinct key — up to 64 rounds of ballots per histogram on a textured crop —
+    // this kernel was 1.05 ms per page of the coupled path.)  Integer counts: the same histograms.
+    __shared__ int sh[1024];
+    __shared__ int l0s;
+    for (int b = threadIdx.x; b < 1024; b += 256) sh[b] = 0;
+    if (threadIdx.x == 0) l0s = l;   // (thread 0 holds the block's first pixel; blocks are only launched for p0 < P)
+    __syncthreads();
+    const int l0 = l0s;
+    if (ok && l == l0) {
+        if (er > 127) atomicAdd(&sh[gr], 1);
+        atomicAdd(&sh[256 + c0], 1);
+        atomicAdd(&sh[512 + c1], 1);
+        atomicAdd(&sh[768 + c2], 1);
+    } else if (ok) {
+        int *dst = hist + (int64_t)l * 1024;
+        if (er > 127) atomicAdd(dst + gr, 1);
+        atomicAdd(dst + 256 + c0, 1);
+        atomicAdd(dst + 512 + c1, 1);
+        atomicAdd(dst + 768 + c2, 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 1024; b += 256) {
+        const int v = sh[b];
+        if (v) atomicAdd(hist + (int64_t)l0 * 1024 + b, v);
+    }
 }
 
 // candidate k of a line: kind 0 = none, 1 = inRange(grey, lo, hi), 2 + c = channel c > lo; invert = take the complement
@@ -137,13 +159,26 @@ __global__ __launch_bounds__(256) void refine_score_kernel(const uint8_t *__rest
         m = pred[(int64_t)(w.y1 + y) * W + w.x1 + x];
         gr = grey[p];
     }
+    // sums of the workgroup's first line in LDS, one global add per candidate and workgroup (as refine_prepare_kernel's histograms)
+    __shared__ unsigned long long ssum[6];
+    __shared__ int l0s;
+    if (threadIdx.x < 6) ssum[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) l0s = l;
+    __syncthreads();
+    const int l0 = l0s;
     for (int k = 0; k < 6; ++k) {
         MitRefineCand c = cands[l * 6 + k];
         const bool on = ok && c.kind != 0;
         if (!on) c.kind = 1;
         const int t = cand_bit(c, gr, px);
-        wave_sum(sums, l * 6 + k, on, t ? 255 - m : m);
+        const int v = t ? 255 - m : m;
+        int tv = (on && l == l0) ? v : 0;   // wave-level sum first (every lane takes part): one LDS add per wave and candidate
+        for (int o = 32; o > 0; o >>= 1) tv += __shfl_xor(tv, o);
+        if ((threadIdx.x & 63) == 0 && tv) atomicAdd(&ssum[k], (unsigned long long)tv);
+        if (on && l != l0) atomicAdd(&sums[l * 6 + k], (unsigned long long)v);
     }
+    __syncthreads();
+    if (threadIdx.x < 6 && ssum[threadIdx.x]) atomicAdd(&sums[l0 * 6 + threadIdx.x], ssum[threadIdx.x]);
 }
 
 // ---- phase C: component-wise merge -----------------------------------------------------------------------------------------
